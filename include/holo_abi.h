@@ -1,0 +1,193 @@
+/*
+ * holo_abi.h — C ABI of libholo_mi355x.so, the MI355X-native denoise-and-render hot path
+ * of HoloDiffusion.
+ *
+ * The reference has no native code and no FFI: the hot path sits behind PyTorch3D-Implicitron
+ * registry plugins.  The Python plugin classes in holo_diffusion_amd/ keep that
+ * surface and bind the entry points below through ctypes; each entry point names the reference
+ * interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative HOLO_E_* code on failure; the message is
+ *     available from holo_last_error() (thread-local).  No exceptions cross the boundary.
+ *   - all tensor pointers are DEVICE pointers owned by the caller (torch) unless a parameter says
+ *     "host"; they must stay valid until the stream work that uses them has completed.
+ *   - no hidden device synchronisation and no allocation inside *_forward / *_step / holo_render:
+ *     the caller supplies the workspace (size from *_workspace_bytes).  *_create / *_set_param /
+ *     *_commit may allocate and synchronise (setup time).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - fp32 everywhere (the reference computes in fp32: unet.py:639 `self.dtype = th.float32`).
+ */
+#ifndef HOLO_ABI_H
+#define HOLO_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOLO_ABI_VERSION 1
+
+enum {
+  HOLO_OK = 0,
+  HOLO_E_INVALID = -1,   /* bad argument / unknown parameter name / shape mismatch */
+  HOLO_E_HIP = -2,       /* a HIP runtime call failed */
+  HOLO_E_WORKSPACE = -3, /* workspace too small */
+  HOLO_E_STATE = -4,     /* parameters missing / not committed */
+  HOLO_E_UNSUPPORTED = -5
+};
+
+enum { HOLO_DTYPE_F32 = 0 };
+
+typedef struct HoloCtx HoloCtx;
+typedef struct HoloUnet HoloUnet;
+typedef struct HoloRenderer HoloRenderer;
+
+int holo_abi_version(void);
+const char* holo_last_error(void);
+
+/* One context per process per GPU (one process per GPU). */
+int holo_ctx_create(int device_id, HoloCtx** out);
+int holo_ctx_destroy(HoloCtx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Denoiser.  Replaces SimpleUnet3D / UNetModel:
+ *   holo_diffusion/utils/diffusion_utils.py:41-86   (plugin + ctor-arg mapping)
+ *   holo_diffusion/guided_diffusion/unet.py:566-837 (UNetModel ctor + forward)
+ * The config fields are SimpleUnet3D's dataclass fields (diffusion_utils.py:43-53).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t image_size;
+  int32_t in_channels;
+  int32_t out_channels;
+  int32_t model_channels;
+  int32_t num_res_blocks;
+  int32_t n_channel_mult;
+  int32_t channel_mult[8];
+  int32_t n_attention_resolutions;
+  int32_t attention_resolutions[8];
+  int32_t num_heads;
+  int32_t homogeneous_resample; /* only 1 is supported (diffusion_utils.py:53 default) */
+} HoloUnetCfg;
+
+int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out);
+int holo_unet_destroy(HoloUnet* net);
+
+/* Parameter enumeration: names are the reference state_dict keys below `net_3d._net.`
+ * (e.g. "input_blocks.1.0.in_layers.2.weight"), shapes the reference shapes. */
+int holo_unet_num_params(const HoloUnet* net);
+int holo_unet_param_info(const HoloUnet* net, int index, char* name, int name_cap, int64_t shape[8], int* ndim);
+
+/* Bind one parameter.  The library keeps a repacked private copy (conv weights
+ * [tap][Cout][Cin], concatenated embedding linears); call again after the caller's tensor changes. */
+int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, int dtype, int ndim,
+                        const int64_t* shape, void* stream);
+
+size_t holo_unet_workspace_bytes(HoloUnet* net, int batch);
+
+/* y = UNetModel.forward(x, timesteps)  (unet.py:800-837).
+ *   x, y        : (batch, C, R, R, R) fp32, NCDHW contiguous (the plugin boundary layout)
+ *   timesteps   : (batch,) int64 on the device (as the reference passes them, gaussian_diffusion.py:630) */
+int holo_unet_forward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug/parity hook: copy an intermediate block output (NCDHW) of the LAST forward into `dst`.
+ * tag = "input_blocks.<i>", "middle_block", "output_blocks.<i>".  Returns element count in *numel. */
+int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t dst_capacity, int64_t* numel,
+                          void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DDPM ancestral step.  Replaces the elementwise tail of GaussianDiffusion.p_sample:
+ *   gaussian_diffusion.py:314-343 (clamp, START_X), :237-240 (posterior mean), :499-506 (noise add)
+ *   tables   : (T, 4) fp32 on the device: {posterior_mean_coef1, posterior_mean_coef2,
+ *              posterior_log_variance_clipped, 0}, cast from the float64 schedule (:1056)
+ *   timesteps: (batch,) int64 on the device
+ *   sample = c1*clamp(model_out) + c2*x_t + [t!=0]*exp(0.5*logvar)*noise ;  pred_xstart = clamp(model_out)
+ * ------------------------------------------------------------------------------------------ */
+int holo_ddpm_step(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
+                   int64_t elems_per_sample, const float* x_t, const float* model_out, const float* noise,
+                   int clip_denoised, float* sample, float* pred_xstart, void* stream);
+
+/* Elementwise helpers on the path: torch.tanh (holo_diffusion_model.py:425) and
+ * torch.clip(x,-1,1) (holo_diffusion_model.py:186). */
+int holo_tanh(HoloCtx* ctx, const float* x, float* y, int64_t n, void* stream);
+int holo_clip(HoloCtx* ctx, const float* x, float* y, float lo, float hi, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Renderer.  Replaces, fused in one kernel per frame:
+ *   AdaptiveRaySampler call            holo_diffusion_model.py:442-448 (+ configs/apple.yaml:135-146)
+ *   GenericModel._render chunk loop    holo_diffusion_model.py:451-457
+ *   HoloMultiPassEmissionAbsorptionRenderer._run_raymarcher   holo_multipass_ea.py:79-125
+ *   HoloVoxelGridImplicitFunction.forward                     holo_voxel_grid_implicit_function.py:182-269
+ *   RenderMLP.forward / MLPWithInputSkips                     holo_voxel_grid_implicit_function.py:107-129,
+ *                                                             custom_modules.py:133-160
+ *   EmissionAbsorptionRaymarcher / RayPointRefiner (PyTorch3D 0.7.4; configs/apple.yaml:147-165)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t resol;            /* HoloDiffusionModel.resol */
+  int32_t feature_size;     /* HoloDiffusionModel.feature_size (= RenderMLP.input_dims) */
+  float volume_extent;      /* 8.0 */
+  float scene_extent;       /* raysampler_AdaptiveRaySampler_args.scene_extent = 4.0 */
+  float scene_center[3];
+  int32_t n_pts_coarse;     /* n_pts_per_ray_evaluation = 64 */
+  int32_t n_pts_fine;       /* n_pts_per_ray_fine_evaluation = 64 (16 in unet_with_no_diffusion.yaml) */
+  int32_t image_height;
+  int32_t image_width;
+  float bg_color[3];
+  float background_opacity; /* 1e10 */
+  int32_t dnet_hidden_dim;  /* 256 */
+  int32_t dir_emb_dims;     /* 4 */
+  float sample_pdf_eps;     /* 1e-5 */
+} HoloRenderCfg;
+
+/* One camera in PyTorch3D PerspectiveCameras/NDC convention (X_cam = X_world R + T), host memory. */
+typedef struct {
+  float R[9]; /* row-major 3x3 */
+  float T[3];
+  float focal[2];
+  float principal_point[2];
+} HoloCamera;
+
+int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** out);
+int holo_renderer_destroy(HoloRenderer* r);
+
+/* RenderMLP parameters by reference name below `..._fn.render_mlp.`:
+ * "_density_net.mlp.{0..3}.0.{weight,bias}", "_radiance_net.mlp.0.0.{weight,bias}". */
+int holo_renderer_set_param(HoloRenderer* r, const char* name, const void* dev_ptr, int dtype, int ndim,
+                            const int64_t* shape, void* stream);
+/* Folds the activation-free density layers (custom_modules.py:108-112 quirk) into one affine map in
+ * float64 and uploads the packed weights.  Must be called after all set_param calls. */
+int holo_renderer_commit(HoloRenderer* r, void* stream);
+
+size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras);
+
+/* Render n_cameras full-grid frames of one voxel grid.
+ *   grid        : (1, C, R, R, R) fp32 NCDHW (what HoloDiffusionModel.forward binds as
+ *                 voxel_grid_features, holo_diffusion_model.py:431-438)
+ *   cameras     : host array of n_cameras HoloCamera (depth bounds are computed per camera)
+ *   images      : (n_cameras, 3, H, W); depths, masks : (n_cameras, 1, H, W)   [fine pass]
+ *   *_coarse    : optional (may be NULL) outputs of the coarse pass (RendererOutput.prev_stage) */
+int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
+                float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
+ * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).
+ * ------------------------------------------------------------------------------------------ */
+int holo_event_timer_create(void** timer);
+int holo_event_timer_start(void* timer, void* stream);
+int holo_event_timer_stop(void* timer, void* stream, float* elapsed_ms); /* synchronises on the stop event */
+int holo_event_timer_destroy(void* timer);
+
+/* Time only the conv3d implicit-GEMM launches of the last-planned forward (batch as planned):
+ * runs every conv op `iters` times, returns total milliseconds and total algorithmic FLOPs. */
+int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t workspace_bytes, int iters,
+                         void* stream, float* total_ms, double* total_flops, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOLO_ABI_H */

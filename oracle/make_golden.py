@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under ``tests/golden/`` from the REAL reference.
+
+Runs ONLY in the development container, where ``/root/reference`` exists.  It imports the
+importable half of the reference (``holo_diffusion/guided_diffusion/{unet,nn,gaussian_diffusion}``,
+torch + numpy only) with ``sys.dont_write_bytecode`` so nothing is written into the read-only
+tree, loads synthetic weights from ``holo_diffusion_amd.weights`` via ``load_state_dict`` and
+records inputs/outputs.  The fixtures are data only (seeds, shapes, tensors, digests).
+
+While generating, it also asserts that the CPU oracle (``oracle/unet_oracle.py``,
+``oracle/diffusion_oracle.py``) reproduces the reference on the same inputs, which is what pins
+the oracle; ``tests/test_oracle_golden.py`` re-checks that against the committed vectors on
+any box (no reference needed).
+
+Usage:  python oracle/make_golden.py            (fast set)
+        python oracle/make_golden.py --full     (+ 32^3x16 and 64^3x32 digests, ~1 min)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+
+from holo_diffusion.guided_diffusion.unet import UNetModel  # noqa: E402  (the reference)
+from holo_diffusion.guided_diffusion.nn import timestep_embedding as ref_timestep_embedding  # noqa: E402
+from holo_diffusion.guided_diffusion.gaussian_diffusion import (  # noqa: E402
+    GaussianDiffusion, LossType, ModelMeanType, ModelVarType, get_named_beta_schedule)
+
+from holo_diffusion_amd.weights import synth_state_dict  # noqa: E402
+from oracle import diffusion_oracle as do  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+from oracle.common import TINY_CFG, PLUMB_CFG, NORTH_CFG, np_noise, digest, seeded_input  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def build_reference(cfg: uo.UNetCfg) -> UNetModel:
+    """Exactly SimpleUnet3D.__post_init__'s ctor call (utils/diffusion_utils.py:56-75)."""
+    return UNetModel(
+        dims=3, image_size=cfg.image_size, in_channels=cfg.in_channels, model_channels=cfg.model_channels,
+        out_channels=cfg.out_channels, num_res_blocks=cfg.num_res_blocks,
+        attention_resolutions=cfg.attention_resolutions, dropout=cfg.dropout, channel_mult=cfg.channel_mult,
+        num_classes=None, use_checkpoint=False, num_heads=cfg.num_heads, num_head_channels=-1,
+        num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=False, zero_last_conv=False,
+        homogeneous_resample=cfg.homogeneous_resample).eval()
+
+
+def load_synth(net: UNetModel, cfg: uo.UNetCfg, seed: int):
+    shapes = uo.unet_param_shapes(cfg)
+    ref_shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in shapes.items()}, "oracle param map != reference state_dict"
+    sd = synth_state_dict(shapes, seed)
+    net.load_state_dict(sd, strict=True)
+    return sd
+
+
+def ref_diffusion(num_steps: int) -> GaussianDiffusion:
+    """== ImplicitronGaussianDiffusion.__post_init__ (utils/diffusion_utils.py:98-112)."""
+    return GaussianDiffusion(betas=get_named_beta_schedule("linear", num_steps, 1e-4, 0.02),
+                             model_mean_type=ModelMeanType.START_X, model_var_type=ModelVarType.FIXED_SMALL,
+                             loss_type=LossType.MSE, rescale_timesteps=False)
+
+
+def check(a: torch.Tensor, b: torch.Tensor, what: str, tol: float = 2e-5):
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    print(f"  oracle vs reference [{what}]: max|d|={err:.3e} (max|ref|={ref:.3e})")
+    assert err <= tol * max(ref, 1.0), what
+
+
+def gen_schedule():
+    out = {}
+    for T in (1000, 250, 20):
+        gd = ref_diffusion(T)
+        tab = do.schedule_tables(do.linear_betas(T))
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+                  "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            ref = np.asarray(getattr(gd, k), dtype=np.float64)
+            assert np.array_equal(ref, tab[k]), (T, k)
+            out[f"T{T}.{k}"] = ref
+    np.savez_compressed(os.path.join(GOLD, "schedule.npz"), **out)
+    print("schedule.npz written (oracle tables bit-equal to reference)")
+
+
+def gen_timestep_embedding():
+    ts = torch.tensor([0, 1, 10, 500, 999])
+    out = {"t": ts.numpy()}
+    for dim in (32, 64):
+        ref = ref_timestep_embedding(ts, dim)
+        assert torch.equal(ref, uo.timestep_embedding(ts, dim))
+        out[f"emb{dim}"] = ref.numpy()
+    np.savez_compressed(os.path.join(GOLD, "timestep_embedding.npz"), **out)
+    print("timestep_embedding.npz written")
+
+
+@torch.no_grad()
+def gen_tiny_unet():
+    cfg = TINY_CFG
+    net = build_reference(cfg)
+    sd = load_synth(net, cfg, 1234)
+    out = {}
+    for t in (0, 500, 999):
+        x = seeded_input(cfg, 7 + t)
+        ts = torch.tensor([t])
+        # reference block outputs via hooks
+        trace_ref = {}
+        hooks = []
+        for i, m in enumerate(net.input_blocks):
+            hooks.append(m.register_forward_hook(lambda mod, inp, o, k=f"input_blocks.{i}": trace_ref.__setitem__(k, o)))
+        hooks.append(net.middle_block.register_forward_hook(lambda mod, inp, o: trace_ref.__setitem__("middle_block", o)))
+        for i, m in enumerate(net.output_blocks):
+            hooks.append(m.register_forward_hook(lambda mod, inp, o, k=f"output_blocks.{i}": trace_ref.__setitem__(k, o)))
+        y_ref = net(x, ts)
+        for h in hooks:
+            h.remove()
+        trace = {}
+        y = uo.unet_forward(sd, cfg, x, ts, trace)
+        check(y, y_ref, f"tiny unet t={t}")
+        for k, v in trace_ref.items():
+            check(trace[k], v, f"tiny {k} t={t}")
+        out[f"t{t}.y"] = y_ref.numpy()
+        if t == 500:
+            for k, v in trace_ref.items():
+                out[f"t{t}.{k}"] = v.numpy()
+            out[f"t{t}.emb"] = net.time_embed(ref_timestep_embedding(ts, cfg.model_channels)).numpy()
+    np.savez_compressed(os.path.join(GOLD, "tiny_unet.npz"), **out)
+    print("tiny_unet.npz written")
+
+    # batch-2 variant (the reference is batch-generic; FiLM and GN are per-sample)
+    x2 = torch.cat([seeded_input(cfg, 100), seeded_input(cfg, 101)])
+    ts2 = torch.tensor([17, 803])
+    y2 = net(x2, ts2)
+    check(uo.unet_forward(sd, cfg, x2, ts2), y2, "tiny unet batch 2")
+    np.savez_compressed(os.path.join(GOLD, "tiny_unet_b2.npz"), y=y2.numpy())
+
+    # per-op goldens from reference modules
+    ops = {}
+    emb = net.time_embed(ref_timestep_embedding(torch.tensor([500]), cfg.model_channels))
+    ops["emb"] = emb.numpy()
+    rb = net.input_blocks[4][0]          # ResBlock 32->64 with 1x1x1 skip (level 1)
+    xin = seeded_input(cfg, 55)[:, :, :4, :4, :4].contiguous()
+    ops["res.x"] = xin.numpy()
+    ops["res.y"] = rb(xin, emb).numpy()
+    check(uo.res_block(sd, "input_blocks.4.0", xin, emb), torch.from_numpy(ops["res.y"]), "ResBlock 32->64")
+    dn = net.input_blocks[3][0]          # Downsample 32->32
+    xin = seeded_input(cfg, 56)
+    ops["down.x"] = xin.numpy()
+    ops["down.y"] = dn(xin).numpy()
+    check(uo.downsample(sd, "input_blocks.3.0", xin, True), torch.from_numpy(ops["down.y"]), "Downsample")
+    at = net.input_blocks[4][1]          # AttentionBlock C64, T=64, non-zero proj_out
+    xin = torch.from_numpy(np_noise(57, (1, 64, 4, 4, 4)))
+    ops["attn.x"] = xin.numpy()
+    ops["attn.y"] = at(xin).numpy()
+    check(uo.attention_block(sd, "input_blocks.4.1", xin, cfg.num_heads), torch.from_numpy(ops["attn.y"]), "Attention")
+    up = net.output_blocks[2][2]         # Upsample 64->64 (4^3 -> 8^3)
+    xin = torch.from_numpy(np_noise(58, (1, 64, 4, 4, 4)))
+    ops["up.x"] = xin.numpy()
+    ops["up.y"] = up(xin).numpy()
+    check(uo.upsample(sd, "output_blocks.2.2", xin, True), torch.from_numpy(ops["up.y"]), "Upsample")
+    np.savez_compressed(os.path.join(GOLD, "tiny_ops.npz"), **ops)
+    print("tiny_ops.npz written")
+    return net, sd
+
+
+@torch.no_grad()
+def gen_sampler(net, sd):
+    cfg = TINY_CFG
+    shape = (1, cfg.in_channels, cfg.image_size, cfg.image_size, cfg.image_size)
+    out = {}
+    for tag, T, max_iter in (("T1000_iter4", 1000, 4), ("T20_full", 20, None)):
+        gd = ref_diffusion(T)
+        ns = lambda t, shp, dev=None, s=900: torch.from_numpy(np_noise(s * 100003 + t, tuple(shp)))  # noqa: E731
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref_steps = list(gd.p_sample_loop_progressive(net, shape, clip_denoised=True, noise_sampler=ns,
+                                                          max_iter=max_iter, device=torch.device("cpu")))
+        orc = do.DiffusionOracle(T)
+        model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+        my_steps = list(orc.p_sample_loop_progressive(model, shape, lambda t, shp: ns(t, shp), True, max_iter))
+        assert len(ref_steps) == len(my_steps)
+        for i, (a, b) in enumerate(zip(my_steps, ref_steps)):
+            check(a["sample"], b["sample"], f"{tag} step {i} sample", 5e-5)
+            check(a["pred_xstart"], b["pred_xstart"], f"{tag} step {i} pred_xstart", 5e-5)
+        out[f"{tag}.indices"] = np.array(orc.indices(max_iter))
+        out[f"{tag}.samples"] = np.stack([s["sample"].numpy() for s in ref_steps])
+        out[f"{tag}.pred_xstart"] = np.stack([s["pred_xstart"].numpy() for s in ref_steps])
+    np.savez_compressed(os.path.join(GOLD, "tiny_sampler.npz"), **out)
+    print("tiny_sampler.npz written")
+
+
+@torch.no_grad()
+def gen_full_digests():
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for tag, cfg in (("plumb32x16", PLUMB_CFG), ("north64x32", NORTH_CFG)):
+        net = build_reference(cfg)
+        sd = load_synth(net, cfg, 1234)
+        for t in (0, 500, 999):
+            x = seeded_input(cfg, 7 + t)
+            y_ref = net(x, torch.tensor([t]))
+            if t == 500:
+                check(uo.unet_forward(sd, cfg, x, torch.tensor([t])), y_ref, f"{tag} t={t}", 1e-4)
+            for k, v in digest(y_ref).items():
+                out[f"{tag}.t{t}.{k}"] = v
+            print(f"  {tag} t={t} done")
+    np.savez_compressed(os.path.join(GOLD, "full_unet_digests.npz"), **out)
+    print("full_unet_digests.npz written")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    gen_schedule()
+    gen_timestep_embedding()
+    net, sd = gen_tiny_unet()
+    gen_sampler(net, sd)
+    if args.full:
+        gen_full_digests()
+
+
+if __name__ == "__main__":
+    main()
