@@ -1,0 +1,134 @@
+// holo_kernels.h — host-side launchers of the gfx950 kernels (definitions in kernels_*.hip).
+// All pointers are device pointers; `stream` is a hipStream_t as void*.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace holo {
+
+// ---------------------------------------------------------------------------------------------
+// conv3d as implicit GEMM on fp32 MFMA (kernels_conv.hip).
+//   out[m][co] = bias[co] + residual[m][co] + sum_{tap,ci} W[tap][co][ci] * in'(m, tap, ci)
+// with m = ((n*OD+od)*OH+oh)*OW+ow over channels-last (NDHWC) activations.
+// in' = optional per-(n,channel) affine (GroupNorm folded with FiLM) + optional SiLU, applied while
+// the tile is staged, zero padding applied AFTER the activation; optional nearest x2 upsample on load;
+// optional virtual channel concat of two sources (UNet skip connection, unet.py:829).
+// ---------------------------------------------------------------------------------------------
+struct ConvParams {
+  const float* src0;
+  const float* src1;  // may be null
+  int C0, C1;         // channels of src0 / src1; C0 % 32 == 0 when src1 != null; (C0+C1) % 4 == 0
+  int N, ID, IH, IW;  // logical input dims (AFTER upsampling when ups=1)
+  int ups;            // 1: sources have dims ID/2 x IH/2 x IW/2 and are read at (z>>1,y>>1,x>>1)
+  int OD, OH, OW;
+  int stride, pad, ksz;  // ksz = 3 (27 taps) or 1
+  int Cout;
+  const float* w;         // [ksz^3][Cout][Cin]
+  const float* coef;      // [N][Cin][2] = (a,b): x' = a*x+b ; null = identity
+  int act;                // 1: SiLU after the affine (only with coef)
+  const float* bias;      // [Cout] or null
+  const float* residual;  // [M][Cout] or null
+  float* out;             // [M][Cout]
+  float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
+  int nsplit;             // split-K factor over (tap, cin-chunk) chunks
+  int chunks_per_split;
+};
+
+// Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
+size_t conv_plan(ConvParams& p, int num_cus);
+int conv_launch(const ConvParams& p, void* stream);
+double conv_flops(const ConvParams& p);
+
+// ---------------------------------------------------------------------------------------------
+// batched GEMM on fp32 MFMA (kernels_gemm.hip):  C[b] = alpha * A[b] * B[b]^T
+//   A[b][m][k] at A + b*sa + m*lda + k            (k contiguous)
+//   B[b][n][k] at B + b*sb + n*ldb + k            (b_kmajor = 0, k contiguous)
+//              at B + b*sb + k*ldb + n            (b_kmajor = 1, n contiguous)
+//   C[b][m][n] at C + b*sc + m*ldc + n
+// batch index b = b0*nb1 + b1 with separate strides for the two levels (sample, head).
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, Nn, K;
+  int lda, ldb, ldc;
+  int nb0, nb1;
+  int64_t sa0, sa1, sb0, sb1, sc0, sc1;
+  int b_kmajor;
+  float alpha;
+};
+int gemm_launch(const GemmParams& p, void* stream);
+
+// in-place row softmax over `rows` rows of length `cols` (unet.py:453, fp32)
+int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);
+
+// ---------------------------------------------------------------------------------------------
+// misc (kernels_misc.hip)
+// ---------------------------------------------------------------------------------------------
+int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream);
+int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream);
+
+// per-(n,c) sum and sum of squares (double) of a channels-last tensor; stats must be zeroed first.
+int gn_stats_launch(const float* x, double* stats, int N, int C, int64_t V, void* stream);
+
+// GroupNorm(32 groups, eps) folded to per-channel (a,b), optionally composed with FiLM
+// (unet.py:248-250): y = GN(x)*(1+scale)+shift.  Channels [0,C0) use stats0, [C0,C0+C1) stats1.
+int gn_finalize_launch(const double* stats0, int C0, const double* stats1, int C1, int N, int64_t V, int groups,
+                       float eps, const float* gamma, const float* beta, const float* film, int film_stride,
+                       int film_cout, float* coef, void* stream);
+
+// emb = Linear2(SiLU(Linear1(timestep_embedding(t, mc))));  writes silu(emb) (all consumers apply SiLU first:
+// unet.py:199-205) and emb itself.
+int time_embed_launch(const int64_t* t, int N, int mc, int ted, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* emb, float* emb_silu, void* stream);
+
+// out[n][r] = bias[r] + sum_k W[r][k] * in[n][k]      (all ResBlock emb_layers concatenated)
+int rows_linear_launch(const float* in, const float* w, const float* bias, float* out, int N, int rows, int K,
+                       void* stream);
+
+int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int batch, int64_t per, const float* x_t,
+                     const float* model_out, const float* noise, int clip, float* sample, float* pred_xstart,
+                     void* stream);
+int tanh_launch(const float* x, float* y, int64_t n, void* stream);
+int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
+
+// OIDHW [Cout][Cin][taps] -> [taps][Cout][Cin]
+int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, void* stream);
+
+// ---------------------------------------------------------------------------------------------
+// renderer (kernels_render.hip)
+// ---------------------------------------------------------------------------------------------
+struct RenderKernelParams {
+  const float* grid_cl;  // (R,R,R,C) channels-last voxel features
+  int R, C;
+  float half_extent;  // 0.5*(R-1)*voxel_size (VolumeLocator local->world scale)
+  // packed RenderMLP (see render_exec.cpp for the layouts)
+  const float* w_feat;   // [Hd][C]   collapsed density-net rows 0..Hd-1 (hidden features)
+  const float* b_feat;   // [Hd]
+  const float* w_dens;   // [C]       collapsed density row
+  float b_dens;
+  const float* w_rad;    // [3][Hd]   radiance weights on the hidden features
+  const float* w_dir;    // [3][27]   radiance weights on the direction embedding
+  float b_rad[3];
+  int Hd;
+  // camera
+  float Rm[9], T[3], focal[2], pp[2];
+  float zmin, zmax;
+  int H, W;
+  float range_x, range_y;  // NDC half ranges
+  int n_coarse, n_fine;
+  float bg[3];
+  float background_opacity;
+  float pdf_eps;
+  // outputs (per camera): CHW planes
+  float* rgb;
+  float* depth;
+  float* mask;
+  float* rgb_c;  // may be null
+  float* depth_c;
+  float* mask_c;
+};
+int render_launch(const RenderKernelParams& p, void* stream);
+
+}  // namespace holo

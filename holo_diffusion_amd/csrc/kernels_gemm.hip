@@ -1,0 +1,205 @@
+// kernels_gemm.hip — batched fp32-MFMA GEMM and row softmax for the UNet attention blocks.
+//
+// Replaces QKVAttentionLegacy (holo_diffusion/guided_diffusion/unet.py:436-455):
+//   weight = einsum("bct,bcs->bts", q*scale, k*scale)     -> gemm (A=q, B=k, alpha=scale^2), k contiguous
+//   weight = softmax(weight.float(), dim=-1)               -> softmax_rows
+//   a      = einsum("bts,bcs->bct", weight, v)             -> gemm (A=weight, B=v with n contiguous)
+// q/k/v are column slices of the token-major qkv buffer [T][3C] (head-major channel order, unet.py:448).
+//
+// Same tile machinery as kernels_conv.hip: 128 x 64 block tile, 32-deep K chunks, LDS rows of 36 floats,
+// v_mfma_f32_32x32x2_f32, lane half h owns k in [16h,16h+16) of a chunk.
+#include "holo_common.h"
+#include "holo_kernels.h"
+
+namespace holo {
+namespace {
+
+constexpr int BM = 128;
+constexpr int BN = 64;
+constexpr int BK = 32;
+constexpr int LDK = 36;
+
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+  constexpr int BUF = (BM + BN) * LDK;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int bz = blockIdx.z;
+  const int b0 = bz / p.nb1, b1 = bz - b0 * p.nb1;
+  const float* A = p.A + b0 * p.sa0 + b1 * p.sa1;
+  const float* B = p.B + b0 * p.sb0 + b1 * p.sb1;
+  float* C = p.C + b0 * p.sc0 + b1 * p.sc1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int nchunks = (p.K + BK - 1) / BK;
+
+  const int q = tid & 7;
+  const int r0 = tid >> 3;
+  // k-major B staging: 16 threads cover 64 n (float4 each), 16 k rows per pass
+  const int nq = tid & 15;
+  const int kr = tid >> 4;
+
+  float4 ra[4], rb[2];
+
+  auto load_chunk = [&](int kc) {
+    const int k = kc * BK + q * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + r0 + 32 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && k < p.K) v = *reinterpret_cast<const float4*>(A + (int64_t)m * p.lda + k);
+      ra[j] = v;
+    }
+    if (!p.b_kmajor) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.Nn && k < p.K) v = *reinterpret_cast<const float4*>(B + (int64_t)n * p.ldb + k);
+        rb[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kk = kc * BK + kr + 16 * j;
+        const int n = n0 + nq * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kk < p.K && n < p.Nn) v = *reinterpret_cast<const float4*>(B + (int64_t)kk * p.ldb + n);
+        rb[j] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* base = lds + buf * BUF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(base + (r0 + 32 * j) * LDK + q * 4) = ra[j];
+    if (!p.b_kmajor) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(base + (BM + r0 + 32 * j) * LDK + q * 4) = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kk = kr + 16 * j;
+        float* d = base + (BM + nq * 4) * LDK + kk;
+        d[0] = rb[j].x;
+        d[LDK] = rb[j].y;
+        d[2 * LDK] = rb[j].z;
+        d[3 * LDK] = rb[j].w;
+      }
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+
+  auto compute = [&](int buf) {
+    const float* base = lds + buf * BUF;
+    float a[16], b[2][16];
+    const float4* ap = reinterpret_cast<const float4*>(base + (wave * 32 + li) * LDK + lh * 16);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float4 t4 = ap[v];
+      a[4 * v + 0] = t4.x;
+      a[4 * v + 1] = t4.y;
+      a[4 * v + 2] = t4.z;
+      a[4 * v + 3] = t4.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4* bp = reinterpret_cast<const float4*>(base + (BM + t * 32 + li) * LDK + lh * 16);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float4 t4 = bp[v];
+        b[t][4 * v + 0] = t4.x;
+        b[t][4 * v + 1] = t4.y;
+        b[t][4 * v + 2] = t4.z;
+        b[t][4 * v + 3] = t4.w;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[t][ks], acc[t], 0, 0, 0);
+  };
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int kc = 0; kc < nchunks; ++kc) {
+    const int buf = kc & 1;
+    const bool more = kc + 1 < nchunks;
+    if (more) load_chunk(kc + 1);
+    compute(buf);
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + t * 32 + li;
+    if (n >= p.Nn) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < p.M) C[(int64_t)m * p.ldc + n] = p.alpha * acc[t][r];
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// one 256-thread block per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int cols) {
+  __shared__ float red[8];
+  float* row = s + (int64_t)blockIdx.x * cols;
+  const int tid = threadIdx.x;
+  float mx = -INFINITY;
+  for (int i = tid; i < cols; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < cols; i += 256) sum += expf(row[i] - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / sum;
+  for (int i = tid; i < cols; i += 256) row[i] = expf(row[i] - mx) * inv;
+}
+
+}  // namespace
+
+int gemm_launch(const GemmParams& p, void* stream) {
+  if ((p.lda & 3) || (p.ldb & 3) || (p.K & 3) || (p.b_kmajor && (p.Nn & 3))) {
+    set_error("gemm_launch: leading dimensions / K must be multiples of 4 (lda=%d ldb=%d K=%d N=%d)", p.lda, p.ldb,
+              p.K, p.Nn);
+    return -1;
+  }
+  dim3 grid((unsigned)cdiv(p.M, BM), (unsigned)cdiv(p.Nn, BN), (unsigned)(p.nb0 * p.nb1));
+  HOLO_LAUNCH(gemm_kernel, grid, dim3(256), stream, p);
+  return 0;
+}
+
+int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream) {
+  HOLO_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), stream, s, cols);
+  return 0;
+}
+
+}  // namespace holo

@@ -1,0 +1,389 @@
+// kernels_misc.hip — HBM-bound kernels around the MFMA ops of the denoiser.
+//
+//   layout     NCDHW (plugin boundary) <-> channels-last (kernel layout); optional tanh
+//              (holo_diffusion_model.py:425)
+//   gn_stats   per-(sample, channel) sum / sum-of-squares of GroupNorm32's input (nn.py:23-25), in double
+//   gn_finalize GroupNorm(32, C, eps=1e-5) folded with affine and FiLM (unet.py:248-252) into (a,b)/channel
+//   time_embed timestep_embedding + time_embed MLP (nn.py:109-127, unet.py:645-650)
+//   rows_linear all ResBlock emb_layers Linear(SiLU(emb)) at once (unet.py:199-205,245)
+//   ddpm_step  clamp + posterior mean + noise (gaussian_diffusion.py:314-343,237-240,499-506)
+#include "holo_common.h"
+#include "holo_kernels.h"
+
+namespace holo {
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// [N][C][V] -> [N][V][C] through a 32x33 LDS tile.  grid = (V/32, C/32, N), block = (32, 8)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int C, int64_t V, int tanh_flag) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int64_t v0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  in += (int64_t)n * C * V;
+  out += (int64_t)n * C * V;
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j;
+    const int64_t v = v0 + tx;
+    float x = 0.f;
+    if (c < C && v < V) x = in[(int64_t)c * V + v];
+    if (tanh_flag) x = tanhf(x);
+    tile[j][tx] = x;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t v = v0 + j;
+    const int c = c0 + tx;
+    if (c < C && v < V) out[v * C + c] = tile[tx][j];
+  }
+}
+
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             int C, int64_t V) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int64_t v0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  in += (int64_t)n * C * V;
+  out += (int64_t)n * C * V;
+  for (int j = ty; j < 32; j += 8) {
+    const int64_t v = v0 + j;
+    const int c = c0 + tx;
+    float x = 0.f;
+    if (c < C && v < V) x = in[v * C + c];
+    tile[j][tx] = x;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j;
+    const int64_t v = v0 + tx;
+    if (c < C && v < V) out[(int64_t)c * V + v] = tile[tx][j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm statistics.  x: [N][V][C] channels-last, C % 4 == 0, C/4 <= 256.
+// block = 256 threads: cq = C/4 threads across channels, rows = 256/cq voxels per pass.
+// grid = (blocks over V, N).  Each thread sums <= 32 values in fp32, then switches to double.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int C,
+                                                       int64_t V, int vox_per_block) {
+  __shared__ double red[256 * 8];
+  const int n = blockIdx.y;
+  const int cq = C >> 2;
+  const int rows = 256 / cq;
+  const int tid = threadIdx.x;
+  const int c4 = tid % cq;
+  const int vr = tid / cq;
+  const int64_t vbeg = (int64_t)blockIdx.x * vox_per_block;
+  int64_t vend = vbeg + vox_per_block;
+  if (vend > V) vend = V;
+  const float* xp = x + (int64_t)n * V * C;
+  double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+  if (vr < rows) {
+    float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+    int cnt = 0;
+    for (int64_t v = vbeg + vr; v < vend; v += rows) {
+      const float4 t = *reinterpret_cast<const float4*>(xp + v * C + c4 * 4);
+      fs[0] += t.x;
+      fs[1] += t.y;
+      fs[2] += t.z;
+      fs[3] += t.w;
+      fq[0] += t.x * t.x;
+      fq[1] += t.y * t.y;
+      fq[2] += t.z * t.z;
+      fq[3] += t.w * t.w;
+      if (++cnt == 32) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ds[e] += fs[e];
+          dq[e] += fq[e];
+          fs[e] = 0.f;
+          fq[e] = 0.f;
+        }
+        cnt = 0;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ds[e] += fs[e];
+      dq[e] += fq[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[tid * 8 + e] = ds[e];
+    red[tid * 8 + 4 + e] = dq[e];
+  }
+  __syncthreads();
+  if (tid < cq) {
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < rows; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[(r * cq + tid) * 8 + e];
+    double* dst = stats + ((int64_t)n * C + tid * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(dst + e * 2 + 0, s[e]);
+      atomicAdd(dst + e * 2 + 1, s[4 + e]);
+    }
+  }
+}
+
+// coef[n][c] = (a, b) with GN(x)*(1+scale)+shift = a*x + b.  grid = (ceil(Cin/256), N)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ stats0, int C0,
+                                                          const double* __restrict__ stats1, int C1, int64_t V,
+                                                          int groups, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ film, int film_stride,
+                                                          int film_cout, float* __restrict__ coef) {
+  const int n = blockIdx.y;
+  const int Cin = C0 + C1;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cin) return;
+  const int cpg = Cin / groups;
+  const int g = c / cpg;
+  double s = 0.0, sq = 0.0;
+  for (int k = 0; k < cpg; ++k) {
+    const int cc = g * cpg + k;
+    const double* p = cc < C0 ? stats0 + ((int64_t)n * C0 + cc) * 2 : stats1 + ((int64_t)n * C1 + (cc - C0)) * 2;
+    s += p[0];
+    sq += p[1];
+  }
+  const double cnt = (double)cpg * (double)V;
+  const double mean = s / cnt;
+  double var = sq / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  double a = rstd * (double)gamma[c];
+  double b = (double)beta[c] - mean * a;
+  if (film) {
+    const double sc = 1.0 + (double)film[(int64_t)n * film_stride + c];
+    const double sh = (double)film[(int64_t)n * film_stride + film_cout + c];
+    a *= sc;
+    b = b * sc + sh;
+  }
+  coef[((int64_t)n * Cin + c) * 2 + 0] = (float)a;
+  coef[((int64_t)n * Cin + c) * 2 + 1] = (float)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// time embedding: one block per sample.  dynamic-free: mc <= 256, ted <= 1024
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ t, int mc, int ted,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2,
+                                                         float* __restrict__ emb, float* __restrict__ emb_silu) {
+  __shared__ float te[256];
+  __shared__ float h1[1024];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float tv = (float)t[n];
+  const int half = mc / 2;
+  for (int i = tid; i < mc; i += 256) {
+    float v = 0.f;
+    if (i < 2 * half) {
+      const int k = i < half ? i : i - half;
+      const float freq = expf((-9.210340371976184f * (float)k) / (float)half);
+      const float arg = tv * freq;
+      v = i < half ? cosf(arg) : sinf(arg);
+    }
+    te[i] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < ted; j += 256) {
+    float acc = 0.f;
+    const float* w = w1 + (int64_t)j * mc;
+    for (int k = 0; k < mc; ++k) acc = fmaf(w[k], te[k], acc);
+    acc += b1[j];
+    h1[j] = acc / (1.0f + expf(-acc));
+  }
+  __syncthreads();
+  for (int j = tid; j < ted; j += 256) {
+    float acc = 0.f;
+    const float* w = w2 + (int64_t)j * ted;
+    for (int k = 0; k < ted; ++k) acc = fmaf(w[k], h1[k], acc);
+    acc += b2[j];
+    emb[(int64_t)n * ted + j] = acc;
+    emb_silu[(int64_t)n * ted + j] = acc / (1.0f + expf(-acc));
+  }
+}
+
+// out[n][r] = bias[r] + W[r][:] . in[n][:]   one wave per (r, n)
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          int rows, int K) {
+  const int n = blockIdx.y;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* wr = w + (int64_t)r * K;
+  const float* x = in + (int64_t)n * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], x[k], acc);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) out[(int64_t)n * rows + r] = acc + bias[r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// DDPM ancestral update, float4 per thread.  grid = (blocks over per/4, batch)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict__ tables, int T,
+                                                        const int64_t* __restrict__ timesteps, int64_t per,
+                                                        const float* __restrict__ x_t,
+                                                        const float* __restrict__ model_out,
+                                                        const float* __restrict__ noise, int clip,
+                                                        float* __restrict__ sample, float* __restrict__ pred) {
+  const int b = blockIdx.y;
+  int64_t tt = timesteps[b];
+  if (tt < 0) tt = 0;
+  if (tt >= T) tt = T - 1;
+  const float c1 = tables[tt * 4 + 0];
+  const float c2 = tables[tt * 4 + 1];
+  const float lv = tables[tt * 4 + 2];
+  const float sig = tt != 0 ? expf(0.5f * lv) : 0.f;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= per) return;
+  const int64_t o = (int64_t)b * per + i;
+  float4 x = *reinterpret_cast<const float4*>(x_t + o);
+  float4 m = *reinterpret_cast<const float4*>(model_out + o);
+  float4 e = *reinterpret_cast<const float4*>(noise + o);
+  if (clip) {
+    m.x = fminf(fmaxf(m.x, -1.f), 1.f);
+    m.y = fminf(fmaxf(m.y, -1.f), 1.f);
+    m.z = fminf(fmaxf(m.z, -1.f), 1.f);
+    m.w = fminf(fmaxf(m.w, -1.f), 1.f);
+  }
+  float4 s;
+  // reference order: (c1*x0 + c2*x) + nonzero*sigma*noise, each product rounded (no fma contraction)
+  s.x = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.x), __fmul_rn(c2, x.x)), __fmul_rn(sig, e.x));
+  s.y = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.y), __fmul_rn(c2, x.y)), __fmul_rn(sig, e.y));
+  s.z = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.z), __fmul_rn(c2, x.z)), __fmul_rn(sig, e.z));
+  s.w = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.w), __fmul_rn(c2, x.w)), __fmul_rn(sig, e.w));
+  *reinterpret_cast<float4*>(sample + o) = s;
+  *reinterpret_cast<float4*>(pred + o) = m;
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = tanhf(x[i]);
+}
+__global__ __launch_bounds__(256) void clip_kernel(const float* __restrict__ x, float* __restrict__ y, float lo,
+                                                   float hi, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+// [Cout][Cin][taps] -> [taps][Cout][Cin]
+__global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                 int Cout, int Cin, int taps) {
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int64_t r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tap = (int)(r / Cout);
+    out[i] = w[((int64_t)co * Cin + ci) * taps + tap];
+  }
+}
+
+}  // namespace
+
+int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream) {
+  dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(C, 32), (unsigned)N);
+  HOLO_LAUNCH(ncdhw_to_ndhwc_kernel, grid, dim3(256), stream, in, out, C, V, tanh_flag);
+  return 0;
+}
+int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream) {
+  dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(C, 32), (unsigned)N);
+  HOLO_LAUNCH(ndhwc_to_ncdhw_kernel, grid, dim3(256), stream, in, out, C, V);
+  return 0;
+}
+
+int gn_stats_launch(const float* x, double* stats, int N, int C, int64_t V, void* stream) {
+  if ((C & 3) || (C >> 2) > 256) {
+    set_error("gn_stats: unsupported C=%d", C);
+    return -1;
+  }
+  const int cq = C >> 2;
+  const int rows = 256 / cq;
+  // ~1024 blocks per sample at most, at least `rows` voxels (one pass) and at most 64 passes per block
+  int64_t vpb = cdiv(V, 1024);
+  if (vpb < rows) vpb = rows;
+  if (vpb > (int64_t)rows * 64) vpb = (int64_t)rows * 64;
+  vpb = cdiv(vpb, rows) * rows;
+  dim3 grid((unsigned)cdiv(V, vpb), (unsigned)N);
+  HOLO_LAUNCH(gn_stats_kernel, grid, dim3(256), stream, x, stats, C, V, (int)vpb);
+  return 0;
+}
+
+int gn_finalize_launch(const double* stats0, int C0, const double* stats1, int C1, int N, int64_t V, int groups,
+                       float eps, const float* gamma, const float* beta, const float* film, int film_stride,
+                       int film_cout, float* coef, void* stream) {
+  const int Cin = C0 + C1;
+  if (Cin % groups) {
+    set_error("gn_finalize: C=%d not divisible by %d groups", Cin, groups);
+    return -1;
+  }
+  dim3 grid((unsigned)cdiv(Cin, 256), (unsigned)N);
+  HOLO_LAUNCH(gn_finalize_kernel, grid, dim3(256), stream, stats0, C0, stats1, C1, V, groups, eps, gamma, beta, film,
+              film_stride, film_cout, coef);
+  return 0;
+}
+
+int time_embed_launch(const int64_t* t, int N, int mc, int ted, const float* w1, const float* b1, const float* w2,
+                      const float* b2, float* emb, float* emb_silu, void* stream) {
+  if (mc > 256 || ted > 1024) {
+    set_error("time_embed: model_channels=%d too large", mc);
+    return -1;
+  }
+  HOLO_LAUNCH(time_embed_kernel, dim3((unsigned)N), dim3(256), stream, t, mc, ted, w1, b1, w2, b2, emb, emb_silu);
+  return 0;
+}
+
+int rows_linear_launch(const float* in, const float* w, const float* bias, float* out, int N, int rows, int K,
+                       void* stream) {
+  dim3 grid((unsigned)cdiv(rows, 4), (unsigned)N);
+  HOLO_LAUNCH(rows_linear_kernel, grid, dim3(256), stream, in, w, bias, out, rows, K);
+  return 0;
+}
+
+int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int batch, int64_t per, const float* x_t,
+                     const float* model_out, const float* noise, int clip, float* sample, float* pred_xstart,
+                     void* stream) {
+  if (per & 3) {
+    set_error("ddpm_step: elems_per_sample must be a multiple of 4");
+    return -1;
+  }
+  dim3 grid((unsigned)cdiv(per / 4, 256), (unsigned)batch);
+  HOLO_LAUNCH(ddpm_step_kernel, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, noise, clip, sample,
+              pred_xstart);
+  return 0;
+}
+
+int tanh_launch(const float* x, float* y, int64_t n, void* stream) {
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  HOLO_LAUNCH(tanh_kernel, dim3((unsigned)blocks), dim3(256), stream, x, y, n);
+  return 0;
+}
+int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream) {
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  HOLO_LAUNCH(clip_kernel, dim3((unsigned)blocks), dim3(256), stream, x, y, lo, hi, n);
+  return 0;
+}
+int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, void* stream) {
+  int64_t total = (int64_t)Cout * Cin * taps;
+  int64_t blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  HOLO_LAUNCH(repack_conv_weight_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, taps);
+  return 0;
+}
+
+}  // namespace holo

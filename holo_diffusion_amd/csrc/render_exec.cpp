@@ -1,0 +1,287 @@
+// render_exec.cpp — host side of the fused renderer: RenderMLP parameter binding, the float64 fold of
+// the activation-free density net, per-camera depth bounds and the frame launch.
+//
+// Reference interfaces replaced (relative to /root/reference/holo_diffusion):
+//   RenderMLP / MLPWithInputSkips parameters   holo_voxel_grid_implicit_function.py:73-92,
+//                                              custom_modules.py:94-113 (state_dict names `mlp.<i>.0.*`)
+//   AdaptiveRaySampler depth bounds            configs/apple.yaml:135-146 (PyTorch3D get_min_max_depth_bounds)
+//   HoloDiffusionModel.forward render section  holo_diffusion_model.py:431-457,515-523
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/holo_abi.h"
+#include "holo_common.h"
+#include "holo_kernels.h"
+
+using namespace holo;
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return HOLO_E_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+struct HoloRenderer {
+  HoloCtx* ctx;
+  HoloRenderCfg cfg;
+  std::map<std::string, std::vector<float>> host;        // raw parameters (host copies)
+  std::map<std::string, std::vector<int64_t>> expected;  // expected shapes
+  float* packed = nullptr;                               // device: w_feat | b_feat | w_dens | w_rad | w_dir
+  float b_dens = 0.f;
+  float b_rad[3] = {0, 0, 0};
+  bool committed = false;
+};
+
+static int dir_emb(const HoloRenderCfg& c) { return 3 * (2 * c.dir_emb_dims + 1); }
+
+extern "C" {
+
+int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** out) {
+  if (!ctx || !cfg || !out) {
+    set_error("holo_renderer_create: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (cfg->dnet_hidden_dim != 256 || cfg->dir_emb_dims != 4 ||
+      !(cfg->feature_size == 16 || cfg->feature_size == 32 || cfg->feature_size == 64) || cfg->n_pts_coarse < 3 ||
+      cfg->n_pts_coarse > 64 || cfg->n_pts_fine < 2 || cfg->resol < 2) {
+    set_error("holo_renderer_create: unsupported configuration (hidden 256, dir_emb 4, feature_size 16/32/64, "
+              "3<=n_pts_coarse<=64, n_pts_fine>=2)");
+    return HOLO_E_UNSUPPORTED;
+  }
+  HoloRenderer* r = new HoloRenderer;
+  r->ctx = ctx;
+  r->cfg = *cfg;
+  const int64_t C = cfg->feature_size, Hd = cfg->dnet_hidden_dim, De = dir_emb(*cfg);
+  r->expected["_density_net.mlp.0.0.weight"] = {Hd, C};
+  r->expected["_density_net.mlp.0.0.bias"] = {Hd};
+  r->expected["_density_net.mlp.1.0.weight"] = {Hd, Hd};
+  r->expected["_density_net.mlp.1.0.bias"] = {Hd};
+  r->expected["_density_net.mlp.2.0.weight"] = {Hd, Hd + C};
+  r->expected["_density_net.mlp.2.0.bias"] = {Hd};
+  r->expected["_density_net.mlp.3.0.weight"] = {Hd + 1, Hd};
+  r->expected["_density_net.mlp.3.0.bias"] = {Hd + 1};
+  r->expected["_radiance_net.mlp.0.0.weight"] = {3, Hd + De};
+  r->expected["_radiance_net.mlp.0.0.bias"] = {3};
+  const size_t n = (size_t)(Hd * C + Hd + C + 3 * Hd + 3 * De + 64);
+  if (hipMalloc((void**)&r->packed, n * sizeof(float)) != hipSuccess) {
+    set_error("holo_renderer_create: hipMalloc failed");
+    delete r;
+    return HOLO_E_HIP;
+  }
+  *out = r;
+  return 0;
+}
+
+int holo_renderer_destroy(HoloRenderer* r) {
+  if (!r) return 0;
+  if (r->packed) (void)hipFree(r->packed);
+  delete r;
+  return 0;
+}
+
+int holo_renderer_set_param(HoloRenderer* r, const char* name, const void* dev_ptr, int dtype, int ndim,
+                            const int64_t* shape, void* stream) {
+  if (!r || !name || !dev_ptr) {
+    set_error("holo_renderer_set_param: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (dtype != HOLO_DTYPE_F32) {
+    set_error("holo_renderer_set_param: only fp32 parameters are supported");
+    return HOLO_E_UNSUPPORTED;
+  }
+  auto it = r->expected.find(name);
+  if (it == r->expected.end()) {
+    set_error("holo_renderer_set_param: unknown parameter '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  bool ok = ndim == (int)it->second.size();
+  int64_t numel = 1;
+  for (int i = 0; ok && i < ndim; ++i) {
+    ok = shape[i] == it->second[i];
+    numel *= shape[i];
+  }
+  if (!ok) {
+    set_error("holo_renderer_set_param: shape mismatch for '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  std::vector<float>& h = r->host[name];
+  h.resize((size_t)numel);
+  HIP_TRY(hipMemcpyAsync(h.data(), dev_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  r->committed = false;
+  return 0;
+}
+
+// Fold  y0=W0 f+b0; y1=W1 y0+b1; y2=W2 [y1;f]+b2; o=W3 y2+b3  (no activation in between:
+// custom_modules.py:108-112) into  o = We f + be, in float64.
+int holo_renderer_commit(HoloRenderer* r, void* stream) {
+  if (!r) {
+    set_error("holo_renderer_commit: null");
+    return HOLO_E_INVALID;
+  }
+  for (auto& kv : r->expected)
+    if (!r->host.count(kv.first)) {
+      set_error("holo_renderer_commit: parameter '%s' has not been set", kv.first.c_str());
+      return HOLO_E_STATE;
+    }
+  const int C = r->cfg.feature_size, Hd = r->cfg.dnet_hidden_dim, De = dir_emb(r->cfg);
+  auto W = [&](const char* n) -> const std::vector<float>& { return r->host[n]; };
+  const auto &W0 = W("_density_net.mlp.0.0.weight"), &b0 = W("_density_net.mlp.0.0.bias");
+  const auto &W1 = W("_density_net.mlp.1.0.weight"), &b1 = W("_density_net.mlp.1.0.bias");
+  const auto &W2 = W("_density_net.mlp.2.0.weight"), &b2 = W("_density_net.mlp.2.0.bias");
+  const auto &W3 = W("_density_net.mlp.3.0.weight"), &b3 = W("_density_net.mlp.3.0.bias");
+  const auto &Wr = W("_radiance_net.mlp.0.0.weight"), &br = W("_radiance_net.mlp.0.0.bias");
+  // A1 = W1 W0 (Hd x C), c1 = W1 b0 + b1
+  std::vector<double> A1((size_t)Hd * C, 0.0), c1(Hd, 0.0);
+  for (int i = 0; i < Hd; ++i) {
+    double cb = b1[i];
+    for (int k = 0; k < Hd; ++k) {
+      const double w = W1[(size_t)i * Hd + k];
+      cb += w * b0[k];
+      for (int j = 0; j < C; ++j) A1[(size_t)i * C + j] += w * W0[(size_t)k * C + j];
+    }
+    c1[i] = cb;
+  }
+  // A2 = W2a A1 + W2b (Hd x C), c2 = W2a c1 + b2 ; W2 = [W2a (Hd x Hd) | W2b (Hd x C)]
+  std::vector<double> A2((size_t)Hd * C, 0.0), c2(Hd, 0.0);
+  const int L2 = Hd + C;
+  for (int i = 0; i < Hd; ++i) {
+    double cb = b2[i];
+    for (int j = 0; j < C; ++j) A2[(size_t)i * C + j] = W2[(size_t)i * L2 + Hd + j];
+    for (int k = 0; k < Hd; ++k) {
+      const double w = W2[(size_t)i * L2 + k];
+      cb += w * c1[k];
+      for (int j = 0; j < C; ++j) A2[(size_t)i * C + j] += w * A1[(size_t)k * C + j];
+    }
+    c2[i] = cb;
+  }
+  // We = W3 A2 ((Hd+1) x C), be = W3 c2 + b3
+  std::vector<double> We((size_t)(Hd + 1) * C, 0.0), be(Hd + 1, 0.0);
+  for (int i = 0; i < Hd + 1; ++i) {
+    double cb = b3[i];
+    for (int k = 0; k < Hd; ++k) {
+      const double w = W3[(size_t)i * Hd + k];
+      cb += w * c2[k];
+      for (int j = 0; j < C; ++j) We[(size_t)i * C + j] += w * A2[(size_t)k * C + j];
+    }
+    be[i] = cb;
+  }
+  // pack: w_feat [Hd][C] | b_feat [Hd] | w_dens [C] | w_rad [3][Hd] | w_dir [3][De]
+  std::vector<float> pk((size_t)Hd * C + Hd + C + 3 * Hd + 3 * De);
+  size_t o = 0;
+  for (int i = 0; i < Hd * C; ++i) pk[o++] = (float)We[i];
+  for (int i = 0; i < Hd; ++i) pk[o++] = (float)be[i];
+  for (int j = 0; j < C; ++j) pk[o++] = (float)We[(size_t)Hd * C + j];
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < Hd; ++i) pk[o++] = Wr[(size_t)c * (Hd + De) + i];
+  for (int c = 0; c < 3; ++c)
+    for (int j = 0; j < De; ++j) pk[o++] = Wr[(size_t)c * (Hd + De) + Hd + j];
+  r->b_dens = (float)be[Hd];
+  for (int c = 0; c < 3; ++c) r->b_rad[c] = br[c];
+  HIP_TRY(hipMemcpyAsync(r->packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  r->committed = true;
+  return 0;
+}
+
+size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
+  (void)n_cameras;
+  if (!r) return 0;
+  const size_t R = r->cfg.resol;
+  return R * R * R * (size_t)r->cfg.feature_size * sizeof(float) + 256;
+}
+
+int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
+                float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
+                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!r || !grid || !cameras || n_cameras < 1 || !images || !depths || !masks || !workspace) {
+    set_error("holo_render: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_render: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  if (workspace_bytes < holo_render_workspace_bytes(r, n_cameras)) {
+    set_error("holo_render: workspace too small");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  const int R = c.resol, C = c.feature_size, Hd = c.dnet_hidden_dim;
+  float* grid_cl = (float*)workspace;
+  int rc = ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream);
+  if (rc) return HOLO_E_INVALID;
+  const int H = c.image_height, Wd = c.image_width;
+  const int64_t npix = (int64_t)H * Wd;
+  for (int ci = 0; ci < n_cameras; ++ci) {
+    const HoloCamera& cam = cameras[ci];
+    RenderKernelParams p;
+    memset(&p, 0, sizeof p);
+    p.grid_cl = grid_cl;
+    p.R = R;
+    p.C = C;
+    const float voxel_size = c.volume_extent / (float)R;
+    p.half_extent = 0.5f * (float)(R - 1) * voxel_size;
+    p.w_feat = r->packed;
+    p.b_feat = p.w_feat + (size_t)Hd * C;
+    p.w_dens = p.b_feat + Hd;
+    p.w_rad = p.w_dens + C;
+    p.w_dir = p.w_rad + 3 * Hd;
+    p.b_dens = r->b_dens;
+    for (int k = 0; k < 3; ++k) p.b_rad[k] = r->b_rad[k];
+    p.Hd = Hd;
+    for (int k = 0; k < 9; ++k) p.Rm[k] = cam.R[k];
+    for (int k = 0; k < 3; ++k) p.T[k] = cam.T[k];
+    for (int k = 0; k < 2; ++k) {
+      p.focal[k] = cam.focal[k];
+      p.pp[k] = cam.principal_point[k];
+    }
+    // AdaptiveRaySampler: near/far from the camera centre C = -T R^T (fp32, as torch computes it)
+    float d2 = 0.f;
+    for (int j = 0; j < 3; ++j) {
+      float cj = -(cam.T[0] * cam.R[j * 3 + 0] + cam.T[1] * cam.R[j * 3 + 1] + cam.T[2] * cam.R[j * 3 + 2]);
+      const float d = cj - c.scene_center[j];
+      d2 += d * d;
+    }
+    if (d2 < 0.001f) d2 = 0.001f;
+    float dist = sqrtf(d2);
+    if (dist < c.scene_extent + 1e-3f) dist = c.scene_extent + 1e-3f;
+    p.zmin = dist - c.scene_extent;
+    p.zmax = dist + c.scene_extent;
+    p.H = H;
+    p.W = Wd;
+    if (Wd >= H) {
+      p.range_x = (float)Wd / (float)H;
+      p.range_y = 1.f;
+    } else {
+      p.range_x = 1.f;
+      p.range_y = (float)H / (float)Wd;
+    }
+    p.n_coarse = c.n_pts_coarse;
+    p.n_fine = c.n_pts_fine;
+    for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
+    p.background_opacity = c.background_opacity;
+    p.pdf_eps = c.sample_pdf_eps;
+    p.rgb = images + (size_t)ci * 3 * npix;
+    p.depth = depths + (size_t)ci * npix;
+    p.mask = masks + (size_t)ci * npix;
+    if (images_coarse && depths_coarse && masks_coarse) {
+      p.rgb_c = images_coarse + (size_t)ci * 3 * npix;
+      p.depth_c = depths_coarse + (size_t)ci * npix;
+      p.mask_c = masks_coarse + (size_t)ci * npix;
+    }
+    rc = render_launch(p, stream);
+    if (rc) return HOLO_E_INVALID;
+  }
+  return 0;
+}
+
+}  // extern "C"

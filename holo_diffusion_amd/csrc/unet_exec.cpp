@@ -1,0 +1,1026 @@
+// unet_exec.cpp — native runtime of the denoiser: builds the static launch plan of
+// UNetModel.forward (holo_diffusion/guided_diffusion/unet.py:800-837, block construction :645-798 as
+// configured by SimpleUnet3D, holo_diffusion/utils/diffusion_utils.py:56-75) and replays it on a stream.
+//
+// Everything is static for a given (config, batch): tensor shapes, workspace offsets, split-K factors,
+// kernel parameters.  The plan is a flat vector of ops; forward() only patches the three caller pointers
+// (x, timesteps, y) and launches.  No allocation, no host synchronisation inside forward().
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/holo_abi.h"
+#include "holo_common.h"
+#include "holo_kernels.h"
+
+namespace holo {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return HOLO_E_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+}  // namespace holo
+
+using namespace holo;
+
+struct HoloCtx {
+  int device;
+  int num_cus;
+};
+
+// ---------------------------------------------------------------------------------------------
+// structure description
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+enum BlockKind { B_CONV, B_RES, B_ATTN, B_DOWN, B_UP };
+struct Block {
+  BlockKind kind;
+  std::string prefix;
+  int cin, cout;
+};
+
+enum ParamKind { P_PLAIN, P_CONV3, P_EMB_W, P_EMB_B };
+struct ParamSlot {
+  std::string name;
+  std::vector<int64_t> shape;
+  int64_t numel;
+  ParamKind kind;
+  float* priv;  // private (repacked) device copy
+  bool set;
+};
+
+struct Arena {
+  size_t top = 0, peak = 0;
+  bool keep = false;
+  std::vector<std::pair<size_t, size_t>> fl;  // free list (off, size), sorted by off
+  static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+  size_t alloc(size_t bytes) {
+    bytes = al(bytes);
+    for (size_t i = 0; i < fl.size(); ++i) {
+      if (fl[i].second >= bytes) {
+        size_t off = fl[i].first;
+        if (fl[i].second == bytes)
+          fl.erase(fl.begin() + i);
+        else {
+          fl[i].first += bytes;
+          fl[i].second -= bytes;
+        }
+        return off;
+      }
+    }
+    size_t off = top;
+    top += bytes;
+    if (top > peak) peak = top;
+    return off;
+  }
+  void free(size_t off, size_t bytes) {
+    if (keep) return;
+    bytes = al(bytes);
+    size_t i = 0;
+    while (i < fl.size() && fl[i].first < off) ++i;
+    fl.insert(fl.begin() + i, std::make_pair(off, bytes));
+    // coalesce
+    if (i + 1 < fl.size() && fl[i].first + fl[i].second == fl[i + 1].first) {
+      fl[i].second += fl[i + 1].second;
+      fl.erase(fl.begin() + i + 1);
+    }
+    if (i > 0 && fl[i - 1].first + fl[i - 1].second == fl[i].first) {
+      fl[i - 1].second += fl[i].second;
+      fl.erase(fl.begin() + i);
+    }
+    if (!fl.empty() && fl.back().first + fl.back().second == top) {
+      top = fl.back().first;
+      fl.pop_back();
+    }
+  }
+};
+
+struct Act {  // channels-last activation [N][R][R][R][C]
+  size_t off = 0, bytes = 0;
+  size_t stats_off = 0;  // in the stats region
+  int C = 0, R = 0;
+  int refs = 0;
+};
+
+enum OpKind { OP_MEMSET, OP_IN, OP_TEMB, OP_EMBLIN, OP_STATS, OP_FINAL, OP_CONV, OP_GEMM, OP_SOFTMAX, OP_OUT };
+struct Op {
+  OpKind kind;
+  ConvParams conv;
+  GemmParams gemm;
+  // generic
+  const float* f0 = nullptr;
+  const float* f1 = nullptr;
+  const float* f2 = nullptr;
+  const float* f3 = nullptr;
+  const float* f4 = nullptr;
+  float* o0 = nullptr;
+  float* o1 = nullptr;
+  const double* d0 = nullptr;
+  const double* d1 = nullptr;
+  double* dout = nullptr;
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
+  int64_t l0 = 0, l1 = 0;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct HoloUnet {
+  HoloCtx* ctx;
+  HoloUnetCfg cfg;
+  std::vector<std::vector<Block>> inputs, outputs;
+  std::vector<Block> middle;
+  int final_ch;
+  int ted;
+  std::vector<ParamSlot> params;
+  std::map<std::string, int> pindex;
+  float* pstore = nullptr;  // one allocation for all private parameter copies
+  // concatenated emb_layers
+  int emb_rows = 0;
+  std::map<std::string, int> emb_row_off;  // resblock prefix -> first row
+  float* emb_w = nullptr;                  // [emb_rows][ted]
+  float* emb_b = nullptr;                  // [emb_rows]
+  bool keep_intermediates = false;
+  // plan
+  int plan_batch = -1;
+  void* plan_ws = nullptr;
+  std::vector<Op> ops;
+  size_t ws_need = 0;
+  std::map<std::string, Act> block_outputs;
+  std::map<int, size_t> ws_cache;
+};
+
+namespace {
+
+void build_structure(HoloUnet* u) {
+  const HoloUnetCfg& c = u->cfg;
+  const int mc = c.model_channels;
+  int ch = c.channel_mult[0] * mc;
+  char buf[128];
+  u->inputs.clear();
+  u->outputs.clear();
+  u->middle.clear();
+  u->inputs.push_back({Block{B_CONV, "input_blocks.0.0", c.in_channels, ch}});
+  std::vector<int> chans{ch};
+  int ds = 1, idx = 1;
+  auto has_attn = [&](int d) {
+    for (int i = 0; i < c.n_attention_resolutions; ++i)
+      if (c.attention_resolutions[i] == d) return true;
+    return false;
+  };
+  for (int level = 0; level < c.n_channel_mult; ++level) {
+    const int mult = c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      std::vector<Block> layers;
+      snprintf(buf, sizeof buf, "input_blocks.%d.0", idx);
+      layers.push_back(Block{B_RES, buf, ch, mult * mc});
+      ch = mult * mc;
+      if (has_attn(ds)) {
+        snprintf(buf, sizeof buf, "input_blocks.%d.1", idx);
+        layers.push_back(Block{B_ATTN, buf, ch, ch});
+      }
+      u->inputs.push_back(layers);
+      chans.push_back(ch);
+      ++idx;
+    }
+    if (level != c.n_channel_mult - 1) {
+      snprintf(buf, sizeof buf, "input_blocks.%d.0", idx);
+      u->inputs.push_back({Block{B_DOWN, buf, ch, ch}});
+      chans.push_back(ch);
+      ds *= 2;
+      ++idx;
+    }
+  }
+  u->middle.push_back(Block{B_RES, "middle_block.0", ch, ch});
+  u->middle.push_back(Block{B_ATTN, "middle_block.1", ch, ch});
+  u->middle.push_back(Block{B_RES, "middle_block.2", ch, ch});
+  int oidx = 0;
+  for (int level = c.n_channel_mult - 1; level >= 0; --level) {
+    const int mult = c.channel_mult[level];
+    for (int i = 0; i < c.num_res_blocks + 1; ++i) {
+      const int ich = chans.back();
+      chans.pop_back();
+      std::vector<Block> layers;
+      snprintf(buf, sizeof buf, "output_blocks.%d.0", oidx);
+      layers.push_back(Block{B_RES, buf, ch + ich, mc * mult});
+      ch = mc * mult;
+      if (has_attn(ds)) {
+        snprintf(buf, sizeof buf, "output_blocks.%d.%d", oidx, (int)layers.size());
+        layers.push_back(Block{B_ATTN, buf, ch, ch});
+      }
+      if (level && i == c.num_res_blocks) {
+        snprintf(buf, sizeof buf, "output_blocks.%d.%d", oidx, (int)layers.size());
+        layers.push_back(Block{B_UP, buf, ch, ch});
+        ds /= 2;
+      }
+      u->outputs.push_back(layers);
+      ++oidx;
+    }
+  }
+  u->final_ch = ch;
+}
+
+void add_param(HoloUnet* u, const std::string& name, std::vector<int64_t> shape, ParamKind kind) {
+  ParamSlot s;
+  s.name = name;
+  s.shape = shape;
+  s.numel = 1;
+  for (auto d : shape) s.numel *= d;
+  s.kind = kind;
+  s.priv = nullptr;
+  s.set = false;
+  u->pindex[name] = (int)u->params.size();
+  u->params.push_back(s);
+}
+
+void enumerate_params(HoloUnet* u) {
+  const HoloUnetCfg& c = u->cfg;
+  const int64_t mc = c.model_channels, ted = 4 * mc;
+  u->ted = (int)ted;
+  add_param(u, "time_embed.0.weight", {ted, mc}, P_PLAIN);
+  add_param(u, "time_embed.0.bias", {ted}, P_PLAIN);
+  add_param(u, "time_embed.2.weight", {ted, ted}, P_PLAIN);
+  add_param(u, "time_embed.2.bias", {ted}, P_PLAIN);
+  u->emb_rows = 0;
+  auto add_block = [&](const Block& b) {
+    const std::string& p = b.prefix;
+    const int64_t ci = b.cin, co = b.cout;
+    switch (b.kind) {
+      case B_CONV:
+        add_param(u, p + ".weight", {co, ci, 3, 3, 3}, P_CONV3);
+        add_param(u, p + ".bias", {co}, P_PLAIN);
+        break;
+      case B_RES:
+        add_param(u, p + ".in_layers.0.weight", {ci}, P_PLAIN);
+        add_param(u, p + ".in_layers.0.bias", {ci}, P_PLAIN);
+        add_param(u, p + ".in_layers.2.weight", {co, ci, 3, 3, 3}, P_CONV3);
+        add_param(u, p + ".in_layers.2.bias", {co}, P_PLAIN);
+        add_param(u, p + ".emb_layers.1.weight", {2 * co, ted}, P_EMB_W);
+        add_param(u, p + ".emb_layers.1.bias", {2 * co}, P_EMB_B);
+        u->emb_row_off[p] = u->emb_rows;
+        u->emb_rows += (int)(2 * co);
+        add_param(u, p + ".out_layers.0.weight", {co}, P_PLAIN);
+        add_param(u, p + ".out_layers.0.bias", {co}, P_PLAIN);
+        add_param(u, p + ".out_layers.3.weight", {co, co, 3, 3, 3}, P_CONV3);
+        add_param(u, p + ".out_layers.3.bias", {co}, P_PLAIN);
+        if (ci != co) {
+          add_param(u, p + ".skip_connection.weight", {co, ci, 1, 1, 1}, P_PLAIN);
+          add_param(u, p + ".skip_connection.bias", {co}, P_PLAIN);
+        }
+        break;
+      case B_ATTN:
+        add_param(u, p + ".norm.weight", {ci}, P_PLAIN);
+        add_param(u, p + ".norm.bias", {ci}, P_PLAIN);
+        add_param(u, p + ".qkv.weight", {3 * ci, ci, 1}, P_PLAIN);
+        add_param(u, p + ".qkv.bias", {3 * ci}, P_PLAIN);
+        add_param(u, p + ".proj_out.weight", {ci, ci, 1}, P_PLAIN);
+        add_param(u, p + ".proj_out.bias", {ci}, P_PLAIN);
+        break;
+      case B_DOWN:
+        add_param(u, p + ".op.weight", {co, ci, 3, 3, 3}, P_CONV3);
+        add_param(u, p + ".op.bias", {co}, P_PLAIN);
+        break;
+      case B_UP:
+        add_param(u, p + ".conv.weight", {co, ci, 3, 3, 3}, P_CONV3);
+        add_param(u, p + ".conv.bias", {co}, P_PLAIN);
+        break;
+    }
+  };
+  for (auto& l : u->inputs)
+    for (auto& b : l) add_block(b);
+  for (auto& b : u->middle) add_block(b);
+  for (auto& l : u->outputs)
+    for (auto& b : l) add_block(b);
+  add_param(u, "out.0.weight", {u->final_ch}, P_PLAIN);
+  add_param(u, "out.0.bias", {u->final_ch}, P_PLAIN);
+  add_param(u, "out.2.weight", {c.out_channels, u->final_ch, 3, 3, 3}, P_CONV3);
+  add_param(u, "out.2.bias", {c.out_channels}, P_PLAIN);
+}
+
+const float* P(HoloUnet* u, const std::string& name) {
+  auto it = u->pindex.find(name);
+  if (it == u->pindex.end()) return nullptr;
+  return u->params[it->second].priv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan builder
+// ---------------------------------------------------------------------------------------------
+struct Planner {
+  HoloUnet* u;
+  int N;
+  char* base;  // workspace base (may be null for a sizing pass)
+  Arena arena;                // big activations, after the small regions
+  size_t small_top = 0;       // coef / emb buffers
+  size_t stats_top = 0;       // GroupNorm statistics (zeroed every forward)
+  size_t stats_cap, small_cap;
+  size_t stats_base, small_base, arena_base;
+  std::vector<Op>& ops;
+
+  Planner(HoloUnet* u_, int N_, void* ws, std::vector<Op>& ops_) : u(u_), N(N_), base((char*)ws), ops(ops_) {
+    // generous fixed regions for the small buffers
+    stats_cap = Arena::al((size_t)N * 16 * 1024 * 128);  // N * sum(C) * 16 B, sum(C) <= 128k
+    small_cap = Arena::al((size_t)N * 8 * 1024 * 256 + (size_t)N * (u->emb_rows + 4 * u->ted) * 4 + 65536);
+    stats_base = 0;
+    small_base = stats_cap;
+    arena_base = stats_cap + small_cap;
+    arena.keep = u->keep_intermediates;
+  }
+  template <class T>
+  T* ptr(size_t off) {
+    return reinterpret_cast<T*>(base + off);
+  }
+  int64_t vox(int R) const { return (int64_t)R * R * R; }
+
+  Act new_act(int C, int R) {
+    Act a;
+    a.C = C;
+    a.R = R;
+    a.bytes = (size_t)N * vox(R) * C * sizeof(float);
+    a.off = arena_base + arena.alloc(a.bytes);
+    a.stats_off = stats_base + stats_top;
+    stats_top += Arena::al((size_t)N * C * 2 * sizeof(double));
+    return a;
+  }
+  void release(Act& a) { arena.free(a.off - arena_base, a.bytes); }
+  size_t small_alloc(size_t bytes) {
+    size_t off = small_base + small_top;
+    small_top += Arena::al(bytes);
+    return off;
+  }
+  size_t scratch_alloc(size_t bytes) { return arena_base + arena.alloc(bytes); }
+  void scratch_free(size_t off, size_t bytes) { arena.free(off - arena_base, bytes); }
+
+  void emit_stats(const Act& a) {
+    Op op;
+    op.kind = OP_STATS;
+    op.f0 = ptr<float>(a.off);
+    op.dout = ptr<double>(a.stats_off);
+    op.i0 = a.C;
+    op.l0 = vox(a.R);
+    ops.push_back(op);
+  }
+  // returns coef offset
+  size_t emit_finalize(const Act& x0, const Act* x1, const float* gamma, const float* beta, const float* film,
+                       int film_cout) {
+    const int Cin = x0.C + (x1 ? x1->C : 0);
+    size_t coef = small_alloc((size_t)N * Cin * 2 * sizeof(float));
+    Op op;
+    op.kind = OP_FINAL;
+    op.d0 = ptr<double>(x0.stats_off);
+    op.i0 = x0.C;
+    op.d1 = x1 ? ptr<double>(x1->stats_off) : nullptr;
+    op.i1 = x1 ? x1->C : 0;
+    op.l0 = vox(x0.R);
+    op.f0 = gamma;
+    op.f1 = beta;
+    op.f2 = film;
+    op.i2 = u->emb_rows;
+    op.i3 = film_cout;
+    op.o0 = ptr<float>(coef);
+    ops.push_back(op);
+    return coef;
+  }
+  void emit_conv(const Act& x0, const Act* x1, int in_R_logical, int ups, int out_R, int stride, int ksz,
+                 const float* w, const float* bias, size_t coef_off, bool has_coef, int act, const float* residual,
+                 float* out, int Cout) {
+    Op op;
+    op.kind = OP_CONV;
+    ConvParams& p = op.conv;
+    memset(&p, 0, sizeof p);
+    p.src0 = ptr<float>(x0.off);
+    p.src1 = x1 ? ptr<float>(x1->off) : nullptr;
+    p.C0 = x0.C;
+    p.C1 = x1 ? x1->C : 0;
+    p.N = N;
+    p.ID = p.IH = p.IW = in_R_logical;
+    p.ups = ups;
+    p.OD = p.OH = p.OW = out_R;
+    p.stride = stride;
+    p.pad = ksz == 3 ? 1 : 0;
+    p.ksz = ksz;
+    p.Cout = Cout;
+    p.w = w;
+    p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
+    p.act = act;
+    p.bias = bias;
+    p.residual = residual;
+    p.out = out;
+    size_t sb = conv_plan(p, u->ctx->num_cus);
+    if (sb) {
+      size_t so = scratch_alloc(sb);
+      p.partial = ptr<float>(so);
+      scratch_free(so, sb);  // stream order protects it until the reduce kernel has run
+    }
+    ops.push_back(op);
+  }
+
+  Act resblock(const Block& b, Act& x0, Act* x1) {
+    const std::string& p = b.prefix;
+    const int R = x0.R;
+    size_t coefA = emit_finalize(x0, x1, P(u, p + ".in_layers.0.weight"), P(u, p + ".in_layers.0.bias"), nullptr, 0);
+    Act h1 = new_act(b.cout, R);
+    emit_conv(x0, x1, R, 0, R, 1, 3, P(u, p + ".in_layers.2.weight"), P(u, p + ".in_layers.2.bias"), coefA, true, 1,
+              nullptr, ptr<float>(h1.off), b.cout);
+    emit_stats(h1);
+    const float* film = ptr<float>(eml_off) + u->emb_row_off[p];
+    size_t coefB =
+        emit_finalize(h1, nullptr, P(u, p + ".out_layers.0.weight"), P(u, p + ".out_layers.0.bias"), film, b.cout);
+    Act s;
+    const float* residual;
+    const bool has_skip = b.cin != b.cout;
+    if (has_skip) {
+      s = new_act(b.cout, R);
+      emit_conv(x0, x1, R, 0, R, 1, 1, P(u, p + ".skip_connection.weight"), P(u, p + ".skip_connection.bias"), 0,
+                false, 0, nullptr, ptr<float>(s.off), b.cout);
+      residual = ptr<float>(s.off);
+    } else {
+      residual = ptr<float>(x0.off);
+    }
+    Act out = new_act(b.cout, R);
+    emit_conv(h1, nullptr, R, 0, R, 1, 3, P(u, p + ".out_layers.3.weight"), P(u, p + ".out_layers.3.bias"), coefB, true,
+              1, residual, ptr<float>(out.off), b.cout);
+    emit_stats(out);
+    release(h1);
+    if (has_skip) release(s);
+    return out;
+  }
+
+  Act attention(const Block& b, Act& x) {
+    const std::string& p = b.prefix;
+    const int C = x.C, R = x.R, H = u->cfg.num_heads, ch = C / H;
+    const int64_t T = vox(R);
+    size_t coef = emit_finalize(x, nullptr, P(u, p + ".norm.weight"), P(u, p + ".norm.bias"), nullptr, 0);
+    const size_t qkv_bytes = (size_t)N * T * 3 * C * sizeof(float);
+    const size_t s_bytes = (size_t)N * H * T * T * sizeof(float);
+    const size_t a_bytes = (size_t)N * T * C * sizeof(float);
+    size_t qkv = scratch_alloc(qkv_bytes);
+    emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
+              ptr<float>(qkv), 3 * C);
+    size_t S = scratch_alloc(s_bytes);
+    {
+      Op op;
+      op.kind = OP_GEMM;
+      GemmParams& g = op.gemm;
+      memset(&g, 0, sizeof g);
+      g.A = ptr<float>(qkv);
+      g.B = ptr<float>(qkv) + ch;
+      g.C = ptr<float>(S);
+      g.M = (int)T;
+      g.Nn = (int)T;
+      g.K = ch;
+      g.lda = 3 * C;
+      g.ldb = 3 * C;
+      g.ldc = (int)T;
+      g.nb0 = N;
+      g.nb1 = H;
+      g.sa0 = T * 3 * C;
+      g.sa1 = 3 * ch;
+      g.sb0 = T * 3 * C;
+      g.sb1 = 3 * ch;
+      g.sc0 = (int64_t)H * T * T;
+      g.sc1 = T * T;
+      g.b_kmajor = 0;
+      const double sc = 1.0 / sqrt(sqrt((double)ch));
+      g.alpha = (float)(sc * sc);
+      ops.push_back(op);
+    }
+    {
+      Op op;
+      op.kind = OP_SOFTMAX;
+      op.o0 = ptr<float>(S);
+      op.l0 = (int64_t)N * H * T;
+      op.i0 = (int)T;
+      ops.push_back(op);
+    }
+    size_t a = scratch_alloc(a_bytes);
+    {
+      Op op;
+      op.kind = OP_GEMM;
+      GemmParams& g = op.gemm;
+      memset(&g, 0, sizeof g);
+      g.A = ptr<float>(S);
+      g.B = ptr<float>(qkv) + 2 * ch;
+      g.C = ptr<float>(a);
+      g.M = (int)T;
+      g.Nn = ch;
+      g.K = (int)T;
+      g.lda = (int)T;
+      g.ldb = 3 * C;
+      g.ldc = C;
+      g.nb0 = N;
+      g.nb1 = H;
+      g.sa0 = (int64_t)H * T * T;
+      g.sa1 = T * T;
+      g.sb0 = T * 3 * C;
+      g.sb1 = 3 * ch;
+      g.sc0 = T * C;
+      g.sc1 = ch;
+      g.b_kmajor = 1;
+      g.alpha = 1.0f;
+      ops.push_back(op);
+    }
+    Act out = new_act(C, R);
+    Act av;  // view of `a` as an activation for the 1x1 conv
+    av.off = a;
+    av.C = C;
+    av.R = R;
+    emit_conv(av, nullptr, R, 0, R, 1, 1, P(u, p + ".proj_out.weight"), P(u, p + ".proj_out.bias"), 0, false, 0,
+              ptr<float>(x.off), ptr<float>(out.off), C);
+    emit_stats(out);
+    scratch_free(qkv, qkv_bytes);
+    scratch_free(S, s_bytes);
+    scratch_free(a, a_bytes);
+    return out;
+  }
+
+  size_t eml_off = 0;
+
+  // runs a TimestepEmbedSequential; consumes (releases) the input activation(s)
+  Act run_layers(const std::vector<Block>& layers, Act h, Act* skip, bool release_h) {
+    bool first = true;
+    for (const Block& b : layers) {
+      Act out;
+      Act* x1 = first ? skip : nullptr;
+      switch (b.kind) {
+        case B_CONV:
+          out = new_act(b.cout, h.R);
+          emit_conv(h, nullptr, h.R, 0, h.R, 1, 3, P(u, b.prefix + ".weight"), P(u, b.prefix + ".bias"), 0, false, 0,
+                    nullptr, ptr<float>(out.off), b.cout);
+          emit_stats(out);
+          break;
+        case B_RES:
+          out = resblock(b, h, x1);
+          break;
+        case B_ATTN:
+          out = attention(b, h);
+          break;
+        case B_DOWN:
+          out = new_act(b.cout, h.R / 2);
+          emit_conv(h, nullptr, h.R, 0, h.R / 2, 2, 3, P(u, b.prefix + ".op.weight"), P(u, b.prefix + ".op.bias"), 0,
+                    false, 0, nullptr, ptr<float>(out.off), b.cout);
+          emit_stats(out);
+          break;
+        case B_UP:
+          out = new_act(b.cout, h.R * 2);
+          emit_conv(h, nullptr, h.R * 2, 1, h.R * 2, 1, 3, P(u, b.prefix + ".conv.weight"),
+                    P(u, b.prefix + ".conv.bias"), 0, false, 0, nullptr, ptr<float>(out.off), b.cout);
+          emit_stats(out);
+          break;
+      }
+      if (!first || release_h) release(h);
+      if (first && skip) release(*skip);
+      h = out;
+      first = false;
+    }
+    return h;
+  }
+
+  void build() {
+    const HoloUnetCfg& c = u->cfg;
+    const int R = c.image_size;
+    ops.clear();
+    u->block_outputs.clear();
+    {
+      Op op;
+      op.kind = OP_MEMSET;
+      op.o0 = ptr<float>(stats_base);
+      op.bytes = stats_cap;
+      ops.push_back(op);
+    }
+    // time embedding
+    size_t emb = small_alloc((size_t)N * u->ted * 4);
+    size_t embs = small_alloc((size_t)N * u->ted * 4);
+    eml_off = small_alloc((size_t)N * u->emb_rows * 4);
+    {
+      Op op;
+      op.kind = OP_TEMB;
+      op.f0 = P(u, "time_embed.0.weight");
+      op.f1 = P(u, "time_embed.0.bias");
+      op.f2 = P(u, "time_embed.2.weight");
+      op.f3 = P(u, "time_embed.2.bias");
+      op.o0 = ptr<float>(emb);
+      op.o1 = ptr<float>(embs);
+      ops.push_back(op);
+    }
+    {
+      Op op;
+      op.kind = OP_EMBLIN;
+      op.f0 = ptr<float>(embs);
+      op.f1 = u->emb_w;
+      op.f2 = u->emb_b;
+      op.o0 = ptr<float>(eml_off);
+      ops.push_back(op);
+    }
+    Act x = new_act(c.in_channels, R);
+    {
+      Op op;
+      op.kind = OP_IN;
+      op.o0 = ptr<float>(x.off);
+      op.i0 = c.in_channels;
+      op.l0 = vox(R);
+      ops.push_back(op);
+    }
+    std::vector<Act> hs;
+    Act h = x;
+    char tag[64];
+    for (size_t i = 0; i < u->inputs.size(); ++i) {
+      // h is also referenced by hs (except the raw input x): do not release it when consumed
+      h = run_layers(u->inputs[i], h, nullptr, /*release_h=*/i == 0);
+      hs.push_back(h);
+      snprintf(tag, sizeof tag, "input_blocks.%d", (int)i);
+      u->block_outputs[tag] = h;
+    }
+    // middle: h == hs.back(); keep it alive for the skip connection
+    h = run_layers(u->middle, h, nullptr, false);
+    u->block_outputs["middle_block"] = h;
+    for (size_t i = 0; i < u->outputs.size(); ++i) {
+      Act skip = hs.back();
+      hs.pop_back();
+      h = run_layers(u->outputs[i], h, &skip, true);
+      snprintf(tag, sizeof tag, "output_blocks.%d", (int)i);
+      u->block_outputs[tag] = h;
+    }
+    size_t coef = emit_finalize(h, nullptr, P(u, "out.0.weight"), P(u, "out.0.bias"), nullptr, 0);
+    Act y = new_act(c.out_channels, R);
+    emit_conv(h, nullptr, R, 0, R, 1, 3, P(u, "out.2.weight"), P(u, "out.2.bias"), coef, true, 1, nullptr,
+              ptr<float>(y.off), c.out_channels);
+    release(h);
+    {
+      Op op;
+      op.kind = OP_OUT;
+      op.f0 = ptr<float>(y.off);
+      op.i0 = c.out_channels;
+      op.l0 = vox(R);
+      ops.push_back(op);
+    }
+    release(y);
+  }
+  size_t total_bytes() const { return arena_base + arena.peak; }
+  bool regions_ok() const { return stats_top <= stats_cap && small_top <= small_cap; }
+};
+
+int ensure_plan(HoloUnet* u, int batch, void* ws) {
+  if (u->plan_batch == batch && u->plan_ws == ws && !u->ops.empty()) return 0;
+  for (auto& s : u->params)
+    if (!s.set) {
+      set_error("holo_unet_forward: parameter '%s' has not been set", s.name.c_str());
+      return HOLO_E_STATE;
+    }
+  Planner pl(u, batch, ws, u->ops);
+  pl.build();
+  if (!pl.regions_ok()) {
+    set_error("internal: small-buffer regions overflow");
+    return HOLO_E_INVALID;
+  }
+  u->ws_need = pl.total_bytes();
+  u->plan_batch = batch;
+  u->plan_ws = ws;
+  return 0;
+}
+
+int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, float* y, void* stream) {
+  switch (op.kind) {
+    case OP_MEMSET:
+      HIP_TRY(hipMemsetAsync(op.o0, 0, op.bytes, (hipStream_t)stream));
+      return 0;
+    case OP_IN:
+      return ncdhw_to_ndhwc_launch(x, op.o0, N, op.i0, op.l0, 0, stream);
+    case OP_TEMB:
+      return time_embed_launch(t, N, u->cfg.model_channels, u->ted, op.f0, op.f1, op.f2, op.f3, op.o0, op.o1, stream);
+    case OP_EMBLIN:
+      return rows_linear_launch(op.f0, op.f1, op.f2, op.o0, N, u->emb_rows, u->ted, stream);
+    case OP_STATS:
+      return gn_stats_launch(op.f0, op.dout, N, op.i0, op.l0, stream);
+    case OP_FINAL:
+      return gn_finalize_launch(op.d0, op.i0, op.d1, op.i1, N, op.l0, 32, 1e-5f, op.f0, op.f1, op.f2, op.i2, op.i3,
+                                op.o0, stream);
+    case OP_CONV:
+      return conv_launch(op.conv, stream);
+    case OP_GEMM:
+      return gemm_launch(op.gemm, stream);
+    case OP_SOFTMAX:
+      return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
+    case OP_OUT:
+      return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int holo_abi_version(void) { return HOLO_ABI_VERSION; }
+const char* holo_last_error(void) { return get_error(); }
+
+int holo_ctx_create(int device_id, HoloCtx** out) {
+  if (!out) {
+    set_error("holo_ctx_create: null out");
+    return HOLO_E_INVALID;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  HoloCtx* c = new HoloCtx;
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = c;
+  return 0;
+}
+int holo_ctx_destroy(HoloCtx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
+  if (!ctx || !cfg || !out) {
+    set_error("holo_unet_create: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (!cfg->homogeneous_resample) {
+    set_error("holo_unet_create: only homogeneous_resample=True is supported");
+    return HOLO_E_UNSUPPORTED;
+  }
+  if (cfg->n_channel_mult < 1 || cfg->n_channel_mult > 8 || cfg->n_attention_resolutions > 8 ||
+      cfg->model_channels % 32 || cfg->in_channels % 4 || cfg->out_channels % 4 || cfg->model_channels > 256 ||
+      cfg->image_size % (1 << (cfg->n_channel_mult - 1))) {
+    set_error("holo_unet_create: unsupported configuration");
+    return HOLO_E_UNSUPPORTED;
+  }
+  HoloUnet* u = new HoloUnet;
+  u->ctx = ctx;
+  u->cfg = *cfg;
+  build_structure(u);
+  enumerate_params(u);
+  const char* dbg = getenv("HOLO_KEEP_INTERMEDIATES");
+  u->keep_intermediates = dbg && dbg[0] == '1';
+  // private parameter storage
+  int64_t total = 0;
+  for (auto& s : u->params)
+    if (s.kind == P_PLAIN || s.kind == P_CONV3) total += (s.numel + 63) & ~(int64_t)63;
+  total += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
+  total += (u->emb_rows + 63) & ~63;
+  if (hipMalloc((void**)&u->pstore, (size_t)total * sizeof(float)) != hipSuccess) {
+    set_error("holo_unet_create: hipMalloc of %lld parameter floats failed", (long long)total);
+    delete u;
+    return HOLO_E_HIP;
+  }
+  float* cur = u->pstore;
+  for (auto& s : u->params)
+    if (s.kind == P_PLAIN || s.kind == P_CONV3) {
+      s.priv = cur;
+      cur += (s.numel + 63) & ~(int64_t)63;
+    }
+  u->emb_w = cur;
+  cur += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
+  u->emb_b = cur;
+  for (auto& s : u->params) {
+    if (s.kind == P_EMB_W || s.kind == P_EMB_B) {
+      std::string prefix = s.name.substr(0, s.name.rfind(".emb_layers"));
+      int row = u->emb_row_off[prefix];
+      s.priv = s.kind == P_EMB_W ? u->emb_w + (int64_t)row * u->ted : u->emb_b + row;
+    }
+  }
+  *out = u;
+  return 0;
+}
+
+int holo_unet_destroy(HoloUnet* net) {
+  if (!net) return 0;
+  if (net->pstore) (void)hipFree(net->pstore);
+  delete net;
+  return 0;
+}
+
+int holo_unet_num_params(const HoloUnet* net) { return net ? (int)net->params.size() : 0; }
+
+int holo_unet_param_info(const HoloUnet* net, int index, char* name, int name_cap, int64_t shape[8], int* ndim) {
+  if (!net || index < 0 || index >= (int)net->params.size()) {
+    set_error("holo_unet_param_info: bad index");
+    return HOLO_E_INVALID;
+  }
+  const ParamSlot& s = net->params[index];
+  if (name && name_cap > 0) {
+    strncpy(name, s.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (ndim) *ndim = (int)s.shape.size();
+  if (shape)
+    for (size_t i = 0; i < s.shape.size() && i < 8; ++i) shape[i] = s.shape[i];
+  return 0;
+}
+
+int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, int dtype, int ndim,
+                        const int64_t* shape, void* stream) {
+  if (!net || !name || !dev_ptr) {
+    set_error("holo_unet_set_param: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (dtype != HOLO_DTYPE_F32) {
+    set_error("holo_unet_set_param: only fp32 parameters are supported");
+    return HOLO_E_UNSUPPORTED;
+  }
+  auto it = net->pindex.find(name);
+  if (it == net->pindex.end()) {
+    set_error("holo_unet_set_param: unknown parameter '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  ParamSlot& s = net->params[it->second];
+  bool ok = ndim == (int)s.shape.size();
+  for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == s.shape[i];
+  if (!ok) {
+    set_error("holo_unet_set_param: shape mismatch for '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  if (s.kind == P_CONV3) {
+    int rc = repack_conv_weight_launch((const float*)dev_ptr, s.priv, (int)s.shape[0], (int)s.shape[1], 27, stream);
+    if (rc) return rc;
+  } else {
+    HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+  }
+  s.set = true;
+  return 0;
+}
+
+size_t holo_unet_workspace_bytes(HoloUnet* net, int batch) {
+  if (!net || batch < 1) return 0;
+  auto it = net->ws_cache.find(batch);
+  if (it != net->ws_cache.end()) return it->second;
+  std::vector<Op> tmp;
+  Planner pl(net, batch, nullptr, tmp);
+  pl.build();
+  size_t b = pl.total_bytes();
+  net->ws_cache[batch] = b;
+  // the sizing pass overwrote block_outputs with null-based offsets; force a re-plan
+  net->plan_batch = -1;
+  net->ops.clear();
+  return b;
+}
+
+int holo_unet_forward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (!net || !x || !timesteps || !y || !workspace || batch < 1) {
+    set_error("holo_unet_forward: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  int rc = ensure_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->ws_need) {
+    set_error("holo_unet_forward: workspace too small (%zu < %zu)", workspace_bytes, net->ws_need);
+    return HOLO_E_WORKSPACE;
+  }
+  for (const Op& op : net->ops) {
+    rc = run_op(net, op, batch, x, timesteps, y, stream);
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  return 0;
+}
+
+int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t dst_capacity, int64_t* numel,
+                          void* workspace, void* stream) {
+  if (!net || !tag || !dst || !workspace) {
+    set_error("holo_unet_fetch_block: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (!net->keep_intermediates) {
+    set_error("holo_unet_fetch_block: create the net with HOLO_KEEP_INTERMEDIATES=1");
+    return HOLO_E_STATE;
+  }
+  if (net->plan_ws != workspace || net->ops.empty()) {
+    set_error("holo_unet_fetch_block: no forward has run on this workspace");
+    return HOLO_E_STATE;
+  }
+  auto it = net->block_outputs.find(tag);
+  if (it == net->block_outputs.end()) {
+    set_error("holo_unet_fetch_block: unknown tag '%s'", tag);
+    return HOLO_E_INVALID;
+  }
+  const Act& a = it->second;
+  const int64_t V = (int64_t)a.R * a.R * a.R;
+  const int64_t n = (int64_t)net->plan_batch * V * a.C;
+  if (numel) *numel = n;
+  if (dst_capacity < n) {
+    set_error("holo_unet_fetch_block: destination too small");
+    return HOLO_E_INVALID;
+  }
+  return ndhwc_to_ncdhw_launch((const float*)((char*)workspace + a.off), dst, net->plan_batch, a.C, V, stream);
+}
+
+int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t workspace_bytes, int iters, void* stream,
+                         float* total_ms, double* total_flops, int* n_launches) {
+  if (!net || !workspace || iters < 1) {
+    set_error("holo_unet_time_convs: invalid argument");
+    return HOLO_E_INVALID;
+  }
+  int rc = ensure_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->ws_need) {
+    set_error("holo_unet_time_convs: workspace too small");
+    return HOLO_E_WORKSPACE;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  double flops = 0.0;
+  int launches = 0;
+  for (const Op& op : net->ops)
+    if (op.kind == OP_CONV && op.conv.ksz == 3) {
+      flops += conv_flops(op.conv);
+      ++launches;
+    }
+  HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+  for (int it = 0; it < iters; ++it)
+    for (const Op& op : net->ops)
+      if (op.kind == OP_CONV && op.conv.ksz == 3) {
+        rc = conv_launch(op.conv, stream);
+        if (rc) return HOLO_E_INVALID;
+      }
+  HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (total_ms) *total_ms = ms / iters;
+  if (total_flops) *total_flops = flops;
+  if (n_launches) *n_launches = launches;
+  return 0;
+}
+
+int holo_ddpm_step(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
+                   int64_t elems_per_sample, const float* x_t, const float* model_out, const float* noise,
+                   int clip_denoised, float* sample, float* pred_xstart, void* stream) {
+  if (!tables || !timesteps || !x_t || !model_out || !noise || !sample || !pred_xstart || batch < 1) {
+    set_error("holo_ddpm_step: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  (void)ctx;
+  int rc = ddpm_step_launch(tables, num_timesteps, timesteps, batch, elems_per_sample, x_t, model_out, noise,
+                            clip_denoised, sample, pred_xstart, stream);
+  return rc ? HOLO_E_INVALID : 0;
+}
+
+int holo_tanh(HoloCtx* ctx, const float* x, float* y, int64_t n, void* stream) {
+  (void)ctx;
+  return tanh_launch(x, y, n, stream);
+}
+int holo_clip(HoloCtx* ctx, const float* x, float* y, float lo, float hi, int64_t n, void* stream) {
+  (void)ctx;
+  return clip_launch(x, y, lo, hi, n, stream);
+}
+
+int holo_event_timer_create(void** timer) {
+  hipEvent_t* ev = new hipEvent_t[2];
+  if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+    set_error("hipEventCreate failed");
+    return HOLO_E_HIP;
+  }
+  *timer = ev;
+  return 0;
+}
+int holo_event_timer_start(void* timer, void* stream) {
+  HIP_TRY(hipEventRecord(((hipEvent_t*)timer)[0], (hipStream_t)stream));
+  return 0;
+}
+int holo_event_timer_stop(void* timer, void* stream, float* elapsed_ms) {
+  hipEvent_t* ev = (hipEvent_t*)timer;
+  HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(ev[1]));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, ev[0], ev[1]));
+  return 0;
+}
+int holo_event_timer_destroy(void* timer) {
+  hipEvent_t* ev = (hipEvent_t*)timer;
+  (void)hipEventDestroy(ev[0]);
+  (void)hipEventDestroy(ev[1]);
+  delete[] ev;
+  return 0;
+}
+
+}  // extern "C"

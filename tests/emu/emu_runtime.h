@@ -1,0 +1,270 @@
+// emu_runtime.h — TEST-ONLY host emulation of the handful of HIP constructs the kernels use.
+//
+// The development container has no GPU.  To catch index / layout / bounds bugs before spending GPU
+// minutes, tests/emu builds the SAME kernel sources with -DHOLO_EMU: every GPU thread becomes a host
+// thread, a workgroup runs to completion before the next starts, __syncthreads() is a barrier, and the
+// wave-collective instructions (MFMA, shuffles) exchange operands through a per-wave buffer using the
+// documented gfx950 lane mappings.  This is not a product path: nothing in holo_diffusion_amd/ links it.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 {
+  float x, y, z, w;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 {
+  float x, y;
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+typedef float f32x16 __attribute__((vector_size(64)));
+typedef float f32x4 __attribute__((vector_size(16)));
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__
+
+namespace emu {
+
+struct SpinBarrier {
+  std::atomic<int> expected{0};
+  std::atomic<int> waiting{0};
+  std::atomic<uint64_t> gen{0};
+  std::mutex m;
+  void init(int n) {
+    expected = n;
+    waiting = 0;
+    gen = 0;
+  }
+  void wait() {
+    uint64_t g;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      g = gen.load();
+      if (waiting.load() + 1 == expected.load()) {
+        waiting = 0;
+        gen.store(g + 1);
+        return;
+      }
+      waiting++;
+    }
+    while (gen.load() == g) std::this_thread::yield();
+  }
+  void drop() {
+    std::lock_guard<std::mutex> lk(m);
+    expected--;
+    if (expected.load() > 0 && waiting.load() == expected.load()) {
+      waiting = 0;
+      gen++;
+    }
+  }
+};
+
+struct WaveCtx {
+  SpinBarrier bar;
+  float a[64], b[64];
+};
+
+struct BlockCtx {
+  SpinBarrier bar;
+  std::vector<WaveCtx> waves;
+};
+
+extern thread_local BlockCtx* t_block;
+extern thread_local int t_tid;  // linear thread id in block
+extern std::mutex g_atomic_mutex;
+
+}  // namespace emu
+
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+static inline void __syncthreads() { emu::t_block->bar.wait(); }
+
+static inline emu::WaveCtx& emu_wave() { return emu::t_block->waves[emu::t_tid >> 6]; }
+
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col = l&31, row = (r&3)+8*(r>>2)+4*(l>>5)
+static inline f32x16 emu_mfma_f32_32x32x2f32(float a, float b, f32x16 c) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  w.a[lane] = a;
+  w.b[lane] = b;
+  w.bar.wait();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int col = lane & 31;
+    float acc = c[r];
+    for (int k = 0; k < 2; ++k) acc = std::fma(w.a[row + 32 * k], w.b[col + 32 * k], acc);
+    c[r] = acc;
+  }
+  w.bar.wait();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32(a, b, c)
+
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D col = l&15, row = 4*(l>>4)+r
+static inline f32x4 emu_mfma_f32_16x16x4f32(float a, float b, f32x4 c) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  w.a[lane] = a;
+  w.b[lane] = b;
+  w.bar.wait();
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    const int col = lane & 15;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = std::fma(w.a[row + 16 * k], w.b[col + 16 * k], acc);
+    c[r] = acc;
+  }
+  w.bar.wait();
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
+
+static inline float __shfl_xor(float v, int mask) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  w.a[lane] = v;
+  w.bar.wait();
+  float r = w.a[(lane ^ mask) & 63];
+  w.bar.wait();
+  return r;
+}
+static inline float __shfl(float v, int src) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  w.a[lane] = v;
+  w.bar.wait();
+  float r = w.a[src & 63];
+  w.bar.wait();
+  return r;
+}
+
+static inline double atomicAdd(double* p, double v) {
+  std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
+  double o = *p;
+  *p = o + v;
+  return o;
+}
+static inline float atomicAdd(float* p, float v) {
+  std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
+  float o = *p;
+  *p = o + v;
+  return o;
+}
+
+static inline float emu_expf(float x) { return std::exp(x); }
+#define __expf(x) emu_expf(x)
+static inline float __fmul_rn(float a, float b) {
+  volatile float r = a * b;
+  return r;
+}
+static inline float __fadd_rn(float a, float b) {
+  volatile float r = a + b;
+  return r;
+}
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+
+static inline void emu_wave_barrier() { emu_wave().bar.wait(); }
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
+
+// ---- minimal HIP runtime API shims (host memory stands in for device memory)
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct EmuEvent { double t; }* hipEvent_t;
+enum { hipSuccess = 0 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+struct hipDeviceProp_t {
+  int multiProcessorCount;
+};
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  p->multiProcessorCount = 4;  // small "chip" so that split-K paths are exercised on tiny problems
+  return hipSuccess;
+}
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n);
+  return *p ? hipSuccess : 1;
+}
+static inline hipError_t hipFree(void* p) {
+  free(p);
+  return hipSuccess;
+}
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+  memcpy(d, s, n);
+  return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  memset(d, v, n);
+  return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) {
+  *e = new EmuEvent{0};
+  return hipSuccess;
+}
+static inline hipError_t hipEventDestroy(hipEvent_t e) {
+  delete e;
+  return hipSuccess;
+}
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) {
+  *ms = 1.f;
+  return hipSuccess;
+}
+
+namespace emu {
+template <class K, class... Args>
+void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+  const int nthreads = (int)(block.x * block.y * block.z);
+  const int nwaves = (nthreads + 63) / 64;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        BlockCtx ctx;
+        ctx.bar.init(nthreads);
+        ctx.waves = std::vector<WaveCtx>(nwaves);
+        for (int w = 0; w < nwaves; ++w) {
+          int n = nthreads - w * 64;
+          ctx.waves[w].bar.init(n > 64 ? 64 : n);
+        }
+        std::vector<std::thread> th;
+        th.reserve(nthreads);
+        for (int t = 0; t < nthreads; ++t) {
+          th.emplace_back([&, t]() {
+            t_block = &ctx;
+            t_tid = t;
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            blockIdx = dim3(bx, by, bz);
+            blockDim = block;
+            gridDim = grid;
+            kernel(args...);
+            ctx.waves[t >> 6].bar.drop();
+            ctx.bar.drop();
+          });
+        }
+        for (auto& x : th) x.join();
+      }
+}
+}  // namespace emu
+
+#define HOLO_LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
