@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py — denoise-steps/s + rendered-rays/s of the HoloDiffusion hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): apple.yaml single-sample DDPM, 64^3 x 32 voxel grid, UNet
+model_channels 64, mult (1,1,2,4,8), attention at ds 4/8, then 400x400 frames (64 coarse + 128 fine samples
+per ray), fp32, synthetic weights/noise/cameras (no network: random-init weights of that architecture).
+
+A "step" is one DDPM ancestral step: UNet forward + clamp/posterior + fresh Gaussian noise, exactly
+gaussian_diffusion.py:459-508 of the reference.  After W warm-up steps EXACTLY K steps are timed between
+barrier + synchronize on both sides; with N>1 every rank (one process per GPU, launched by torch.distributed.run)
+runs its own independent chain (weak scaling, no data-path collective) and the MAX time over ranks is used.
+The render leg (frames of the same grid) is timed the same way and reported in the same JSON line.
+
+  roofline      conv3d implicit-GEMM launches of one UNet forward, timed with hipEvents on the launch stream
+                (holo_unet_time_convs), algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline  the CPU oracle (torch-CPU restatement proven bit-equal to the reference, oracle/) on a bounded
+                sample: a few UNet forwards + posterior at 64^3x32 and one small frame, all host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import warnings
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+UNET_FLOPS_PER_STEP = 1180.8e9  # BASELINE.md §2 (reference module trace, 2*MACs) at 64^3x32
+
+NORTH = dict(resol=64, feature_size=32, model_channels=64, channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8))
+SMALL = dict(resol=32, feature_size=16, model_channels=64, channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8))
+
+
+def build_model(w, H, W, device, n_fine=64):
+    import holo_diffusion_amd as hda
+    from holo_diffusion_amd.structure import unet_param_shapes
+    from holo_diffusion_amd.weights import synth_state_dict
+    model = hda.HoloDiffusionModel(
+        resol=w["resol"], feature_size=w["feature_size"], render_image_width=W, render_image_height=H,
+        net_3d_SimpleUnet3D_args=dict(model_channels=w["model_channels"], channel_mult=w["channel_mult"],
+                                      attention_resolutions=w["attention_resolutions"]),
+        diffusion_args=dict(num_steps=1000),
+        renderer_HoloMultiPassEmissionAbsorptionRenderer_args=dict(n_pts_per_ray_fine_evaluation=n_fine))
+    usd = synth_state_dict(unet_param_shapes(w["resol"], w["feature_size"], w["feature_size"], w["model_channels"], 2,
+                                             w["channel_mult"], w["attention_resolutions"]), 1234)
+    mlp = model._implicit_functions[0]._fn.render_mlp
+    msd = synth_state_dict({k: tuple(v.shape) for k, v in mlp.state_dict().items()}, 4321)
+    full = {"net_3d._net." + k: v for k, v in usd.items()}
+    for i in range(model.num_passes):
+        full.update({f"_implicit_functions.{i}._fn.render_mlp." + k: v for k, v in msd.items()})
+    model.load_state_dict(full)
+    return model.to(device), usd, msd
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x: float, world: int, device) -> float:
+    if world == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(w, usd, msd, budget_s=25.0):
+    """Bounded CPU sample of the same workload through the oracle (kind 'port')."""
+    from oracle import diffusion_oracle as do
+    from oracle import render_oracle as ro
+    from oracle import unet_oracle as uo
+    from oracle.common import np_noise
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = uo.UNetCfg(image_size=w["resol"], in_channels=w["feature_size"], out_channels=w["feature_size"],
+                     model_channels=w["model_channels"], num_res_blocks=2, channel_mult=w["channel_mult"],
+                     attention_resolutions=w["attention_resolutions"], num_heads=2)
+    orc = do.DiffusionOracle(1000)
+    shape = (1, w["feature_size"]) + (w["resol"],) * 3
+    x = torch.from_numpy(np_noise(1, shape))
+    eps = torch.from_numpy(np_noise(2, shape))
+    model = lambda a, b: uo.unet_forward(usd, cfg, a, b)  # noqa: E731
+    t0 = time.time()
+    orc.p_sample(model, x, torch.tensor([999]), eps)  # warm-up
+    warm = time.time() - t0
+    n = max(1, min(5, int(budget_s * 0.6 / max(warm, 1e-3))))
+    t0 = time.time()
+    for i in range(n):
+        x = orc.p_sample(model, x, torch.tensor([998 - i]), eps)["sample"]
+    steps_per_s = n / (time.time() - t0)
+    # one small frame of the same grid size
+    Hs = Ws = 48
+    rcfg = ro.RenderCfg(resol=w["resol"], feature_size=w["feature_size"], image_height=Hs, image_width=Ws)
+    grid = torch.tanh(torch.from_numpy(np_noise(7, shape)))
+    cams = ro.simple_360_cameras(4)
+    t0 = time.time()
+    ro.render(grid, msd, {k: v[1:2] for k, v in cams.items()}, rcfg)
+    rays_per_s = Hs * Ws / (time.time() - t0)
+    return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
+            "rays_per_sec": rays_per_s,
+            "sample": f"{n} oracle DDPM steps (UNet fwd + posterior) at {w['resol']}^3x{w['feature_size']} after 1 "
+                      f"warm-up; one {Hs}x{Ws} frame (64+128 samples/ray) of a {w['resol']}^3 grid; torch CPU, "
+                      f"{cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=5, help="timed 400x400 frames in the render leg")
+    ap.add_argument("--image-size", type=int, default=400)
+    ap.add_argument("--workload", choices=["north", "small"], default="north")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+    w = NORTH if args.workload == "north" else SMALL
+    H = W = args.image_size
+    warnings.simplefilter("ignore")
+    model, usd, msd = build_model(w, H, W, device)
+    net, diff = model.net_3d, model.diffusion
+    shape = (1, w["feature_size"]) + (w["resol"],) * 3
+    torch.manual_seed(42 + rank)
+
+    # ---------------- denoise leg: K ancestral steps of one chain per GPU
+    K, Wm = args.steps, args.warmup
+    img = torch.randn(*shape, device=device)
+    ts = torch.arange(999, 999 - (K + Wm), -1, device=device, dtype=torch.int64).clamp_min(0)[:, None].contiguous()
+
+    def one_step(x, k):
+        t = ts[k]
+        out = net(x, t)
+        eps = torch.randn_like(x)
+        sample, _ = diff._step(x, t, out, eps, True)
+        return sample
+
+    with torch.no_grad():
+        for k in range(Wm):
+            img = one_step(img, k)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            img = one_step(img, k)
+        barrier_sync(world)
+        dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, world, device)
+    assert torch.isfinite(img).all()
+    steps_per_s = world * K / dt
+
+    # ---------------- render leg: frames of one grid per GPU (UNet-at-t=0 refinement hoisted, cached)
+    import holo_diffusion_amd as hda
+    F = args.frames
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, max(F, 2), -30.0 * (2 * math.pi / 360), 10,
+                                                (0.0, -1.0, 0.0), 3.2).to(device)
+    vf = torch.clamp(img, -1, 1)
+    with torch.no_grad():
+        model.render_views(vf, cams[[0]])  # warm-up (also caches tanh(net_3d(vf, 0)))
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        out = model.render_views(vf, cams[list(range(F))])
+        barrier_sync(world)
+        dtr = time.perf_counter() - t0
+    dtr = max_over_ranks(dtr, world, device)
+    assert torch.isfinite(out["images_render"]).all()
+    rays_per_s = world * F * H * W / dtr
+
+    # ---------------- roofline of the dominant kernel (conv3d implicit GEMM), hipEvents on the launch stream
+    roof = None
+    if rank == 0:
+        ms, flops, nl = net.time_convs(1, args.conv_iters, device)
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3 conv3d launches of one UNet forward)",
+                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None, "launches_per_forward": nl, "avg_launch_ms": ms / nl, "ms_per_forward": ms,
+                "algorithmic_gflop_per_forward": flops / 1e9}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, usd, msd)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        # render roofline (logical gather bytes and collapsed-MLP flops per ray)
+        C = w["feature_size"]
+        samples = 64 + 128
+        gather_bytes_per_ray = samples * 8 * C * 4
+        mlp_flops_per_ray = samples * (2 * 257 * C + 2 * 3 * 256 + 2 * 3 * 27)
+        line = {
+            "metric": "denoise-steps/sec + rendered-rays/sec, 64^3x32 grid @400^2 render",
+            "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; "
+                                    if args.workload == "north" else "32^3x16 plumbing grid; ")
+                       + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
+                       "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
+            "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
+            "unet_tflops": UNET_FLOPS_PER_STEP * steps_per_s / world / 1e12 if args.workload == "north" else None,
+            "roofline": roof,
+            "roofline_render": {"bound": "mfma+gather", "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,
+                                "peak_hbm_GBps": PEAK_HBM_GBPS,
+                                "mlp_tflops_collapsed": mlp_flops_per_ray * rays_per_s / world / 1e12,
+                                "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
+                                "frac_mfma": mlp_flops_per_ray * rays_per_s / world / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

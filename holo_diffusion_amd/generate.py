@@ -1,0 +1,126 @@
+"""Sampling driver: DDPM-sample voxel grids and render fly-arounds, sharded over the GPUs of a node.
+
+Mirrors the callers of the hot path in the reference:
+  * ``generate_samples`` (/root/reference/generate_samples.py:37-138): serial loop over
+    ``sample_00000..`` sequences, per-sample seeding, ``render_flyaround(sample_mode=True)``
+  * ``render_flyaround`` sample-mode branch (holo_diffusion/utils/render_utils/flyaround.py:150-153,
+    176-184,219-253): simple-360 trajectory (radius 10, elevation -30 deg, focal 3.2), one
+    ``model(**batch, voxel_features=...)`` per camera, optional progressive denoising renders (:240-245)
+
+Multi-GPU: samples are independent DDPM chains, so sample ``i`` goes to rank
+``i % world_size`` (one process per GPU, weights replicated); the only communication is one
+``all_gather`` of the rendered frames at the end (RCCL over xGMI when the backend is ``nccl``,
+``gloo`` in the CPU tests).  Video encoding / visdom / shaded-depth output are out of scope.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .cameras import PerspectiveCameras, get_simple_360_camera_trajectory
+from .render import EvaluationMode
+
+CANONICAL_CO3D_UP_AXIS: Tuple[float, float, float] = (-0.0396, -0.8306, -0.5554)  # visualize_reconstruction.py:35
+
+
+def shard_indices(num_items: int, rank: int, world_size: int) -> List[int]:
+    """Round-robin assignment of independent samples to ranks."""
+    return list(range(rank, num_items, world_size))
+
+
+def dist_info() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_frames(local: Dict[int, torch.Tensor], num_items: int, frame_shape: Sequence[int],
+                  device: torch.device) -> Optional[torch.Tensor]:
+    """all_gather of per-sample frame stacks.  ``local`` maps sample index -> tensor of ``frame_shape``.
+    Returns (num_items, *frame_shape) on every rank (None if nothing was rendered)."""
+    rank, world = dist_info()
+    per_rank = math.ceil(num_items / world) if world > 0 else num_items
+    buf = torch.zeros((per_rank,) + tuple(frame_shape), dtype=torch.float32, device=device)
+    for slot, idx in enumerate(shard_indices(num_items, rank, world)):
+        buf[slot] = local[idx]
+    if world == 1:
+        return buf[:num_items]
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = torch.zeros((num_items,) + tuple(frame_shape), dtype=torch.float32, device=device)
+    for r in range(world):
+        for slot, idx in enumerate(shard_indices(num_items, r, world)):
+            out[idx] = parts[r][slot]
+    return out
+
+
+@torch.no_grad()
+def render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
+                     camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
+                     hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
+                     device: torch.device = torch.device("cuda"), progressive_sampling_steps_per_render: int = -1,
+                     voxel_features: Optional[torch.Tensor] = None, batched: bool = True,
+                     sampler_kwargs: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """Sample (unless ``voxel_features`` is given) and render one fly-around.  Returns stacked
+    ``images_render (n,3,H,W)``, ``depths_render``, ``masks_render (n,1,H,W)`` and ``voxel_features``."""
+    cams = get_simple_360_camera_trajectory(max_angle, n_flyaround_poses, camera_elevation, hemispherical_radius, up,
+                                            camera_focal_length).to(device)
+    sampler_kwargs = dict(sampler_kwargs or {})
+    gen = None
+    if voxel_features is None and progressive_sampling_steps_per_render <= 0:
+        voxel_features = model.sample_random_voxel_features(**sampler_kwargs)
+    if progressive_sampling_steps_per_render > 0:
+        gen = model.sample_random_voxel_features_progressive(**sampler_kwargs)
+    if gen is None and batched:
+        out = model.render_views(voxel_features, cams)
+        out["voxel_features"] = voxel_features
+        return out
+    frames = {"images_render": [], "depths_render": [], "masks_render": []}
+    for n in range(n_flyaround_poses):
+        if gen is not None:
+            for _ in range(progressive_sampling_steps_per_render):
+                try:
+                    voxel_features = next(gen)
+                except StopIteration:
+                    break
+        preds = model(camera=cams[n], evaluation_mode=EvaluationMode.EVALUATION, voxel_features=voxel_features)
+        for k in frames:
+            frames[k].append(preds[k])
+    out = {k: torch.cat(v, dim=0) for k, v in frames.items()}
+    out["voxel_features"] = voxel_features
+    return out
+
+
+@torch.no_grad()
+def generate_samples(model, num_samples: int = 2, n_eval_cameras: int = 25 * 3, seed: int = 3,
+                     up: Tuple[float, float, float] = CANONICAL_CO3D_UP_AXIS,
+                     camera_elevation: float = -30.0 * (2 * math.pi / 360),
+                     progressive_sampling_steps_per_render: int = -1, device: Optional[torch.device] = None,
+                     gather: bool = True, sampler_kwargs: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """Sharded counterpart of generate_samples.py:105-138.  Every rank renders its own samples; with
+    ``gather`` all ranks end up with the frames of all samples."""
+    rank, world = dist_info()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    mine = shard_indices(num_samples, rank, world)
+    local_img: Dict[int, torch.Tensor] = {}
+    local_dep: Dict[int, torch.Tensor] = {}
+    local_msk: Dict[int, torch.Tensor] = {}
+    H, W = model.render_image_height, model.render_image_width
+    for i in mine:
+        torch.manual_seed(seed + i)  # per-sample seed
+        out = render_flyaround(model, n_flyaround_poses=n_eval_cameras, up=up, camera_elevation=camera_elevation,
+                               device=device,
+                               progressive_sampling_steps_per_render=progressive_sampling_steps_per_render,
+                               sampler_kwargs=sampler_kwargs)
+        local_img[i], local_dep[i], local_msk[i] = out["images_render"], out["depths_render"], out["masks_render"]
+    if not gather:
+        return {"images_render": local_img, "depths_render": local_dep, "masks_render": local_msk}
+    return {
+        "images_render": gather_frames(local_img, num_samples, (n_eval_cameras, 3, H, W), device),
+        "depths_render": gather_frames(local_dep, num_samples, (n_eval_cameras, 1, H, W), device),
+        "masks_render": gather_frames(local_msk, num_samples, (n_eval_cameras, 1, H, W), device),
+    }

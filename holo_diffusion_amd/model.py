@@ -1,0 +1,195 @@
+"""``HoloDiffusionModel`` — the model plugin the sampling scripts drive.
+
+Mirrors /root/reference/holo_diffusion/holo_diffusion_model.py:
+  * config fields resol / volume_extent / feature_size / num_passes / net_3d_* / diffusion_* (:47-61)
+    plus the GenericModel fields the released YAMLs set (configs/apple.yaml:104-165)
+  * ``create_net_3d`` (:118-130): net_3d args overridden with in/out_channels=feature_size, image_size=resol
+  * ``create_diffusion`` (:132-136)
+  * ``_construct_implicit_functions`` (:138-171): resol / volume_extent / n_hidden=feature_size /
+    feature_dim=0 forced, ONE implicit function shared by all passes
+  * ``sample_random_voxel_features`` (:188-199) and ``..._progressive`` (:173-186)
+  * ``forward`` EVALUATION branch with ``voxel_features`` (:247-326,376-540): range checks,
+    ``tanh(net_3d(vf, t=0))``, bind, ray sampler, render, ``images_render / depths_render / masks_render``
+
+Training-side branches (view pooling :327-374, diffusion training/bootstrap :386-418, losses) are
+outside the hot path ("next" rows).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, runtime
+from .cameras import PerspectiveCameras
+from .diffusion import ImplicitronGaussianDiffusion
+from .registry import ReplaceableBase, apply_config, get_default_args, registry
+from .render import (AdaptiveRaySampler, BaseRenderer, EvaluationMode, HoloMultiPassEmissionAbsorptionRenderer,
+                     HoloVoxelGridImplicitFunction, ImplicitFunctionBase, ImplicitFunctionWrapper, RenderSamplingMode)
+from .unet import SimpleUnet3D, Unet3DBase
+
+logger = logging.getLogger(__name__)
+
+
+class ImplicitronModelBase(ReplaceableBase):
+    pass
+
+
+@registry.register
+class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
+    # ---- model config (holo_diffusion_model.py:47-61)
+    resol: int = 32
+    volume_extent: float = 8.0
+    feature_size: int = 128
+    num_passes: int = 2
+    net_3d_enabled: bool = True
+    net_3d_class_type: str = "SimpleUnet3D"
+    net_3d_SimpleUnet3D_args: Optional[dict] = None
+    diffusion_enabled: bool = True
+    diffusion_args: Optional[dict] = None
+    enable_bootstrap: bool = True
+    bootstrap_prob: float = 0.5
+    # ---- GenericModel fields used on the path (configs/apple.yaml:104-165)
+    render_image_width: int = 400
+    render_image_height: int = 400
+    bg_color: Tuple[float, float, float] = (1.0, 1.0, 1.0)
+    chunk_size_grid: int = 163840        # accepted for config compatibility; the fused renderer is chunk-free
+    n_train_target_views: int = 10
+    sampling_mode_training: str = "mask_sample"
+    sampling_mode_evaluation: str = "full_grid"
+    raysampler_class_type: str = "AdaptiveRaySampler"
+    raysampler_AdaptiveRaySampler_args: Optional[dict] = None
+    renderer_class_type: str = "HoloMultiPassEmissionAbsorptionRenderer"
+    renderer_HoloMultiPassEmissionAbsorptionRenderer_args: Optional[dict] = None
+    implicit_function_class_type: str = "HoloVoxelGridImplicitFunction"
+    implicit_function_HoloVoxelGridImplicitFunction_args: Optional[dict] = None
+    # host-side switch: the reference re-runs tanh(net_3d(vf, 0)) for EVERY rendered frame even when vf is
+    # unchanged (holo_diffusion_model.py:420-426); cache it on the identity of the voxel_features tensor.
+    cache_refined_features: bool = True
+    check_ranges: bool = False           # the reference's per-call min/max asserts (:381,426,428) force host syncs
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        self.create_net_3d()
+        self.create_diffusion()
+        rs_args = dict(self.raysampler_AdaptiveRaySampler_args or {})
+        rs_args.setdefault("scene_extent", 4.0)
+        rs_args["image_width"], rs_args["image_height"] = self.render_image_width, self.render_image_height
+        if self.raysampler_class_type != "AdaptiveRaySampler":
+            raise NotImplementedError("only AdaptiveRaySampler is supported")
+        self.raysampler = AdaptiveRaySampler(**rs_args)
+        r_args = dict(self.renderer_HoloMultiPassEmissionAbsorptionRenderer_args or {})
+        rm = dict(r_args.get("raymarcher_EmissionAbsorptionRaymarcher_args") or {})
+        rm.setdefault("bg_color", tuple(self.bg_color))  # GenericModel passes its bg_color to the raymarcher
+        r_args["raymarcher_EmissionAbsorptionRaymarcher_args"] = rm
+        self.renderer = registry.get(BaseRenderer, self.renderer_class_type)(**r_args)
+        self._implicit_functions = self._construct_implicit_functions()
+        self._refined_cache = None
+
+    def create_net_3d(self):
+        self.net_3d = None
+        if self.net_3d_enabled:
+            extra = dict(in_channels=self.feature_size, out_channels=self.feature_size, image_size=self.resol)
+            args = dict(getattr(self, "net_3d_" + self.net_3d_class_type + "_args") or {})
+            self.net_3d = registry.get(Unet3DBase, self.net_3d_class_type)(**{**args, **extra})
+
+    def create_diffusion(self):
+        self.diffusion = None
+        if self.diffusion_enabled:
+            self.diffusion = ImplicitronGaussianDiffusion(**dict(self.diffusion_args or {}))
+
+    def _construct_implicit_functions(self):
+        if self.implicit_function_class_type != "HoloVoxelGridImplicitFunction":
+            raise ValueError(f"{type(self)} supports only HoloVoxelGridImplicitFunction!")
+        extra = dict(resol=self.resol, volume_extent=self.volume_extent, n_hidden=self.feature_size, feature_dim=0)
+        cfg = dict(self.implicit_function_HoloVoxelGridImplicitFunction_args or {})
+        fn_type = registry.get(ImplicitFunctionBase, self.implicit_function_class_type)
+        if_ = ImplicitFunctionWrapper(fn_type(**{**cfg, **extra}))
+        return torch.nn.ModuleList([if_ for _ in range(self.num_passes)])
+
+    # ---- sampling (holo_diffusion_model.py:173-199) -----------------------------------------
+    def _shape(self):
+        return (1, self.feature_size, self.resol, self.resol, self.resol)
+
+    def sample_random_voxel_features_progressive(self, **loop_kwargs):
+        assert self.net_3d_enabled and self.diffusion_enabled
+        for sample in self.diffusion.p_sample_loop_progressive(model=self.net_3d, shape=self._shape(),
+                                                               clip_denoised=True, progress=False, **loop_kwargs):
+            s = sample["sample"]
+            out = torch.empty_like(s)
+            L = runtime.lib()
+            _lib.check(L, L.holo_clip(runtime.ctx(s.device), runtime.ptr(s), runtime.ptr(out), -1.0, 1.0, s.numel(),
+                                      runtime.stream_ptr(s.device)), "holo_clip")
+            yield out
+
+    def sample_random_voxel_features(self, **loop_kwargs) -> torch.Tensor:
+        assert self.net_3d_enabled and self.diffusion_enabled
+        logger.info("generating random voxel features through denoising diffusion ...")
+        return self.diffusion.p_sample_loop(model=self.net_3d, shape=self._shape(), clip_denoised=True,
+                                            progress=loop_kwargs.pop("progress", False), **loop_kwargs)
+
+    # ---- render (holo_diffusion_model.py:201-540, evaluation branch) ------------------------
+    def _refine(self, voxel_features: torch.Tensor) -> torch.Tensor:
+        """tanh(net_3d(vf, t=0)) (:420-426)."""
+        key = (voxel_features.data_ptr(), voxel_features._version, tuple(voxel_features.shape))
+        if self.cache_refined_features and self._refined_cache is not None and self._refined_cache[0] == key:
+            return self._refined_cache[1]
+        dev = voxel_features.device
+        t0 = torch.zeros((1,), dtype=torch.long, device=dev)
+        y = self.net_3d(voxel_features, t0)
+        out = torch.empty_like(y)
+        L = runtime.lib()
+        _lib.check(L, L.holo_tanh(runtime.ctx(dev), runtime.ptr(y), runtime.ptr(out), y.numel(),
+                                  runtime.stream_ptr(dev)), "holo_tanh")
+        if self.cache_refined_features:
+            self._refined_cache = (key, out)
+        return out
+
+    def forward(self, *, image_rgb=None, camera: PerspectiveCameras, fg_probability=None, mask_crop=None,
+                depth_map=None, sequence_name=None, frame_timestamp=None,
+                evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION,
+                voxel_features: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, Any]:
+        if evaluation_mode != EvaluationMode.EVALUATION or image_rgb is not None:
+            raise NotImplementedError("only the evaluation/sampling branch (image_rgb=None) is on the hot path")
+        n_targets = 1  # EVALUATION renders one target camera per call (:263-269)
+        target_cameras = camera[list(range(n_targets))]
+        sampling_mode = RenderSamplingMode(self.sampling_mode_evaluation)
+        if sampling_mode != RenderSamplingMode.FULL_GRID:
+            raise NotImplementedError("evaluation uses full_grid sampling")
+        if voxel_features is None:
+            voxel_features = self.sample_random_voxel_features()
+        if self.check_ranges:
+            assert voxel_features.min() >= -1.0 and voxel_features.max() <= 1.0
+        if self.net_3d_enabled:
+            voxel_features = self._refine(voxel_features)
+        assert voxel_features.shape[1] == self.feature_size, "Wrong voxel feature size!"
+        for func in self._implicit_functions:
+            func.bind_args(voxel_grid_features=voxel_features)
+        ray_bundle = self.raysampler(target_cameras, evaluation_mode, mask=None)
+        rendered = self.renderer(ray_bundle=ray_bundle, implicit_functions=list(self._implicit_functions),
+                                 evaluation_mode=evaluation_mode)
+        for func in self._implicit_functions:
+            func.unbind_args()
+        preds: Dict[str, Any] = {"rendered": rendered, "ray_bundle": ray_bundle}
+        preds["images_render"] = rendered.features.permute(0, 3, 1, 2)
+        preds["depths_render"] = rendered.depths.permute(0, 3, 1, 2)
+        preds["masks_render"] = rendered.masks.permute(0, 3, 1, 2)
+        return preds
+
+    def render_views(self, voxel_features: torch.Tensor, cameras: PerspectiveCameras) -> Dict[str, torch.Tensor]:
+        """Batched turntable render: all cameras of a fly-around in ONE holo_render call (BASELINE config 4).
+        Equivalent to calling forward() once per camera with the same voxel_features."""
+        if self.net_3d_enabled:
+            voxel_features = self._refine(voxel_features)
+        for func in self._implicit_functions:
+            func.bind_args(voxel_grid_features=voxel_features)
+        bundle = self.raysampler(cameras, EvaluationMode.EVALUATION)
+        rendered = self.renderer(ray_bundle=bundle, implicit_functions=list(self._implicit_functions),
+                                 evaluation_mode=EvaluationMode.EVALUATION)
+        for func in self._implicit_functions:
+            func.unbind_args()
+        return {"images_render": rendered.features.permute(0, 3, 1, 2),
+                "depths_render": rendered.depths.permute(0, 3, 1, 2),
+                "masks_render": rendered.masks.permute(0, 3, 1, 2)}

@@ -1,0 +1,358 @@
+"""Render-side plugins backed by the fused HIP renderer.
+
+Reference interfaces mirrored (paths relative to /root/reference/holo_diffusion):
+  * ``RenderMLP`` (holo_voxel_grid_implicit_function.py:48-145): config fields :49-60, parameter names
+    ``_density_net.mlp.<i>.0.{weight,bias}`` / ``_radiance_net.mlp.0.0.{weight,bias}``
+    (custom_modules.py:94-113 wraps every Linear in a Sequential, hence the ``.0``)
+  * ``HoloVoxelGridImplicitFunction`` (:148-269): config fields :150-160, ``allows_multiple_passes``,
+    nested ``render_mlp`` built with ``input_dims = n_hidden`` (:165-172)
+  * ``ImplicitFunctionWrapper.bind_args / unbind_args`` as used at holo_diffusion_model.py:166-168,437-438,466-467
+  * ``HoloMultiPassEmissionAbsorptionRenderer`` (holo_multipass_ea.py:15-125) with the config fields of
+    configs/apple.yaml:147-165; ``forward(ray_bundle, implicit_functions, evaluation_mode) -> RendererOutput``
+  * ``AdaptiveRaySampler`` call at holo_diffusion_model.py:442-448 (configs/apple.yaml:135-146)
+
+All arithmetic (ray generation, voxel fetch, RenderMLP, emission-absorption compositing, importance
+resampling, fine pass) happens inside ``holo_render`` (csrc/kernels_render.hip); the classes here carry
+configuration and parameters and keep the call structure of the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, runtime
+from .cameras import PerspectiveCameras
+from .registry import Configurable, ReplaceableBase, apply_config, registry
+
+COLOUR_DIMS = 3
+
+
+class EvaluationMode(enum.Enum):
+    TRAINING = "training"
+    EVALUATION = "evaluation"
+
+
+class RenderSamplingMode(enum.Enum):
+    MASK_SAMPLE = "mask_sample"
+    FULL_GRID = "full_grid"
+
+
+class HiddenActivation(enum.Enum):
+    RELU = "relu"
+    SOFTPLUS = "softplus"
+    LEAKYRELU = "leakyrelu"
+
+
+@dataclass
+class ImplicitronRayBundle:
+    """Full-grid ray bundle.  The fused kernel regenerates origins/directions/lengths from the camera, so the
+    tensors are only materialised on request (``materialize()``), e.g. for inspection."""
+    camera: PerspectiveCameras
+    image_height: int
+    image_width: int
+    n_pts_per_ray: int
+    scene_extent: float
+    scene_center: Tuple[float, float, float]
+    origins: Optional[torch.Tensor] = None
+    directions: Optional[torch.Tensor] = None
+    lengths: Optional[torch.Tensor] = None
+    xys: Optional[torch.Tensor] = None
+
+
+@dataclass
+class RendererOutput:
+    features: torch.Tensor
+    depths: torch.Tensor
+    masks: torch.Tensor
+    prev_stage: Optional["RendererOutput"] = None
+    normals: Optional[torch.Tensor] = None
+    weights: Optional[torch.Tensor] = None
+    aux: Dict[str, Any] = field(default_factory=dict)
+
+
+class _Node(torch.nn.Module):
+    pass
+
+
+def _add_param(root: torch.nn.Module, dotted: str, p: torch.nn.Parameter) -> None:
+    parts = dotted.split(".")
+    m = root
+    for part in parts[:-1]:
+        if part not in m._modules:
+            m.add_module(part, _Node())
+        m = m._modules[part]
+    m.register_parameter(parts[-1], p)
+
+
+class RenderMLP(Configurable, torch.nn.Module):
+    input_dims: int = 128
+    output_feature_dims: int = COLOUR_DIMS
+    output_vp_independent_feature_dims: int = 64
+    feat_emb_dims: int = 0
+    dir_emb_dims: int = 4
+    dnet_num_layers: int = 4
+    dnet_hidden_dim: int = 256
+    dnet_input_skips: Tuple[int, ...] = (2,)
+    rnet_num_layers: int = 1
+    rnet_hidden_dim: int = 128
+    rnet_input_skips: Tuple[int, ...] = ()
+    activation_fn: HiddenActivation = HiddenActivation.LEAKYRELU
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        if isinstance(self.activation_fn, str):
+            self.activation_fn = HiddenActivation[self.activation_fn]
+        unsupported = []
+        if self.feat_emb_dims != 0:
+            unsupported.append("feat_emb_dims != 0")
+        if self.dnet_num_layers != 4 or tuple(self.dnet_input_skips) != (2,):
+            unsupported.append("density net other than 4 layers with input skip at layer 2")
+        if self.rnet_num_layers != 1 or tuple(self.rnet_input_skips) != ():
+            unsupported.append("radiance net other than a single layer")
+        if self.activation_fn != HiddenActivation.LEAKYRELU:
+            unsupported.append("activation_fn other than LEAKYRELU")
+        if self.output_feature_dims != COLOUR_DIMS or self.output_vp_independent_feature_dims != 0:
+            unsupported.append("extra rendered features (HoloDiffusionModel forces feature_dim=0, "
+                               "holo_diffusion_model.py:156)")
+        if unsupported:
+            raise NotImplementedError("RenderMLP: the fused renderer supports the released configuration only; got "
+                                      + "; ".join(unsupported))
+        self._density_net = _Node()
+        self._radiance_net = _Node()
+        for name, shape in self.param_shapes().items():
+            w = torch.empty(shape)
+            if name.endswith("weight"):
+                torch.nn.init.xavier_uniform_(w)  # _xavier_init (custom_modules.py:104-105)
+            else:
+                w.zero_()
+            _add_param(self, name, torch.nn.Parameter(w, requires_grad=False))
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        Cf, Hd = self.input_dims, self.dnet_hidden_dim
+        demb = 3 * (2 * self.dir_emb_dims + 1)
+        return {
+            "_density_net.mlp.0.0.weight": (Hd, Cf), "_density_net.mlp.0.0.bias": (Hd,),
+            "_density_net.mlp.1.0.weight": (Hd, Hd), "_density_net.mlp.1.0.bias": (Hd,),
+            "_density_net.mlp.2.0.weight": (Hd, Hd + Cf), "_density_net.mlp.2.0.bias": (Hd,),
+            "_density_net.mlp.3.0.weight": (Hd + 1, Hd), "_density_net.mlp.3.0.bias": (Hd + 1,),
+            "_radiance_net.mlp.0.0.weight": (COLOUR_DIMS, Hd + demb), "_radiance_net.mlp.0.0.bias": (COLOUR_DIMS,),
+        }
+
+
+class ImplicitFunctionBase(ReplaceableBase):
+    @staticmethod
+    def allows_multiple_passes() -> bool:
+        return False
+
+
+@registry.register
+class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
+    resol: int = 32
+    volume_extent: float = 8.0
+    n_hidden: int = 128
+    feature_dim: int = 64
+    init_density_bias: float = 1e-4
+    render_normals: bool = False
+    render_mlp_args: Optional[dict] = None
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        self.create_render_mlp()
+
+    def create_render_mlp(self):
+        args = dict(self.render_mlp_args or {})
+        args.update({"input_dims": self.n_hidden, "output_feature_dims": COLOUR_DIMS,
+                     "output_vp_independent_feature_dims": self.feature_dim})
+        self.render_mlp = RenderMLP(**args)
+
+    @staticmethod
+    def allows_multiple_passes() -> bool:
+        return True
+
+    def forward(self, *, ray_bundle=None, fun_viewpool=None, camera=None, global_code=None, run_id=None,
+                pass_number=None, pts_3d=None, voxel_grid_features=None, **kwargs):
+        raise NotImplementedError(
+            "Per-point evaluation is fused into HoloMultiPassEmissionAbsorptionRenderer.forward (holo_render); "
+            "the stand-alone (densities, features) entry point is scheduled for the next round (DESIGN.md §f).")
+
+
+class ImplicitFunctionWrapper(torch.nn.Module):
+    def __init__(self, fn: torch.nn.Module):
+        super().__init__()
+        self._fn = fn
+        self.bound_args: Dict[str, Any] = {}
+
+    def bind_args(self, **bound_args):
+        self.bound_args = bound_args
+        self._fn.on_bind_args() if hasattr(self._fn, "on_bind_args") else None
+
+    def unbind_args(self):
+        self.bound_args = {}
+
+    def forward(self, *args, **kwargs):
+        return self._fn(*args, **{**kwargs, **self.bound_args})
+
+
+class AdaptiveRaySampler(Configurable):
+    """Evaluation-mode (full grid, no stratification) subset of PyTorch3D's AdaptiveRaySampler."""
+    image_width: int = 400
+    image_height: int = 400
+    n_pts_per_ray_training: int = 64
+    n_pts_per_ray_evaluation: int = 64
+    n_rays_per_image_sampled_from_mask: int = 1024
+    n_rays_total_training: Optional[int] = None
+    stratified_point_sampling_training: bool = True
+    stratified_point_sampling_evaluation: bool = False
+    scene_extent: float = 8.0
+    scene_center: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+
+    def __init__(self, **kwargs):
+        apply_config(self, kwargs)
+
+    def __call__(self, cameras: PerspectiveCameras, evaluation_mode: EvaluationMode, mask=None) -> ImplicitronRayBundle:
+        if evaluation_mode != EvaluationMode.EVALUATION:
+            raise NotImplementedError("training-mode (mask-sampled, stratified) ray sampling is out of scope")
+        if self.stratified_point_sampling_evaluation:
+            raise NotImplementedError("stratified sampling at evaluation time is not supported")
+        return ImplicitronRayBundle(camera=cameras, image_height=self.image_height, image_width=self.image_width,
+                                    n_pts_per_ray=self.n_pts_per_ray_evaluation, scene_extent=self.scene_extent,
+                                    scene_center=tuple(self.scene_center))
+
+
+class BaseRenderer(ReplaceableBase):
+    pass
+
+
+@registry.register
+class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
+    raymarcher_class_type: str = "EmissionAbsorptionRaymarcher"
+    n_pts_per_ray_fine_training: int = 64
+    n_pts_per_ray_fine_evaluation: int = 64
+    stratified_sampling_coarse_training: bool = True
+    stratified_sampling_coarse_evaluation: bool = False
+    append_coarse_samples_to_fine: bool = True
+    density_noise_std_train: float = 1.0
+    return_weights: bool = False
+    raymarcher_EmissionAbsorptionRaymarcher_args: Optional[dict] = None
+
+    _RAYMARCHER_DEFAULTS = dict(surface_thickness=1, bg_color=(0.0,), replicate_last_interval=False,
+                                background_opacity=1e10, density_relu=True, blend_output=False)
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        rm = dict(self._RAYMARCHER_DEFAULTS)
+        rm.update(self.raymarcher_EmissionAbsorptionRaymarcher_args or {})
+        self._raymarcher_args = rm
+        bad = []
+        if self.raymarcher_class_type != "EmissionAbsorptionRaymarcher":
+            bad.append("raymarcher_class_type")
+        if rm["surface_thickness"] != 1 or rm["replicate_last_interval"] or not rm["density_relu"] or rm["blend_output"]:
+            bad.append("raymarcher args other than the released ones (configs/apple.yaml:156-165)")
+        if not self.append_coarse_samples_to_fine or self.stratified_sampling_coarse_evaluation or self.return_weights:
+            bad.append("refiner/weights options other than the released ones (configs/apple.yaml:147-155)")
+        if bad:
+            raise NotImplementedError("HoloMultiPassEmissionAbsorptionRenderer: unsupported " + "; ".join(bad))
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_key = None
+        self._param_versions = None
+
+    def _bg_color(self) -> Tuple[float, float, float]:
+        bg = tuple(float(v) for v in self._raymarcher_args["bg_color"])
+        return bg * 3 if len(bg) == 1 else bg
+
+    def _ensure_handle(self, fn: HoloVoxelGridImplicitFunction, bundle: ImplicitronRayBundle, device) -> C.c_void_p:
+        L = runtime.lib()
+        mlp = fn.render_mlp
+        key = (device, fn.resol, fn.n_hidden, float(fn.volume_extent), bundle.image_height, bundle.image_width,
+               bundle.n_pts_per_ray, self.n_pts_per_ray_fine_evaluation, float(bundle.scene_extent),
+               tuple(bundle.scene_center), self._bg_color(), float(self._raymarcher_args["background_opacity"]),
+               mlp.dnet_hidden_dim, mlp.dir_emb_dims)
+        params = dict(mlp.named_parameters())
+        versions = tuple((k, p.data_ptr(), p._version) for k, p in params.items())
+        if self._handle is None or key != self._handle_key:
+            if self._handle is not None:
+                L.holo_renderer_destroy(self._handle)
+            cfg = _lib.make_render_cfg(fn.resol, fn.n_hidden, bundle.image_height, bundle.image_width,
+                                       volume_extent=fn.volume_extent, scene_extent=bundle.scene_extent,
+                                       scene_center=bundle.scene_center, n_pts_coarse=bundle.n_pts_per_ray,
+                                       n_pts_fine=self.n_pts_per_ray_fine_evaluation, bg_color=self._bg_color(),
+                                       background_opacity=self._raymarcher_args["background_opacity"],
+                                       dnet_hidden_dim=mlp.dnet_hidden_dim, dir_emb_dims=mlp.dir_emb_dims)
+            h = C.c_void_p()
+            _lib.check(L, L.holo_renderer_create(runtime.ctx(device), C.byref(cfg), C.byref(h)), "holo_renderer_create")
+            self._handle, self._handle_key, self._param_versions = h, key, None
+        if versions != self._param_versions:
+            st = runtime.stream_ptr(device)
+            for k, p in params.items():
+                if p.device != device or p.dtype != torch.float32:
+                    raise _lib.HoloError(f"RenderMLP parameter '{k}' is {p.dtype} on {p.device}; expected float32 on {device}")
+                t = p.detach().contiguous()
+                _lib.check(L, L.holo_renderer_set_param(self._handle, k.encode(), runtime.ptr(t), _lib.HOLO_DTYPE_F32,
+                                                       t.dim(), _lib.shape_array(t.shape), st), f"set_param({k})")
+            _lib.check(L, L.holo_renderer_commit(self._handle, st), "holo_renderer_commit")
+            self._param_versions = versions
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                runtime.lib().holo_renderer_destroy(self._handle)
+        except Exception:
+            pass
+
+    def forward(self, ray_bundle: ImplicitronRayBundle, implicit_functions: List[ImplicitFunctionWrapper],
+                evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION, **kwargs) -> RendererOutput:
+        if evaluation_mode != EvaluationMode.EVALUATION:
+            raise NotImplementedError("training-mode rendering (density noise, stratified sampling) is out of scope")
+        if not implicit_functions:
+            raise ValueError("EA renderer expects implicit functions")
+        wrapper = implicit_functions[0]
+        fn = wrapper._fn
+        if not isinstance(fn, HoloVoxelGridImplicitFunction):
+            raise NotImplementedError("only HoloVoxelGridImplicitFunction is supported")
+        grid = wrapper.bound_args.get("voxel_grid_features")
+        if grid is None:
+            raise ValueError("voxel_grid_features must be bound to the implicit function (bind_args)")
+        runtime.require_device(grid, "HoloMultiPassEmissionAbsorptionRenderer.forward")
+        dev = grid.device
+        if tuple(grid.shape) != (1, fn.n_hidden, fn.resol, fn.resol, fn.resol):
+            raise _lib.HoloError(f"voxel grid must be (1,{fn.n_hidden},{fn.resol}^3), got {tuple(grid.shape)}")
+        h = self._ensure_handle(fn, ray_bundle, dev)
+        L = runtime.lib()
+        cams = ray_bundle.camera
+        n_cam = len(cams)
+        H, W = ray_bundle.image_height, ray_bundle.image_width
+        arr = (_lib.HoloCamera * n_cam)()
+        Rc, Tc = cams.R.detach().cpu().float(), cams.T.detach().cpu().float()
+        fc, pc = cams.focal_xy().detach().cpu().float(), cams.principal_point.detach().cpu().float()
+        for i in range(n_cam):
+            for j, v in enumerate(Rc[i].reshape(-1).tolist()):
+                arr[i].R[j] = v
+            for j in range(3):
+                arr[i].T[j] = float(Tc[i, j])
+            for j in range(2):
+                arr[i].focal[j] = float(fc[i, j])
+                arr[i].principal_point[j] = float(pc[i, j])
+        grid = grid.contiguous().float()
+        img = torch.empty(n_cam, 3, H, W, device=dev)
+        dep = torch.empty(n_cam, 1, H, W, device=dev)
+        msk = torch.empty(n_cam, 1, H, W, device=dev)
+        imgc, depc, mskc = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(msk)
+        nbytes = L.holo_render_workspace_bytes(h, n_cam)
+        ws = runtime.workspace(dev, f"render{id(self)}", nbytes)
+        _lib.check(L, L.holo_render(h, runtime.ptr(grid), arr, n_cam, runtime.ptr(img), runtime.ptr(dep),
+                                    runtime.ptr(msk), runtime.ptr(imgc), runtime.ptr(depc), runtime.ptr(mskc),
+                                    runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_render")
+        coarse = RendererOutput(features=imgc.permute(0, 2, 3, 1), depths=depc.permute(0, 2, 3, 1),
+                                masks=mskc.permute(0, 2, 3, 1))
+        if len(implicit_functions) == 1:
+            return coarse
+        return RendererOutput(features=img.permute(0, 2, 3, 1), depths=dep.permute(0, 2, 3, 1),
+                              masks=msk.permute(0, 2, 3, 1), prev_stage=coarse)

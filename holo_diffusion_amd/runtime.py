@@ -1,0 +1,55 @@
+"""Per-process device runtime: library handle, context, stream and workspace plumbing.
+
+PyTorch is used here for device memory and streams only (one process per GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib
+
+_CTX: Dict[int, C.c_void_p] = {}
+_WS: Dict[Tuple[int, str], torch.Tensor] = {}
+
+
+def lib() -> C.CDLL:
+    return _lib.load()
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.HoloError(
+            f"{what}: tensor is on '{t.device}', but the HoloDiffusion hot path only runs on an MI355X "
+            "(HIP) device; there is no CPU fallback.")
+
+
+def ctx(device: torch.device) -> C.c_void_p:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CTX:
+        h = C.c_void_p()
+        L = lib()
+        _lib.check(L, L.holo_ctx_create(int(idx), C.byref(h)), "holo_ctx_create")
+        _CTX[idx] = h
+    return _CTX[idx]
+
+
+def stream_ptr(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def workspace(device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
+    """A cached byte buffer of at least ``nbytes`` for (device, tag)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

@@ -1,0 +1,200 @@
+"""Denoiser plugin: ``SimpleUnet3D`` backed by the HIP library.
+
+Mirrors /root/reference/holo_diffusion/utils/diffusion_utils.py:30-86:
+  * ``Unet3DBase(ReplaceableBase, torch.nn.Module)`` with
+    ``forward(x, timesteps, cond_features=None, **kwargs)`` (:30-38)
+  * ``@registry.register class SimpleUnet3D(Unet3DBase)`` with the config fields of :43-53 and
+    ``forward`` = optional channel concat of ``cond_features`` then ``self._net(x, timesteps)`` (:82-86)
+
+The parameters live in ordinary ``torch.nn.Parameter`` tensors under ``_net.<guided-diffusion name>``
+so that ``state_dict()`` / ``load_state_dict()`` are interchangeable with the reference's checkpoints
+(``net_3d._net.*`` keys, trainer/model_factory.py:115-126).  The arithmetic of ``UNetModel.forward``
+(guided_diffusion/unet.py:800-837) runs entirely in ``libholo_mi355x.so`` (``holo_unet_forward``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, runtime
+from .registry import ReplaceableBase, apply_config, registry
+
+
+class Unet3DBase(ReplaceableBase, torch.nn.Module):
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor, cond_features: Optional[torch.Tensor] = None,
+                **kwargs) -> torch.Tensor:
+        raise NotImplementedError()
+
+
+class _Node(torch.nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _add_param(root: torch.nn.Module, dotted: str, p: torch.nn.Parameter) -> None:
+    parts = dotted.split(".")
+    m = root
+    for part in parts[:-1]:
+        if part not in m._modules:
+            m.add_module(part, _Node())
+        m = m._modules[part]
+    m.register_parameter(parts[-1], p)
+
+
+def _init_param(name: str, shape: Tuple[int, ...]) -> torch.Tensor:
+    """Initialisation as the reference leaves it after SimpleUnet3D.__post_init__
+    (diffusion_utils.py:77-80: Xavier-uniform Conv3d/Linear weights, zero biases; GroupNorm 1/0;
+    Conv1d qkv keeps torch's default init; proj_out is zero, unet.py:392)."""
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = len(shape) == 1 and any(s in name for s in (".in_layers.0.", ".out_layers.0.", ".norm.", "out.0."))
+    if is_norm:
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+    if ".proj_out." in name:
+        return torch.zeros(shape)
+    if ".qkv." in name:
+        fan_in = shape[1] if len(shape) > 1 else shape[0]
+        bound = 1.0 / math.sqrt(fan_in)
+        return torch.empty(shape).uniform_(-bound, bound)
+    if leaf == "bias":
+        return torch.zeros(shape)
+    w = torch.empty(shape)
+    torch.nn.init.xavier_uniform_(w)
+    return w
+
+
+@registry.register
+class SimpleUnet3D(Unet3DBase):
+    image_size: int = 64
+    in_channels: int = 128
+    out_channels: int = 128
+    model_channels: int = 128
+    num_res_blocks: int = 2
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 8)
+    attention_resolutions: Tuple[int, ...] = (8, 16)
+    num_heads: int = 2
+    dropout: float = 0.0
+    # 3d down/upsamples have the same size in all 3 dims
+    homogeneous_resample: bool = True
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        if self.dropout != 0.0:
+            raise _lib.HoloError("SimpleUnet3D: dropout must be 0 on the sampling path")
+        self._net = _Node()
+        self._handle: Optional[C.c_void_p] = None
+        self._handle_device: Optional[torch.device] = None
+        self._dirty = True
+        self._param_names = []
+        self._create_parameters()
+
+    # ---- parameter tree -------------------------------------------------------------------
+    def _cfg_struct(self):
+        return _lib.make_unet_cfg(self.image_size, self.in_channels, self.out_channels, self.model_channels,
+                                  self.num_res_blocks, self.channel_mult, self.attention_resolutions, self.num_heads,
+                                  self.homogeneous_resample)
+
+    def _create_parameters(self) -> None:
+        """Parameter names/shapes come from the library's own enumeration (single source of truth)."""
+        for name, shape in self.param_shapes().items():
+            _add_param(self._net, name, torch.nn.Parameter(_init_param(name, shape), requires_grad=False))
+            self._param_names.append(name)
+
+    def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        from .structure import unet_param_shapes
+        return unet_param_shapes(self.image_size, self.in_channels, self.out_channels, self.model_channels,
+                                 self.num_res_blocks, self.channel_mult, self.attention_resolutions)
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move the tensors: re-bind on next forward
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._dirty = True
+        return super().load_state_dict(*a, **k)
+
+    def mark_parameters_changed(self) -> None:
+        """Call after modifying parameter tensors in place so the library re-packs its private copies."""
+        self._dirty = True
+
+    # ---- native handle --------------------------------------------------------------------
+    def _ensure_handle(self, device: torch.device) -> C.c_void_p:
+        L = runtime.lib()
+        if self._handle is None or self._handle_device != device:
+            if self._handle is not None:
+                L.holo_unet_destroy(self._handle)
+            h = C.c_void_p()
+            cfg = self._cfg_struct()
+            _lib.check(L, L.holo_unet_create(runtime.ctx(device), C.byref(cfg), C.byref(h)), "holo_unet_create")
+            # cross-check the library's enumeration against the Python tree
+            n = L.holo_unet_num_params(h)
+            name = C.create_string_buffer(256)
+            shp = (C.c_int64 * 8)()
+            nd = C.c_int()
+            shapes = self.param_shapes()
+            if n != len(shapes):
+                raise _lib.HoloError(f"parameter count mismatch: library {n}, python {len(shapes)}")
+            for i in range(n):
+                _lib.check(L, L.holo_unet_param_info(h, i, name, 256, shp, C.byref(nd)), "holo_unet_param_info")
+                k = name.value.decode()
+                if tuple(shp[:nd.value]) != tuple(shapes.get(k, ())):
+                    raise _lib.HoloError(f"parameter '{k}': library shape {tuple(shp[:nd.value])} != {shapes.get(k)}")
+            self._handle, self._handle_device, self._dirty = h, device, True
+        if self._dirty:
+            sd = dict(self._net.named_parameters())
+            st = runtime.stream_ptr(device)
+            for k in self._param_names:
+                p = sd[k]
+                if p.device != device or p.dtype != torch.float32:
+                    raise _lib.HoloError(f"parameter '{k}' is {p.dtype} on {p.device}; expected float32 on {device}")
+                t = p.detach().contiguous()
+                _lib.check(L, L.holo_unet_set_param(self._handle, k.encode(), runtime.ptr(t), _lib.HOLO_DTYPE_F32,
+                                                   t.dim(), _lib.shape_array(t.shape), st), f"holo_unet_set_param({k})")
+            torch.cuda.current_stream(device).synchronize()  # temporaries from .contiguous() must outlive the copies
+            self._dirty = False
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                runtime.lib().holo_unet_destroy(self._handle)
+        except Exception:
+            pass
+
+    # ---- forward --------------------------------------------------------------------------
+    def forward(self, x, timesteps, cond_features=None, **kwargs):
+        if cond_features is not None:
+            x = torch.cat([x, cond_features], dim=1)
+        runtime.require_device(x, "SimpleUnet3D.forward")
+        if x.dim() != 5 or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != (self.image_size,) * 3:
+            raise _lib.HoloError(f"SimpleUnet3D.forward: expected (N,{self.in_channels},{self.image_size}^3), "
+                                 f"got {tuple(x.shape)}")
+        dev = x.device
+        h = self._ensure_handle(dev)
+        L = runtime.lib()
+        x = x.contiguous().float()
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        B = x.shape[0]
+        if t.shape != (B,):
+            raise _lib.HoloError("SimpleUnet3D.forward: timesteps must have shape (N,)")
+        nbytes = L.holo_unet_workspace_bytes(h, B)
+        ws = runtime.workspace(dev, f"unet{id(self)}", nbytes)
+        y = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
+        _lib.check(L, L.holo_unet_forward(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
+                                          ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
+        return y
+
+    # ---- measurement helper (bench.py) ----------------------------------------------------
+    def time_convs(self, batch: int, iters: int, device: torch.device):
+        """Average ms per forward spent in the conv3d implicit-GEMM launches, their FLOPs and launch count
+        (hipEvents on the stream the kernels run on)."""
+        h = self._ensure_handle(device)
+        L = runtime.lib()
+        nbytes = L.holo_unet_workspace_bytes(h, batch)
+        ws = runtime.workspace(device, f"unet{id(self)}", nbytes)
+        ms, fl, nl = C.c_float(), C.c_double(), C.c_int()
+        _lib.check(L, L.holo_unet_time_convs(h, batch, runtime.ptr(ws), ws.numel(), iters, runtime.stream_ptr(device),
+                                             C.byref(ms), C.byref(fl), C.byref(nl)), "holo_unet_time_convs")
+        return ms.value, fl.value, nl.value

@@ -1,0 +1,80 @@
+"""GPU parity: DDPM ancestral sampler through ImplicitronGaussianDiffusion (HIP UNet + fused step kernel)
+vs trajectories recorded from the reference's GaussianDiffusion.p_sample_loop_progressive."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import holo_diffusion_amd as hda  # noqa: E402
+from oracle import diffusion_oracle as do  # noqa: E402
+from oracle.common import TINY_CFG, np_noise  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import tests.gpu_utils as g
+    return g
+
+
+def _ns(dev):
+    return lambda t, shp, device=None: torch.from_numpy(np_noise(900 * 100003 + t, tuple(shp))).to(dev)
+
+
+@pytest.mark.parametrize("tag,T,max_iter", [("T1000_iter4", 1000, 4), ("T20_full", 20, None)])
+def test_sampler_trajectory_vs_reference(gu, golden_dir, tag, T, max_iter):
+    g = np.load(os.path.join(golden_dir, "tiny_sampler.npz"))
+    net, _ = gu.make_unet(TINY_CFG)
+    with np.errstate(divide="ignore"):
+        diff = hda.ImplicitronGaussianDiffusion(num_steps=T)
+    shape = (1, TINY_CFG.in_channels) + (TINY_CFG.image_size,) * 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        steps = list(diff.p_sample_loop_progressive(net, shape, clip_denoised=True, noise_sampler=_ns(gu.DEV),
+                                                    max_iter=max_iter))
+    assert len(steps) == g[f"{tag}.samples"].shape[0]
+    for i, s in enumerate(steps):
+        assert set(s) == {"sample", "pred_xstart", "noise"}
+        # errors compound along the chain; per-step tolerance 5e-3 of the dynamic range
+        assert gu.rel_err(s["sample"], torch.from_numpy(g[f"{tag}.samples"][i])) < 5e-3, (tag, i)
+        assert gu.rel_err(s["pred_xstart"], torch.from_numpy(g[f"{tag}.pred_xstart"][i])) < 5e-3, (tag, i)
+    final = diff.p_sample_loop(net, shape, noise_sampler=_ns(gu.DEV), max_iter=max_iter)
+    assert torch.equal(final, steps[-1]["sample"])
+    assert final.min() >= -1 and final.max() <= 1  # t=0 step returns the clipped x0
+
+
+def test_step_kernel_bit_exact_vs_oracle(gu):
+    """The fused elementwise tail is a fixed sequence of fp32 mul/add: bit-exact vs the oracle
+    (up to the device exp in sigma, hence 1-ulp tolerance on the noisy steps)."""
+    diff = hda.ImplicitronGaussianDiffusion()
+    orc = do.DiffusionOracle(1000)
+    shape = (2, 8, 4, 4, 4)
+    x, mo, nz = (torch.from_numpy(np_noise(s, shape)) for s in (1, 2, 3))
+    mo = mo * 1.5
+    for tt in (999, 500, 1, 0):
+        t = torch.tensor([tt, max(tt - 1, 0)])
+        ref = orc.p_sample(lambda a, b: mo, x, t, nz, True)
+        out = diff.p_sample(lambda a, b: mo.to(gu.DEV), x.to(gu.DEV), t.to(gu.DEV),
+                            noise_sampler=lambda ti, shp, dev: nz.to(dev))
+        torch.testing.assert_close(out["sample"].cpu(), ref["sample"], rtol=3e-7, atol=1e-7)
+        assert torch.equal(out["pred_xstart"].cpu(), ref["pred_xstart"])
+    pmv = diff.p_mean_variance(lambda a, b: mo.to(gu.DEV), x.to(gu.DEV), torch.tensor([7, 7], device=gu.DEV))
+    refm = orc.p_mean_variance(lambda a, b: mo, x, torch.tensor([7, 7]))
+    for k in ("mean", "variance", "log_variance", "pred_xstart"):
+        torch.testing.assert_close(pmv[k].cpu(), refm[k], rtol=1e-6, atol=1e-7)
+
+
+def test_default_noise_path_runs_and_is_seeded(gu):
+    net, _ = gu.make_unet(TINY_CFG)
+    diff = hda.ImplicitronGaussianDiffusion()
+    shape = (1, TINY_CFG.in_channels) + (TINY_CFG.image_size,) * 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(5)
+        a = diff.p_sample_loop(net, shape, max_iter=3)
+        torch.manual_seed(5)
+        b = diff.p_sample_loop(net, shape, max_iter=3)
+    assert torch.equal(a, b) and torch.isfinite(a).all()

@@ -1,0 +1,67 @@
+"""GPU parity: HoloDiffusionModel end to end (sample -> tanh(net_3d(vf,0)) -> render) vs the oracle pipeline."""
+import math
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import holo_diffusion_amd as hda  # noqa: E402
+from holo_diffusion_amd.generate import generate_samples, render_flyaround  # noqa: E402
+from oracle import diffusion_oracle as do  # noqa: E402
+from oracle import render_oracle as ro  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+from oracle.common import np_noise  # noqa: E402
+
+TINY_UNET = dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2))
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import tests.gpu_utils as g
+    return g
+
+
+def test_sample_then_render_matches_oracle_pipeline(gu):
+    H, W = 12, 20
+    model, ucfg, usd, rcfg, msd = gu.make_model(8, 32, H, W, TINY_UNET, diffusion_args=dict(num_steps=1000))
+    ns = lambda t, shp, dev=None: torch.from_numpy(np_noise(77 * 100003 + t, tuple(shp)))  # noqa: E731
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vf = model.sample_random_voxel_features(max_iter=3,
+                                                noise_sampler=lambda t, s, d: ns(t, s).to(gu.DEV))
+        orc = do.DiffusionOracle(1000)
+        unet = lambda x, t: uo.unet_forward(usd, ucfg, x, t)  # noqa: E731
+        steps = list(orc.p_sample_loop_progressive(unet, (1, 32, 8, 8, 8), ns, True, 3))
+    vf_ref = steps[-1]["sample"]
+    assert gu.rel_err(vf, vf_ref) < 5e-3
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2)
+    preds = model(camera=cams[1].to(gu.DEV), voxel_features=vf_ref.to(gu.DEV))
+    grid_ref = torch.tanh(uo.unet_forward(usd, ucfg, vf_ref, torch.zeros(1, dtype=torch.long)))
+    ref = ro.render(grid_ref, msd, gu.cam_dict(cams, 1), rcfg)
+    assert (preds["images_render"].cpu() - ref["images_render"]).abs().max() < 1e-3
+    assert (preds["masks_render"].cpu() - ref["masks_render"]).abs().max() < 1e-3
+
+
+def test_progressive_generator_clips_and_flyaround_shapes(gu):
+    model, *_ = gu.make_model(8, 32, 8, 8, TINY_UNET, diffusion_args=dict(num_steps=1000))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.manual_seed(0)
+        outs = list(model.sample_random_voxel_features_progressive(max_iter=3))
+        assert len(outs) == 3 and all(o.min() >= -1 and o.max() <= 1 for o in outs)
+        torch.manual_seed(0)
+        fly = render_flyaround(model, n_flyaround_poses=3, device=gu.DEV, sampler_kwargs=dict(max_iter=2))
+        assert fly["images_render"].shape == (3, 3, 8, 8) and fly["voxel_features"].shape == (1, 32, 8, 8, 8)
+        torch.manual_seed(0)
+        fly2 = render_flyaround(model, n_flyaround_poses=3, device=gu.DEV, sampler_kwargs=dict(max_iter=2),
+                                batched=False)
+        assert torch.equal(fly["images_render"], fly2["images_render"])
+        prog = render_flyaround(model, n_flyaround_poses=2, device=gu.DEV, progressive_sampling_steps_per_render=1,
+                                sampler_kwargs=dict(max_iter=2))
+        assert prog["images_render"].shape == (2, 3, 8, 8)
+        res = generate_samples(model, num_samples=2, n_eval_cameras=2, seed=3, device=gu.DEV,
+                               sampler_kwargs=dict(max_iter=2))
+        assert res["images_render"].shape == (2, 2, 3, 8, 8) and torch.isfinite(res["images_render"]).all()

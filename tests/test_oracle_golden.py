@@ -1,0 +1,95 @@
+"""CPU: the oracle (oracle/*.py) reproduces the golden vectors recorded from the REAL reference
+(oracle/make_golden.py, development container).  This is what pins the denoiser half of the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as do
+from oracle import unet_oracle as uo
+from oracle.common import TINY_CFG, PLUMB_CFG, digest, np_noise, seeded_input
+from holo_diffusion_amd.weights import synth_state_dict
+
+
+def test_schedule_tables_bit_equal(golden_dir):
+    g = np.load(os.path.join(golden_dir, "schedule.npz"))
+    for T in (1000, 250, 20):
+        with np.errstate(divide="ignore"):
+            tab = do.schedule_tables(do.linear_betas(T))
+        for k, v in tab.items():
+            assert np.array_equal(v, g[f"T{T}.{k}"]), (T, k)
+    # known-answer values measured on the reference
+    t = do.schedule_tables(do.linear_betas(1000))
+    assert t["posterior_variance"][0] == 0.0
+    np.testing.assert_allclose(t["posterior_variance"][1], 5.45318766e-05, rtol=1e-8)
+    np.testing.assert_allclose(t["posterior_log_variance_clipped"][0], -9.81672514, rtol=1e-8)
+    np.testing.assert_allclose(t["posterior_mean_coef1"][999], 1.2835148717e-4, rtol=1e-8)
+    np.testing.assert_allclose(t["posterior_mean_coef2"][999], 0.98994867827, rtol=1e-8)
+
+
+def test_timestep_embedding(golden_dir):
+    g = np.load(os.path.join(golden_dir, "timestep_embedding.npz"))
+    ts = torch.from_numpy(g["t"])
+    for dim in (32, 64):
+        assert torch.equal(uo.timestep_embedding(ts, dim), torch.from_numpy(g[f"emb{dim}"]))
+
+
+def test_tiny_unet_and_blocks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_unet.npz"))
+    sd = synth_state_dict(uo.unet_param_shapes(TINY_CFG), 1234)
+    for t in (0, 500, 999):
+        trace = {}
+        y = uo.unet_forward(sd, TINY_CFG, seeded_input(TINY_CFG, 7 + t), torch.tensor([t]), trace)
+        torch.testing.assert_close(y, torch.from_numpy(g[f"t{t}.y"]), rtol=1e-5, atol=1e-5)
+        if t == 500:
+            for k in g.files:
+                if k.startswith("t500.") and k not in ("t500.y",):
+                    torch.testing.assert_close(trace[k[5:]], torch.from_numpy(g[k]), rtol=1e-5, atol=1e-5)
+
+
+def test_tiny_unet_batch2(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_unet_b2.npz"))
+    sd = synth_state_dict(uo.unet_param_shapes(TINY_CFG), 1234)
+    x2 = torch.cat([seeded_input(TINY_CFG, 100), seeded_input(TINY_CFG, 101)])
+    y = uo.unet_forward(sd, TINY_CFG, x2, torch.tensor([17, 803]))
+    torch.testing.assert_close(y, torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-5)
+
+
+def test_tiny_ops(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_ops.npz"))
+    sd = synth_state_dict(uo.unet_param_shapes(TINY_CFG), 1234)
+    emb = torch.from_numpy(g["emb"])
+    T = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    torch.testing.assert_close(uo.res_block(sd, "input_blocks.4.0", T("res.x"), emb), T("res.y"), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(uo.downsample(sd, "input_blocks.3.0", T("down.x"), True), T("down.y"), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(uo.attention_block(sd, "input_blocks.4.1", T("attn.x"), 2), T("attn.y"), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(uo.upsample(sd, "output_blocks.2.2", T("up.x"), True), T("up.y"), rtol=1e-5, atol=1e-5)
+
+
+def test_sampler_trajectories(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_sampler.npz"))
+    sd = synth_state_dict(uo.unet_param_shapes(TINY_CFG), 1234)
+    cfg = TINY_CFG
+    shape = (1, cfg.in_channels, cfg.image_size, cfg.image_size, cfg.image_size)
+    model = lambda x, t: uo.unet_forward(sd, cfg, x, t)  # noqa: E731
+    ns = lambda t, shp: torch.from_numpy(np_noise(900 * 100003 + t, tuple(shp)))  # noqa: E731
+    for tag, T, max_iter in (("T1000_iter4", 1000, 4),):
+        with np.errstate(divide="ignore"):
+            orc = do.DiffusionOracle(T)
+        assert orc.indices(max_iter) == g[f"{tag}.indices"].tolist()
+        steps = list(orc.p_sample_loop_progressive(model, shape, ns, True, max_iter))
+        for i, s in enumerate(steps):
+            torch.testing.assert_close(s["sample"], torch.from_numpy(g[f"{tag}.samples"][i]), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(s["pred_xstart"], torch.from_numpy(g[f"{tag}.pred_xstart"][i]), rtol=1e-4, atol=1e-4)
+    assert do.DiffusionOracle(1000).indices(4) == [999, 666, 333, 0]
+
+
+@pytest.mark.slow
+def test_plumbing_unet_digest(golden_dir):
+    g = np.load(os.path.join(golden_dir, "full_unet_digests.npz"))
+    sd = synth_state_dict(uo.unet_param_shapes(PLUMB_CFG), 1234)
+    y = uo.unet_forward(sd, PLUMB_CFG, seeded_input(PLUMB_CFG, 7 + 500), torch.tensor([500]))
+    d = digest(y)
+    np.testing.assert_allclose(d["head"], g["plumb32x16.t500.head"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(d["mean"], g["plumb32x16.t500.mean"], rtol=1e-4, atol=1e-5)
