@@ -83,7 +83,8 @@ def cpu_baseline(w, usd, msd, budget_s=25.0):
     from oracle import render_oracle as ro
     from oracle import unet_oracle as uo
     from oracle.common import np_noise
-    cores = os.cpu_count() or 1
+    # torch's CPU conv3d/GEMM stop scaling (and regress) far below the 256 hardware threads of the GPU box
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = uo.UNetCfg(image_size=w["resol"], in_channels=w["feature_size"], out_channels=w["feature_size"],
                      model_channels=w["model_channels"], num_res_blocks=2, channel_mult=w["channel_mult"],

@@ -32,6 +32,7 @@ struct ConvParams {
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
+  int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
 };
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
@@ -69,14 +70,16 @@ int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);
 int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream);
 int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream);
 
-// per-(n,c) sum and sum of squares (double) of a channels-last tensor; stats must be zeroed first.
-int gn_stats_launch(const float* x, double* stats, int N, int C, int64_t V, void* stream);
+// GroupNorm statistics, stage 1: partial[n][b][c] = (sum, sumsq) in double over voxel slab b (deterministic,
+// no atomics).  gn_stats_geometry gives the slab count B(C, V) the buffers must be sized for.
+void gn_stats_geometry(int C, int64_t V, int* n_blocks, int* vox_per_block);
+int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream);
 
-// GroupNorm(32 groups, eps) folded to per-channel (a,b), optionally composed with FiLM
-// (unet.py:248-250): y = GN(x)*(1+scale)+shift.  Channels [0,C0) use stats0, [C0,C0+C1) stats1.
-int gn_finalize_launch(const double* stats0, int C0, const double* stats1, int C1, int N, int64_t V, int groups,
-                       float eps, const float* gamma, const float* beta, const float* film, int film_stride,
-                       int film_cout, float* coef, void* stream);
+// stage 2: GroupNorm(32 groups, eps) folded to per-channel (a,b), optionally composed with FiLM
+// (unet.py:248-250): y = GN(x)*(1+scale)+shift.  Channels [0,C0) use part0 (B0 slabs), [C0,C0+C1) part1.
+int gn_finalize_launch(const double* part0, int C0, int B0, const double* part1, int C1, int B1, int N, int64_t V,
+                       int groups, float eps, const float* gamma, const float* beta, const float* film,
+                       int film_stride, int film_cout, float* coef, void* stream);
 
 // emb = Linear2(SiLU(Linear1(timestep_embedding(t, mc))));  writes silu(emb) (all consumers apply SiLU first:
 // unet.py:199-205) and emb itself.

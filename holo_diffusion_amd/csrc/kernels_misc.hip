@@ -66,12 +66,15 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm statistics.  x: [N][V][C] channels-last, C % 4 == 0, C/4 <= 256.
-// block = 256 threads: cq = C/4 threads across channels, rows = 256/cq voxels per pass.
-// grid = (blocks over V, N).  Each thread sums <= 32 values in fp32, then switches to double.
+// GroupNorm statistics, two deterministic stages (no atomics, fixed summation order):
+//   stage 1 (gn_stats):    partial[n][b][c] = (sum, sum of squares) over voxel slab b, in double.
+//                          x: [N][V][C] channels-last, C % 4 == 0, C/4 <= 256.  block = 256 threads:
+//                          cq = C/4 threads across channels, rows = 256/cq voxels per pass; grid = (B, N).
+//   stage 2 (gn_finalize): one block per (group, sample) reduces the partials of its channels over all
+//                          slabs, then folds GroupNorm(eps) + affine (+ FiLM) into per-channel (a, b).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int C,
-                                                       int64_t V, int vox_per_block) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
+                                                       int C, int64_t V, int vox_per_block) {
   __shared__ double red[256 * 8];
   const int n = blockIdx.y;
   const int cq = C >> 2;
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   if (vr < rows) {
     float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
     int cnt = 0;
+#pragma unroll 4
     for (int64_t v = vbeg + vr; v < vend; v += rows) {
       const float4 t = *reinterpret_cast<const float4*>(xp + v * C + c4 * 4);
       fs[0] += t.x;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
       fq[1] += t.y * t.y;
       fq[2] += t.z * t.z;
       fq[3] += t.w * t.w;
-      if (++cnt == 32) {
+      if (++cnt == 32) {  // fp32 partial sums stay short; long sums are carried in double
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           ds[e] += fs[e];
@@ -125,50 +129,76 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     for (int r = 0; r < rows; ++r)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += red[(r * cq + tid) * 8 + e];
-    double* dst = stats + ((int64_t)n * C + tid * 4) * 2;
+    double* dst = partial + (((int64_t)n * gridDim.x + blockIdx.x) * C + tid * 4) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(dst + e * 2 + 0, s[e]);
-      atomicAdd(dst + e * 2 + 1, s[4 + e]);
+      dst[e * 2 + 0] = s[e];
+      dst[e * 2 + 1] = s[4 + e];
     }
   }
 }
 
-// coef[n][c] = (a, b) with GN(x)*(1+scale)+shift = a*x + b.  grid = (ceil(Cin/256), N)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ stats0, int C0,
-                                                          const double* __restrict__ stats1, int C1, int64_t V,
+// coef[n][c] = (a, b) with GN(x)*(1+scale)+shift = a*x + b.  grid = (groups, N), block = 256
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part0, int C0, int B0,
+                                                          const double* __restrict__ part1, int C1, int B1, int64_t V,
                                                           int groups, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ film, int film_stride,
                                                           int film_cout, float* __restrict__ coef) {
-  const int n = blockIdx.y;
+  __shared__ double rs[256], rq[256];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int Cin = C0 + C1;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cin) return;
   const int cpg = Cin / groups;
-  const int g = c / cpg;
   double s = 0.0, sq = 0.0;
   for (int k = 0; k < cpg; ++k) {
     const int cc = g * cpg + k;
-    const double* p = cc < C0 ? stats0 + ((int64_t)n * C0 + cc) * 2 : stats1 + ((int64_t)n * C1 + (cc - C0)) * 2;
-    s += p[0];
-    sq += p[1];
+    const double* p;
+    int Cs, cs, B;
+    if (cc < C0) {
+      p = part0;
+      Cs = C0;
+      cs = cc;
+      B = B0;
+    } else {
+      p = part1;
+      Cs = C1;
+      cs = cc - C0;
+      B = B1;
+    }
+    for (int b = tid; b < B; b += 256) {
+      const double* e = p + (((int64_t)n * B + b) * Cs + cs) * 2;
+      s += e[0];
+      sq += e[1];
+    }
   }
-  const double cnt = (double)cpg * (double)V;
-  const double mean = s / cnt;
-  double var = sq / cnt - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  double a = rstd * (double)gamma[c];
-  double b = (double)beta[c] - mean * a;
-  if (film) {
-    const double sc = 1.0 + (double)film[(int64_t)n * film_stride + c];
-    const double sh = (double)film[(int64_t)n * film_stride + film_cout + c];
-    a *= sc;
-    b = b * sc + sh;
+  rs[tid] = s;
+  rq[tid] = sq;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      rs[tid] += rs[tid + o];
+      rq[tid] += rq[tid + o];
+    }
+    __syncthreads();
   }
-  coef[((int64_t)n * Cin + c) * 2 + 0] = (float)a;
-  coef[((int64_t)n * Cin + c) * 2 + 1] = (float)b;
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    const double cnt = (double)cpg * (double)V;
+    const double mean = rs[0] / cnt;
+    double var = rq[0] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    double a = rstd * (double)gamma[c];
+    double b = (double)beta[c] - mean * a;
+    if (film) {
+      const double sc = 1.0 + (double)film[(int64_t)n * film_stride + c];
+      const double sh = (double)film[(int64_t)n * film_stride + film_cout + c];
+      a *= sc;
+      b = b * sc + sh;
+    }
+    coef[((int64_t)n * Cin + c) * 2 + 0] = (float)a;
+    coef[((int64_t)n * Cin + c) * 2 + 1] = (float)b;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -305,34 +335,40 @@ int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, 
   return 0;
 }
 
-int gn_stats_launch(const float* x, double* stats, int N, int C, int64_t V, void* stream) {
+// slab decomposition shared by the planner (buffer sizes) and the launcher
+void gn_stats_geometry(int C, int64_t V, int* n_blocks, int* vox_per_block) {
+  const int cq = C >> 2;
+  const int rows = 256 / cq;
+  int64_t B = cdiv(V, rows);
+  if (B > 256) B = 256;
+  int64_t vpb = cdiv(cdiv(V, B), rows) * rows;
+  *n_blocks = (int)cdiv(V, vpb);
+  *vox_per_block = (int)vpb;
+}
+
+int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream) {
   if ((C & 3) || (C >> 2) > 256) {
     set_error("gn_stats: unsupported C=%d", C);
     return -1;
   }
-  const int cq = C >> 2;
-  const int rows = 256 / cq;
-  // ~1024 blocks per sample at most, at least `rows` voxels (one pass) and at most 64 passes per block
-  int64_t vpb = cdiv(V, 1024);
-  if (vpb < rows) vpb = rows;
-  if (vpb > (int64_t)rows * 64) vpb = (int64_t)rows * 64;
-  vpb = cdiv(vpb, rows) * rows;
-  dim3 grid((unsigned)cdiv(V, vpb), (unsigned)N);
-  HOLO_LAUNCH(gn_stats_kernel, grid, dim3(256), stream, x, stats, C, V, (int)vpb);
+  int B, vpb;
+  gn_stats_geometry(C, V, &B, &vpb);
+  dim3 grid((unsigned)B, (unsigned)N);
+  HOLO_LAUNCH(gn_stats_kernel, grid, dim3(256), stream, x, partial, C, V, vpb);
   return 0;
 }
 
-int gn_finalize_launch(const double* stats0, int C0, const double* stats1, int C1, int N, int64_t V, int groups,
-                       float eps, const float* gamma, const float* beta, const float* film, int film_stride,
-                       int film_cout, float* coef, void* stream) {
+int gn_finalize_launch(const double* part0, int C0, int B0, const double* part1, int C1, int B1, int N, int64_t V,
+                       int groups, float eps, const float* gamma, const float* beta, const float* film,
+                       int film_stride, int film_cout, float* coef, void* stream) {
   const int Cin = C0 + C1;
-  if (Cin % groups) {
-    set_error("gn_finalize: C=%d not divisible by %d groups", Cin, groups);
+  if (Cin % groups || Cin / groups > 256) {
+    set_error("gn_finalize: C=%d not compatible with %d groups", Cin, groups);
     return -1;
   }
-  dim3 grid((unsigned)cdiv(Cin, 256), (unsigned)N);
-  HOLO_LAUNCH(gn_finalize_kernel, grid, dim3(256), stream, stats0, C0, stats1, C1, V, groups, eps, gamma, beta, film,
-              film_stride, film_cout, coef);
+  dim3 grid((unsigned)groups, (unsigned)N);
+  HOLO_LAUNCH(gn_finalize_kernel, grid, dim3(256), stream, part0, C0, B0, part1, C1, B1, V, groups, eps, gamma, beta,
+              film, film_stride, film_cout, coef);
   return 0;
 }
 

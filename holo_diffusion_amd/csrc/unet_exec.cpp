@@ -118,7 +118,8 @@ struct Arena {
 
 struct Act {  // channels-last activation [N][R][R][R][C]
   size_t off = 0, bytes = 0;
-  size_t stats_off = 0;  // in the stats region
+  size_t stats_off = 0, stats_bytes = 0;  // GroupNorm partial sums [N][stats_B][C][2] doubles
+  int stats_B = 0;
   int C = 0, R = 0;
   int refs = 0;
 };
@@ -139,7 +140,7 @@ struct Op {
   const double* d0 = nullptr;
   const double* d1 = nullptr;
   double* dout = nullptr;
-  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0;
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
   int64_t l0 = 0, l1 = 0;
   size_t bytes = 0;
 };
@@ -340,7 +341,7 @@ struct Planner {
 
   Planner(HoloUnet* u_, int N_, void* ws, std::vector<Op>& ops_) : u(u_), N(N_), base((char*)ws), ops(ops_) {
     // generous fixed regions for the small buffers
-    stats_cap = Arena::al((size_t)N * 16 * 1024 * 128);  // N * sum(C) * 16 B, sum(C) <= 128k
+    stats_cap = 0;
     small_cap = Arena::al((size_t)N * 8 * 1024 * 256 + (size_t)N * (u->emb_rows + 4 * u->ted) * 4 + 65536);
     stats_base = 0;
     small_base = stats_cap;
@@ -359,11 +360,16 @@ struct Planner {
     a.R = R;
     a.bytes = (size_t)N * vox(R) * C * sizeof(float);
     a.off = arena_base + arena.alloc(a.bytes);
-    a.stats_off = stats_base + stats_top;
-    stats_top += Arena::al((size_t)N * C * 2 * sizeof(double));
+    int vpb;
+    gn_stats_geometry(C, vox(R), &a.stats_B, &vpb);
+    a.stats_bytes = (size_t)N * a.stats_B * C * 2 * sizeof(double);
+    a.stats_off = arena_base + arena.alloc(a.stats_bytes);
     return a;
   }
-  void release(Act& a) { arena.free(a.off - arena_base, a.bytes); }
+  void release(Act& a) {
+    arena.free(a.off - arena_base, a.bytes);
+    arena.free(a.stats_off - arena_base, a.stats_bytes);
+  }
   size_t small_alloc(size_t bytes) {
     size_t off = small_base + small_top;
     small_top += Arena::al(bytes);
@@ -392,6 +398,8 @@ struct Planner {
     op.i0 = x0.C;
     op.d1 = x1 ? ptr<double>(x1->stats_off) : nullptr;
     op.i1 = x1 ? x1->C : 0;
+    op.i4 = x0.stats_B;
+    op.i5 = x1 ? x1->stats_B : 0;
     op.l0 = vox(x0.R);
     op.f0 = gamma;
     op.f1 = beta;
@@ -602,13 +610,6 @@ struct Planner {
     const int R = c.image_size;
     ops.clear();
     u->block_outputs.clear();
-    {
-      Op op;
-      op.kind = OP_MEMSET;
-      op.o0 = ptr<float>(stats_base);
-      op.bytes = stats_cap;
-      ops.push_back(op);
-    }
     // time embedding
     size_t emb = small_alloc((size_t)N * u->ted * 4);
     size_t embs = small_alloc((size_t)N * u->ted * 4);
@@ -714,8 +715,8 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
     case OP_STATS:
       return gn_stats_launch(op.f0, op.dout, N, op.i0, op.l0, stream);
     case OP_FINAL:
-      return gn_finalize_launch(op.d0, op.i0, op.d1, op.i1, N, op.l0, 32, 1e-5f, op.f0, op.f1, op.f2, op.i2, op.i3,
-                                op.o0, stream);
+      return gn_finalize_launch(op.d0, op.i0, op.i4, op.d1, op.i1, op.i5, N, op.l0, 32, 1e-5f, op.f0, op.f1, op.f2,
+                                op.i2, op.i3, op.o0, stream);
     case OP_CONV:
       return conv_launch(op.conv, stream);
     case OP_GEMM:

@@ -11,7 +11,7 @@ echo "== pytest -m gpu" ; timeout 1500 python -m pytest tests -m gpu -q --tb=sho
 tail -40 $OUT/pytest_gpu.log
 echo "== bench" ; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err ; echo "bench rc=$?" ; cat $OUT/bench.json ; tail -5 $OUT/bench.err
 echo "== rocprofv3 kernel trace"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --frames 2 --no-cpu-baseline --conv-iters 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err ; echo "rocprof rc=$?" )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --frames 2 --no-cpu-baseline --conv-iters 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err ; echo "rocprof rc=$?" )
 find /tmp/prof_$TAG -name "*stats*" | head ; 
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 head -30 $OUT/kernel_stats.csv 2>/dev/null

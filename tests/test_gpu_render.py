@@ -102,10 +102,14 @@ def test_constant_density_slab_closed_form(gu):
     assert torch.all(p["masks_render"] == 1.0)
     col = torch.sigmoid(torch.nn.functional.leaky_relu(torch.tensor([0.3, -0.2, 1.0]), 0.2))
     torch.testing.assert_close(p["images_render"][0, :, 3, 4].cpu(), col, rtol=1e-5, atol=1e-5)
-    # depth is the same for every ray (uniform medium) and close to near + 1/s for a dense sampling
+    # depth is the same for every ray (uniform medium); closed form for the 64 coarse + 64 fine depths
     d = p["depths_render"]
     assert (d.max() - d.min()) < 1e-3
-    assert abs(d.mean().item() - (6.0 + 1.0 / s)) < 0.2
+    zc = torch.linspace(6.0, 14.0, 64, dtype=torch.float64)
+    wts = torch.exp(-s * (zc - zc[0])) * (1 - torch.exp(-s * torch.cat([zc[1:] - zc[:-1], torch.tensor([1e10])])))
+    zf = ro.refine_lengths(zc.float()[None], wts.float()[None], rcfg)[0].double()
+    wf = torch.exp(-s * (zf - zf[0])) * (1 - torch.exp(-s * torch.cat([zf[1:] - zf[:-1], torch.tensor([1e10])])))
+    assert abs(d.mean().item() - float((wf * zf).sum())) < 2e-3
 
 
 def test_batched_views_equal_single_views_and_are_deterministic(gu):
