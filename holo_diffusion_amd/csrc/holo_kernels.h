@@ -23,7 +23,8 @@ struct ConvParams {
   int OD, OH, OW;
   int stride, pad, ksz;  // ksz = 3 (27 taps) or 1
   int Cout;
-  const float* w;         // [ksz^3][Cout][Cin]
+  const float* w;         // [ksz^3][CoutP][CinP], zero padded: CoutP, CinP = Cout, Cin rounded up to 32
+  int CoutP, CinP;
   const float* coef;      // [N][Cin][2] = (a,b): x' = a*x+b ; null = identity
   int act;                // 1: SiLU after the affine (only with coef)
   const float* bias;      // [Cout] or null
@@ -96,25 +97,32 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
 int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
 
-// OIDHW [Cout][Cin][taps] -> [taps][Cout][Cin]
-int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, void* stream);
+// OIDHW [Cout][Cin][taps] -> zero padded [taps][CoutP][CinP]
+int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
+                              void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // renderer (kernels_render.hip)
 // ---------------------------------------------------------------------------------------------
+// packed RenderMLP (built by render_exec.cpp::holo_renderer_commit)
+struct MlpParams {
+  const float* w_feat;  // [Hd][C]   folded density-net rows 0..Hd-1 (hidden features)
+  const float* b_feat;  // [Hd]
+  const float* w_dens;  // [C]       folded density row
+  float b_dens;
+  const float* w_rad;   // [3][Hd]   radiance weights on the hidden features
+  const float* u_rad;   // [3][C]    0.6 * W_eff[:Hd]^T w_rad[c]  (linear part of LeakyReLU folded)
+  const float* w_dir;   // [3][27]   radiance weights on the direction embedding
+  float b_rad[3];
+  float k_rad[3];       // 0.6 * w_rad[c] . b_eff[:Hd]
+  int Hd;
+};
+
 struct RenderKernelParams {
   const float* grid_cl;  // (R,R,R,C) channels-last voxel features
   int R, C;
   float half_extent;  // 0.5*(R-1)*voxel_size (VolumeLocator local->world scale)
-  // packed RenderMLP (see render_exec.cpp for the layouts)
-  const float* w_feat;   // [Hd][C]   collapsed density-net rows 0..Hd-1 (hidden features)
-  const float* b_feat;   // [Hd]
-  const float* w_dens;   // [C]       collapsed density row
-  float b_dens;
-  const float* w_rad;    // [3][Hd]   radiance weights on the hidden features
-  const float* w_dir;    // [3][27]   radiance weights on the direction embedding
-  float b_rad[3];
-  int Hd;
+  MlpParams mlp;
   // camera
   float Rm[9], T[3], focal[2], pp[2];
   float zmin, zmax;
@@ -132,6 +140,23 @@ struct RenderKernelParams {
   float* depth_c;
   float* mask_c;
 };
+
+// stand-alone implicit function: densities[P], colours[P][3] at world points pts[P][3];
+// direction of point i is dirs[i / pts_per_dir] (pts_per_dir = 1: one direction per point)
+struct ImplicitEvalParams {
+  const float* grid_cl;
+  int R, C;
+  float half_extent;
+  MlpParams mlp;
+  const float* pts;
+  const float* dirs;
+  float* rdir;  // scratch [ceil(n_points / pts_per_dir)][3]: radiance direction term per direction
+  int64_t n_points;
+  int64_t pts_per_dir;
+  float* densities;
+  float* colours;
+};
+int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
 int render_launch(const RenderKernelParams& p, void* stream);
 
 }  // namespace holo

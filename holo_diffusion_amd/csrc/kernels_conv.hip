@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
   float4 ra[4];
   float4 rb[NT];
+  float4 rc01[4], rc23[4];
+  unsigned amask = 0;
 
+  // loads are unconditional from clamped addresses (see the halo kernel for why); validity is a mask
   auto load_chunk = [&](int kc) {
     const int tap = kc / ncc;
     const int cc = kc - tap * ncc;
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
       kh = (tap - kd * 9) / 3;
       kw = tap - kd * 9 - kh * 3;
     }
-    const int c = cc * BK + q * 4;  // channel in the concatenated input
+    int c = cc * BK + q * 4;  // channel in the concatenated input
     const bool cvalid = c < Cin;
+    if (!cvalid) c = 0;
     const float* src = p.src0;
     int Cs = p.C0, cs = c;
     if (c >= p.C0) {
@@ -100,49 +104,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
       Cs = p.C1;
       cs = c - p.C0;
     }
+    amask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int z = az[j] + kd, y = ay[j] + kh, x = ax[j] + kw;
-      bool ok = av[j] && cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        if (p.ups) {
-          z >>= 1;
-          y >>= 1;
-          x >>= 1;
-        }
-        int64_t idx = ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs;
-        v = *reinterpret_cast<const float4*>(src + idx);
-        if (p.coef) {
-          const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
-          float4 c01 = cf[0], c23 = cf[1];
-          v.x = v.x * c01.x + c01.y;
-          v.y = v.y * c01.z + c01.w;
-          v.z = v.z * c23.x + c23.y;
-          v.w = v.w * c23.z + c23.w;
-          if (p.act) {
-            v.x = silu_f(v.x);
-            v.y = silu_f(v.y);
-            v.z = silu_f(v.z);
-            v.w = silu_f(v.w);
-          }
-        }
+      const bool ok = av[j] && cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+      z = min(max(z, 0), p.ID - 1);
+      y = min(max(y, 0), p.IH - 1);
+      x = min(max(x, 0), p.IW - 1);
+      if (p.ups) {
+        z >>= 1;
+        y >>= 1;
+        x >>= 1;
       }
-      ra[j] = v;
+      const int64_t idx = ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs;
+      ra[j] = *reinterpret_cast<const float4*>(src + idx);
+      amask |= (ok ? 1u : 0u) << j;
+      if (p.coef) {
+        const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
+        rc01[j] = cf[0];
+        rc23[j] = cf[1];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      int co = n0 + r0 + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (co < p.Cout && cvalid) v = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.Cout + co) * Cin + c);
-      rb[j] = v;
+      const int co = n0 + r0 + 32 * j;  // < CoutP by construction of the grid
+      rb[j] = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.CoutP + co) * p.CinP + cc * BK + q * 4);
     }
   };
 
   auto store_chunk = [&](int buf) {
     float* base = lds + buf * BUF;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(base + (r0 + 32 * j) * LDK + q * 4) = ra[j];
+    for (int j = 0; j < 4; ++j) {
+      float4 v = ra[j];
+      if (p.coef) {
+        v.x = v.x * rc01[j].x + rc01[j].y;
+        v.y = v.y * rc01[j].z + rc01[j].w;
+        v.z = v.z * rc23[j].x + rc23[j].y;
+        v.w = v.w * rc23[j].z + rc23[j].w;
+        if (p.act) {
+          v.x = silu_f(v.x);
+          v.y = silu_f(v.y);
+          v.z = silu_f(v.z);
+          v.w = silu_f(v.w);
+        }
+      }
+      const float keep = ((amask >> j) & 1u) ? 1.f : 0.f;
+      v.x *= keep;
+      v.y *= keep;
+      v.z *= keep;
+      v.w *= keep;
+      *reinterpret_cast<float4*>(base + (r0 + 32 * j) * LDK + q * 4) = v;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(base + (BM + r0 + 32 * j) * LDK + q * 4) = rb[j];
   };
@@ -226,29 +240,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Halo variant for stride-1 3x3x3 convolutions (the 95% of the FLOPs): the block's output tile is
-// 2 x 8 x 8 voxels (z,y,x) = 128 GEMM rows; for one 32-channel chunk its 4 x 10 x 10 input halo is staged
-// ONCE in LDS (GroupNorm/FiLM/SiLU applied once per element) and all 27 taps read their A fragments from it
-// at shifted addresses, so global loads, activation math and LDS writes of the A operand drop 8.6x
-// (27 taps * 128 voxels / 400 halo voxels) relative to the per-tap gather above.  Only the 64 x 32 weight
-// tile changes per tap (double buffered, one barrier per tap).  Split-K runs over channel chunks.
-// LDS: halo 400 x 36 floats (57.6 KB) + 2 x (32*NT) x 36 floats  ->  two workgroups per CU.
+// Halo kernel for stride-1 3x3x3 convolutions (95% of the FLOPs).
+//
+// Block = 4 waves, output tile = 2 x 8 x 8 voxels (z,y,x) = 128 GEMM rows x (16*NWN) output channels.
+// For one 32-channel chunk the 4 x 10 x 10 input halo of the tile is staged ONCE in LDS (GroupNorm/FiLM/
+// SiLU applied once per element, zero padding after the activation) and all 27 taps read their A
+// fragments from it at shifted addresses: global loads, activation math and LDS writes of the A operand
+// drop 8.6x (27*128/400) relative to the per-tap gather kernel above.
+//
+// Work split inside the block: each wave OWNS a 16-wide Cout slice and sweeps the voxels of the tile with
+// v_mfma_f32_16x16x4_f32 (A = 16 voxels x 4 channels, B = 4 channels x 16 Cout).  Consequences:
+//   * the weights of a tap are needed by exactly one wave, so they go global -> registers directly
+//     (two 16-byte loads per lane per tap, prefetched one tap ahead), never through LDS: the 27-tap
+//     loop has NO barrier and no wave re-fetches another wave's weights;
+//   * the A operand is the block-shared LDS halo; a tap's A fragments for the wave's MT voxel tiles are
+//     2*MT ds_read_b128 per lane, software-pipelined in two halves behind the MFMAs.
+// K index inside a chunk: lane quarter kq = lane>>4 (the MFMA k index) owns channels [8kq, 8kq+8), k-step
+// ks of the 8 per tap uses channel 8kq+ks, so a lane's operands for a whole tap are 8 contiguous floats.
+// The halo of the NEXT channel chunk is requested under the last tap and committed after it (two
+// barriers per chunk).  Split-K runs over channel chunks.
+// LDS: 400 x 36 floats = 57.6 KB -> two workgroups per CU.
 // ---------------------------------------------------------------------------------------------
 constexpr int HZ = 4, HY = 10, HX = 10;
 constexpr int HALO_VOX = HZ * HY * HX;
+constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // halo rows per thread (8 threads cover one row's 32 channels)
 
-template <int NT>
+template <int NWN>  // waves along Cout: 4 -> 64 channels per block, 2 -> 32 channels per block
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
-  constexpr int BN = 32 * NT;
-  constexpr int WBUF = BN * LDK;
+  constexpr int BN = 16 * NWN;
+  constexpr int MT = 2 * NWN;  // 16-voxel tiles per wave: 8 (all 128 voxels) or 4 (64 voxels)
   __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * LDK];
-  __shared__ __attribute__((aligned(16))) float s_wt[2 * WBUF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int li = lane & 31;
-  const int lh = lane >> 5;
+  const int lj = lane & 15;
+  const int kq = lane >> 4;
+  const int wn = wave % NWN;
+  const int wm = wave / NWN;
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
   // spatial tile decode
@@ -270,25 +299,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 
   const int q = tid & 7;
   const int r0 = tid >> 3;
-  float4 rb[NT];
 
-  auto load_w = [&](int cc, int tap) {
-    const int c = cc * BK + q * 4;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int co = n0 + r0 + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (co < p.Cout && c < Cin) v = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.Cout + co) * Cin + c);
-      rb[j] = v;
-    }
-  };
-  auto store_w = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(s_wt + buf * WBUF + (r0 + 32 * j) * LDK + q * 4) = rb[j];
-  };
-  auto stage_halo = [&](int cc) {
-    const int c = cc * BK + q * 4;
+  // ---- halo staging, split in "issue the loads" / "transform + write LDS"
+  float4 hreg[HALO_IT];
+  unsigned hmask = 0;  // bit i: element i is inside the volume (zero padding otherwise)
+  int hcoef_c = 0;
+  auto halo_issue = [&](int cc) {
+    int c = cc * BK + q * 4;
+    hcoef_c = c;
     const bool cvalid = c < Cin;
+    if (!cvalid) c = 0;  // clamped, masked below
     const float* src = p.src0;
     int Cs = p.C0, cs = c;
     if (c >= p.C0) {
@@ -296,112 +316,156 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
       Cs = p.C1;
       cs = c - p.C0;
     }
-    float4 c01 = make_float4(1.f, 0.f, 1.f, 0.f), c23 = c01;
-    if (p.coef && cvalid) {
-      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + c) * 2);
-      c01 = cf[0];
-      c23 = cf[1];
-    }
-    for (int hv = r0; hv < HALO_VOX; hv += 32) {
+    hmask = 0;
+    // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards:
+    // a "load or zero" branch would make the compiler wait for each load before the next one is issued.
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int hv = min(r0 + 32 * i, HALO_VOX - 1);
       const int hz = hv / (HY * HX);
       const int rem = hv - hz * (HY * HX);
       const int hy = rem / HX;
       const int hx = rem - hy * HX;
       int z = tz0 + hz - 1, y = ty0 + hy - 1, x = tx0 + hx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW) {
-        if (p.ups) {
-          z >>= 1;
-          y >>= 1;
-          x >>= 1;
-        }
-        v = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + y) * SW + x) * Cs + cs);
-        if (p.coef) {
-          v.x = v.x * c01.x + c01.y;
-          v.y = v.y * c01.z + c01.w;
-          v.z = v.z * c23.x + c23.y;
-          v.w = v.w * c23.z + c23.w;
-          if (p.act) {
-            v.x = silu_f(v.x);
-            v.y = silu_f(v.y);
-            v.z = silu_f(v.z);
-            v.w = silu_f(v.w);
-          }
+      const bool ok = cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+      z = min(max(z, 0), p.ID - 1);
+      y = min(max(y, 0), p.IH - 1);
+      x = min(max(x, 0), p.IW - 1);
+      if (p.ups) {
+        z >>= 1;
+        y >>= 1;
+        x >>= 1;
+      }
+      hreg[i] = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + y) * SW + x) * Cs + cs);
+      hmask |= (ok ? 1u : 0u) << i;
+    }
+  };
+  auto halo_commit = [&]() {
+    float4 c01 = make_float4(1.f, 0.f, 1.f, 0.f), c23 = c01;
+    if (p.coef) {
+      const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
+      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
+      c01 = cf[0];
+      c23 = cf[1];
+    }
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int hv = r0 + 32 * i;
+      float4 v = hreg[i];
+      if (p.coef) {
+        v.x = v.x * c01.x + c01.y;
+        v.y = v.y * c01.z + c01.w;
+        v.z = v.z * c23.x + c23.y;
+        v.w = v.w * c23.z + c23.w;
+        if (p.act) {
+          v.x = silu_f(v.x);
+          v.y = silu_f(v.y);
+          v.z = silu_f(v.z);
+          v.w = silu_f(v.w);
         }
       }
-      *reinterpret_cast<float4*>(s_halo + hv * LDK + q * 4) = v;
+      const float keep = ((hmask >> i) & 1u) ? 1.f : 0.f;  // zero padding is applied AFTER the activation
+      v.x *= keep;
+      v.y *= keep;
+      v.z *= keep;
+      v.w *= keep;
+      if (hv < HALO_VOX) *reinterpret_cast<float4*>(s_halo + hv * LDK + q * 4) = v;
     }
   };
 
-  f32x16 acc[NT];
+  f32x4 acc[MT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 
-  // this lane's output voxel inside the tile: m = wave*32 + li -> (z = m>>6, y = (m>>3)&7, x = m&7)
-  const int mz = wave >> 1, my = ((wave & 1) << 2) + (li >> 3), mx = li & 7;
-  const int hbase = (mz * HY + my) * HX + mx;
+  // A addressing: voxel tile mt of this wave covers block rows m = (wm*MT + mt)*16 + lj
+  //   -> (z = m>>6, y = (m>>3)&7, x = m&7); lane reads 8 channels starting at 8*kq
+  int a_off[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int m = (wm * MT + t) * 16 + lj;
+    a_off[t] = (((m >> 6) * HY + ((m >> 3) & 7)) * HX + (m & 7)) * LDK + kq * 8;
+  }
+  // B addressing: weight row of this lane's output channel, 8 channels starting at 8*kq of the chunk
+  const float* w_row = p.w + (int64_t)(n0 + wn * 16 + lj) * p.CinP + kq * 8;
+  const int64_t w_tap_stride = (int64_t)p.CoutP * p.CinP;
 
+  auto load_a = [&](float4 (&a)[MT], int tap, int half) {
+    const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+    const int toff = ((kd * HY + kh) * HX + kw) * LDK + half * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(s_halo + a_off[t] + toff);
+  };
+  auto load_b = [&](float4 (&b)[2], int cc, int tap) {
+    const float4* wp = reinterpret_cast<const float4*>(w_row + tap * w_tap_stride + cc * BK);
+    b[0] = wp[0];
+    b[1] = wp[1];
+  };
+  auto mfma_half = [&](const float4 (&a)[MT], const float4& b) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
+  };
+
+  float4 aA[MT], aB[MT], aC[MT];  // rotating A buffers: first half of this tap, second half, first half of next tap
+  float4 b0[2], b1[2];
+
+  // one tap: on entry `cur` holds the first-half A operands of `tap` and `bc` its weights
+  auto tap_body = [&](float4 (&cur)[MT], float4 (&nxt)[MT], float4 (&bc)[2], float4 (&bn)[2], int cc, int tap,
+                      bool prefetch) {
+    load_a(aB, tap, 1);
+    if (prefetch) load_b(bn, cc, tap + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above AHEAD of the MFMAs that hide their latency
+    mfma_half(cur, bc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prefetch) load_a(nxt, tap + 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(aB, bc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  halo_issue(cc_begin);
   for (int cc = cc_begin; cc < cc_end; ++cc) {
-    stage_halo(cc);
-    load_w(cc, 0);
-    store_w(0);
-    __syncthreads();
-    for (int tap = 0; tap < 27; ++tap) {
-      const int buf = tap & 1;
-      if (tap + 1 < 27) load_w(cc, tap + 1);
-      const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
-      const float4* ap = reinterpret_cast<const float4*>(s_halo + (hbase + (kd * HY + kh) * HX + kw) * LDK + lh * 16);
-      float a[16];
-      float b[NT][16];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 t4 = ap[v];
-        a[4 * v + 0] = t4.x;
-        a[4 * v + 1] = t4.y;
-        a[4 * v + 2] = t4.z;
-        a[4 * v + 3] = t4.w;
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float4* bp = reinterpret_cast<const float4*>(s_wt + buf * WBUF + (t * 32 + li) * LDK + lh * 16);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const float4 t4 = bp[v];
-          b[t][4 * v + 0] = t4.x;
-          b[t][4 * v + 1] = t4.y;
-          b[t][4 * v + 2] = t4.z;
-          b[t][4 * v + 3] = t4.w;
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[t][ks], acc[t], 0, 0, 0);
-      if (tap + 1 < 27) store_w(buf ^ 1);
-      __syncthreads();
+    halo_commit();
+    load_b(b0, cc, 0);
+    __syncthreads();  // halo of chunk cc visible
+    load_a(aA, 0, 0);
+    for (int tap = 0; tap < 26; tap += 2) {
+      tap_body(aA, aC, b0, b1, cc, tap, true);
+      tap_body(aC, aA, b1, b0, cc, tap + 1, true);
     }
+    // the next chunk's halo loads fly under the last tap
+    if (cc + 1 < cc_end) halo_issue(cc + 1);
+    tap_body(aA, aC, b0, b1, cc, 26, false);
+    __syncthreads();  // everyone done reading this halo before it is overwritten
   }
 
+  // ---- epilogue: 16x16x4 D layout: col = lane&15 (Cout), row = 4*(lane>>4) + r (voxel inside the tile)
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int co = n0 + t * 32 + li;
-    if (co >= p.Cout) continue;
+  const int co = n0 + wn * 16 + lj;
+  if (co < p.Cout) {
     const float bv = (p.nsplit == 1 && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int z = row >> 6, y = (row >> 3) & 7, x = row & 7;
-      const int64_t m = (((int64_t)n * p.OD + tz0 + z) * p.OH + ty0 + y) * p.OW + tx0 + x;
-      float v = acc[t][r];
-      if (p.nsplit == 1) {
-        v += bv;
-        if (p.residual) v += p.residual[m * p.Cout + co];
-        p.out[m * p.Cout + co] = v;
-      } else {
-        p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (wm * MT + t) * 16 + 4 * kq + r;
+        const int z = row >> 6, y = (row >> 3) & 7, x = row & 7;
+        const int64_t m = (((int64_t)n * p.OD + tz0 + z) * p.OH + ty0 + y) * p.OW + tx0 + x;
+        float v = acc[t][r];
+        if (p.nsplit == 1) {
+          v += bv;
+          if (p.residual) v += p.residual[m * p.Cout + co];
+          p.out[m * p.Cout + co] = v;
+        } else {
+          p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
+        }
       }
     }
   }
@@ -452,7 +516,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   int nsplit = 1;
   const int64_t target = 2 * (int64_t)num_cus;
   p.mode = (p.ksz == 3 && p.stride == 1 && p.pad == 1 && (p.OD % 2) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 &&
-            p.ID == p.OD && p.IH == p.OH && p.IW == p.OW)
+            p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0)
                ? 1
                : 0;
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
@@ -502,9 +566,9 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)(M / BM), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     if (wide) {
-      HOLO_LAUNCH(conv_halo_kernel<2>, hgrid, block, stream, p);
+      HOLO_LAUNCH(conv_halo_kernel<4>, hgrid, block, stream, p);
     } else {
-      HOLO_LAUNCH(conv_halo_kernel<1>, hgrid, block, stream, p);
+      HOLO_LAUNCH(conv_halo_kernel<2>, hgrid, block, stream, p);
     }
   } else if (wide) {
     HOLO_LAUNCH(conv_igemm_kernel<2>, grid, block, stream, p);

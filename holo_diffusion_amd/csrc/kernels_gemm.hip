@@ -41,51 +41,68 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   const int kr = tid >> 4;
 
   float4 ra[4], rb[2];
+  unsigned amask = 0, bmask = 0;
 
+  // unconditional loads from clamped addresses, masked at LDS-store time (a "load or zero" branch would make
+  // the compiler serialise the loads)
   auto load_chunk = [&](int kc) {
     const int k = kc * BK + q * 4;
+    const bool kok = k < p.K;
+    const int kc4 = kok ? k : 0;
+    amask = 0;
+    bmask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + r0 + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M && k < p.K) v = *reinterpret_cast<const float4*>(A + (int64_t)m * p.lda + k);
-      ra[j] = v;
+      ra[j] = *reinterpret_cast<const float4*>(A + (int64_t)min(m, p.M - 1) * p.lda + kc4);
+      amask |= ((m < p.M && kok) ? 1u : 0u) << j;
     }
     if (!p.b_kmajor) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int n = n0 + r0 + 32 * j;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.Nn && k < p.K) v = *reinterpret_cast<const float4*>(B + (int64_t)n * p.ldb + k);
-        rb[j] = v;
+        rb[j] = *reinterpret_cast<const float4*>(B + (int64_t)min(n, p.Nn - 1) * p.ldb + kc4);
+        bmask |= ((n < p.Nn && kok) ? 1u : 0u) << j;
       }
     } else {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int kk = kc * BK + kr + 16 * j;
         const int n = n0 + nq * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < p.K && n < p.Nn) v = *reinterpret_cast<const float4*>(B + (int64_t)kk * p.ldb + n);
-        rb[j] = v;
+        rb[j] = *reinterpret_cast<const float4*>(B + (int64_t)min(kk, p.K - 1) * p.ldb + min(n, p.Nn - 4));
+        bmask |= ((kk < p.K && n < p.Nn) ? 1u : 0u) << j;
       }
     }
   };
   auto store_chunk = [&](int buf) {
     float* base = lds + buf * BUF;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(base + (r0 + 32 * j) * LDK + q * 4) = ra[j];
-    if (!p.b_kmajor) {
+    for (int j = 0; j < 4; ++j) {
+      const float keep = ((amask >> j) & 1u) ? 1.f : 0.f;
+      float4 v = ra[j];
+      v.x *= keep;
+      v.y *= keep;
+      v.z *= keep;
+      v.w *= keep;
+      *reinterpret_cast<float4*>(base + (r0 + 32 * j) * LDK + q * 4) = v;
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(base + (BM + r0 + 32 * j) * LDK + q * 4) = rb[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j) {
+      const float keep = ((bmask >> j) & 1u) ? 1.f : 0.f;
+      float4 v = rb[j];
+      v.x *= keep;
+      v.y *= keep;
+      v.z *= keep;
+      v.w *= keep;
+      if (!p.b_kmajor) {
+        *reinterpret_cast<float4*>(base + (BM + r0 + 32 * j) * LDK + q * 4) = v;
+      } else {
         const int kk = kr + 16 * j;
         float* d = base + (BM + nq * 4) * LDK + kk;
-        d[0] = rb[j].x;
-        d[LDK] = rb[j].y;
-        d[2 * LDK] = rb[j].z;
-        d[3 * LDK] = rb[j].w;
+        d[0] = v.x;
+        d[LDK] = v.y;
+        d[2 * LDK] = v.z;
+        d[3 * LDK] = v.w;
       }
     }
   };

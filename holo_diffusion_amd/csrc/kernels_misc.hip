@@ -309,16 +309,16 @@ __global__ __launch_bounds__(256) void clip_kernel(const float* __restrict__ x, 
     y[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
-// [Cout][Cin][taps] -> [taps][Cout][Cin]
+// [Cout][Cin][taps] -> zero padded [taps][CoutP][CinP]
 __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                                 int Cout, int Cin, int taps) {
-  const int64_t total = (int64_t)Cout * Cin * taps;
+                                                                 int Cout, int Cin, int taps, int CoutP, int CinP) {
+  const int64_t total = (int64_t)CoutP * CinP * taps;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Cin);
-    const int64_t r = i / Cin;
-    const int co = (int)(r % Cout);
-    const int tap = (int)(r / Cout);
-    out[i] = w[((int64_t)co * Cin + ci) * taps + tap];
+    const int ci = (int)(i % CinP);
+    const int64_t r = i / CinP;
+    const int co = (int)(r % CoutP);
+    const int tap = (int)(r / CoutP);
+    out[i] = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
   }
 }
 
@@ -414,11 +414,13 @@ int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* s
   HOLO_LAUNCH(clip_kernel, dim3((unsigned)blocks), dim3(256), stream, x, y, lo, hi, n);
   return 0;
 }
-int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, void* stream) {
-  int64_t total = (int64_t)Cout * Cin * taps;
+int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
+                              void* stream) {
+  int64_t total = (int64_t)CoutP * CinP * taps;
   int64_t blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
-  HOLO_LAUNCH(repack_conv_weight_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, taps);
+  HOLO_LAUNCH(repack_conv_weight_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, taps, CoutP,
+              CinP);
   return 0;
 }
 

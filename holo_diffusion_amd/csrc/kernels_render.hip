@@ -1,6 +1,7 @@
-// kernels_render.hip — one fused kernel per rendered frame, replacing the PyTorch3D/Implicitron render
-// path of the reference (chunk loop + ~60 ATen launches per chunk, 63 chunks per 400^2 frame):
+// kernels_render.hip — the render side of the hot path.
 //
+// render_kernel: one fused kernel per rendered frame, replacing the PyTorch3D/Implicitron render path of
+// the reference (chunk loop + ~60 ATen launches per chunk, 63 chunks per 400^2 frame):
 //   ray generation   NDCMultinomialRaysampler/_xy_to_ray_bundle + AdaptiveRaySampler bounds
 //                    (invoked at holo_diffusion_model.py:442-448; configs/apple.yaml:135-146)
 //   voxel fetch      VolumeLocator.world_to_local_coords + F.grid_sample(bilinear, zeros, align_corners)
@@ -13,38 +14,198 @@
 //   resampling       RayPointRefiner + sample_pdf (det.) + sort (holo_multipass_ea.py:116), done as a
 //                    lazily generated inverse-CDF stream merged with the coarse depths
 //   fine pass        holo_multipass_ea.py:117-123
+// implicit_eval_kernel: the stand-alone HoloVoxelGridImplicitFunction.forward (densities, colours) for
+// arbitrary points (holo_voxel_grid_implicit_function.py:182-269, incl. the pts_3d entry the reference's
+// tests use).
 //
-// Mapping: block = 4 waves, wave = 32 rays; lanes l and l+32 share ray (l&31) and split the feature
-// channels in halves (lane half h owns channels [h*CH, h*CH+CH)), which is exactly the k index of
-// v_mfma_f32_32x32x2_f32.  Per march step a wave evaluates 32 samples (one per ray):
+// Mapping: block = 4 waves, wave = 32 rays/points; lanes l and l+32 share item (l&31) and split the
+// feature channels in halves (lane half h owns channels [h*CH, h*CH+CH)), which is exactly the k index of
+// v_mfma_f32_32x32x2_f32.  Per step a wave evaluates 32 samples:
 //   D[hidden][sample] += W_eff[hidden][ch] * f[sample][ch]   (A = weights from LDS, B = the lane's own
-//   interpolated features) so every lane ends up with 16 hidden units of ITS ray per 32-row tile; the
+//   interpolated features) so every lane ends up with 16 hidden units of ITS sample per 32-row tile; the
 //   LeakyReLU + 3x256 radiance dot product is then lane-local and only one cross-half shuffle is needed.
+// LeakyReLU_0.2(h) = 0.6 h + 0.4 |h|: the 0.6 h part of the radiance sum is linear in f and is folded on the
+// host into a C-vector per colour (u_rad); only sum_rows 0.4 w |h| is accumulated per row (one FMA with a
+// free |.| input modifier per colour) — two VALU ops per row fewer than max(h, 0.2h) * w.
 // The voxel grid is channels-last so a corner is CH*4 contiguous bytes per lane; the 33.5 MB grid stays
-// resident in the 256 MB Infinity Cache / L2 across the frame.
+// resident in the 256 MB Infinity Cache / L2 across the frame.  All eight corner fetches of a sample are
+// issued unconditionally from clamped addresses (zeros padding = zero weight).
 #include "holo_common.h"
 #include "holo_kernels.h"
 
 namespace holo {
 namespace {
 
-constexpr int HD = 256;       // RenderMLP.dnet_hidden_dim
+constexpr int HD = 256;  // RenderMLP.dnet_hidden_dim
 constexpr int NTILE = HD / 32;
-constexpr int MAXC = 64;      // max coarse samples per ray held in LDS (cdf rows)
+constexpr int MAXC = 64;  // max coarse samples per ray held in LDS (cdf rows)
 
 __device__ __forceinline__ float lin_space(float start, float end, float step, int i, int steps) {
   // torch.linspace: symmetric evaluation around the midpoint
   return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
 }
 __device__ __forceinline__ float leaky02(float v) { return fmaxf(v, 0.2f * v); }
+__device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+
+// LDS image of the packed MLP shared by the block
+template <int CH>
+struct MlpLds {
+  static constexpr int C = 2 * CH;
+  static constexpr int LDW = C + 4;
+  float w[HD * LDW];              // W_eff rows (hidden features), padded rows
+  float aux[NTILE * 2 * 16 * 4];  // per D row {b_feat, 0.4*wr0, 0.4*wr1, 0.4*wr2}
+  float u[2 * 4 * CH];            // per half: {w_dens, u_rad0, u_rad1, u_rad2} slices of CH floats
+};
+
+template <int CH>
+__device__ __forceinline__ void stage_mlp(MlpLds<CH>& L, const MlpParams& m, int tid) {
+  constexpr int C = 2 * CH;
+  constexpr int LDW = C + 4;
+  for (int i = tid; i < HD * (C / 4); i += 256) {
+    const int row = i / (C / 4), c4 = i - row * (C / 4);
+    *reinterpret_cast<float4*>(L.w + row * LDW + c4 * 4) = *reinterpret_cast<const float4*>(m.w_feat + row * C + c4 * 4);
+  }
+  for (int i = tid; i < NTILE * 2 * 16; i += 256) {
+    const int r = i & 15, h = (i >> 4) & 1, t = i >> 5;
+    const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    L.aux[i * 4 + 0] = m.b_feat[row];
+    L.aux[i * 4 + 1] = 0.4f * m.w_rad[0 * HD + row];
+    L.aux[i * 4 + 2] = 0.4f * m.w_rad[1 * HD + row];
+    L.aux[i * 4 + 3] = 0.4f * m.w_rad[2 * HD + row];
+  }
+  for (int i = tid; i < 2 * 4 * CH; i += 256) {
+    const int k = i % CH, j = (i / CH) & 3, h = i / (4 * CH);
+    L.u[i] = (j == 0) ? m.w_dens[h * CH + k] : m.u_rad[(j - 1) * C + h * CH + k];
+  }
+}
+
+// direction term of the radiance layer (constant along a ray): b_rad + k_rad + W_dir . harmonic(normalize(d))
+__device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy, float dz, float (&rdir)[3]) {
+  const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);  // F.normalize eps
+  const float dn[3] = {dx / nrm, dy / nrm, dz / nrm};
+  float e[27];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const float arg = dn[a] * (float)(1 << f);
+      e[a * 4 + f] = sinf(arg);
+      e[12 + a * 4 + f] = cosf(arg);
+    }
+    e[24 + a] = dn[a];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = m.b_rad[c] + m.k_rad[c];
+    for (int j = 0; j < 27; ++j) s = fmaf(m.w_dir[c * 27 + j], e[j], s);
+    rdir[c] = s;
+  }
+}
+
+// One sample of the implicit function for the lane's item: world point -> raw density, colour.
+template <int CH>
+__device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __restrict__ gbase, int R, float Rm1,
+                                           float half_extent, float b_dens, int li, int lh, float px, float py,
+                                           float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
+                                           float& cb) {
+  constexpr int C = 2 * CH;
+  constexpr int LDW = C + 4;
+  float f[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) f[k] = 0.f;
+  {
+    const float lx = px / half_extent, ly = py / half_extent, lz = pz / half_extent;
+    const float ix = ((lx + 1.f) * 0.5f) * Rm1, iy = ((ly + 1.f) * 0.5f) * Rm1, iz = ((lz + 1.f) * 0.5f) * Rm1;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    // zeros padding as per-axis weights: a corner outside [0, R-1] gets weight 0.  All 8 corner fetches are
+    // issued UNCONDITIONALLY from clamped addresses: a per-corner "if (inside) load" makes the compiler wait
+    // for each load before issuing the next, i.e. eight serial L2 round trips per sample.
+    const float wxa = (fx0 >= 0.f && fx0 <= Rm1) ? (fx0 + 1.f) - ix : 0.f;
+    const float wxb = (fx0 >= -1.f && fx0 <= Rm1 - 1.f) ? ix - fx0 : 0.f;
+    const float wya = (fy0 >= 0.f && fy0 <= Rm1) ? (fy0 + 1.f) - iy : 0.f;
+    const float wyb = (fy0 >= -1.f && fy0 <= Rm1 - 1.f) ? iy - fy0 : 0.f;
+    const float wza = (fz0 >= 0.f && fz0 <= Rm1) ? (fz0 + 1.f) - iz : 0.f;
+    const float wzb = (fz0 >= -1.f && fz0 <= Rm1 - 1.f) ? iz - fz0 : 0.f;
+    const int x0 = (int)fminf(fmaxf(fx0, -1.f), Rm1), y0 = (int)fminf(fmaxf(fy0, -1.f), Rm1),
+              z0 = (int)fminf(fmaxf(fz0, -1.f), Rm1);
+    const int xa = max(x0, 0), xb = min(x0 + 1, R - 1);
+    const int ya = max(y0, 0), yb = min(y0 + 1, R - 1);
+    const int za = max(z0, 0), zb = min(z0 + 1, R - 1);
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+      const float w = ((dx ? wxb : wxa) * (dy ? wyb : wya)) * (dz ? wzb : wza);
+      const int xx = dx ? xb : xa, yy = dy ? yb : ya, zz = dz ? zb : za;
+      const float4* g = reinterpret_cast<const float4*>(gbase + ((int64_t)(zz * R + yy) * R + xx) * C);
+#pragma unroll
+      for (int v = 0; v < CH / 4; ++v) {
+        const float4 t = g[v];
+        f[4 * v + 0] = fmaf(w, t.x, f[4 * v + 0]);
+        f[4 * v + 1] = fmaf(w, t.y, f[4 * v + 1]);
+        f[4 * v + 2] = fmaf(w, t.z, f[4 * v + 2]);
+        f[4 * v + 3] = fmaf(w, t.w, f[4 * v + 3]);
+      }
+    }
+  }
+  // lane-local half dot products: density row and the linear (0.6 h) part of the three radiance sums
+  float dpart = 0.f, rp0 = 0.f, rp1 = 0.f, rp2 = 0.f;
+  {
+    const float4* up = reinterpret_cast<const float4*>(L.u + lh * 4 * CH);
+#pragma unroll
+    for (int v = 0; v < CH / 4; ++v) {
+      const float4 a = up[v], b = up[CH / 4 + v], c = up[2 * (CH / 4) + v], d = up[3 * (CH / 4) + v];
+      dpart = fmaf(a.x, f[4 * v], fmaf(a.y, f[4 * v + 1], fmaf(a.z, f[4 * v + 2], fmaf(a.w, f[4 * v + 3], dpart))));
+      rp0 = fmaf(b.x, f[4 * v], fmaf(b.y, f[4 * v + 1], fmaf(b.z, f[4 * v + 2], fmaf(b.w, f[4 * v + 3], rp0))));
+      rp1 = fmaf(c.x, f[4 * v], fmaf(c.y, f[4 * v + 1], fmaf(c.z, f[4 * v + 2], fmaf(c.w, f[4 * v + 3], rp1))));
+      rp2 = fmaf(d.x, f[4 * v], fmaf(d.y, f[4 * v + 1], fmaf(d.z, f[4 * v + 2], fmaf(d.w, f[4 * v + 3], rp2))));
+    }
+  }
+  // hidden features on the matrix cores, tile by tile
+#pragma unroll 1
+  for (int t = 0; t < NTILE; ++t) {
+    // the LDS-resident weights are loop invariant across march steps: keep the compiler from hoisting
+    // (and spilling) 8 tiles of operands out of the sample loops
+    asm volatile("" ::: "memory");
+    const float4* aux = reinterpret_cast<const float4*>(L.aux + ((t * 2 + lh) * 16) * 4);
+    const float4* ap = reinterpret_cast<const float4*>(L.w + (t * 32 + li) * LDW + lh * CH);
+    float a[CH];
+#pragma unroll
+    for (int v = 0; v < CH / 4; ++v) {
+      const float4 t4 = ap[v];
+      a[4 * v + 0] = t4.x;
+      a[4 * v + 1] = t4.y;
+      a[4 * v + 2] = t4.z;
+      a[4 * v + 3] = t4.w;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = aux[r].x;  // accumulator starts at the bias of the lane's own rows
+#pragma unroll
+    for (int k = 0; k < CH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], f[k], acc, 0, 0, 0);
+    // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float4 w4 = aux[r];
+      const float ah = fabsf(acc[r]);
+      rp0 = fmaf(w4.y, ah, rp0);
+      rp1 = fmaf(w4.z, ah, rp1);
+      rp2 = fmaf(w4.w, ah, rp2);
+    }
+  }
+  dpart += __shfl_xor(dpart, 32);
+  rp0 += __shfl_xor(rp0, 32);
+  rp1 += __shfl_xor(rp1, 32);
+  rp2 += __shfl_xor(rp2, 32);
+  sigma = leaky02(dpart + b_dens);
+  cr = fast_sigmoid(leaky02(rp0 + rdir[0]));
+  cg = fast_sigmoid(leaky02(rp1 + rdir[1]));
+  cb = fast_sigmoid(leaky02(rp2 + rdir[2]));
+}
 
 template <int CH>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
-  constexpr int C = 2 * CH;
-  constexpr int LDW = C + 4;
-  __shared__ __attribute__((aligned(16))) float s_w[HD * LDW];           // W_eff rows (hidden features)
-  __shared__ __attribute__((aligned(16))) float s_aux[NTILE * 2 * 16 * 4];  // {b_feat, wr0, wr1, wr2} per D row
-  __shared__ float s_cdf[4 * MAXC * 32];                                   // per wave: [j][ray]
+  __shared__ __attribute__((aligned(16))) MlpLds<CH> s_mlp;
+  __shared__ float s_cdf[4 * MAXC * 32];  // per wave: [j][ray]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -52,22 +213,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  // ---- stage the packed MLP
-  for (int i = tid; i < HD * (C / 4); i += 256) {
-    const int row = i / (C / 4), c4 = i - row * (C / 4);
-    *reinterpret_cast<float4*>(s_w + row * LDW + c4 * 4) = *reinterpret_cast<const float4*>(p.w_feat + row * C + c4 * 4);
-  }
-  for (int i = tid; i < NTILE * 2 * 16; i += 256) {
-    const int r = i & 15, h = (i >> 4) & 1, t = i >> 5;
-    const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    s_aux[i * 4 + 0] = p.b_feat[row];
-    s_aux[i * 4 + 1] = p.w_rad[0 * HD + row];
-    s_aux[i * 4 + 2] = p.w_rad[1 * HD + row];
-    s_aux[i * 4 + 3] = p.w_rad[2 * HD + row];
-  }
-  float wd[CH];
-#pragma unroll
-  for (int k = 0; k < CH; ++k) wd[k] = p.w_dens[lh * CH + k];
+  stage_mlp<CH>(s_mlp, p.mlp, tid);
   __syncthreads();
 
   // ---- ray setup (pytorch3d NDC grid: +x left, +y up; pixel centres)
@@ -91,117 +237,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
     dir[j] = p2 - p1;
     org[j] = p1 - dir[j];
   }
-  // view-direction term of the radiance layer: constant along the ray
   float rdir[3];
-  {
-    const float nrm = fmaxf(sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), 1e-12f);
-    const float dn[3] = {dir[0] / nrm, dir[1] / nrm, dir[2] / nrm};
-    float e[27];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const float arg = dn[a] * (float)(1 << f);
-        e[a * 4 + f] = sinf(arg);
-        e[12 + a * 4 + f] = cosf(arg);
-      }
-      e[24 + a] = dn[a];
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float s = p.b_rad[c];
-      for (int j = 0; j < 27; ++j) s = fmaf(p.w_dir[c * 27 + j], e[j], s);
-      rdir[c] = s;
-    }
-  }
+  dir_term(p.mlp, dir[0], dir[1], dir[2], rdir);
 
   const int R = p.R;
   const float Rm1 = (float)(R - 1);
   const float* gbase = p.grid_cl + lh * CH;
 
-  // ---- one sample of the implicit function for this lane's ray; returns raw density and colour
   auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb) {
-    float f[CH];
-#pragma unroll
-    for (int k = 0; k < CH; ++k) f[k] = 0.f;
-    {
-      const float lx = (org[0] + z * dir[0]) / p.half_extent;
-      const float ly = (org[1] + z * dir[1]) / p.half_extent;
-      const float lz = (org[2] + z * dir[2]) / p.half_extent;
-      const float ix = ((lx + 1.f) * 0.5f) * Rm1, iy = ((ly + 1.f) * 0.5f) * Rm1, iz = ((lz + 1.f) * 0.5f) * Rm1;
-      const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
-      // guard the float->int conversion for far-away points
-      const bool near_grid = fx0 >= -2.f && fx0 <= Rm1 + 1.f && fy0 >= -2.f && fy0 <= Rm1 + 1.f && fz0 >= -2.f &&
-                             fz0 <= Rm1 + 1.f;
-      if (near_grid) {
-        const int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
-        const float wx1 = ix - fx0, wy1 = iy - fy0, wz1 = iz - fz0;
-        const float wx0 = (fx0 + 1.f) - ix, wy0 = (fy0 + 1.f) - iy, wz0 = (fz0 + 1.f) - iz;
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-          const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-          const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-          const bool ok = xx >= 0 && xx < R && yy >= 0 && yy < R && zz >= 0 && zz < R;
-          if (ok) {
-            const float w = ((dx ? wx1 : wx0) * (dy ? wy1 : wy0)) * (dz ? wz1 : wz0);
-            const float4* g = reinterpret_cast<const float4*>(gbase + ((int64_t)(zz * R + yy) * R + xx) * C);
-#pragma unroll
-            for (int v = 0; v < CH / 4; ++v) {
-              const float4 t = g[v];
-              f[4 * v + 0] = fmaf(w, t.x, f[4 * v + 0]);
-              f[4 * v + 1] = fmaf(w, t.y, f[4 * v + 1]);
-              f[4 * v + 2] = fmaf(w, t.z, f[4 * v + 2]);
-              f[4 * v + 3] = fmaf(w, t.w, f[4 * v + 3]);
-            }
-          }
-        }
-      }
-    }
-    // density row: lane-local half dot product
-    float dpart = 0.f;
-#pragma unroll
-    for (int k = 0; k < CH; ++k) dpart = fmaf(wd[k], f[k], dpart);
-    // hidden features on the matrix cores, tile by tile
-    float rp0 = 0.f, rp1 = 0.f, rp2 = 0.f;
-#pragma unroll 1
-    for (int t = 0; t < NTILE; ++t) {
-      // the LDS-resident weights are loop invariant across march steps: keep the compiler from hoisting
-      // (and spilling) 8 tiles of operands out of the sample loops
-      asm volatile("" ::: "memory");
-      const float4* aux = reinterpret_cast<const float4*>(s_aux + ((t * 2 + lh) * 16) * 4);
-      const float4* ap = reinterpret_cast<const float4*>(s_w + (t * 32 + li) * LDW + lh * CH);
-      float a[CH];
-#pragma unroll
-      for (int v = 0; v < CH / 4; ++v) {
-        const float4 t4 = ap[v];
-        a[4 * v + 0] = t4.x;
-        a[4 * v + 1] = t4.y;
-        a[4 * v + 2] = t4.z;
-        a[4 * v + 3] = t4.w;
-      }
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = aux[r].x;  // accumulator starts at the bias of the lane's own rows
-#pragma unroll
-      for (int k = 0; k < CH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], f[k], acc, 0, 0, 0);
-      // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float4 w4 = aux[r];
-        const float hv = leaky02(acc[r]);
-        rp0 = fmaf(w4.y, hv, rp0);
-        rp1 = fmaf(w4.z, hv, rp1);
-        rp2 = fmaf(w4.w, hv, rp2);
-      }
-    }
-    dpart += __shfl_xor(dpart, 32);
-    rp0 += __shfl_xor(rp0, 32);
-    rp1 += __shfl_xor(rp1, 32);
-    rp2 += __shfl_xor(rp2, 32);
-    sigma = leaky02(dpart + p.b_dens);
-    cr = 1.f / (1.f + expf(-leaky02(rp0 + rdir[0])));
-    cg = 1.f / (1.f + expf(-leaky02(rp1 + rdir[1])));
-    cb = 1.f / (1.f + expf(-leaky02(rp2 + rdir[2])));
+    eval_point<CH>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0], org[1] + z * dir[1],
+                   org[2] + z * dir[2], rdir, sigma, cr, cg, cb);
   };
 
   // ---- coarse pass
@@ -217,9 +262,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
       eval(zi, sg, cr, cg, cb);
       const float delta = (i + 1 < nc) ? zn - zi : p.background_opacity;
       const float x = delta * fmaxf(sg, 0.f);
-      const float cap = 1.f - expf(-x);
+      const float cap = 1.f - __expf(-x);
       cum += x;
-      O = 1.f - expf(-cum);
+      O = 1.f - __expf(-cum);
       const float w = cap * Tr;
       ar = fmaf(w, cr, ar);
       ag = fmaf(w, cg, ag);
@@ -238,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
     }
   }
 
-  // ---- weights[1:-1] -> pdf -> cdf (in place; both halves write identical values)
+  // ---- weights[1:-1] -> pdf -> cdf (in place, done by lane half 0)
   // cdf has nb = nc-1 entries, cdf[0] = 0;  bins (interval mid points) also nb entries
   const int nb = nc - 1;
   __builtin_amdgcn_wave_barrier();
@@ -299,9 +344,9 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
       eval(zi, sg, cr, cg, cb);
       const float delta = (s + 1 < total) ? zn - zi : p.background_opacity;
       const float x = delta * fmaxf(sg, 0.f);
-      const float cap = 1.f - expf(-x);
+      const float cap = 1.f - __expf(-x);
       cum += x;
-      O = 1.f - expf(-cum);
+      O = 1.f - __expf(-cum);
       const float w = cap * Tr;
       ar = fmaf(w, cr, ar);
       ag = fmaf(w, cg, ag);
@@ -320,11 +365,55 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
   }
 }
 
+// radiance direction term per ray direction (one thread per direction)
+__global__ __launch_bounds__(256) void dir_term_kernel(MlpParams m, const float* __restrict__ dirs, int64_t n_dirs,
+                                                       float* __restrict__ rdir_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_dirs) return;
+  float rdir[3];
+  dir_term(m, dirs[i * 3 + 0], dirs[i * 3 + 1], dirs[i * 3 + 2], rdir);
+  rdir_out[i * 3 + 0] = rdir[0];
+  rdir_out[i * 3 + 1] = rdir[1];
+  rdir_out[i * 3 + 2] = rdir[2];
+}
+
+// (densities, colours) for arbitrary points: grid-stride over groups of 128 points per block
+template <int CH>
+__global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParams p) {
+  __shared__ __attribute__((aligned(16))) MlpLds<CH> s_mlp;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  stage_mlp<CH>(s_mlp, p.mlp, tid);
+  __syncthreads();
+  const float Rm1 = (float)(p.R - 1);
+  const float* gbase = p.grid_cl + lh * CH;
+  const int64_t ngroups = (p.n_points + 127) / 128;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t i = g * 128 + wave * 32 + li;
+    const bool active = i < p.n_points;
+    const int64_t ii = active ? i : p.n_points - 1;
+    const float px = p.pts[ii * 3 + 0], py = p.pts[ii * 3 + 1], pz = p.pts[ii * 3 + 2];
+    const int64_t di = ii / p.pts_per_dir;
+    const float rdir[3] = {p.rdir[di * 3 + 0], p.rdir[di * 3 + 1], p.rdir[di * 3 + 2]};
+    float sg, cr, cg, cb;
+    eval_point<CH>(s_mlp, gbase, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg, cr, cg, cb);
+    if (active && lh == 0) {
+      p.densities[i] = sg;
+      p.colours[i * 3 + 0] = cr;
+      p.colours[i * 3 + 1] = cg;
+      p.colours[i * 3 + 2] = cb;
+    }
+  }
+}
+
 }  // namespace
 
 int render_launch(const RenderKernelParams& p, void* stream) {
-  if (p.Hd != HD) {
-    set_error("render: dnet_hidden_dim must be %d (got %d)", HD, p.Hd);
+  if (p.mlp.Hd != HD) {
+    set_error("render: dnet_hidden_dim must be %d (got %d)", HD, p.mlp.Hd);
     return -1;
   }
   if (p.n_coarse < 3 || p.n_coarse > MAXC || p.n_fine < 2) {
@@ -345,6 +434,34 @@ int render_launch(const RenderKernelParams& p, void* stream) {
       break;
     default:
       set_error("render: feature_size must be 16, 32 or 64 (got %d)", p.C);
+      return -1;
+  }
+  return 0;
+}
+
+int implicit_eval_launch(const ImplicitEvalParams& p, void* stream) {
+  if (p.mlp.Hd != HD) {
+    set_error("implicit_eval: dnet_hidden_dim must be %d (got %d)", HD, p.mlp.Hd);
+    return -1;
+  }
+  if (p.n_points <= 0) return 0;
+  const int64_t n_dirs = cdiv(p.n_points, p.pts_per_dir);
+  HOLO_LAUNCH(dir_term_kernel, dim3((unsigned)cdiv(n_dirs, 256)), dim3(256), stream, p.mlp, p.dirs, n_dirs, p.rdir);
+  int64_t groups = cdiv(p.n_points, 128);
+  if (groups > 4096) groups = 4096;
+  dim3 grid((unsigned)groups);
+  switch (p.C) {
+    case 16:
+      HOLO_LAUNCH(implicit_eval_kernel<8>, grid, dim3(256), stream, p);
+      break;
+    case 32:
+      HOLO_LAUNCH(implicit_eval_kernel<16>, grid, dim3(256), stream, p);
+      break;
+    case 64:
+      HOLO_LAUNCH(implicit_eval_kernel<32>, grid, dim3(256), stream, p);
+      break;
+    default:
+      set_error("implicit_eval: feature_size must be 16, 32 or 64 (got %d)", p.C);
       return -1;
   }
   return 0;

@@ -34,7 +34,8 @@ struct HoloRenderer {
   HoloRenderCfg cfg;
   std::map<std::string, std::vector<float>> host;        // raw parameters (host copies)
   std::map<std::string, std::vector<int64_t>> expected;  // expected shapes
-  float* packed = nullptr;                               // device: w_feat | b_feat | w_dens | w_rad | w_dir
+  float* packed = nullptr;  // device: w_feat | b_feat | w_dens | w_rad | w_dir | u_rad
+  float k_rad[3] = {0, 0, 0};
   float b_dens = 0.f;
   float b_rad[3] = {0, 0, 0};
   bool committed = false;
@@ -70,7 +71,7 @@ int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** 
   r->expected["_density_net.mlp.3.0.bias"] = {Hd + 1};
   r->expected["_radiance_net.mlp.0.0.weight"] = {3, Hd + De};
   r->expected["_radiance_net.mlp.0.0.bias"] = {3};
-  const size_t n = (size_t)(Hd * C + Hd + C + 3 * Hd + 3 * De + 64);
+  const size_t n = (size_t)(Hd * C + Hd + C + 3 * Hd + 3 * De + 3 * C + 64);
   if (hipMalloc((void**)&r->packed, n * sizeof(float)) != hipSuccess) {
     set_error("holo_renderer_create: hipMalloc failed");
     delete r;
@@ -174,8 +175,8 @@ int holo_renderer_commit(HoloRenderer* r, void* stream) {
     }
     be[i] = cb;
   }
-  // pack: w_feat [Hd][C] | b_feat [Hd] | w_dens [C] | w_rad [3][Hd] | w_dir [3][De]
-  std::vector<float> pk((size_t)Hd * C + Hd + C + 3 * Hd + 3 * De);
+  // pack: w_feat [Hd][C] | b_feat [Hd] | w_dens [C] | w_rad [3][Hd] | w_dir [3][De] | u_rad [3][C]
+  std::vector<float> pk((size_t)Hd * C + Hd + C + 3 * Hd + 3 * De + 3 * C);
   size_t o = 0;
   for (int i = 0; i < Hd * C; ++i) pk[o++] = (float)We[i];
   for (int i = 0; i < Hd; ++i) pk[o++] = (float)be[i];
@@ -184,12 +185,41 @@ int holo_renderer_commit(HoloRenderer* r, void* stream) {
     for (int i = 0; i < Hd; ++i) pk[o++] = Wr[(size_t)c * (Hd + De) + i];
   for (int c = 0; c < 3; ++c)
     for (int j = 0; j < De; ++j) pk[o++] = Wr[(size_t)c * (Hd + De) + Hd + j];
+  // LeakyReLU_0.2(h) = 0.6 h + 0.4 |h|: fold the linear part of sum_rows w_rad[c][row] * leaky(h[row]) into
+  // u_rad[c] = 0.6 * W_eff[:Hd]^T w_rad[c] (a C-vector) and k_rad[c] = 0.6 * w_rad[c] . b_eff[:Hd]
+  for (int c = 0; c < 3; ++c) {
+    double kc = 0.0;
+    std::vector<double> uc(C, 0.0);
+    for (int i = 0; i < Hd; ++i) {
+      const double w = Wr[(size_t)c * (Hd + De) + i];
+      kc += w * be[i];
+      for (int j = 0; j < C; ++j) uc[j] += w * We[(size_t)i * C + j];
+    }
+    for (int j = 0; j < C; ++j) pk[o++] = (float)(0.6 * uc[j]);
+    r->k_rad[c] = (float)(0.6 * kc);
+  }
   r->b_dens = (float)be[Hd];
   for (int c = 0; c < 3; ++c) r->b_rad[c] = br[c];
   HIP_TRY(hipMemcpyAsync(r->packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   r->committed = true;
   return 0;
+}
+
+static void fill_mlp(const HoloRenderer* r, MlpParams& m) {
+  const int C = r->cfg.feature_size, Hd = r->cfg.dnet_hidden_dim, De = dir_emb(r->cfg);
+  m.w_feat = r->packed;
+  m.b_feat = m.w_feat + (size_t)Hd * C;
+  m.w_dens = m.b_feat + Hd;
+  m.w_rad = m.w_dens + C;
+  m.w_dir = m.w_rad + 3 * Hd;
+  m.u_rad = m.w_dir + 3 * De;
+  m.b_dens = r->b_dens;
+  for (int k = 0; k < 3; ++k) {
+    m.b_rad[k] = r->b_rad[k];
+    m.k_rad[k] = r->k_rad[k];
+  }
+  m.Hd = Hd;
 }
 
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
@@ -215,7 +245,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     return HOLO_E_WORKSPACE;
   }
   const HoloRenderCfg& c = r->cfg;
-  const int R = c.resol, C = c.feature_size, Hd = c.dnet_hidden_dim;
+  const int R = c.resol, C = c.feature_size;
   float* grid_cl = (float*)workspace;
   int rc = ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream);
   if (rc) return HOLO_E_INVALID;
@@ -230,14 +260,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.C = C;
     const float voxel_size = c.volume_extent / (float)R;
     p.half_extent = 0.5f * (float)(R - 1) * voxel_size;
-    p.w_feat = r->packed;
-    p.b_feat = p.w_feat + (size_t)Hd * C;
-    p.w_dens = p.b_feat + Hd;
-    p.w_rad = p.w_dens + C;
-    p.w_dir = p.w_rad + 3 * Hd;
-    p.b_dens = r->b_dens;
-    for (int k = 0; k < 3; ++k) p.b_rad[k] = r->b_rad[k];
-    p.Hd = Hd;
+    fill_mlp(r, p.mlp);
     for (int k = 0; k < 9; ++k) p.Rm[k] = cam.R[k];
     for (int k = 0; k < 3; ++k) p.T[k] = cam.T[k];
     for (int k = 0; k < 2; ++k) {
@@ -282,6 +305,44 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     if (rc) return HOLO_E_INVALID;
   }
   return 0;
+}
+
+int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
+                       int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  if (!r || !grid || !pts || !dirs || !densities || !colours || !workspace || n_points < 0 || pts_per_dir < 1) {
+    set_error("holo_implicit_eval: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_implicit_eval: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  const size_t grid_bytes = holo_render_workspace_bytes(r, 1);
+  const int64_t n_dirs = (n_points + pts_per_dir - 1) / pts_per_dir;
+  if (workspace_bytes < grid_bytes + (size_t)n_dirs * 3 * sizeof(float)) {
+    set_error("holo_implicit_eval: workspace too small (need holo_render_workspace_bytes + 12 bytes per direction)");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  float* grid_cl = (float*)workspace;
+  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, c.feature_size, (int64_t)c.resol * c.resol * c.resol, 0, stream))
+    return HOLO_E_INVALID;
+  ImplicitEvalParams p;
+  memset(&p, 0, sizeof p);
+  p.grid_cl = grid_cl;
+  p.R = c.resol;
+  p.C = c.feature_size;
+  p.half_extent = 0.5f * (float)(c.resol - 1) * (c.volume_extent / (float)c.resol);
+  fill_mlp(r, p.mlp);
+  p.pts = pts;
+  p.dirs = dirs;
+  p.rdir = (float*)((char*)workspace + grid_bytes);
+  p.n_points = n_points;
+  p.pts_per_dir = pts_per_dir;
+  p.densities = densities;
+  p.colours = colours;
+  return implicit_eval_launch(p, stream) ? HOLO_E_INVALID : 0;
 }
 
 }  // extern "C"

@@ -60,7 +60,12 @@ struct Block {
   int cin, cout;
 };
 
-enum ParamKind { P_PLAIN, P_CONV3, P_EMB_W, P_EMB_B };
+enum ParamKind { P_PLAIN, P_CONV3, P_CONV1, P_EMB_W, P_EMB_B };
+
+// packed conv weights are zero padded to [taps][CoutP][CinP]: CoutP a multiple of the kernel's Cout tile
+// (64 when Cout >= 64, else 32), CinP a multiple of the 32-channel K chunk
+static inline int pad_cout(int c) { return c >= 64 ? (c + 63) / 64 * 64 : 32; }
+static inline int pad_cin(int c) { return (c + 31) / 32 * 32; }
 struct ParamSlot {
   std::string name;
   std::vector<int64_t> shape;
@@ -286,16 +291,16 @@ void enumerate_params(HoloUnet* u) {
         add_param(u, p + ".out_layers.3.weight", {co, co, 3, 3, 3}, P_CONV3);
         add_param(u, p + ".out_layers.3.bias", {co}, P_PLAIN);
         if (ci != co) {
-          add_param(u, p + ".skip_connection.weight", {co, ci, 1, 1, 1}, P_PLAIN);
+          add_param(u, p + ".skip_connection.weight", {co, ci, 1, 1, 1}, P_CONV1);
           add_param(u, p + ".skip_connection.bias", {co}, P_PLAIN);
         }
         break;
       case B_ATTN:
         add_param(u, p + ".norm.weight", {ci}, P_PLAIN);
         add_param(u, p + ".norm.bias", {ci}, P_PLAIN);
-        add_param(u, p + ".qkv.weight", {3 * ci, ci, 1}, P_PLAIN);
+        add_param(u, p + ".qkv.weight", {3 * ci, ci, 1}, P_CONV1);
         add_param(u, p + ".qkv.bias", {3 * ci}, P_PLAIN);
-        add_param(u, p + ".proj_out.weight", {ci, ci, 1}, P_PLAIN);
+        add_param(u, p + ".proj_out.weight", {ci, ci, 1}, P_CONV1);
         add_param(u, p + ".proj_out.bias", {ci}, P_PLAIN);
         break;
       case B_DOWN:
@@ -429,6 +434,8 @@ struct Planner {
     p.pad = ksz == 3 ? 1 : 0;
     p.ksz = ksz;
     p.Cout = Cout;
+    p.CoutP = pad_cout(Cout);
+    p.CinP = pad_cin(p.C0 + p.C1);
     p.w = w;
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
@@ -782,8 +789,13 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
   u->keep_intermediates = dbg && dbg[0] == '1';
   // private parameter storage
   int64_t total = 0;
+  auto priv_numel = [](const ParamSlot& s) -> int64_t {
+    if (s.kind == P_CONV3 || s.kind == P_CONV1)
+      return (int64_t)(s.kind == P_CONV3 ? 27 : 1) * pad_cout((int)s.shape[0]) * pad_cin((int)s.shape[1]);
+    return s.numel;
+  };
   for (auto& s : u->params)
-    if (s.kind == P_PLAIN || s.kind == P_CONV3) total += (s.numel + 63) & ~(int64_t)63;
+    if (s.kind == P_PLAIN || s.kind == P_CONV3 || s.kind == P_CONV1) total += (priv_numel(s) + 63) & ~(int64_t)63;
   total += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
   total += (u->emb_rows + 63) & ~63;
   if (hipMalloc((void**)&u->pstore, (size_t)total * sizeof(float)) != hipSuccess) {
@@ -793,9 +805,9 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
   }
   float* cur = u->pstore;
   for (auto& s : u->params)
-    if (s.kind == P_PLAIN || s.kind == P_CONV3) {
+    if (s.kind == P_PLAIN || s.kind == P_CONV3 || s.kind == P_CONV1) {
       s.priv = cur;
-      cur += (s.numel + 63) & ~(int64_t)63;
+      cur += (priv_numel(s) + 63) & ~(int64_t)63;
     }
   u->emb_w = cur;
   cur += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
@@ -858,8 +870,10 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
     set_error("holo_unet_set_param: shape mismatch for '%s'", name);
     return HOLO_E_INVALID;
   }
-  if (s.kind == P_CONV3) {
-    int rc = repack_conv_weight_launch((const float*)dev_ptr, s.priv, (int)s.shape[0], (int)s.shape[1], 27, stream);
+  if (s.kind == P_CONV3 || s.kind == P_CONV1) {
+    int rc = repack_conv_weight_launch((const float*)dev_ptr, s.priv, (int)s.shape[0], (int)s.shape[1],
+                                       s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]),
+                                       stream);
     if (rc) return rc;
   } else {
     HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,

@@ -62,6 +62,35 @@ class ImplicitronRayBundle:
     lengths: Optional[torch.Tensor] = None
     xys: Optional[torch.Tensor] = None
 
+    def materialize(self) -> "ImplicitronRayBundle":
+        """Fill origins (n,H,W,3), directions (n,H,W,3), lengths (n,H,W,P), xys (n,H,W,2) with plain torch ops
+        (PyTorch3D NDCMultinomialRaysampler/_xy_to_ray_bundle + AdaptiveRaySampler bounds).  The fused renderer
+        never needs these tensors; they exist for inspection and for the stand-alone implicit function."""
+        cams, H, W = self.camera, self.image_height, self.image_width
+        dev = cams.R.device
+        rx, ry = (W / H, 1.0) if W >= H else (1.0, H / W)
+        xs = torch.linspace(rx - rx / W, -rx + rx / W, W, dtype=torch.float32, device=dev)
+        ys = torch.linspace(ry - ry / H, -ry + ry / H, H, dtype=torch.float32, device=dev)
+        Y, X = torch.meshgrid(ys, xs, indexing="ij")
+        xy = torch.stack([X, Y], dim=-1).reshape(1, -1, 2)
+        f, pp = cams.focal_xy()[:, None, :], cams.principal_point[:, None, :]
+        d_cam = torch.cat([(xy - pp) / f, torch.ones_like(xy[..., :1]).expand(len(cams), -1, -1)], dim=-1)
+        Rt = cams.R.transpose(1, 2)
+        p1 = torch.bmm(d_cam - cams.T[:, None, :], Rt)
+        p2 = torch.bmm(2.0 * d_cam - cams.T[:, None, :], Rt)
+        dirs = p2 - p1
+        centre = cams.get_camera_center()
+        sc = torch.tensor(self.scene_center, dtype=torch.float32, device=dev)
+        dist = ((centre - sc) ** 2).sum(-1).clamp(0.001).sqrt().clamp(self.scene_extent + 1e-3)
+        n = len(cams)
+        self.origins = (p1 - dirs).reshape(n, H, W, 3)
+        self.directions = dirs.reshape(n, H, W, 3)
+        self.lengths = torch.stack([torch.linspace(float(d - self.scene_extent), float(d + self.scene_extent),
+                                                   self.n_pts_per_ray, dtype=torch.float32, device=dev)
+                                    for d in dist])[:, None, None, :].expand(n, H, W, -1).contiguous()
+        self.xys = xy.reshape(1, H, W, 2).expand(n, -1, -1, -1)
+        return self
+
 
 @dataclass
 class RendererOutput:
@@ -144,6 +173,51 @@ class RenderMLP(Configurable, torch.nn.Module):
         }
 
 
+class _NativeRenderMlp:
+    """Owns a HoloRenderer handle for one (implicit function, render config) and keeps the packed RenderMLP in
+    sync with the torch parameters (re-committed when a parameter's storage or version changes)."""
+
+    def __init__(self):
+        self.handle: Optional[C.c_void_p] = None
+        self.key = None
+        self.versions = None
+
+    def ensure(self, device, mlp: "RenderMLP", cfg_kwargs: dict) -> C.c_void_p:
+        L = runtime.lib()
+        key = (device,) + tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v)
+                                       for k, v in cfg_kwargs.items()))
+        params = dict(mlp.named_parameters())
+        versions = tuple((k, p.data_ptr(), p._version) for k, p in params.items())
+        if self.handle is None or key != self.key:
+            self.close()
+            cfg = _lib.make_render_cfg(**cfg_kwargs)
+            h = C.c_void_p()
+            _lib.check(L, L.holo_renderer_create(runtime.ctx(device), C.byref(cfg), C.byref(h)), "holo_renderer_create")
+            self.handle, self.key, self.versions = h, key, None
+        if versions != self.versions:
+            st = runtime.stream_ptr(device)
+            for k, p in params.items():
+                if p.device != device or p.dtype != torch.float32:
+                    raise _lib.HoloError(f"RenderMLP parameter '{k}' is {p.dtype} on {p.device}; expected float32 on {device}")
+                t = p.detach().contiguous()
+                _lib.check(L, L.holo_renderer_set_param(self.handle, k.encode(), runtime.ptr(t), _lib.HOLO_DTYPE_F32,
+                                                       t.dim(), _lib.shape_array(t.shape), st), f"set_param({k})")
+            _lib.check(L, L.holo_renderer_commit(self.handle, st), "holo_renderer_commit")
+            self.versions = versions
+        return self.handle
+
+    def close(self):
+        if self.handle is not None:
+            try:
+                runtime.lib().holo_renderer_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
 class ImplicitFunctionBase(ReplaceableBase):
     @staticmethod
     def allows_multiple_passes() -> bool:
@@ -177,9 +251,51 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
 
     def forward(self, *, ray_bundle=None, fun_viewpool=None, camera=None, global_code=None, run_id=None,
                 pass_number=None, pts_3d=None, voxel_grid_features=None, **kwargs):
-        raise NotImplementedError(
-            "Per-point evaluation is fused into HoloMultiPassEmissionAbsorptionRenderer.forward (holo_render); "
-            "the stand-alone (densities, features) entry point is scheduled for the next round (DESIGN.md §f).")
+        """Stand-alone evaluation (holo_voxel_grid_implicit_function.py:182-269): trilinear fetch of the voxel
+        grid at the ray points (or at ``pts_3d``) + RenderMLP -> ``(densities (...,1), features (...,3), aux)``.
+        The fused renderer does not go through this method; it exists for drop-in parity with the reference
+        (and its tests, which call it with ``pts_3d``)."""
+        assert voxel_grid_features is not None, "voxel_grid_features must be provided!"
+        assert ray_bundle is not None or pts_3d is not None, "either ray_bundle or pts_3d must be provided!"
+        if self.render_normals:
+            raise NotImplementedError("render_normals: the reference computes normals and never exports them "
+                                      "(holo_diffusion_model.py drops aux['normals']); not implemented")
+        if pts_3d is None:
+            if ray_bundle.origins is None:
+                ray_bundle.materialize()
+            pts = (ray_bundle.origins[..., None, :]
+                   + ray_bundle.lengths[..., :, None] * ray_bundle.directions[..., None, :])
+            dirs = ray_bundle.directions
+        else:
+            pts = pts_3d
+            dirs = torch.ones(*pts.shape[:-2], 3, dtype=torch.float32, device=pts.device)  # dummy directions (:229-236)
+        runtime.require_device(pts, "HoloVoxelGridImplicitFunction.forward")
+        dev = pts.device
+        grid = voxel_grid_features
+        if tuple(grid.shape) != (1, self.n_hidden, self.resol, self.resol, self.resol):
+            raise _lib.HoloError(f"voxel grid must be (1,{self.n_hidden},{self.resol}^3), got {tuple(grid.shape)}")
+        spatial = tuple(pts.shape[:-1])
+        per_dir = spatial[-1]
+        ptsf = pts.reshape(-1, 3).contiguous().float()
+        dirsf = dirs.reshape(-1, 3).contiguous().float()
+        n = ptsf.shape[0]
+        if dirsf.shape[0] * per_dir != n:
+            raise _lib.HoloError("directions do not match the ray points")
+        if not hasattr(self, "_native"):
+            self._native = _NativeRenderMlp()
+        h = self._native.ensure(dev, self.render_mlp, dict(
+            resol=self.resol, feature_size=self.n_hidden, image_height=8, image_width=8,
+            volume_extent=float(self.volume_extent), dnet_hidden_dim=self.render_mlp.dnet_hidden_dim,
+            dir_emb_dims=self.render_mlp.dir_emb_dims))
+        L = runtime.lib()
+        dens = torch.empty(n, device=dev)
+        col = torch.empty(n, 3, device=dev)
+        nbytes = L.holo_render_workspace_bytes(h, 1) + 12 * dirsf.shape[0] + 256
+        ws = runtime.workspace(dev, f"implicit{id(self)}", nbytes)
+        _lib.check(L, L.holo_implicit_eval(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf),
+                                           runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens), runtime.ptr(col),
+                                           runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_implicit_eval")
+        return dens.reshape(*spatial, 1), col.reshape(*spatial, COLOUR_DIMS), {}
 
 
 class ImplicitFunctionWrapper(torch.nn.Module):

@@ -173,6 +173,15 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
                 float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stand-alone implicit function.  Replaces HoloVoxelGridImplicitFunction.forward
+ * (holo_voxel_grid_implicit_function.py:182-269): trilinear fetch of `grid` at the world points, RenderMLP.
+ *   pts        : (n_points, 3) world coordinates; dirs : (n_points / pts_per_dir, 3) ray directions
+ *                (normalised inside like F.normalize, :239); point i uses dirs[i / pts_per_dir]
+ *   densities  : (n_points,) raw densities (no softplus, :113-114); colours : (n_points, 3) after sigmoid */
+int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
+                       int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
  * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).

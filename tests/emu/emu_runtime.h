@@ -33,6 +33,10 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4 __attribute__((vector_size(16)));
 
+#include <algorithm>
+using std::max;
+using std::min;
+
 #define __global__
 #define __device__
 #define __host__
@@ -182,6 +186,7 @@ static inline float __fadd_rn(float a, float b) {
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline void emu_wave_barrier() { emu_wave().bar.wait(); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 

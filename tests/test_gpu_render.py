@@ -148,3 +148,32 @@ def test_north_star_frame_properties(gu):
     # (density does not depend on the view direction; colour does, so only mask and depth are compared)
     assert (p2["masks_render"] - msk).abs().max() < 2e-3
     assert (p2["depths_render"] - dep).abs().max() < 2e-2
+
+
+def test_standalone_implicit_function_vs_oracle(gu):
+    """HoloVoxelGridImplicitFunction.forward(pts_3d=...) — the entry the reference's own tests call
+    (holo_diffusion/tests/test_voxel_grid_implicit_function.py:28-55) — and the ray_bundle entry."""
+    model, _, _, rcfg, msd = gu.make_model(8, 32, 6, 10, TINY_UNET, density_bias=0.05)
+    fn = model._implicit_functions[0]._fn
+    grid = torch.tanh(torch.from_numpy(np_noise(21, (1, 32, 8, 8, 8))))
+    # points partly outside the volume (zeros padding) like the reference test: rand scaled to +-extent/2
+    pts = (torch.rand(2, 5, 7, 16, 3, generator=torch.Generator().manual_seed(3)) - 0.5) * 9.0
+    dens, feats, aux = fn(pts_3d=pts.to(gu.DEV), voxel_grid_features=grid.to(gu.DEV))
+    assert dens.shape == (2, 5, 7, 16, 1) and feats.shape == (2, 5, 7, 16, 3) and aux == {}
+    f = ro.trilinear(grid, pts, rcfg)
+    dn = torch.nn.functional.normalize(torch.ones(2, 5, 7, 3), dim=-1)[..., None, :].expand(2, 5, 7, 16, 3)
+    d_ref, c_ref = ro.render_mlp(msd, f, dn, rcfg)
+    assert (dens.cpu() - d_ref).abs().max() < 1e-4 and (feats.cpu() - c_ref).abs().max() < 1e-4
+    assert not torch.isnan(dens).any() and not torch.isnan(feats).any()  # what the reference test asserts
+    # ray-bundle entry: points generated from a camera-backed bundle
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2).to(gu.DEV)
+    bundle = model.raysampler(cams[[1]], EvaluationMode.EVALUATION)
+    dens2, feats2, _ = fn(ray_bundle=bundle, voxel_grid_features=grid.to(gu.DEV))
+    assert dens2.shape == (1, 6, 10, 64, 1)
+    o, d, l = ro.make_rays(gu.cam_dict(cams, 1), rcfg)
+    torch.testing.assert_close(bundle.origins.reshape(-1, 3).cpu(), o, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bundle.directions.reshape(-1, 3).cpu(), d, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bundle.lengths.reshape(-1, 64).cpu(), l, rtol=1e-5, atol=1e-5)
+    d_ref2, c_ref2 = ro.implicit_function(grid, msd, o, d, l, rcfg)
+    assert (dens2.reshape(-1, 64, 1).cpu() - d_ref2).abs().max() < 1e-4
+    assert (feats2.reshape(-1, 64, 3).cpu() - c_ref2).abs().max() < 1e-4
