@@ -33,6 +33,7 @@ struct ConvParams {
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
+  int stagger;            // halo kernel: de-phase co-resident workgroups (0 = off)
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
 };
 
@@ -61,6 +62,17 @@ struct GemmParams {
   float alpha;
 };
 int gemm_launch(const GemmParams& p, void* stream);
+
+// Flash-style attention over the token-major qkv buffer [N][T][3C] (head-major channel order: q,k,v blocks of
+// C/H channels per head, unet.py:448); out is token-major [N][T][C].  scale2 = 1/sqrt(head channels).
+struct AttnParams {
+  const float* qkv;
+  float* out;
+  int N, T, C, H;
+  float scale2;
+};
+bool flash_attn_supported(int T, int head_channels);
+int flash_attn_launch(const AttnParams& p, void* stream);
 
 // in-place row softmax over `rows` rows of length `cols` (unet.py:453, fp32)
 int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);

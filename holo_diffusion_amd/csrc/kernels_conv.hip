@@ -22,6 +22,8 @@
 // (and 16 per B tile) for the 16 MFMA k-steps of the chunk with four ds_read_b128.
 // Double buffered: global loads of chunk k+1 are issued before the MFMAs of chunk k and written to the
 // other LDS buffer afterwards; one barrier per chunk.
+#include <stdlib.h>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -430,6 +432,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // Co-resident workgroups start together and do identical work, so their halo-staging phases (when no MFMA
+  // issues) would coincide for the whole kernel; delaying every other workgroup by about half a chunk
+  // de-phases them so that one workgroup's staging hides under the other's tap loop.
+  if (p.stagger) {
+    const unsigned sel = p.stagger == 1 ? (blockIdx.x >> 3) : p.stagger == 2 ? (blockIdx.x >> 8) : (blockIdx.x * 2654435761u) >> 16;
+    if (sel & 1u) {
+      for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   halo_issue(cc_begin);
   for (int cc = cc_begin; cc < cc_end; ++cc) {
     halo_commit();
@@ -520,6 +531,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
                ? 1
                : 0;
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
+    const char* sg = getenv("HOLO_CONV_STAGGER");
+    p.stagger = sg ? atoi(sg) : 0;
     if (tiles < target) {
       nsplit = (int)cdiv(target, tiles);
       if (nsplit > ncc) nsplit = ncc;

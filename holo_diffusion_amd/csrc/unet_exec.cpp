@@ -129,11 +129,12 @@ struct Act {  // channels-last activation [N][R][R][R][C]
   int refs = 0;
 };
 
-enum OpKind { OP_MEMSET, OP_IN, OP_TEMB, OP_EMBLIN, OP_STATS, OP_FINAL, OP_CONV, OP_GEMM, OP_SOFTMAX, OP_OUT };
+enum OpKind { OP_MEMSET, OP_IN, OP_TEMB, OP_EMBLIN, OP_STATS, OP_FINAL, OP_CONV, OP_GEMM, OP_SOFTMAX, OP_FLASH, OP_OUT };
 struct Op {
   OpKind kind;
   ConvParams conv;
   GemmParams gemm;
+  AttnParams attn;
   // generic
   const float* f0 = nullptr;
   const float* f1 = nullptr;
@@ -493,7 +494,22 @@ struct Planner {
     size_t qkv = scratch_alloc(qkv_bytes);
     emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
               ptr<float>(qkv), 3 * C);
-    size_t S = scratch_alloc(s_bytes);
+    size_t a = scratch_alloc(a_bytes);
+    const bool flash = flash_attn_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_ATTN");
+    if (flash) {
+      Op op;
+      op.kind = OP_FLASH;
+      op.attn.qkv = ptr<float>(qkv);
+      op.attn.out = ptr<float>(a);
+      op.attn.N = N;
+      op.attn.T = (int)T;
+      op.attn.C = C;
+      op.attn.H = H;
+      const double sc = 1.0 / sqrt(sqrt((double)ch));
+      op.attn.scale2 = (float)(sc * sc);
+      ops.push_back(op);
+    } else {
+      size_t S = scratch_alloc(s_bytes);
     {
       Op op;
       op.kind = OP_GEMM;
@@ -529,7 +545,6 @@ struct Planner {
       op.i0 = (int)T;
       ops.push_back(op);
     }
-    size_t a = scratch_alloc(a_bytes);
     {
       Op op;
       op.kind = OP_GEMM;
@@ -556,6 +571,8 @@ struct Planner {
       g.alpha = 1.0f;
       ops.push_back(op);
     }
+      scratch_free(S, s_bytes);
+    }
     Act out = new_act(C, R);
     Act av;  // view of `a` as an activation for the 1x1 conv
     av.off = a;
@@ -565,7 +582,6 @@ struct Planner {
               ptr<float>(x.off), ptr<float>(out.off), C);
     emit_stats(out);
     scratch_free(qkv, qkv_bytes);
-    scratch_free(S, s_bytes);
     scratch_free(a, a_bytes);
     return out;
   }
@@ -730,6 +746,8 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
       return gemm_launch(op.gemm, stream);
     case OP_SOFTMAX:
       return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
+    case OP_FLASH:
+      return flash_attn_launch(op.attn, stream);
     case OP_OUT:
       return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
   }

@@ -187,6 +187,7 @@ static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 static inline void emu_wave_barrier() { emu_wave().bar.wait(); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 
