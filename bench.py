@@ -58,6 +58,8 @@ def build_model(w, H, W, device, n_fine=64):
     full = {"net_3d._net." + k: v for k, v in usd.items()}
     for i in range(model.num_passes):
         full.update({f"_implicit_functions.{i}._fn.render_mlp." + k: v for k, v in msd.items()})
+    if os.environ.get("HOLO_BENCH_ZERO"):  # DVFS probe: all-zero operands draw less power (never a reported number)
+        full = {k: torch.zeros_like(v) for k, v in full.items()}
     model.load_state_dict(full)
     return model.to(device), usd, msd
 

@@ -30,16 +30,17 @@ struct ConvParams {
   const float* bias;      // [Cout] or null
   const float* residual;  // [M][Cout] or null
   float* out;             // [M][Cout]
+  double* stats;          // optional: GroupNorm partial sums of `out`, [N][conv_stats_slabs(p)][Cout][2]
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
-  int stagger;            // halo kernel: de-phase co-resident workgroups (0 = off)
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
 };
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
 size_t conv_plan(ConvParams& p, int num_cus);
 int conv_launch(const ConvParams& p, void* stream);
+int conv_stats_slabs(const ConvParams& p);
 double conv_flops(const ConvParams& p);
 
 // ---------------------------------------------------------------------------------------------

@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, acc[t], 0, 0, 0);
   };
 
-  float4 aA[MT], aB[MT], aC[MT];  // rotating A buffers: first half of this tap, second half, first half of next tap
-  float4 b0[2], b1[2];
+  float4 aA[MT] = {}, aB[MT] = {}, aC[MT] = {};  // rotating A buffers: first half of this tap, second half, first half of next tap
+  float4 b0[2] = {}, b1[2] = {};
 
   // one tap: on entry `cur` holds the first-half A operands of `tap` and `bc` its weights
   auto tap_body = [&](float4 (&cur)[MT], float4 (&nxt)[MT], float4 (&bc)[2], float4 (&bn)[2], int cc, int tap,
@@ -432,15 +432,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // Co-resident workgroups start together and do identical work, so their halo-staging phases (when no MFMA
-  // issues) would coincide for the whole kernel; delaying every other workgroup by about half a chunk
-  // de-phases them so that one workgroup's staging hides under the other's tap loop.
-  if (p.stagger) {
-    const unsigned sel = p.stagger == 1 ? (blockIdx.x >> 3) : p.stagger == 2 ? (blockIdx.x >> 8) : (blockIdx.x * 2654435761u) >> 16;
-    if (sel & 1u) {
-      for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   halo_issue(cc_begin);
   for (int cc = cc_begin; cc < cc_end; ++cc) {
     halo_commit();
@@ -460,15 +451,240 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   // ---- epilogue: 16x16x4 D layout: col = lane&15 (Cout), row = 4*(lane>>4) + r (voxel inside the tile)
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int co = n0 + wn * 16 + lj;
+  const int coc = co < p.Cout ? co : p.Cout - 1;
+  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (wm * MT + t) * 16 + 4 * kq + r;
+      const int z = row >> 6, y = (row >> 3) & 7, x = row & 7;
+      const int64_t m = (((int64_t)n * p.OD + tz0 + z) * p.OH + ty0 + y) * p.OW + tx0 + x;
+      float v = acc[t][r];
+      if (p.nsplit == 1) {
+        v += bv;
+        if (p.residual) v += p.residual[m * p.Cout + coc];
+        if (co < p.Cout) p.out[m * p.Cout + co] = v;
+        ssum += v;
+        ssq += v * v;
+      } else if (co < p.Cout) {
+        p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
+      }
+    }
+  }
+  // GroupNorm statistics of the tensor just produced (nn.py:23-25): per output channel (sum, sum of squares)
+  // over this workgroup's voxels, one slab per (workgroup, wave row) -> stats[n][slab][Cout][2], reduced by
+  // gn_finalize.  Saves a full read pass over the activation.
+  if (p.stats && p.nsplit == 1) {
+    ssum += __shfl_xor(ssum, 16);
+    ssq += __shfl_xor(ssq, 16);
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (kq == 0 && co < p.Cout) {
+      const int tiles_per_sample = ntx * nty * ntz;
+      const int slab = ((int)(blockIdx.x % tiles_per_sample)) * (4 / NWN) + wm;
+      const int nslab = tiles_per_sample * (4 / NWN);
+      double* d = p.stats + (((int64_t)n * nslab + slab) * p.Cout + co) * 2;
+      d[0] = (double)ssum;
+      d[1] = (double)ssq;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Small-M variant of the gather kernel for the deepest UNet levels (4^3 / 2^3 voxels: M = 64 rows, K up to
+// 27*1024).  These launches are pure weight streaming (28-56 MB of weights for ~1 GFLOP), so the design goal
+// is bytes in flight, not MFMA rate:
+//   * block tile 64 voxels x 64 Cout; each wave OWNS 16 output channels (v_mfma_f32_16x16x4_f32 over the four
+//     16-voxel tiles), so its weights go global -> registers with no LDS and no sharing;
+//   * the weights of up to SG = 8 consecutive K chunks are requested up front (16 x 16 B per lane in flight)
+//     before the chunk loop touches them; the small, L2-resident activation tile is gathered one chunk ahead
+//     into a double-buffered LDS tile shared by the four waves;
+//   * split-K over (tap, chunk) fills the chip with ~3 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int SM_ROWS = 64;
+constexpr int SG = 8;
+
+__global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) float s_a[2 * SM_ROWS * LDK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lj = lane & 15;
+  const int kq = lane >> 4;
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + BK - 1) / BK;
+  const int ntaps = p.ksz * p.ksz * p.ksz;
+  const int nchunks = ntaps * ncc;
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int64_t m0 = (int64_t)blockIdx.x * SM_ROWS;
+  const int n0 = blockIdx.y * 64;
+  const int kc_begin = blockIdx.z * p.chunks_per_split;
+  int kc_end = kc_begin + p.chunks_per_split;
+  if (kc_end > nchunks) kc_end = nchunks;
+
+  const int q = tid & 7;
+  const int r0 = tid >> 3;  // rows r0 and r0 + 32
+  int an[2], az[2], ay[2], ax[2];
+  bool av[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int64_t m = m0 + r0 + 32 * j;
+    av[j] = m < M;
+    if (!av[j]) m = 0;
+    int ow = (int)(m % p.OW);
+    int64_t t = m / p.OW;
+    int oh = (int)(t % p.OH);
+    t /= p.OH;
+    int od = (int)(t % p.OD);
+    an[j] = (int)(t / p.OD);
+    az[j] = od * p.stride - p.pad;
+    ay[j] = oh * p.stride - p.pad;
+    ax[j] = ow * p.stride - p.pad;
+  }
+  const int SD = p.ups ? (p.ID >> 1) : p.ID;
+  const int SH = p.ups ? (p.IH >> 1) : p.IH;
+  const int SW = p.ups ? (p.IW >> 1) : p.IW;
+
+  float4 ra[2], rc01[2], rc23[2];
+  unsigned amask = 0;
+  auto load_a = [&](int kc) {
+    const int tap = kc / ncc;
+    const int cc = kc - tap * ncc;
+    int kd = 0, kh = 0, kw = 0;
+    if (p.ksz == 3) {
+      kd = tap / 9;
+      kh = (tap - kd * 9) / 3;
+      kw = tap - kd * 9 - kh * 3;
+    }
+    int c = cc * BK + q * 4;
+    const bool cvalid = c < Cin;
+    if (!cvalid) c = 0;
+    const float* src = p.src0;
+    int Cs = p.C0, cs = c;
+    if (c >= p.C0) {
+      src = p.src1;
+      Cs = p.C1;
+      cs = c - p.C0;
+    }
+    amask = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int z = az[j] + kd, y = ay[j] + kh, x = ax[j] + kw;
+      const bool ok = av[j] && cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+      z = min(max(z, 0), p.ID - 1);
+      y = min(max(y, 0), p.IH - 1);
+      x = min(max(x, 0), p.IW - 1);
+      if (p.ups) {
+        z >>= 1;
+        y >>= 1;
+        x >>= 1;
+      }
+      ra[j] = *reinterpret_cast<const float4*>(src + ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs);
+      amask |= (ok ? 1u : 0u) << j;
+      if (p.coef) {
+        const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
+        rc01[j] = cf[0];
+        rc23[j] = cf[1];
+      }
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 v = ra[j];
+      if (p.coef) {
+        v.x = v.x * rc01[j].x + rc01[j].y;
+        v.y = v.y * rc01[j].z + rc01[j].w;
+        v.z = v.z * rc23[j].x + rc23[j].y;
+        v.w = v.w * rc23[j].z + rc23[j].w;
+        if (p.act) {
+          v.x = silu_f(v.x);
+          v.y = silu_f(v.y);
+          v.z = silu_f(v.z);
+          v.w = silu_f(v.w);
+        }
+      }
+      const float keep = ((amask >> j) & 1u) ? 1.f : 0.f;
+      v.x *= keep;
+      v.y *= keep;
+      v.z *= keep;
+      v.w *= keep;
+      *reinterpret_cast<float4*>(s_a + buf * (SM_ROWS * LDK) + (r0 + 32 * j) * LDK + q * 4) = v;
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+
+  const float* w_row = p.w + (int64_t)(n0 + wave * 16 + lj) * p.CinP + kq * 8;
+  const int64_t w_tap_stride = (int64_t)p.CoutP * p.CinP;
+
+  for (int g = kc_begin; g < kc_end; g += SG) {
+    // all weights of this group of chunks are requested before anything waits on them
+    float4 bw[SG][2];
+#pragma unroll
+    for (int i = 0; i < SG; ++i) {
+      const int kc = min(g + i, kc_end - 1);
+      const int tap = kc / ncc;
+      const int cc = kc - tap * ncc;
+      const float4* wp = reinterpret_cast<const float4*>(w_row + tap * w_tap_stride + cc * BK);
+      bw[i][0] = wp[0];
+      bw[i][1] = wp[1];
+    }
+    load_a(g);
+    store_a(0);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SG; ++i) {
+      const int kc = g + i;
+      if (kc < kc_end) {  // uniform
+        const int buf = i & 1;
+        load_a(min(kc + 1, kc_end - 1));  // unconditional (clamped) prefetch of the next activation tile
+        const float* ab = s_a + buf * (SM_ROWS * LDK) + lj * LDK + kq * 8;
+        float4 a0[4], a1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          a0[t] = *reinterpret_cast<const float4*>(ab + t * 16 * LDK);
+          a1[t] = *reinterpret_cast<const float4*>(ab + t * 16 * LDK + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].x, bw[i][0].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].y, bw[i][0].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].z, bw[i][0].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].w, bw[i][0].w, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].x, bw[i][1].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].y, bw[i][1].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].z, bw[i][1].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].w, bw[i][1].w, acc[t], 0, 0, 0);
+        store_a(buf ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: col = lane&15 (Cout), row = 4*(lane>>4) + r inside each 16-voxel tile
+  const int co = n0 + wave * 16 + lj;
   if (co < p.Cout) {
     const float bv = (p.nsplit == 1 && p.bias) ? p.bias[co] : 0.f;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
+    for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = (wm * MT + t) * 16 + 4 * kq + r;
-        const int z = row >> 6, y = (row >> 3) & 7, x = row & 7;
-        const int64_t m = (((int64_t)n * p.OD + tz0 + z) * p.OH + ty0 + y) * p.OW + tx0 + x;
+        const int64_t m = m0 + t * 16 + 4 * kq + r;
+        if (m >= M) continue;
         float v = acc[t][r];
         if (p.nsplit == 1) {
           v += bv;
@@ -482,37 +698,76 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   }
 }
 
-// out = sum_s partial[s] + bias + residual   (float4 over [M][Cout], Cout % 4 == 0)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, int64_t MC,
-                                                            int Cout, const float* __restrict__ bias,
+// out = sum_s partial[s] + bias + residual, fused with the GroupNorm statistics of `out`.
+// Thread layout of gn_stats_kernel: cq = Cout/4 threads across channels (float4), rows = 256/cq voxels per
+// pass, one workgroup per voxel slab of one sample; grid = (B, N) with B, vox_per_block from
+// gn_stats_geometry(Cout, V).  stats (optional): [n][B][Cout][2] doubles.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int nsplit,
+                                                            int64_t MC, int Cout, int64_t V, int vox_per_block,
+                                                            const float* __restrict__ bias,
                                                             const float* __restrict__ residual,
-                                                            float* __restrict__ out) {
-  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= MC) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < nsplit; ++k) {
-    float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
-    s.x += v.x;
-    s.y += v.y;
-    s.z += v.z;
-    s.w += v.w;
+                                                            float* __restrict__ out, double* __restrict__ stats) {
+  __shared__ double red[256 * 8];
+  const int n = blockIdx.y;
+  const int cq = Cout >> 2;
+  const int rows = 256 / cq;
+  const int tid = threadIdx.x;
+  const int c4 = tid % cq;
+  const int vr = tid / cq;
+  const int64_t vbeg = (int64_t)blockIdx.x * vox_per_block;
+  int64_t vend = vbeg + vox_per_block;
+  if (vend > V) vend = V;
+  float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
+  if (vr < rows) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+    for (int64_t v = vbeg + vr; v < vend; v += rows) {
+      const int64_t i = ((int64_t)n * V + v) * Cout + c4 * 4;
+      float4 s = b;
+      for (int k = 0; k < nsplit; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
+        s.x += t.x;
+        s.y += t.y;
+        s.z += t.z;
+        s.w += t.w;
+      }
+      if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + i);
+        s.x += r.x;
+        s.y += r.y;
+        s.z += r.z;
+        s.w += r.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = s;
+      fs[0] += s.x;
+      fs[1] += s.y;
+      fs[2] += s.z;
+      fs[3] += s.w;
+      fq[0] += s.x * s.x;
+      fq[1] += s.y * s.y;
+      fq[2] += s.z * s.z;
+      fq[3] += s.w * s.w;
+    }
   }
-  if (bias) {
-    int co = (int)(i % Cout);
-    float4 b = *reinterpret_cast<const float4*>(bias + co);
-    s.x += b.x;
-    s.y += b.y;
-    s.z += b.z;
-    s.w += b.w;
+  if (!stats) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[tid * 8 + e] = (double)fs[e];
+    red[tid * 8 + 4 + e] = (double)fq[e];
   }
-  if (residual) {
-    float4 r = *reinterpret_cast<const float4*>(residual + i);
-    s.x += r.x;
-    s.y += r.y;
-    s.z += r.z;
-    s.w += r.w;
+  __syncthreads();
+  if (tid < cq) {
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < rows; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[(r * cq + tid) * 8 + e];
+    double* dst = stats + (((int64_t)n * gridDim.x + blockIdx.x) * Cout + tid * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[e * 2 + 0] = s[e];
+      dst[e * 2 + 1] = s[4 + e];
+    }
   }
-  *reinterpret_cast<float4*>(out + i) = s;
 }
 
 }  // namespace
@@ -530,9 +785,21 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0)
                ? 1
                : 0;
+  if (p.mode == 0 && p.ksz == 3 && M <= 256 && p.Cout >= 64) {  // deepest levels: weight-streaming small-M kernel
+    p.mode = 2;
+    const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
+    const int64_t tgt = 3 * (int64_t)num_cus;
+    nsplit = t2 < tgt ? (int)cdiv(tgt, t2) : 1;
+    int max_split = nchunks / 4;
+    if (max_split < 1) max_split = 1;
+    if (nsplit > max_split) nsplit = max_split;
+    int cps = (int)cdiv(nchunks, nsplit);
+    nsplit = (int)cdiv(nchunks, cps);
+    p.nsplit = nsplit;
+    p.chunks_per_split = cps;
+    return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
+  }
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
-    const char* sg = getenv("HOLO_CONV_STAGGER");
-    p.stagger = sg ? atoi(sg) : 0;
     if (tiles < target) {
       nsplit = (int)cdiv(target, tiles);
       if (nsplit > ncc) nsplit = ncc;
@@ -556,6 +823,19 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
 }
 
+// Number of GroupNorm-statistics slabs per sample the launch of `p` writes into p.stats (0 = this launch cannot
+// produce them: un-split gather kernel; use gn_stats_launch on the output instead).
+int conv_stats_slabs(const ConvParams& p) {
+  const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+  if (p.nsplit > 1) {
+    int B, vpb;
+    gn_stats_geometry(p.Cout, V, &B, &vpb);
+    return B;
+  }
+  if (p.mode == 1) return (int)(V / BM) * (p.Cout >= 64 ? 1 : 2);
+  return 0;
+}
+
 double conv_flops(const ConvParams& p) {
   const double M = (double)p.N * p.OD * p.OH * p.OW;
   return 2.0 * M * p.Cout * (double)(p.C0 + p.C1) * p.ksz * p.ksz * p.ksz;
@@ -563,7 +843,7 @@ double conv_flops(const ConvParams& p) {
 
 int conv_launch(const ConvParams& p, void* stream) {
   const int Cin = p.C0 + p.C1;
-  if ((Cin & 3) || (p.C0 & 3) || (p.Cout & 3) || (p.src1 && (p.C0 % BK))) {
+  if ((Cin & 3) || (p.C0 & 3) || (p.Cout & 3) || (p.src1 && (p.C0 % BK)) || (p.nsplit > 1 && (p.Cout >> 2) > 256)) {
     set_error("conv_launch: unsupported channel counts C0=%d C1=%d Cout=%d", p.C0, p.C1, p.Cout);
     return -1;
   }
@@ -583,6 +863,9 @@ int conv_launch(const ConvParams& p, void* stream) {
     } else {
       HOLO_LAUNCH(conv_halo_kernel<2>, hgrid, block, stream, p);
     }
+  } else if (p.mode == 2) {
+    dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
+    HOLO_LAUNCH(conv_small_kernel, sgrid, block, stream, p);
   } else if (wide) {
     HOLO_LAUNCH(conv_igemm_kernel<2>, grid, block, stream, p);
   } else {
@@ -590,9 +873,11 @@ int conv_launch(const ConvParams& p, void* stream) {
   }
   if (p.nsplit > 1) {
     const int64_t MC = M * p.Cout;
-    dim3 g2((unsigned)cdiv(MC / 4, 256));
-    HOLO_LAUNCH(splitk_reduce_kernel, g2, dim3(256), stream, (const float*)p.partial, p.nsplit, MC, p.Cout, p.bias,
-                p.residual, p.out);
+    const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+    int B, vpb;
+    gn_stats_geometry(p.Cout, V, &B, &vpb);
+    HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N), dim3(256), stream, (const float*)p.partial,
+                p.nsplit, MC, p.Cout, V, vpb, p.bias, p.residual, p.out, p.stats);
   }
   return 0;
 }

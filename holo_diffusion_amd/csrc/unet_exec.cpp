@@ -366,15 +366,17 @@ struct Planner {
     a.R = R;
     a.bytes = (size_t)N * vox(R) * C * sizeof(float);
     a.off = arena_base + arena.alloc(a.bytes);
-    int vpb;
-    gn_stats_geometry(C, vox(R), &a.stats_B, &vpb);
-    a.stats_bytes = (size_t)N * a.stats_B * C * 2 * sizeof(double);
-    a.stats_off = arena_base + arena.alloc(a.stats_bytes);
     return a;
+  }
+  // GroupNorm partial-sum buffer [N][slabs][C][2] doubles; the slab count depends on the producing kernel
+  void alloc_stats(Act& a, int slabs) {
+    a.stats_B = slabs;
+    a.stats_bytes = (size_t)N * slabs * a.C * 2 * sizeof(double);
+    a.stats_off = arena_base + arena.alloc(a.stats_bytes);
   }
   void release(Act& a) {
     arena.free(a.off - arena_base, a.bytes);
-    arena.free(a.stats_off - arena_base, a.stats_bytes);
+    if (a.stats_bytes) arena.free(a.stats_off - arena_base, a.stats_bytes);
   }
   size_t small_alloc(size_t bytes) {
     size_t off = small_base + small_top;
@@ -384,7 +386,10 @@ struct Planner {
   size_t scratch_alloc(size_t bytes) { return arena_base + arena.alloc(bytes); }
   void scratch_free(size_t off, size_t bytes) { arena.free(off - arena_base, bytes); }
 
-  void emit_stats(const Act& a) {
+  void emit_stats(Act& a) {
+    int B, vpb;
+    gn_stats_geometry(a.C, vox(a.R), &B, &vpb);
+    alloc_stats(a, B);
     Op op;
     op.kind = OP_STATS;
     op.f0 = ptr<float>(a.off);
@@ -418,7 +423,7 @@ struct Planner {
   }
   void emit_conv(const Act& x0, const Act* x1, int in_R_logical, int ups, int out_R, int stride, int ksz,
                  const float* w, const float* bias, size_t coef_off, bool has_coef, int act, const float* residual,
-                 float* out, int Cout) {
+                 float* out, int Cout, Act* stats_of = nullptr) {
     Op op;
     op.kind = OP_CONV;
     ConvParams& p = op.conv;
@@ -449,7 +454,15 @@ struct Planner {
       p.partial = ptr<float>(so);
       scratch_free(so, sb);  // stream order protects it until the reduce kernel has run
     }
+    // GroupNorm statistics of the output: from the conv / split-K-reduce epilogue when the launch can
+    // produce them, else by a separate pass over the output
+    const int slabs = stats_of ? conv_stats_slabs(p) : 0;
+    if (slabs > 0) {
+      alloc_stats(*stats_of, slabs);
+      p.stats = ptr<double>(stats_of->stats_off);
+    }
     ops.push_back(op);
+    if (stats_of && slabs == 0) emit_stats(*stats_of);
   }
 
   Act resblock(const Block& b, Act& x0, Act* x1) {
@@ -458,8 +471,7 @@ struct Planner {
     size_t coefA = emit_finalize(x0, x1, P(u, p + ".in_layers.0.weight"), P(u, p + ".in_layers.0.bias"), nullptr, 0);
     Act h1 = new_act(b.cout, R);
     emit_conv(x0, x1, R, 0, R, 1, 3, P(u, p + ".in_layers.2.weight"), P(u, p + ".in_layers.2.bias"), coefA, true, 1,
-              nullptr, ptr<float>(h1.off), b.cout);
-    emit_stats(h1);
+              nullptr, ptr<float>(h1.off), b.cout, &h1);
     const float* film = ptr<float>(eml_off) + u->emb_row_off[p];
     size_t coefB =
         emit_finalize(h1, nullptr, P(u, p + ".out_layers.0.weight"), P(u, p + ".out_layers.0.bias"), film, b.cout);
@@ -476,8 +488,7 @@ struct Planner {
     }
     Act out = new_act(b.cout, R);
     emit_conv(h1, nullptr, R, 0, R, 1, 3, P(u, p + ".out_layers.3.weight"), P(u, p + ".out_layers.3.bias"), coefB, true,
-              1, residual, ptr<float>(out.off), b.cout);
-    emit_stats(out);
+              1, residual, ptr<float>(out.off), b.cout, &out);
     release(h1);
     if (has_skip) release(s);
     return out;
@@ -579,8 +590,7 @@ struct Planner {
     av.C = C;
     av.R = R;
     emit_conv(av, nullptr, R, 0, R, 1, 1, P(u, p + ".proj_out.weight"), P(u, p + ".proj_out.bias"), 0, false, 0,
-              ptr<float>(x.off), ptr<float>(out.off), C);
-    emit_stats(out);
+              ptr<float>(x.off), ptr<float>(out.off), C, &out);
     scratch_free(qkv, qkv_bytes);
     scratch_free(a, a_bytes);
     return out;
@@ -598,8 +608,7 @@ struct Planner {
         case B_CONV:
           out = new_act(b.cout, h.R);
           emit_conv(h, nullptr, h.R, 0, h.R, 1, 3, P(u, b.prefix + ".weight"), P(u, b.prefix + ".bias"), 0, false, 0,
-                    nullptr, ptr<float>(out.off), b.cout);
-          emit_stats(out);
+                    nullptr, ptr<float>(out.off), b.cout, &out);
           break;
         case B_RES:
           out = resblock(b, h, x1);
@@ -610,14 +619,12 @@ struct Planner {
         case B_DOWN:
           out = new_act(b.cout, h.R / 2);
           emit_conv(h, nullptr, h.R, 0, h.R / 2, 2, 3, P(u, b.prefix + ".op.weight"), P(u, b.prefix + ".op.bias"), 0,
-                    false, 0, nullptr, ptr<float>(out.off), b.cout);
-          emit_stats(out);
+                    false, 0, nullptr, ptr<float>(out.off), b.cout, &out);
           break;
         case B_UP:
           out = new_act(b.cout, h.R * 2);
           emit_conv(h, nullptr, h.R * 2, 1, h.R * 2, 1, 3, P(u, b.prefix + ".conv.weight"),
-                    P(u, b.prefix + ".conv.bias"), 0, false, 0, nullptr, ptr<float>(out.off), b.cout);
-          emit_stats(out);
+                    P(u, b.prefix + ".conv.bias"), 0, false, 0, nullptr, ptr<float>(out.off), b.cout, &out);
           break;
       }
       if (!first || release_h) release(h);
