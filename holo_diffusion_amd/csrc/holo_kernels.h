@@ -34,6 +34,7 @@ struct ConvParams {
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
+  int tz;                 // halo kernel tile depth (set by conv_plan)
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
 };
 

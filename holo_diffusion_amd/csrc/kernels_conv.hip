@@ -261,16 +261,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 // ks of the 8 per tap uses channel 8kq+ks, so a lane's operands for a whole tap are 8 contiguous floats.
 // The halo of the NEXT channel chunk is requested under the last tap and committed after it (two
 // barriers per chunk).  Split-K runs over channel chunks.
-// LDS: 400 x 36 floats = 57.6 KB -> two workgroups per CU.
+// LDS: (TZ+2) x 10 x 10 x 36 floats = 57.6 KB (TZ=2) / 43.2 KB (TZ=1).
 // ---------------------------------------------------------------------------------------------
-constexpr int HZ = 4, HY = 10, HX = 10;
-constexpr int HALO_VOX = HZ * HY * HX;
-constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // halo rows per thread (8 threads cover one row's 32 channels)
+constexpr int HY = 10, HX = 10;
 
-template <int NWN>  // waves along Cout: 4 -> 64 channels per block, 2 -> 32 channels per block
+// NWN: waves along Cout (4 -> 64 channels per block, 2 -> 32).  TZ: tile depth in voxels (2 -> 128-voxel tiles
+// for the 64^3 level; 1 -> 64-voxel tiles so that the 32^3..8^3 levels launch twice the workgroups and the 32^3
+// level needs no split-K)
+template <int NWN, int TZ>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   constexpr int BN = 16 * NWN;
-  constexpr int MT = 2 * NWN;  // 16-voxel tiles per wave: 8 (all 128 voxels) or 4 (64 voxels)
+  constexpr int MT = TZ * NWN;  // 16-voxel tiles per wave
+  constexpr int HZ = TZ + 2;
+  constexpr int HALO_VOX = HZ * HY * HX;
+  constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // halo rows per thread (8 threads cover one row's 32 channels)
   __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * LDK];
 
   const int tid = threadIdx.x;
@@ -283,13 +287,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
   // spatial tile decode
-  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD >> 1;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD / TZ;
   int bt = blockIdx.x;
   const int tx0 = (bt % ntx) << 3;
   bt /= ntx;
   const int ty0 = (bt % nty) << 3;
   bt /= nty;
-  const int tz0 = (bt % ntz) << 1;
+  const int tz0 = (bt % ntz) * TZ;
   const int n = bt / ntz;
   const int n0 = blockIdx.y * BN;
   const int cc_begin = blockIdx.z * p.chunks_per_split;
@@ -709,7 +713,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ out, double* __restrict__ stats) {
   __shared__ double red[256 * 8];
   const int n = blockIdx.y;
-  const int cq = Cout >> 2;
+  const int c_base = blockIdx.z * 1024;  // column blocks of <= 1024 channels (qkv convs are up to 1536 wide)
+  const int Cb = (Cout - c_base) < 1024 ? (Cout - c_base) : 1024;
+  const int cq = Cb >> 2;
   const int rows = 256 / cq;
   const int tid = threadIdx.x;
   const int c4 = tid % cq;
@@ -720,11 +726,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
   if (vr < rows) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+    if (bias) b = *reinterpret_cast<const float4*>(bias + c_base + c4 * 4);
     for (int64_t v = vbeg + vr; v < vend; v += rows) {
-      const int64_t i = ((int64_t)n * V + v) * Cout + c4 * 4;
+      const int64_t i = ((int64_t)n * V + v) * Cout + c_base + c4 * 4;
       float4 s = b;
-      for (int k = 0; k < nsplit; ++k) {
+      int k = 0;
+      for (; k + 4 <= nsplit; k += 4) {  // four independent loads in flight per thread
+        const float4 t0 = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
+        const float4 t1 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 1) * MC + i);
+        const float4 t2 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 2) * MC + i);
+        const float4 t3 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 3) * MC + i);
+        s.x += (t0.x + t1.x) + (t2.x + t3.x);
+        s.y += (t0.y + t1.y) + (t2.y + t3.y);
+        s.z += (t0.z + t1.z) + (t2.z + t3.z);
+        s.w += (t0.w + t1.w) + (t2.w + t3.w);
+      }
+      for (; k < nsplit; ++k) {
         const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
         s.x += t.x;
         s.y += t.y;
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int r = 0; r < rows; ++r)
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += red[(r * cq + tid) * 8 + e];
-    double* dst = stats + (((int64_t)n * gridDim.x + blockIdx.x) * Cout + tid * 4) * 2;
+    double* dst = stats + (((int64_t)n * gridDim.x + blockIdx.x) * Cout + c_base + tid * 4) * 2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       dst[e * 2 + 0] = s[e];
@@ -781,7 +798,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   const int64_t tiles = cdiv(M, BM) * cdiv(p.Cout, bn);
   int nsplit = 1;
   const int64_t target = 2 * (int64_t)num_cus;
-  p.mode = (p.ksz == 3 && p.stride == 1 && p.pad == 1 && (p.OD % 2) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 &&
+  p.mode = (p.ksz == 3 && p.stride == 1 && p.pad == 1 && (p.OD % 2) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 &&  // (TZ=1 tiles need no z divisibility)
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0)
                ? 1
                : 0;
@@ -800,8 +817,14 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
-    if (tiles < target) {
-      nsplit = (int)cdiv(target, tiles);
+    p.tz = 2;
+    int64_t htiles = tiles;
+    if (tiles < target) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
+      p.tz = 1;
+      htiles = (M / 64) * cdiv(p.Cout, bn);
+    }
+    if (htiles < target) {
+      nsplit = (int)cdiv(target, htiles);
       if (nsplit > ncc) nsplit = ncc;
     }
     int cps = (int)cdiv(ncc, nsplit);
@@ -829,10 +852,10 @@ int conv_stats_slabs(const ConvParams& p) {
   const int64_t V = (int64_t)p.OD * p.OH * p.OW;
   if (p.nsplit > 1) {
     int B, vpb;
-    gn_stats_geometry(p.Cout, V, &B, &vpb);
+    gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     return B;
   }
-  if (p.mode == 1) return (int)(V / BM) * (p.Cout >= 64 ? 1 : 2);
+  if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   return 0;
 }
 
@@ -843,7 +866,7 @@ double conv_flops(const ConvParams& p) {
 
 int conv_launch(const ConvParams& p, void* stream) {
   const int Cin = p.C0 + p.C1;
-  if ((Cin & 3) || (p.C0 & 3) || (p.Cout & 3) || (p.src1 && (p.C0 % BK)) || (p.nsplit > 1 && (p.Cout >> 2) > 256)) {
+  if ((Cin & 3) || (p.C0 & 3) || (p.Cout & 3) || (p.src1 && (p.C0 % BK))) {
     set_error("conv_launch: unsupported channel counts C0=%d C1=%d Cout=%d", p.C0, p.C1, p.Cout);
     return -1;
   }
@@ -857,11 +880,15 @@ int conv_launch(const ConvParams& p, void* stream) {
   dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
   dim3 block(256);
   if (p.mode == 1) {
-    dim3 hgrid((unsigned)(M / BM), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
-    if (wide) {
-      HOLO_LAUNCH(conv_halo_kernel<4>, hgrid, block, stream, p);
+    dim3 hgrid((unsigned)(M / (64 * p.tz)), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
+    if (wide && p.tz == 2) {
+      HOLO_LAUNCH((conv_halo_kernel<4, 2>), hgrid, block, stream, p);
+    } else if (wide) {
+      HOLO_LAUNCH((conv_halo_kernel<4, 1>), hgrid, block, stream, p);
+    } else if (p.tz == 2) {
+      HOLO_LAUNCH((conv_halo_kernel<2, 2>), hgrid, block, stream, p);
     } else {
-      HOLO_LAUNCH(conv_halo_kernel<2>, hgrid, block, stream, p);
+      HOLO_LAUNCH((conv_halo_kernel<2, 1>), hgrid, block, stream, p);
     }
   } else if (p.mode == 2) {
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
@@ -875,8 +902,9 @@ int conv_launch(const ConvParams& p, void* stream) {
     const int64_t MC = M * p.Cout;
     const int64_t V = (int64_t)p.OD * p.OH * p.OW;
     int B, vpb;
-    gn_stats_geometry(p.Cout, V, &B, &vpb);
-    HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N), dim3(256), stream, (const float*)p.partial,
+    gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
+    HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N, (unsigned)cdiv(p.Cout, 1024)), dim3(256), stream,
+                (const float*)p.partial,
                 p.nsplit, MC, p.Cout, V, vpb, p.bias, p.residual, p.out, p.stats);
   }
   return 0;
