@@ -30,6 +30,13 @@ struct ConvParams {
   const float* bias;      // [Cout] or null
   const float* residual;  // [M][Cout] or null
   float* out;             // [M][Cout]
+  // optional fused 1x1x1 skip connection (halo kernel only): out += skip_w . [skip_src0 | skip_src1] + skip_bias
+  const float* skip_src0;
+  const float* skip_src1;
+  int skip_C0, skip_C1;
+  const float* skip_w;    // [CoutP][skip_CinP]
+  int skip_CinP;
+  const float* skip_bias;
   double* stats;          // optional: GroupNorm partial sums of `out`, [N][conv_stats_slabs(p)][Cout][2]
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks

@@ -268,7 +268,7 @@ constexpr int HY = 10, HX = 10;
 // NWN: waves along Cout (4 -> 64 channels per block, 2 -> 32).  TZ: tile depth in voxels (2 -> 128-voxel tiles
 // for the 64^3 level; 1 -> 64-voxel tiles so that the 32^3..8^3 levels launch twice the workgroups and the 32^3
 // level needs no split-K)
-template <int NWN, int TZ>
+template <int NWN, int TZ, bool SKIP>  // SKIP: a 1x1x1 skip connection is fused as extra K chunks
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   constexpr int BN = 16 * NWN;
   constexpr int MT = TZ * NWN;  // 16-voxel tiles per wave
@@ -296,9 +296,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   const int tz0 = (bt % ntz) * TZ;
   const int n = bt / ntz;
   const int n0 = blockIdx.y * BN;
+  // K chunks: [0, ncc) main 3x3x3 chunks, [ncc, ncc + nsk) the fused 1x1x1 skip connection of a ResBlock
+  // (unet.py:222,256: skip_connection(x) + h): same output tile, source = the block input, centre tap only
+  const int SCin = p.skip_C0 + p.skip_C1;
+  const int nsk = SKIP ? (SCin + BK - 1) / BK : 0;
   const int cc_begin = blockIdx.z * p.chunks_per_split;
   int cc_end = cc_begin + p.chunks_per_split;
-  if (cc_end > ncc) cc_end = ncc;
+  if (cc_end > ncc + nsk) cc_end = ncc + nsk;
   const int SD = p.ups ? (p.ID >> 1) : p.ID;
   const int SH = p.ups ? (p.IH >> 1) : p.IH;
   const int SW = p.ups ? (p.IW >> 1) : p.IW;
@@ -310,17 +314,20 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   float4 hreg[HALO_IT];
   unsigned hmask = 0;  // bit i: element i is inside the volume (zero padding otherwise)
   int hcoef_c = 0;
+  bool h_is_skip = false;
   auto halo_issue = [&](int cc) {
-    int c = cc * BK + q * 4;
+    h_is_skip = SKIP && cc >= ncc;
+    int c = (h_is_skip ? cc - ncc : cc) * BK + q * 4;
     hcoef_c = c;
-    const bool cvalid = c < Cin;
+    const bool cvalid = c < (h_is_skip ? SCin : Cin);
     if (!cvalid) c = 0;  // clamped, masked below
-    const float* src = p.src0;
-    int Cs = p.C0, cs = c;
-    if (c >= p.C0) {
-      src = p.src1;
-      Cs = p.C1;
-      cs = c - p.C0;
+    const float* src = h_is_skip ? p.skip_src0 : p.src0;
+    const int C0s = h_is_skip ? p.skip_C0 : p.C0;
+    int Cs = C0s, cs = c;
+    if (c >= C0s) {
+      src = h_is_skip ? p.skip_src1 : p.src1;
+      Cs = h_is_skip ? p.skip_C1 : p.C1;
+      cs = c - C0s;
     }
     hmask = 0;
     // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards:
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
       z = min(max(z, 0), p.ID - 1);
       y = min(max(y, 0), p.IH - 1);
       x = min(max(x, 0), p.IW - 1);
-      if (p.ups) {
+      if (p.ups) {  // (never set together with a fused skip: ResBlocks do not resample)
         z >>= 1;
         y >>= 1;
         x >>= 1;
@@ -348,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   };
   auto halo_commit = [&]() {
     float4 c01 = make_float4(1.f, 0.f, 1.f, 0.f), c23 = c01;
-    if (p.coef) {
+    const bool xform = p.coef && !h_is_skip;  // the skip path reads the raw block input
+    if (xform) {
       const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
       const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
       c01 = cf[0];
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     for (int i = 0; i < HALO_IT; ++i) {
       const int hv = r0 + 32 * i;
       float4 v = hreg[i];
-      if (p.coef) {
+      if (xform) {
         v.x = v.x * c01.x + c01.y;
         v.y = v.y * c01.z + c01.w;
         v.z = v.z * c23.x + c23.y;
@@ -436,8 +444,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  halo_issue(cc_begin);
-  for (int cc = cc_begin; cc < cc_end; ++cc) {
+  // Without a fused skip the next chunk's halo is prefetched under the last tap of the current one.  The SKIP
+  // instantiation keeps the staging registers short-lived instead (request + commit back to back): carrying
+  // them across its two loops pushes the allocator over the 256-VGPR budget into scratch spills.
+  const int cc_main_end = cc_end < ncc ? cc_end : ncc;
+  if (!SKIP) halo_issue(cc_begin);
+  for (int cc = cc_begin; cc < cc_main_end; ++cc) {
+    if (SKIP) halo_issue(cc);
     halo_commit();
     load_b(b0, cc, 0);
     __syncthreads();  // halo of chunk cc visible
@@ -446,17 +459,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
       tap_body(aA, aC, b0, b1, cc, tap, true);
       tap_body(aC, aA, b1, b0, cc, tap + 1, true);
     }
-    // the next chunk's halo loads fly under the last tap
-    if (cc + 1 < cc_end) halo_issue(cc + 1);
+    if (!SKIP && cc + 1 < cc_end) halo_issue(cc + 1);  // flies under the last tap
     tap_body(aA, aC, b0, b1, cc, 26, false);
     __syncthreads();  // everyone done reading this halo before it is overwritten
+  }
+  if (SKIP) {
+    // fused 1x1x1 skip connection: centre tap (13) of the block-input halo, its own [CoutP][skip_CinP] weights
+    for (int cc = cc_begin > ncc ? cc_begin : ncc; cc < cc_end; ++cc) {
+      halo_issue(cc);
+      halo_commit();
+      const float4* wp = reinterpret_cast<const float4*>(p.skip_w + (int64_t)(n0 + wn * 16 + lj) * p.skip_CinP +
+                                                         (cc - ncc) * BK + kq * 8);
+      b0[0] = wp[0];
+      b0[1] = wp[1];
+      __syncthreads();
+      load_a(aA, 13, 0);
+      load_a(aB, 13, 1);
+      mfma_half(aA, b0[0]);
+      mfma_half(aB, b0[1]);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: 16x16x4 D layout: col = lane&15 (Cout), row = 4*(lane>>4) + r (voxel inside the tile)
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int co = n0 + wn * 16 + lj;
   const int coc = co < p.Cout ? co : p.Cout - 1;
-  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  if (p.nsplit == 1 && p.skip_bias) bv += p.skip_bias[coc];
   float ssum = 0.f, ssq = 0.f;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
@@ -709,6 +739,7 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int nsplit,
                                                             int64_t MC, int Cout, int64_t V, int vox_per_block,
                                                             const float* __restrict__ bias,
+                                                            const float* __restrict__ bias2,
                                                             const float* __restrict__ residual,
                                                             float* __restrict__ out, double* __restrict__ stats) {
   __shared__ double red[256 * 8];
@@ -727,6 +758,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (vr < rows) {
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) b = *reinterpret_cast<const float4*>(bias + c_base + c4 * 4);
+    if (bias2) {
+      const float4 b2 = *reinterpret_cast<const float4*>(bias2 + c_base + c4 * 4);
+      b.x += b2.x;
+      b.y += b2.y;
+      b.z += b2.z;
+      b.w += b2.w;
+    }
     for (int64_t v = vbeg + vr; v < vend; v += rows) {
       const int64_t i = ((int64_t)n * V + v) * Cout + c_base + c4 * 4;
       float4 s = b;
@@ -823,12 +861,13 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
+    const int nck = ncc + (p.skip_w ? (p.skip_C0 + p.skip_C1 + BK - 1) / BK : 0);  // + fused skip chunks
     if (htiles < target) {
       nsplit = (int)cdiv(target, htiles);
       if (nsplit > ncc) nsplit = ncc;
     }
-    int cps = (int)cdiv(ncc, nsplit);
-    nsplit = (int)cdiv(ncc, cps);
+    int cps = (int)cdiv(nck, nsplit);
+    nsplit = (int)cdiv(nck, cps);
     p.nsplit = nsplit;
     p.chunks_per_split = cps;
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
@@ -861,7 +900,7 @@ int conv_stats_slabs(const ConvParams& p) {
 
 double conv_flops(const ConvParams& p) {
   const double M = (double)p.N * p.OD * p.OH * p.OW;
-  return 2.0 * M * p.Cout * (double)(p.C0 + p.C1) * p.ksz * p.ksz * p.ksz;
+  return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * p.ksz * p.ksz * p.ksz + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
 }
 
 int conv_launch(const ConvParams& p, void* stream) {
@@ -881,14 +920,22 @@ int conv_launch(const ConvParams& p, void* stream) {
   dim3 block(256);
   if (p.mode == 1) {
     dim3 hgrid((unsigned)(M / (64 * p.tz)), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
-    if (wide && p.tz == 2) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 2>), hgrid, block, stream, p);
+    const bool sk = p.skip_w != nullptr;
+    if (wide && p.tz == 2 && sk) {
+      HOLO_LAUNCH((conv_halo_kernel<4, 2, true>), hgrid, block, stream, p);
+    } else if (wide && p.tz == 2) {
+      HOLO_LAUNCH((conv_halo_kernel<4, 2, false>), hgrid, block, stream, p);
+    } else if (wide && sk) {
+      HOLO_LAUNCH((conv_halo_kernel<4, 1, true>), hgrid, block, stream, p);
     } else if (wide) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 1>), hgrid, block, stream, p);
+      HOLO_LAUNCH((conv_halo_kernel<4, 1, false>), hgrid, block, stream, p);
+    } else if (sk) {
+      set_error("conv_launch: fused skip needs Cout >= 64");
+      return -1;
     } else if (p.tz == 2) {
-      HOLO_LAUNCH((conv_halo_kernel<2, 2>), hgrid, block, stream, p);
+      HOLO_LAUNCH((conv_halo_kernel<2, 2, false>), hgrid, block, stream, p);
     } else {
-      HOLO_LAUNCH((conv_halo_kernel<2, 1>), hgrid, block, stream, p);
+      HOLO_LAUNCH((conv_halo_kernel<2, 1, false>), hgrid, block, stream, p);
     }
   } else if (p.mode == 2) {
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
@@ -905,7 +952,7 @@ int conv_launch(const ConvParams& p, void* stream) {
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N, (unsigned)cdiv(p.Cout, 1024)), dim3(256), stream,
                 (const float*)p.partial,
-                p.nsplit, MC, p.Cout, V, vpb, p.bias, p.residual, p.out, p.stats);
+                p.nsplit, MC, p.Cout, V, vpb, p.bias, p.skip_bias, p.residual, p.out, p.stats);
   }
   return 0;
 }

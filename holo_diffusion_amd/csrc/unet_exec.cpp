@@ -423,7 +423,8 @@ struct Planner {
   }
   void emit_conv(const Act& x0, const Act* x1, int in_R_logical, int ups, int out_R, int stride, int ksz,
                  const float* w, const float* bias, size_t coef_off, bool has_coef, int act, const float* residual,
-                 float* out, int Cout, Act* stats_of = nullptr) {
+                 float* out, int Cout, Act* stats_of = nullptr, const Act* skip0 = nullptr,
+                 const Act* skip1 = nullptr, const float* skip_w = nullptr, const float* skip_bias = nullptr) {
     Op op;
     op.kind = OP_CONV;
     ConvParams& p = op.conv;
@@ -448,6 +449,15 @@ struct Planner {
     p.bias = bias;
     p.residual = residual;
     p.out = out;
+    if (skip_w) {  // 1x1x1 skip connection fused as extra K chunks (halo kernel)
+      p.skip_src0 = ptr<float>(skip0->off);
+      p.skip_src1 = skip1 ? ptr<float>(skip1->off) : nullptr;
+      p.skip_C0 = skip0->C;
+      p.skip_C1 = skip1 ? skip1->C : 0;
+      p.skip_w = skip_w;
+      p.skip_CinP = pad_cin(p.skip_C0 + p.skip_C1);
+      p.skip_bias = skip_bias;
+    }
     size_t sb = conv_plan(p, u->ctx->num_cus);
     if (sb) {
       size_t so = scratch_alloc(sb);
@@ -478,19 +488,28 @@ struct Planner {
     Act s;
     const float* residual;
     const bool has_skip = b.cin != b.cout;
-    if (has_skip) {
+    // the 1x1x1 skip conv rides inside the second 3x3x3 conv (halo kernel) wherever that kernel applies
+    const bool fuse_skip = has_skip && (R % 8) == 0 && b.cout >= 64 && !getenv("HOLO_NO_SKIP_FUSION");
+    if (has_skip && !fuse_skip) {
       s = new_act(b.cout, R);
       emit_conv(x0, x1, R, 0, R, 1, 1, P(u, p + ".skip_connection.weight"), P(u, p + ".skip_connection.bias"), 0,
                 false, 0, nullptr, ptr<float>(s.off), b.cout);
       residual = ptr<float>(s.off);
+    } else if (has_skip) {
+      residual = nullptr;
     } else {
       residual = ptr<float>(x0.off);
     }
     Act out = new_act(b.cout, R);
-    emit_conv(h1, nullptr, R, 0, R, 1, 3, P(u, p + ".out_layers.3.weight"), P(u, p + ".out_layers.3.bias"), coefB, true,
-              1, residual, ptr<float>(out.off), b.cout, &out);
+    if (fuse_skip)
+      emit_conv(h1, nullptr, R, 0, R, 1, 3, P(u, p + ".out_layers.3.weight"), P(u, p + ".out_layers.3.bias"), coefB,
+                true, 1, nullptr, ptr<float>(out.off), b.cout, &out, &x0, x1, P(u, p + ".skip_connection.weight"),
+                P(u, p + ".skip_connection.bias"));
+    else
+      emit_conv(h1, nullptr, R, 0, R, 1, 3, P(u, p + ".out_layers.3.weight"), P(u, p + ".out_layers.3.bias"), coefB,
+                true, 1, residual, ptr<float>(out.off), b.cout, &out);
     release(h1);
-    if (has_skip) release(s);
+    if (has_skip && !fuse_skip) release(s);
     return out;
   }
 
