@@ -153,6 +153,11 @@ struct RenderKernelParams {
   float bg[3];
   float background_opacity;
   float pdf_eps;
+  // scratch, per wave (4 * ceil(H*W/128) waves): cdf_ws 64*64 floats (per-lane coarse weights / CDF columns),
+  // val_ws (64 + n_fine)*32 float4 (sigma, rgb of coarse and importance samples), fz_ws n_fine*32 floats
+  float* cdf_ws;
+  float* val_ws;
+  float* fz_ws;
   // outputs (per camera): CHW planes
   float* rgb;
   float* depth;

@@ -11,9 +11,12 @@
 //                    LeakyReLU to the last layer only), so render_exec.cpp folds it to ONE affine map
 //                    hidden = W_eff f + b_eff in float64; the kernel evaluates that map on the matrix cores
 //   composite        EmissionAbsorptionRaymarcher (holo_multipass_ea.py:96-100)
-//   resampling       RayPointRefiner + sample_pdf (det.) + sort (holo_multipass_ea.py:116), done as a
-//                    lazily generated inverse-CDF stream merged with the coarse depths
-//   fine pass        holo_multipass_ea.py:117-123
+//   resampling       RayPointRefiner + sample_pdf (det.) + sort (holo_multipass_ea.py:116): inverse CDF of the
+//                    coarse weights; the sort of [coarse | new] depths is a merge of two sorted lists
+//   fine pass        holo_multipass_ea.py:117-123.  The reference re-evaluates the 64 coarse points inside its
+//                    128-point fine pass; those values are bit-identical to the coarse pass, so the kernel
+//                    evaluates only the 64 new points and composites the merged list from stored values
+//                    (128 instead of 192 implicit-function evaluations per ray, same result)
 // implicit_eval_kernel: the stand-alone HoloVoxelGridImplicitFunction.forward (densities, colours) for
 // arbitrary points (holo_voxel_grid_implicit_function.py:182-269, incl. the pts_3d entry the reference's
 // tests use).
@@ -202,10 +205,13 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
   cb = fast_sigmoid(leaky02(rp2 + rdir[2]));
 }
 
+// The per-ray coarse weights / CDF (64 floats per ray) live in a global scratch, one private column per LANE
+// ([workgroup][wave][j][lane], L2-resident, coalesced when the lanes share j): keeping them in LDS (32 KB per
+// workgroup) capped the kernel at two workgroups per CU and left the matrix pipe idle whenever both resident
+// waves of a SIMD were in their gather / VALU phases.
 template <int CH>
-__global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
+__global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderKernelParams p) {
   __shared__ __attribute__((aligned(16))) MlpLds<CH> s_mlp;
-  __shared__ float s_cdf[4 * MAXC * 32];  // per wave: [j][ray]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -249,10 +255,19 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
                    org[2] + z * dir[2], rdir, sigma, cr, cg, cb);
   };
 
-  // ---- coarse pass
+  // Scratch columns of this wave (L2-resident, written and read back by the same lanes only):
+  //   cdf  [64][64 lanes]        coarse weights, then the CDF (every lane keeps its own copy)
+  //   cval [64][32 rays] float4  (sigma_raw, r, g, b) of the coarse samples
+  //   fz   [nf][32 rays]         importance-sampled depths,  fval [nf][32] float4 their (sigma_raw, r, g, b)
   const int nc = p.n_coarse, nf = p.n_fine;
   const float zstep = (p.zmax - p.zmin) / (float)(nc - 1);
-  float* cdf = s_cdf + wave * (MAXC * 32) + li;  // element j at cdf[j*32]
+  const int64_t wslot = (int64_t)blockIdx.x * 4 + wave;
+  float* cdf = p.cdf_ws + wslot * (MAXC * 64) + lane;  // element j at cdf[j*64]
+  float4* cval = reinterpret_cast<float4*>(p.val_ws) + wslot * ((int64_t)(MAXC + p.n_fine) * 32) + li;
+  float4* fval = cval + MAXC * 32;
+  float* fz = p.fz_ws + wslot * ((int64_t)p.n_fine * 32) + li;
+
+  // ---- coarse pass (all rays of the wave in lock step): evaluate, composite, keep weights + values
   {
     float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
     float zi = lin_space(p.zmin, p.zmax, zstep, 0, nc);
@@ -260,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
       const float zn = (i + 1 < nc) ? lin_space(p.zmin, p.zmax, zstep, i + 1, nc) : 0.f;
       float sg, cr, cg, cb;
       eval(zi, sg, cr, cg, cb);
+      if (lh == 0) cval[i * 32] = make_float4(sg, cr, cg, cb);
       const float delta = (i + 1 < nc) ? zn - zi : p.background_opacity;
       const float x = delta * fmaxf(sg, 0.f);
       const float cap = 1.f - __expf(-x);
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
       ag = fmaf(w, cg, ag);
       ab = fmaf(w, cb, ab);
       ad = fmaf(w, zi, ad);
-      if (lh == 0) cdf[i * 32] = w;  // weights for now; turned into the cdf below
+      cdf[i * 64] = w;  // weights for now; turned into the cdf below (each lane keeps its own copy)
       Tr = 1.f - O;
       zi = zn;
     }
@@ -283,79 +299,95 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderKernelParams p) {
     }
   }
 
-  // ---- weights[1:-1] -> pdf -> cdf (in place, done by lane half 0)
+  // ---- weights[1:-1] -> pdf -> cdf (in place in the lane's private column)
   // cdf has nb = nc-1 entries, cdf[0] = 0;  bins (interval mid points) also nb entries
   const int nb = nc - 1;
-  __builtin_amdgcn_wave_barrier();
-  if (lh == 0) {
+  {
     float S = 0.f;
-    for (int m = 1; m < nc - 1; ++m) S += cdf[m * 32] + p.pdf_eps;
+    for (int m = 1; m < nc - 1; ++m) S += cdf[m * 64] + p.pdf_eps;
     float run = 0.f;
     cdf[0] = 0.f;
     for (int j = 1; j < nb; ++j) {  // cdf[j] = cdf[j-1] + (w[j] + eps)/S ; slot j still holds w[j] here
-      run += (cdf[j * 32] + p.pdf_eps) / S;
-      cdf[j * 32] = run;
+      run += (cdf[j * 64] + p.pdf_eps) / S;
+      cdf[j * 64] = run;
     }
   }
-  __builtin_amdgcn_wave_barrier();
 
-  // ---- fine pass: merge of the coarse depths with the lazily generated inverse-CDF samples
+  auto zcoarse = [&](int i) { return lin_space(p.zmin, p.zmax, zstep, i, nc); };
+
+  // ---- importance samples: inverse CDF at u = linspace(0,1,nf) (monotone, so the bin pointer only advances),
+  //      evaluated in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
+  //      those values are bit-identical to the coarse pass, so only the nf NEW points are evaluated here.
   {
     const float ustep = 1.0f / (float)(nf - 1);
-    int ci = 0, k = 0, ind = 0;
-    auto zcoarse = [&](int i) { return lin_space(p.zmin, p.zmax, zstep, i, nc); };
+    int ind = 0;
     auto mid = [&](int i) {
       const float a0 = zcoarse(i), a1 = zcoarse(i + 1);
       return a0 - (a0 - a1) * 0.5f;  // torch.lerp(z[1:], z[:-1], 0.5)
     };
-    auto gen_fine = [&](int kk) {
+    for (int kk = 0; kk < nf; ++kk) {
       const float u = lin_space(0.f, 1.f, ustep, kk, nf);
-      while (ind < nb && cdf[ind * 32] <= u) ++ind;  // searchsorted(right=True)
+      while (ind < nb && cdf[ind * 64] <= u) ++ind;  // searchsorted(right=True)
       const int below = ind - 1 > 0 ? ind - 1 : 0;
       const int above = ind < nb - 1 ? ind : nb - 1;
-      const float cb_ = cdf[below * 32], ca_ = cdf[above * 32];
+      const float cb_ = cdf[below * 64], ca_ = cdf[above * 64];
       float den = ca_ - cb_;
       if (den < p.pdf_eps) den = 1.f;
       const float tt = (u - cb_) / den;
       const float bb = mid(below), ba = mid(above);
-      return bb + tt * (ba - bb);
-    };
+      const float zf = bb + tt * (ba - bb);
+      float sg, cr, cg, cb;
+      eval(zf, sg, cr, cg, cb);
+      if (lh == 0) {
+        fz[kk * 32] = zf;
+        fval[kk * 32] = make_float4(sg, cr, cg, cb);
+      }
+    }
+  }
+
+  // ---- fine composite: merge of the two sorted depth lists (== torch.sort of their concatenation), per ray,
+  //      no evaluation.  One lane per ray (half 0); no wave-collective operations below this point.
+  if (lh == 0) {
+    int ci = 0, k = 0;
     float zc_head = zcoarse(0);
-    float zf_head = nf > 0 ? gen_fine(0) : 0.f;
-    auto pop = [&]() {
+    float zf_head = fz[0];
+    float4 vhead = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto pop = [&](float4& val) {
       float v;
       if (ci < nc && (k >= nf || zc_head <= zf_head)) {
         v = zc_head;
+        val = cval[ci * 32];
         ++ci;
         if (ci < nc) zc_head = zcoarse(ci);
       } else {
         v = zf_head;
+        val = fval[k * 32];
         ++k;
-        if (k < nf) zf_head = gen_fine(k);
+        if (k < nf) zf_head = fz[k * 32];
       }
       return v;
     };
     const int total = nc + nf;
     float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
-    float zi = pop();
-    for (int s = 0; s < total; ++s) {
-      const float zn = (s + 1 < total) ? pop() : 0.f;
-      float sg, cr, cg, cb;
-      eval(zi, sg, cr, cg, cb);
-      const float delta = (s + 1 < total) ? zn - zi : p.background_opacity;
-      const float x = delta * fmaxf(sg, 0.f);
+    float zi = pop(vhead);
+    for (int s2 = 0; s2 < total; ++s2) {
+      float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float zn = (s2 + 1 < total) ? pop(vnext) : 0.f;
+      const float delta = (s2 + 1 < total) ? zn - zi : p.background_opacity;
+      const float x = delta * fmaxf(vhead.x, 0.f);
       const float cap = 1.f - __expf(-x);
       cum += x;
       O = 1.f - __expf(-cum);
       const float w = cap * Tr;
-      ar = fmaf(w, cr, ar);
-      ag = fmaf(w, cg, ag);
-      ab = fmaf(w, cb, ab);
+      ar = fmaf(w, vhead.y, ar);
+      ag = fmaf(w, vhead.z, ag);
+      ab = fmaf(w, vhead.w, ab);
       ad = fmaf(w, zi, ad);
       Tr = 1.f - O;
       zi = zn;
+      vhead = vnext;
     }
-    if (active && lh == 0) {
+    if (active) {
       p.rgb[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
       p.rgb[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
       p.rgb[2 * npix + ray] = ab + (1.f - O) * p.bg[2];

@@ -222,11 +222,26 @@ static void fill_mlp(const HoloRenderer* r, MlpParams& m) {
   m.Hd = Hd;
 }
 
-size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
-  (void)n_cameras;
-  if (!r) return 0;
+static size_t grid_cl_bytes(const HoloRenderer* r) {
   const size_t R = r->cfg.resol;
-  return R * R * R * (size_t)r->cfg.feature_size * sizeof(float) + 256;
+  return ((R * R * R * (size_t)r->cfg.feature_size * sizeof(float)) + 255) & ~(size_t)255;
+}
+static size_t n_render_waves(const HoloRenderer* r) {
+  const size_t npix = (size_t)r->cfg.image_height * r->cfg.image_width;
+  return ((npix + 127) / 128) * 4;
+}
+static size_t cdf_ws_bytes(const HoloRenderer* r) { return n_render_waves(r) * 64 * 64 * sizeof(float); }
+static size_t val_ws_bytes(const HoloRenderer* r) {
+  return n_render_waves(r) * (size_t)(64 + r->cfg.n_pts_fine) * 32 * 4 * sizeof(float);
+}
+static size_t fz_ws_bytes(const HoloRenderer* r) {
+  return ((n_render_waves(r) * (size_t)r->cfg.n_pts_fine * 32 * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
+  (void)n_cameras;  // frames are rendered one after the other on the stream and share the scratch
+  if (!r) return 0;
+  return grid_cl_bytes(r) + cdf_ws_bytes(r) + val_ws_bytes(r) + fz_ws_bytes(r) + 256;
 }
 
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
@@ -293,6 +308,9 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
     p.background_opacity = c.background_opacity;
     p.pdf_eps = c.sample_pdf_eps;
+    p.cdf_ws = (float*)((char*)workspace + grid_cl_bytes(r));
+    p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r));
+    p.fz_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r) + val_ws_bytes(r));
     p.rgb = images + (size_t)ci * 3 * npix;
     p.depth = depths + (size_t)ci * npix;
     p.mask = masks + (size_t)ci * npix;
@@ -318,7 +336,7 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
     set_error("holo_implicit_eval: call holo_renderer_commit after setting the RenderMLP parameters");
     return HOLO_E_STATE;
   }
-  const size_t grid_bytes = holo_render_workspace_bytes(r, 1);
+  const size_t grid_bytes = grid_cl_bytes(r);
   const int64_t n_dirs = (n_points + pts_per_dir - 1) / pts_per_dir;
   if (workspace_bytes < grid_bytes + (size_t)n_dirs * 3 * sizeof(float)) {
     set_error("holo_implicit_eval: workspace too small (need holo_render_workspace_bytes + 12 bytes per direction)");
