@@ -11,8 +11,10 @@ barrier + synchronize on both sides; with N>1 every rank (one process per GPU, l
 runs its own independent chain (weak scaling, no data-path collective) and the MAX time over ranks is used.
 The render leg (frames of the same grid) is timed the same way and reported in the same JSON line.
 
-  roofline      conv3d implicit-GEMM launches of one UNet forward, timed with hipEvents on the launch stream
-                (holo_unet_time_convs), algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 MFMA peak
+  roofline      the dominant kernel (the 64^3-level LDS voxel-halo conv3d), every launch of one UNet forward timed
+                with hipEvents on the launch stream (holo_unet_time_ops): algorithmic FLOPs / average launch
+                time vs the 157.3 TFLOP/s fp32 MFMA peak; `traffic` = HBM bytes per launch from the committed PMC
+                pass (profiles/pmc_traffic.json); all conv launches together under `all_conv_launches`
   cpu_baseline  the CPU oracle (torch-CPU restatement proven bit-equal to the reference, oracle/) on a bounded
                 sample: a few UNet forwards + posterior at 64^3x32 and one small frame, all host cores
 """
@@ -58,8 +60,6 @@ def build_model(w, H, W, device, n_fine=64):
     full = {"net_3d._net." + k: v for k, v in usd.items()}
     for i in range(model.num_passes):
         full.update({f"_implicit_functions.{i}._fn.render_mlp." + k: v for k, v in msd.items()})
-    if os.environ.get("HOLO_BENCH_ZERO"):  # DVFS probe: all-zero operands draw less power (never a reported number)
-        full = {k: torch.zeros_like(v) for k, v in full.items()}
     model.load_state_dict(full)
     return model.to(device), usd, msd
 
@@ -191,15 +191,47 @@ def main():
     assert torch.isfinite(out["images_render"]).all()
     rays_per_s = world * F * H * W / dtr
 
-    # ---------------- roofline of the dominant kernel (conv3d implicit GEMM), hipEvents on the launch stream
+    # ---------------- roofline of the dominant kernel, hipEvents on the launch stream (holo_unet_time_ops)
     roof = None
     if rank == 0:
-        ms, flops, nl = net.time_convs(1, args.conv_iters, device)
-        ach = flops / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (3x3x3 conv3d launches of one UNet forward)",
+        all_ops = net.time_ops(1, args.conv_iters, device)
+        ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
+        variants = {}
+        for o in ops:
+            key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"]) if o["kernel"] == "conv_halo_kernel" \
+                else (o["kernel"], 0, False, 0)
+            v = variants.setdefault(key, dict(ms=0.0, flops=0.0, n=0))
+            v["ms"] += o["ms"]; v["flops"] += o["flops"]; v["n"] += 1
+        (kname, tz, sk, od), dom = max(variants.items(), key=lambda kv: kv[1]["ms"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        all_ms = sum(o["ms"] for o in ops)
+        all_fl = sum(o["flops"] for o in ops)
+        label = f"{kname}<4, {tz}, {'true' if sk else 'false'}> at {od}^3 output" if kname == "conv_halo_kernel" else kname
+        traffic = None
+        try:  # HBM bytes per launch of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+            pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            ent = pmc.get(label)
+            if ent and args.workload == "north":
+                traffic = {"bytes_per_launch": ent["fetch_bytes"] + ent["write_bytes"], "fetch_bytes": ent["fetch_bytes"],
+                           "write_bytes": ent["write_bytes"], "algorithmic_bytes_per_launch": ent.get("algorithmic_bytes"),
+                           "source": ent.get("source")}
+        except (OSError, ValueError):
+            pass
+        roof = {"bound": "mfma", "kernel": label + " (3x3x3 conv3d, LDS voxel-halo implicit GEMM, fp32 MFMA)",
                 "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "launches_per_forward": nl, "avg_launch_ms": ms / nl, "ms_per_forward": ms,
-                "algorithmic_gflop_per_forward": flops / 1e9}
+                "traffic": traffic, "launches_per_forward": dom["n"], "avg_launch_ms": dom["ms"] / dom["n"],
+                "algorithmic_gflop_per_launch": dom["flops"] / dom["n"] / 1e9,
+                "share_of_conv_time": dom["ms"] / all_ms,
+                "all_conv_launches": {"launches_per_forward": len(ops), "ms_per_forward": all_ms,
+                                      "algorithmic_gflop_per_forward": all_fl / 1e9,
+                                      "achieved": all_fl / (all_ms * 1e-3) / 1e12,
+                                      "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                "by_variant": [{"kernel": k[0], "tile_depth": k[1], "fused_skip": k[2], "out_dim": k[3],
+                                "launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
+                               for k, v in sorted(variants.items(), key=lambda kv: -kv[1]["ms"])]}
+        if os.environ.get("HOLO_BENCH_OPS"):
+            for o in all_ops:
+                print("# op", json.dumps({**o, "tflops": o["flops"] / (o["ms"] * 1e-3) / 1e12}), file=sys.stderr)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, usd, msd)
@@ -209,8 +241,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         # render roofline (logical gather bytes and collapsed-MLP flops per ray)
+        # the reference evaluates 64 coarse + 128 fine points per ray; the kernel evaluates each of the 128 distinct
+        # points once (the fine pass re-uses the 64 coarse values it already holds), so the executed work is 128
         C = w["feature_size"]
-        samples = 64 + 128
+        samples_ref, samples = 64 + 128, 128
         gather_bytes_per_ray = samples * 8 * C * 4
         mlp_flops_per_ray = samples * (2 * 257 * C + 2 * 3 * 256 + 2 * 3 * 27)
         line = {
@@ -225,7 +259,9 @@ def main():
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
             "unet_tflops": UNET_FLOPS_PER_STEP * steps_per_s / world / 1e12 if args.workload == "north" else None,
             "roofline": roof,
-            "roofline_render": {"bound": "mfma+gather", "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,
+            "roofline_render": {"bound": "mfma+gather", "kernel": "render_kernel<16> (one launch per frame)",
+                                "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,
+                                "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,
                                 "peak_hbm_GBps": PEAK_HBM_GBPS,
                                 "mlp_tflops_collapsed": mlp_flops_per_ray * rays_per_s / world / 1e12,
                                 "peak_tflops": PEAK_FP32_MFMA_TFLOPS,

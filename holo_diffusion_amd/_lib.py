@@ -46,6 +46,13 @@ class HoloCamera(C.Structure):
                 ("principal_point", C.c_float * 2)]
 
 
+class HoloOpTiming(C.Structure):
+    _fields_ = [("op", C.c_int32), ("kernel", C.c_int32), ("tile_depth", C.c_int32), ("fused_skip", C.c_int32),
+                ("nsplit", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("out_dim", C.c_int32),
+                ("stride", C.c_int32), ("upsample", C.c_int32), ("ksz", C.c_int32), ("ms", C.c_float),
+                ("flops", C.c_double)]
+
+
 _vp = C.c_void_p
 _i64p = C.POINTER(C.c_int64)
 
@@ -65,6 +72,8 @@ SIGNATURES = {
     "holo_unet_fetch_block": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _i64p, _vp, _vp]),
     "holo_unet_time_convs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_int, _vp, C.POINTER(C.c_float),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "holo_unet_time_ops": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, C.c_int, _vp,
+                                     C.POINTER(HoloOpTiming), C.c_int, C.POINTER(C.c_int)]),
     "holo_ddpm_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "holo_tanh": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "holo_clip": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_int64, _vp]),

@@ -11,12 +11,35 @@
 
 #ifdef HOLO_EMU
 #include "emu_runtime.h"
+#define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
+#define HOLO_PROBE_CLOCK() 0ull
+#define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
+#define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
+// Passes a per-lane value through an empty asm: the optimiser can no longer prove it loop-invariant, so index
+// arithmetic derived from it is recomputed where it is used instead of being hoisted and kept live in VGPRs.
+#define HOLO_LAUNDER(x) asm volatile("" : "+v"(x))
+#define HOLO_PROBE_CLOCK() wall_clock64()
+// Delays the waves that landed in an odd wave slot of their SIMD (= the second resident workgroup of the CU).
+#define HOLO_PHASE_DELAY(ticks)                                                      \
+  do {                                                                               \
+    unsigned hw_;                                                                    \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                \
+    if ((ticks) > 0 && (hw_ & 1u)) {                                                 \
+      const unsigned long long t_ = wall_clock64();                                  \
+      while (wall_clock64() - t_ < (unsigned long long)(ticks)) __builtin_amdgcn_s_sleep(16); \
+    }                                                                                \
+  } while (0)
+#define HOLO_PROBE_HWID(hw, xcc)                                          \
+  do {                                                                    \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));      \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));    \
+  } while (0)
 #endif
 
 #define HOLO_WAVE 64

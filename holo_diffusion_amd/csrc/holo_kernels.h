@@ -23,7 +23,8 @@ struct ConvParams {
   int OD, OH, OW;
   int stride, pad, ksz;  // ksz = 3 (27 taps) or 1
   int Cout;
-  const float* w;         // [ksz^3][CoutP][CinP], zero padded: CoutP, CinP = Cout, Cin rounded up to 32
+  const float* w;         // packed [ksz^3][CinP/32][CoutP/16][2][4][16][4] (repack_conv_weight_launch), zero padded:
+                          // CinP = Cin rounded up to 32, CoutP = Cout rounded up to 64 (32 when Cout < 64)
   int CoutP, CinP;
   const float* coef;      // [N][Cin][2] = (a,b): x' = a*x+b ; null = identity
   int act;                // 1: SiLU after the affine (only with coef)
@@ -34,14 +35,19 @@ struct ConvParams {
   const float* skip_src0;
   const float* skip_src1;
   int skip_C0, skip_C1;
-  const float* skip_w;    // [CoutP][skip_CinP]
+  const float* skip_w;    // packed like w with one tap
   int skip_CinP;
   const float* skip_bias;
   double* stats;          // optional: GroupNorm partial sums of `out`, [N][conv_stats_slabs(p)][Cout][2]
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
+  int skip_chunks_per_split;  // halo kernel with a fused skip: skip chunks are dealt evenly to the same splits
   int tz;                 // halo kernel tile depth (set by conv_plan)
+  int grid_x;             // halo kernel: persistent workgroups along x (set by conv_plan)
+  int stagger_ticks;      // halo kernel: phase offset (100 MHz ticks) of the workgroup in the odd slot of a CU
+  unsigned long long* dbg;  // optional timeline probe (scripts/conv_timeline.cpp): [tile][8] {t_start, t_first_halo,
+                            // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
 };
 
@@ -118,7 +124,7 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
 int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
 
-// OIDHW [Cout][Cin][taps] -> zero padded [taps][CoutP][CinP]
+// OIDHW [Cout][Cin][taps] -> zero padded MFMA-fragment-packed layout (see ConvParams::w)
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
                               void* stream);
 

@@ -37,6 +37,14 @@ constexpr int LDK = 36;
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
+// Packed conv weights (repack_conv_weight_kernel): [tap][chunk = cin/32][slice = cout/16][half][kq][lj][4], i.e. one
+// 2 KB block per (tap, 32-channel chunk, 16-Cout slice) holding exactly the B fragments of a v_mfma_f32_16x16x4_f32
+// wave (lane = 16*kq + lj owns k = 8*kq + 4*half + e of output channel 16*slice + lj): a wave's B load is two fully
+// coalesced 1 KB reads and a workgroup's weights for a chunk are one contiguous 8 KB run.
+__device__ inline int64_t wpack_block(int tap, int cc, int slice, int ncc, int nslice) {
+  return (((int64_t)tap * ncc + cc) * nslice + slice) * 512;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int BN = 32 * NT;
@@ -58,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   if (kc_end > nchunks) kc_end = nchunks;
 
   // ---- per-thread staging assignment: 8 threads cover the 32 channels (float4 each) of one row
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;  // packed-weight geometry (wpack_block)
   const int q = tid & 7;
   const int r0 = tid >> 3;  // 0..31
   int an[4], az[4], ay[4], ax[4];
@@ -131,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = n0 + r0 + 32 * j;  // < CoutP by construction of the grid
-      rb[j] = *reinterpret_cast<const float4*>(p.w + ((int64_t)tap * p.CoutP + co) * p.CinP + cc * BK + q * 4);
+      rb[j] = *reinterpret_cast<const float4*>(p.w + wpack_block(tap, cc, co >> 4, wncc, wnsl) + (q & 1) * 256 +
+                                               ((q >> 1) * 16 + (co & 15)) * 4);
     }
   };
 
@@ -221,21 +231,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int co = n0 + t * 32 + li;
-    if (co >= p.Cout) continue;
-    const float bv = (p.nsplit == 1 && p.bias) ? p.bias[co] : 0.f;
+    const int coc = co < p.Cout ? co : p.Cout - 1;
+    const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+    int64_t mo[16];
+    bool mv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int64_t m = m0 + row;
-      if (m >= M) continue;
-      float v = acc[t][r];
-      if (p.nsplit == 1) {
-        v += bv;
-        if (p.residual) v += p.residual[m * p.Cout + co];
-        p.out[m * p.Cout + co] = v;
-      } else {
-        p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
+      const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      mv[r] = m < M && co < p.Cout;
+      mo[r] = (m < M ? m : M - 1) * p.Cout;
+    }
+    if (p.nsplit == 1) {
+      if (p.residual) {  // one batch of loads (clamped addresses), no per-element branch
+        float res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) res[r] = p.residual[mo[r] + coc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += res[r];
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (mv[r]) p.out[mo[r] + co] = acc[t][r] + bv;
+    } else {
+      float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + coc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (mv[r]) pp[mo[r]] = acc[t][r];
     }
   }
 }
@@ -286,23 +307,34 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   const int wm = wave / NWN;
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
-  // spatial tile decode
+  // Spatial tiles: the workgroup is PERSISTENT over blockIdx.x (conv_plan sizes gridDim.x to the resident slots
+  // of the chip): it walks tiles blockIdx.x, +gridDim.x, ... so that workgroup dispatch, the exposed first halo
+  // load and the epilogue are paid once per slot instead of once per tile (the first halo of the next tile is
+  // requested under the last tap of the current one).
   const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD / TZ;
-  int bt = blockIdx.x;
-  const int tx0 = (bt % ntx) << 3;
-  bt /= ntx;
-  const int ty0 = (bt % nty) << 3;
-  bt /= nty;
-  const int tz0 = (bt % ntz) * TZ;
-  const int n = bt / ntz;
+  const int ntiles = ntx * nty * ntz * p.N;
+  int tx0 = 0, ty0 = 0, tz0 = 0, n = 0;      // tile whose halo is being STAGED (halo_issue)
+  int ctx0 = 0, cty0 = 0, ctz0 = 0, cn = 0;  // tile being COMPUTED / written (epilogue)
+  auto decode_tile = [&](int bt) {
+    tx0 = (bt % ntx) << 3;
+    bt /= ntx;
+    ty0 = (bt % nty) << 3;
+    bt /= nty;
+    tz0 = (bt % ntz) * TZ;
+    n = bt / ntz;
+  };
   const int n0 = blockIdx.y * BN;
   // K chunks: [0, ncc) main 3x3x3 chunks, [ncc, ncc + nsk) the fused 1x1x1 skip connection of a ResBlock
   // (unet.py:222,256: skip_connection(x) + h): same output tile, source = the block input, centre tap only
   const int SCin = p.skip_C0 + p.skip_C1;
   const int nsk = SKIP ? (SCin + BK - 1) / BK : 0;
+  // split-K: every split takes an equal share of the main chunks AND an equal share of the (27x cheaper) skip chunks
   const int cc_begin = blockIdx.z * p.chunks_per_split;
   int cc_end = cc_begin + p.chunks_per_split;
-  if (cc_end > ncc + nsk) cc_end = ncc + nsk;
+  if (cc_end > ncc) cc_end = ncc;
+  const int sk_begin = ncc + blockIdx.z * p.skip_chunks_per_split;
+  int sk_end = sk_begin + p.skip_chunks_per_split;
+  if (sk_end > ncc + nsk) sk_end = ncc + nsk;
   const int SD = p.ups ? (p.ID >> 1) : p.ID;
   const int SH = p.ups ? (p.IH >> 1) : p.IH;
   const int SW = p.ups ? (p.IW >> 1) : p.IW;
@@ -332,9 +364,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     hmask = 0;
     // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards:
     // a "load or zero" branch would make the compiler wait for each load before the next one is issued.
+    // (r0 is laundered through an empty asm so that the per-row halo coordinates below are recomputed at every
+    //  call: hoisted out of the persistent tile loop they would pin ~40 VGPRs and push the kernel into scratch)
+    int r0l = r0;
+    HOLO_LAUNDER(r0l);
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
-      const int hv = min(r0 + 32 * i, HALO_VOX - 1);
+      const int hv = min(r0l + 32 * i, HALO_VOX - 1);
       const int hz = hv / (HY * HX);
       const int rem = hv - hz * (HY * HX);
       const int hy = rem / HX;
@@ -388,22 +424,21 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   };
 
   f32x4 acc[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 
-  // A addressing: voxel tile mt of this wave covers block rows m = (wm*MT + mt)*16 + lj
-  //   -> (z = m>>6, y = (m>>3)&7, x = m&7); lane reads 8 channels starting at 8*kq
+  // A addressing: lane reads 8 channels starting at 8*kq of its voxel
+  // The 16 voxels of MFMA tile T (0 .. 4*TZ-1) are x = 0..7 of rows y = (T&3) and (T&3)+4 of slab z = T>>2: the
+  // two rows are 4*HX*LDK = 1440 = 32 (mod 64) floats apart, which makes the 16 lanes of every ds_read_b128
+  // group hit 64 distinct banks (adjacent rows, 40 mod 64 apart, gave 2-way conflicts on a quarter of the lanes).
   int a_off[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int m = (wm * MT + t) * 16 + lj;
-    a_off[t] = (((m >> 6) * HY + ((m >> 3) & 7)) * HX + (m & 7)) * LDK + kq * 8;
+    const int T = wm * MT + t;
+    a_off[t] = (((T >> 2) * HY + (T & 3) + 4 * (lj >> 3)) * HX + (lj & 7)) * LDK + kq * 8;
   }
   // B addressing: weight row of this lane's output channel, 8 channels starting at 8*kq of the chunk
-  const float* w_row = p.w + (int64_t)(n0 + wn * 16 + lj) * p.CinP + kq * 8;
-  const int64_t w_tap_stride = (int64_t)p.CoutP * p.CinP;
+  // (packed layout: the two 16-byte B fragments of a lane for one (tap, chunk) sit at lane*16 B in two 1 KB planes)
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
+  const float* w_lane = p.w + (int64_t)((n0 >> 4) + wn) * 512 + lane * 4;
 
   auto load_a = [&](float4 (&a)[MT], int tap, int half) {
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
@@ -412,9 +447,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(s_halo + a_off[t] + toff);
   };
   auto load_b = [&](float4 (&b)[2], int cc, int tap) {
-    const float4* wp = reinterpret_cast<const float4*>(w_row + tap * w_tap_stride + cc * BK);
-    b[0] = wp[0];
-    b[1] = wp[1];
+    const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 512;
+    b[0] = *reinterpret_cast<const float4*>(wp);
+    b[1] = *reinterpret_cast<const float4*>(wp + 256);
   };
   auto mfma_half = [&](const float4 (&a)[MT], const float4& b) {
 #pragma unroll
@@ -444,34 +479,52 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // Without a fused skip the next chunk's halo is prefetched under the last tap of the current one.  The SKIP
-  // instantiation keeps the staging registers short-lived instead (request + commit back to back): carrying
-  // them across its two loops pushes the allocator over the 256-VGPR budget into scratch spills.
-  const int cc_main_end = cc_end < ncc ? cc_end : ncc;
+  HOLO_PHASE_DELAY(p.stagger_ticks);
+  // Without a fused skip the next halo is prefetched under the last tap of the current chunk.  The SKIP
+  // instantiation requests and commits back to back instead: measured on MI355X the prefetch makes it 7% SLOWER
+  // (225 instead of 171 VGPRs, and its chunks are short).
+  decode_tile(blockIdx.x);
   if (!SKIP) halo_issue(cc_begin);
-  for (int cc = cc_begin; cc < cc_main_end; ++cc) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  ctx0 = tx0, cty0 = ty0, ctz0 = tz0, cn = n;
+  unsigned long long* dbg = p.dbg ? p.dbg + ((int64_t)tile * gridDim.y + blockIdx.y) * 8 : nullptr;
+  if (dbg && tid == 0) dbg[0] = HOLO_PROBE_CLOCK();
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+  const bool more_tiles = tile + (int)gridDim.x < ntiles;
+  for (int cc = cc_begin; cc < cc_end; ++cc) {
     if (SKIP) halo_issue(cc);
     halo_commit();
     load_b(b0, cc, 0);
     __syncthreads();  // halo of chunk cc visible
+    if (dbg && tid == 0 && cc == cc_begin) dbg[1] = HOLO_PROBE_CLOCK();
     load_a(aA, 0, 0);
     for (int tap = 0; tap < 26; tap += 2) {
       tap_body(aA, aC, b0, b1, cc, tap, true);
       tap_body(aC, aA, b1, b0, cc, tap + 1, true);
     }
-    if (!SKIP && cc + 1 < cc_end) halo_issue(cc + 1);  // flies under the last tap
+    // the next halo flies under the last tap: next chunk of this tile or first chunk of the workgroup's next tile
+    if (!SKIP) {
+      if (cc + 1 < cc_end) {
+        halo_issue(cc + 1);
+      } else if (more_tiles) {
+        decode_tile(tile + gridDim.x);
+        halo_issue(cc_begin);
+      }
+    }
     tap_body(aA, aC, b0, b1, cc, 26, false);
     __syncthreads();  // everyone done reading this halo before it is overwritten
   }
   if (SKIP) {
-    // fused 1x1x1 skip connection: centre tap (13) of the block-input halo, its own [CoutP][skip_CinP] weights
-    for (int cc = cc_begin > ncc ? cc_begin : ncc; cc < cc_end; ++cc) {
+    // fused 1x1x1 skip connection: centre tap (13) of the block-input halo, its own packed weights
+    for (int cc = sk_begin; cc < sk_end; ++cc) {
       halo_issue(cc);
       halo_commit();
-      const float4* wp = reinterpret_cast<const float4*>(p.skip_w + (int64_t)(n0 + wn * 16 + lj) * p.skip_CinP +
-                                                         (cc - ncc) * BK + kq * 8);
-      b0[0] = wp[0];
-      b0[1] = wp[1];
+      const float* wp = p.skip_w + ((int64_t)(cc - ncc) * wnsl + (n0 >> 4) + wn) * 512 + lane * 4;
+      b0[0] = *reinterpret_cast<const float4*>(wp);
+      b0[1] = *reinterpret_cast<const float4*>(wp + 256);
       __syncthreads();
       load_a(aA, 13, 0);
       load_a(aB, 13, 1);
@@ -481,6 +534,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     }
   }
 
+  if (dbg && tid == 0) dbg[2] = HOLO_PROBE_CLOCK();
   // ---- epilogue: 16x16x4 D layout: col = lane&15 (Cout), row = 4*(lane>>4) + r (voxel inside the tile)
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int co = n0 + wn * 16 + lj;
@@ -488,23 +542,50 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
   if (p.nsplit == 1 && p.skip_bias) bv += p.skip_bias[coc];
   float ssum = 0.f, ssq = 0.f;
+  // Output rows of this lane: a uniform 64-bit tile base plus 32-bit in-tile offsets.  With a residual, ALL its loads
+  // are issued as one batch under a uniform branch: a per-element "if (residual) load" makes the compiler wait
+  // for every load (and the store before it) in turn.
+  const int64_t tbase = ((((int64_t)cn * p.OD + ctz0) * p.OH + cty0) * p.OW + ctx0) * p.Cout;
+  int kql = kq;
+  HOLO_LAUNDER(kql);  // recompute the offsets per tile instead of keeping them live across the tile loop
+  int off[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
+    const int T = wm * MT + t;  // D rows 4*kq .. 4*kq+3 of tile T: same z, y, consecutive x (see a_off)
+    off[t] = (((T >> 2) * p.OH + (T & 3) + 4 * (kql >> 1)) * p.OW + 4 * (kql & 1)) * p.Cout;
+  }
+  if (p.nsplit == 1) {
+    if (p.residual) {
+      const float* rp = p.residual + tbase + coc;
+      float res[MT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = (wm * MT + t) * 16 + 4 * kq + r;
-      const int z = row >> 6, y = (row >> 3) & 7, x = row & 7;
-      const int64_t m = (((int64_t)n * p.OD + tz0 + z) * p.OH + ty0 + y) * p.OW + tx0 + x;
-      float v = acc[t][r];
-      if (p.nsplit == 1) {
-        v += bv;
-        if (p.residual) v += p.residual[m * p.Cout + coc];
-        if (co < p.Cout) p.out[m * p.Cout + co] = v;
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += res[t][r];
+    }
+    float* op = p.out + tbase + coc;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[t][r] + bv;
+        if (co < p.Cout) op[off[t] + r * p.Cout] = v;
         ssum += v;
         ssq += v * v;
-      } else if (co < p.Cout) {
-        p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the address arithmetic of later tiles from being hoisted (VGPRs)
+    }
+  } else if (co < p.Cout) {
+    float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + co;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[off[t] + r * p.Cout] = acc[t][r];
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // GroupNorm statistics of the tensor just produced (nn.py:23-25): per output channel (sum, sum of squares)
@@ -517,32 +598,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     ssq += __shfl_xor(ssq, 32);
     if (kq == 0 && co < p.Cout) {
       const int tiles_per_sample = ntx * nty * ntz;
-      const int slab = ((int)(blockIdx.x % tiles_per_sample)) * (4 / NWN) + wm;
+      const int slab = (tile % tiles_per_sample) * (4 / NWN) + wm;
       const int nslab = tiles_per_sample * (4 / NWN);
-      double* d = p.stats + (((int64_t)n * nslab + slab) * p.Cout + co) * 2;
+      double* d = p.stats + (((int64_t)cn * nslab + slab) * p.Cout + co) * 2;
       d[0] = (double)ssum;
       d[1] = (double)ssq;
     }
   }
+  if (dbg && tid == 0) {
+    dbg[3] = HOLO_PROBE_CLOCK();
+    unsigned hw, xcc;
+    HOLO_PROBE_HWID(hw, xcc);
+    dbg[4] = hw;
+    dbg[5] = xcc;
+  }
+  if (SKIP && more_tiles) decode_tile(tile + gridDim.x);
+  }  // tile loop
 }
 
 
 // ---------------------------------------------------------------------------------------------
-// Small-M variant of the gather kernel for the deepest UNet levels (4^3 / 2^3 voxels: M = 64 rows, K up to
-// 27*1024).  These launches are pure weight streaming (28-56 MB of weights for ~1 GFLOP), so the design goal
-// is bytes in flight, not MFMA rate:
+// Row-tile kernel for the latency-bound launches: the deepest UNet levels (4^3 / 2^3 voxels: M = 64 rows, K up
+// to 27*1024, pure weight streaming: 28-56 MB of weights for ~1 GFLOP) and every 1x1x1 convolution (attention
+// qkv / proj_out, un-fused skip connections).  The design goal is round trips, not MFMA rate:
 //   * block tile 64 voxels x 64 Cout; each wave OWNS 16 output channels (v_mfma_f32_16x16x4_f32 over the four
 //     16-voxel tiles), so its weights go global -> registers with no LDS and no sharing;
-//   * the weights of up to SG = 8 consecutive K chunks are requested up front (16 x 16 B per lane in flight)
-//     before the chunk loop touches them; the small, L2-resident activation tile is gathered one chunk ahead
-//     into a double-buffered LDS tile shared by the four waves;
-//   * split-K over (tap, chunk) fills the chip with ~3 workgroups per CU.
+//   * K is walked in groups of SG = 8 chunks (256 channels of one tap).  For a group, ALL weights (16 x 16 B per
+//     lane) and ALL activation rows (gathered, GroupNorm/FiLM/SiLU applied, zero padded) are requested up
+//     front, the activations land in an SG-deep LDS tile, and the 8 x 32 MFMAs of the group then run with no
+//     global access and no barrier: one memory round trip per 256 K-channels instead of one per 32;
+//   * split-K over (tap, chunk) fills the chip with ~2 workgroups per CU; un-split launches produce the
+//     GroupNorm statistics of their output in the epilogue.
 // ---------------------------------------------------------------------------------------------
 constexpr int SM_ROWS = 64;
 constexpr int SG = 8;
+constexpr int SGH = 4;  // activation chunks requested per staging batch (register budget)
 
-__global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
-  __shared__ __attribute__((aligned(16))) float s_a[2 * SM_ROWS * LDK];
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) float s_a[SG * SM_ROWS * LDK];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -582,9 +675,9 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
   const int SH = p.ups ? (p.IH >> 1) : p.IH;
   const int SW = p.ups ? (p.IW >> 1) : p.IW;
 
-  float4 ra[2], rc01[2], rc23[2];
-  unsigned amask = 0;
-  auto load_a = [&](int kc) {
+  float4 ra[SGH][2], rc01[SGH][2], rc23[SGH][2];
+  unsigned amask[SGH];
+  auto load_a = [&](int i, int kc) {
     const int tap = kc / ncc;
     const int cc = kc - tap * ncc;
     int kd = 0, kh = 0, kw = 0;
@@ -603,7 +696,7 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
       Cs = p.C1;
       cs = c - p.C0;
     }
-    amask = 0;
+    amask[i] = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int z = az[j] + kd, y = ay[j] + kh, x = ax[j] + kw;
@@ -616,24 +709,25 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
         y >>= 1;
         x >>= 1;
       }
-      ra[j] = *reinterpret_cast<const float4*>(src + ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs);
-      amask |= (ok ? 1u : 0u) << j;
+      // unconditional load from a clamped address, masked afterwards (see the halo kernel)
+      ra[i][j] = *reinterpret_cast<const float4*>(src + ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs);
+      amask[i] |= (ok ? 1u : 0u) << j;
       if (p.coef) {
         const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
-        rc01[j] = cf[0];
-        rc23[j] = cf[1];
+        rc01[i][j] = cf[0];
+        rc23[i][j] = cf[1];
       }
     }
   };
-  auto store_a = [&](int buf) {
+  auto store_a = [&](int i, int slot) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      float4 v = ra[j];
+      float4 v = ra[i][j];
       if (p.coef) {
-        v.x = v.x * rc01[j].x + rc01[j].y;
-        v.y = v.y * rc01[j].z + rc01[j].w;
-        v.z = v.z * rc23[j].x + rc23[j].y;
-        v.w = v.w * rc23[j].z + rc23[j].w;
+        v.x = v.x * rc01[i][j].x + rc01[i][j].y;
+        v.y = v.y * rc01[i][j].z + rc01[i][j].w;
+        v.z = v.z * rc23[i][j].x + rc23[i][j].y;
+        v.w = v.w * rc23[i][j].z + rc23[i][j].w;
         if (p.act) {
           v.x = silu_f(v.x);
           v.y = silu_f(v.y);
@@ -641,12 +735,12 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
           v.w = silu_f(v.w);
         }
       }
-      const float keep = ((amask >> j) & 1u) ? 1.f : 0.f;
+      const float keep = ((amask[i] >> j) & 1u) ? 1.f : 0.f;  // zero padding AFTER the activation
       v.x *= keep;
       v.y *= keep;
       v.z *= keep;
       v.w *= keep;
-      *reinterpret_cast<float4*>(s_a + buf * (SM_ROWS * LDK) + (r0 + 32 * j) * LDK + q * 4) = v;
+      *reinterpret_cast<float4*>(s_a + slot * (SM_ROWS * LDK) + (r0 + 32 * j) * LDK + q * 4) = v;
     }
   };
 
@@ -656,31 +750,39 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 
-  const float* w_row = p.w + (int64_t)(n0 + wave * 16 + lj) * p.CinP + kq * 8;
-  const int64_t w_tap_stride = (int64_t)p.CoutP * p.CinP;
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
+  const float* w_lane = p.w + (int64_t)((n0 >> 4) + wave) * 512 + lane * 4;  // 1 KB contiguous per wave instruction
 
   for (int g = kc_begin; g < kc_end; g += SG) {
-    // all weights of this group of chunks are requested before anything waits on them
+    if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
+    // 1. the (small, L2-resident) activation rows of the whole group: two short round trips
+#pragma unroll
+    for (int h = 0; h < SG; h += SGH) {
+      if (g + h < kc_end) {  // uniform
+#pragma unroll
+        for (int i = 0; i < SGH; ++i) load_a(i, min(g + h + i, kc_end - 1));
+#pragma unroll
+        for (int i = 0; i < SGH; ++i) store_a(i, h + i);
+      }
+    }
+    // 2. every weight of the group is requested at once, AFTER the activations: memory returns a wave's loads in
+    //    order, so the chunk loop below can start on chunk 0 as soon as ITS weights are back while the rest of the
+    //    group is still streaming (requested first, they would hold the activation loads behind 28+ MB of weights)
     float4 bw[SG][2];
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
       const int kc = min(g + i, kc_end - 1);
       const int tap = kc / ncc;
       const int cc = kc - tap * ncc;
-      const float4* wp = reinterpret_cast<const float4*>(w_row + tap * w_tap_stride + cc * BK);
-      bw[i][0] = wp[0];
-      bw[i][1] = wp[1];
+      const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 512;
+      bw[i][0] = *reinterpret_cast<const float4*>(wp);
+      bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
     }
-    load_a(g);
-    store_a(0);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
-      const int kc = g + i;
-      if (kc < kc_end) {  // uniform
-        const int buf = i & 1;
-        load_a(min(kc + 1, kc_end - 1));  // unconditional (clamped) prefetch of the next activation tile
-        const float* ab = s_a + buf * (SM_ROWS * LDK) + lj * LDK + kq * 8;
+      if (g + i < kc_end) {  // uniform
+        const float* ab = s_a + i * (SM_ROWS * LDK) + lj * LDK + kq * 8;
         float4 a0[4], a1[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -703,31 +805,70 @@ __global__ __launch_bounds__(256, 3) void conv_small_kernel(ConvParams p) {
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].z, bw[i][1].z, acc[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].w, bw[i][1].w, acc[t], 0, 0, 0);
-        store_a(buf ^ 1);
-        __syncthreads();
       }
     }
   }
 
   // ---- epilogue: col = lane&15 (Cout), row = 4*(lane>>4) + r inside each 16-voxel tile
   const int co = n0 + wave * 16 + lj;
-  if (co < p.Cout) {
-    const float bv = (p.nsplit == 1 && p.bias) ? p.bias[co] : 0.f;
+  const int coc = co < p.Cout ? co : p.Cout - 1;
+  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+  int64_t mo[4][4];  // clamped row offsets (masked at the store): residual loads are issued as ONE batch
+  bool mv[4][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + t * 16 + 4 * kq + r;
+      mv[t][r] = m < M && co < p.Cout;
+      mo[t][r] = (m < M ? m : M - 1) * p.Cout;
+    }
+  if (p.nsplit == 1) {
+    if (p.residual) {
+      float res[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[t][r] = p.residual[mo[t][r] + coc];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += res[t][r];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t m = m0 + t * 16 + 4 * kq + r;
-        if (m >= M) continue;
-        float v = acc[t][r];
-        if (p.nsplit == 1) {
-          v += bv;
-          if (p.residual) v += p.residual[m * p.Cout + co];
-          p.out[m * p.Cout + co] = v;
-        } else {
-          p.partial[((int64_t)blockIdx.z * M + m) * p.Cout + co] = v;
+        const float v = acc[t][r] + bv;
+        if (mv[t][r]) {
+          p.out[mo[t][r] + co] = v;
+          ssum += v;
+          ssq += v * v;
         }
       }
+  } else {
+    float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + coc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (mv[t][r]) pp[mo[t][r]] = acc[t][r];
+  }
+  // GroupNorm statistics of the output (un-split launches whose row tiles do not straddle samples:
+  // conv_stats_slabs): one slab per row tile -> stats[n][slab][Cout][2]
+  if (p.stats && p.nsplit == 1) {
+    ssum += __shfl_xor(ssum, 16);
+    ssq += __shfl_xor(ssq, 16);
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (kq == 0 && co < p.Cout) {
+      const int tiles_per_sample = (int)(((int64_t)p.OD * p.OH * p.OW) / SM_ROWS);
+      const int n = (int)(blockIdx.x / tiles_per_sample);
+      const int slab = (int)(blockIdx.x % tiles_per_sample);
+      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
+      d[0] = (double)ssum;
+      d[1] = (double)ssq;
     }
   }
 }
@@ -769,6 +910,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       const int64_t i = ((int64_t)n * V + v) * Cout + c_base + c4 * 4;
       float4 s = b;
       int k = 0;
+      for (; k + 16 <= nsplit; k += 16) {  // deep splits (row-tile kernel): sixteen independent loads in flight
+        float4 t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(k + u) * MC + i);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) {
+          s.x += (t[u].x + t[u + 1].x) + (t[u + 2].x + t[u + 3].x);
+          s.y += (t[u].y + t[u + 1].y) + (t[u + 2].y + t[u + 3].y);
+          s.z += (t[u].z + t[u + 1].z) + (t[u + 2].z + t[u + 3].z);
+          s.w += (t[u].w + t[u + 1].w) + (t[u + 2].w + t[u + 3].w);
+        }
+      }
       for (; k + 4 <= nsplit; k += 4) {  // four independent loads in flight per thread
         const float4 t0 = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
         const float4 t1 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 1) * MC + i);
@@ -840,12 +993,12 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0)
                ? 1
                : 0;
-  if (p.mode == 0 && p.ksz == 3 && M <= 256 && p.Cout >= 64) {  // deepest levels: weight-streaming small-M kernel
+  if (p.mode == 0 && p.Cout >= 64) {  // 1x1x1, strided and deepest-level convs: row-tile kernel
     p.mode = 2;
     const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
-    const int64_t tgt = 3 * (int64_t)num_cus;
+    const int64_t tgt = 2 * (int64_t)num_cus;
     nsplit = t2 < tgt ? (int)cdiv(tgt, t2) : 1;
-    int max_split = nchunks / 4;
+    int max_split = nchunks / SG;  // a split below one full staging group only adds a reduce launch
     if (max_split < 1) max_split = 1;
     if (nsplit > max_split) nsplit = max_split;
     int cps = (int)cdiv(nchunks, nsplit);
@@ -861,15 +1014,20 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
-    const int nck = ncc + (p.skip_w ? (p.skip_C0 + p.skip_C1 + BK - 1) / BK : 0);  // + fused skip chunks
+    const int nsk = p.skip_w ? (p.skip_C0 + p.skip_C1 + BK - 1) / BK : 0;  // fused skip chunks (one tap each)
     if (htiles < target) {
       nsplit = (int)cdiv(target, htiles);
       if (nsplit > ncc) nsplit = ncc;
     }
-    int cps = (int)cdiv(nck, nsplit);
-    nsplit = (int)cdiv(nck, cps);
+    int cps = (int)cdiv(ncc, nsplit);
+    nsplit = (int)cdiv(ncc, cps);
     p.nsplit = nsplit;
     p.chunks_per_split = cps;
+    p.skip_chunks_per_split = (int)cdiv(nsk, nsplit);
+    // One workgroup per tile.  (The kernel can also walk several tiles per workgroup - grid_x < tiles - with the
+    // next tile's halo prefetched under the last tap; measured on MI355X that is no faster than letting the
+    // dispatcher refill the slots, which also balances the load dynamically: tools/conv_timeline.cpp.)
+    p.grid_x = (int)(M / (64 * p.tz));
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (tiles < target) {
@@ -895,6 +1053,7 @@ int conv_stats_slabs(const ConvParams& p) {
     return B;
   }
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
+  if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
   return 0;
 }
 
@@ -919,7 +1078,7 @@ int conv_launch(const ConvParams& p, void* stream) {
   dim3 grid((unsigned)cdiv(M, BM), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
   dim3 block(256);
   if (p.mode == 1) {
-    dim3 hgrid((unsigned)(M / (64 * p.tz)), (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
+    dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
     if (wide && p.tz == 2 && sk) {
       HOLO_LAUNCH((conv_halo_kernel<4, 2, true>), hgrid, block, stream, p);

@@ -309,15 +309,25 @@ __global__ __launch_bounds__(256) void clip_kernel(const float* __restrict__ x, 
     y[i] = fminf(fmaxf(x[i], lo), hi);
 }
 
-// [Cout][Cin][taps] -> zero padded [taps][CoutP][CinP]
+// OIDHW [Cout][Cin][taps] -> zero padded packed layout [tap][CinP/32][CoutP/16][half][kq][lj][4]
+// (see wpack_block in kernels_conv.hip): element (tap, co, ci) with k = ci % 32 goes to
+//   block(tap, ci/32, co/16) + (k>>2 & 1)*256 + ((k>>3)*16 + co%16)*4 + (k & 3)
 __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out,
                                                                  int Cout, int Cin, int taps, int CoutP, int CinP) {
   const int64_t total = (int64_t)CoutP * CinP * taps;
+  const int ncc = CinP >> 5, nsl = CoutP >> 4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % CinP);
-    const int64_t r = i / CinP;
-    const int co = (int)(r % CoutP);
-    const int tap = (int)(r / CoutP);
+    const int e = (int)(i & 3);
+    const int lj = (int)((i >> 2) & 15);
+    const int kq = (int)((i >> 6) & 3);
+    const int half = (int)((i >> 8) & 1);
+    int64_t blk = i >> 9;
+    const int slice = (int)(blk % nsl);
+    blk /= nsl;
+    const int cc = (int)(blk % ncc);
+    const int tap = (int)(blk / ncc);
+    const int co = slice * 16 + lj;
+    const int ci = cc * 32 + kq * 8 + half * 4 + e;
     out[i] = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
   }
 }

@@ -801,6 +801,10 @@ int holo_ctx_create(int device_id, HoloCtx** out) {
   HoloCtx* c = new HoloCtx;
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("HOLO_NUM_CUS")) {  // test knob: planners size grids / split-K for this many CUs
+    const int v = atoi(e);
+    if (v > 0) c->num_cus = v;
+  }
   *out = c;
   return 0;
 }
@@ -1029,6 +1033,68 @@ int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t works
   if (total_ms) *total_ms = ms / iters;
   if (total_flops) *total_flops = flops;
   if (n_launches) *n_launches = launches;
+  return 0;
+}
+
+int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
+                       size_t workspace_bytes, int iters, void* stream, HoloOpTiming* out, int cap, int* n_ops) {
+  if (!net || !workspace || !x || !timesteps || !y || iters < 1 || !n_ops || (cap > 0 && !out)) {
+    set_error("holo_unet_time_ops: invalid argument");
+    return HOLO_E_INVALID;
+  }
+  int rc = ensure_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->ws_need) {
+    set_error("holo_unet_time_ops: workspace too small");
+    return HOLO_E_WORKSPACE;
+  }
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  int n = 0;
+  for (const Op& op : net->ops) {
+    rc = run_op(net, op, batch, x, timesteps, y, stream);  // untimed first touch (also keeps the data flow valid)
+    if (rc) return HOLO_E_INVALID;
+    if (n < cap) {
+      HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+      for (int it = 0; it < iters; ++it) run_op(net, op, batch, x, timesteps, y, stream);
+      HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+      HIP_TRY(hipEventSynchronize(e1));
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+      HoloOpTiming& t = out[n];
+      memset(&t, 0, sizeof(t));
+      t.op = (int)op.kind;
+      t.ms = ms / iters;
+      if (op.kind == OP_CONV) {
+        const ConvParams& c = op.conv;
+        t.kernel = c.mode;
+        t.tile_depth = c.mode == 1 ? c.tz : 0;
+        t.fused_skip = c.skip_w ? 1 : 0;
+        t.nsplit = c.nsplit;
+        t.cin = c.C0 + c.C1;
+        t.cout = c.Cout;
+        t.out_dim = c.OD;
+        t.stride = c.stride;
+        t.upsample = c.ups;
+        t.ksz = c.ksz;
+        t.flops = conv_flops(c);
+      } else if (op.kind == OP_FLASH) {
+        t.cin = t.cout = op.attn.C;
+        t.out_dim = op.attn.T;
+        t.flops = 4.0 * op.attn.N * (double)op.attn.T * op.attn.T * op.attn.C;
+      } else if (op.kind == OP_GEMM) {
+        t.cin = op.gemm.K;
+        t.cout = op.gemm.Nn;
+        t.out_dim = op.gemm.M;
+        t.flops = 2.0 * op.gemm.nb0 * op.gemm.nb1 * (double)op.gemm.M * op.gemm.Nn * op.gemm.K;
+      }
+    }
+    ++n;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *n_ops = n;
   return 0;
 }
 

@@ -186,6 +186,22 @@ class SimpleUnet3D(Unet3DBase):
                                           ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
         return y
 
+    def fetch_block(self, tag: str, shape) -> torch.Tensor:
+        """Debug/parity hook: output of block ``tag`` ("input_blocks.<i>", "middle_block", "output_blocks.<i>") of
+        the LAST forward as an NCDHW tensor.  Needs HOLO_KEEP_INTERMEDIATES=1 when the net is created."""
+        if self._handle is None:
+            raise _lib.HoloError("fetch_block: no forward has run yet")
+        dev = self._handle_device
+        L = runtime.lib()
+        ws = runtime.workspace(dev, f"unet{id(self)}", 0)
+        dst = torch.empty(tuple(shape), device=dev)
+        n = C.c_int64()
+        _lib.check(L, L.holo_unet_fetch_block(self._handle, tag.encode(), runtime.ptr(dst), dst.numel(), C.byref(n),
+                                              runtime.ptr(ws), runtime.stream_ptr(dev)), f"fetch_block {tag}")
+        if n.value != dst.numel():
+            raise _lib.HoloError(f"fetch_block {tag}: {n.value} elements, expected {dst.numel()}")
+        return dst
+
     # ---- measurement helper (bench.py) ----------------------------------------------------
     def time_convs(self, batch: int, iters: int, device: torch.device):
         """Average ms per forward spent in the conv3d implicit-GEMM launches, their FLOPs and launch count
@@ -198,3 +214,33 @@ class SimpleUnet3D(Unet3DBase):
         _lib.check(L, L.holo_unet_time_convs(h, batch, runtime.ptr(ws), ws.numel(), iters, runtime.stream_ptr(device),
                                              C.byref(ms), C.byref(fl), C.byref(nl)), "holo_unet_time_convs")
         return ms.value, fl.value, nl.value
+
+    OP_NAMES = ("memset", "layout_in", "time_embed", "emb_linears", "gn_stats", "gn_finalize", "conv", "gemm",
+                "softmax", "flash_attn", "layout_out")
+    CONV_KERNELS = ("conv_igemm_kernel", "conv_halo_kernel", "conv_small_kernel")
+
+    def time_ops(self, batch: int, iters: int, device: torch.device):
+        """Per-op timing of one forward in execution order (hipEvents on the launch stream): list of dicts."""
+        h = self._ensure_handle(device)
+        L = runtime.lib()
+        nbytes = L.holo_unet_workspace_bytes(h, batch)
+        ws = runtime.workspace(device, f"unet{id(self)}", nbytes)
+        R = self.image_size
+        x = torch.randn(batch, self.in_channels, R, R, R, device=device)
+        y = torch.empty(batch, self.out_channels, R, R, R, device=device)
+        t = torch.full((batch,), 500, dtype=torch.int64, device=device)
+        cap = 1024
+        arr = (_lib.HoloOpTiming * cap)()
+        n = C.c_int()
+        _lib.check(L, L.holo_unet_time_ops(h, batch, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
+                                           ws.numel(), iters, runtime.stream_ptr(device), arr, cap, C.byref(n)),
+                   "holo_unet_time_ops")
+        ops = []
+        for i in range(min(n.value, cap)):
+            a = arr[i]
+            d = dict(op=self.OP_NAMES[a.op], ms=a.ms, flops=a.flops, cin=a.cin, cout=a.cout, out_dim=a.out_dim)
+            if a.op == 6:
+                d.update(kernel=self.CONV_KERNELS[a.kernel], tile_depth=a.tile_depth, fused_skip=bool(a.fused_skip),
+                         nsplit=a.nsplit, stride=a.stride, upsample=bool(a.upsample), ksz=a.ksz)
+            ops.append(d)
+        return ops

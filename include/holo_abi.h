@@ -196,6 +196,25 @@ int holo_event_timer_destroy(void* timer);
 int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t workspace_bytes, int iters,
                          void* stream, float* total_ms, double* total_flops, int* n_launches);
 
+/* Per-op variant of the above: every op of the planned forward is timed on its own (one untimed launch, then
+ * `iters` back-to-back launches between two events on `stream`), in execution order.
+ *   op     : 0 memset, 1 layout-in, 2 time-embed, 3 emb linears, 4 GroupNorm stats, 5 GroupNorm finalize,
+ *            6 conv, 7 GEMM, 8 softmax, 9 flash attention, 10 layout-out
+ *   conv ops: kernel 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = small-M weight-streaming kernel;
+ *            tile_depth / fused_skip / nsplit describe the variant (they select the template instantiation that
+ *            rocprofv3 reports); ms includes the split-K reduce launch when nsplit > 1; flops = 2*MACs incl. the
+ *            fused 1x1x1 skip.  Attention/GEMM ops report their 2*MACs as well; other ops report flops 0.
+ * x / timesteps / y as in holo_unet_forward (y is overwritten).  Returns the op count in *n_ops (at most `cap`
+ * entries are written). */
+typedef struct {
+  int32_t op, kernel, tile_depth, fused_skip, nsplit;
+  int32_t cin, cout, out_dim, stride, upsample, ksz;
+  float ms;
+  double flops;
+} HoloOpTiming;
+int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
+                       size_t workspace_bytes, int iters, void* stream, HoloOpTiming* out, int cap, int* n_ops);
+
 #ifdef __cplusplus
 }
 #endif

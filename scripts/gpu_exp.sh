@@ -1,18 +1,18 @@
 export TMPDIR=/tmp
-( cd /tmp && timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/clk -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames 1 --no-cpu-baseline --conv-iters 1 > /dev/null 2>&1 )
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --frames 1 --no-cpu-baseline --conv-iters 1"
+pass () { n=$1; shift; ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/px_$n -o p -- $CMD > /dev/null 2>&1 ); }
+pass a SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
+pass b GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU
 python3 - <<'PY'
 import csv, glob, collections
-cc = glob.glob('/tmp/clk/**/*counter_collection.csv', recursive=True)[0]
-kt = glob.glob('/tmp/clk/**/*kernel_trace.csv', recursive=True)[0]
-dur = {}
-for r in csv.DictReader(open(kt)):
-    dur[r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-agg = collections.OrderedDict()
-for r in csv.DictReader(open(cc)):
-    if r['Counter_Name'] != 'GRBM_GUI_ACTIVE': continue
-    if 'conv_halo' not in r['Kernel_Name'] and 'render_kernel' not in r['Kernel_Name']: continue
-    k = (r['Kernel_Name'][34:58], r.get('Grid_Size', ''))
-    a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += float(r['Counter_Value']); a[2] += dur[r['Dispatch_Id']]
-for k, a in agg.items():
-    print(k, 'n', a[0], 'avg_us %.1f' % (a[2]/a[0]/1e3), 'clock GHz (GRBM/8/time) %.3f' % (a[1]/8/a[2]))
+for n in 'ab':
+    f = glob.glob(f'/tmp/px_{n}/**/*counter_collection.csv', recursive=True)
+    if not f: print('no data', n); continue
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(f[0])):
+        kn = r['Kernel_Name']
+        if 'render_kernel' not in kn and 'conv_halo_kernel<4, 2, false>' not in kn: continue
+        k = (kn[34:66], r['Counter_Name'])
+        a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r['Counter_Value'])
+    for k, a in agg.items(): print(k[0], k[1], 'n', a[0], 'avg %.4g' % (a[1]/a[0]))
 PY

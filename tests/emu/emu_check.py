@@ -107,6 +107,35 @@ def check_unet():
     return ok
 
 
+def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16):
+    """Wider tiny net: model_channels 64 puts the ResBlocks of the top level on the LDS-halo kernel with the fused
+    1x1x1 skip connection and split-K (no reference golden at this size: compared with the pinned oracle)."""
+    print(f"== wide tiny UNet (image {image}, mc {mc}, mult {mult}) through the emulated kernels vs oracle")
+    cfg = uo.UNetCfg(image_size=image, in_channels=in_ch, out_channels=in_ch, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    sd = synth_state_dict(uo.unet_param_shapes(cfg), 99)
+    ctx = make_ctx()
+    net = make_unet(ctx, cfg, sd)
+    x = torch.from_numpy(np_noise(11, (1, in_ch, image, image, image)))
+    t = torch.tensor([321], dtype=torch.int64)
+    trace = {}
+    ref = uo.unet_forward(sd, cfg, x, t, trace)
+    t0 = time.time()
+    y, ws = unet_forward(net, cfg, x, t)
+    print(f"  forward took {time.time() - t0:.1f}s (emulated)")
+    ok = True
+    for tag, r in trace.items():
+        if not (tag.startswith("input_blocks") or tag.startswith("output_blocks") or tag == "middle_block"):
+            continue
+        dst = torch.empty_like(r)
+        numel = C.c_int64()
+        _lib.check(lib, lib.holo_unet_fetch_block(net, tag.encode(), ptr(dst), dst.numel(), C.byref(numel), ptr(ws),
+                                                  None), f"fetch {tag}")
+        ok &= report(tag, dst, r)
+    ok &= report("y", y, ref)
+    return ok
+
+
 def check_ddpm():
     print("== ddpm step vs oracle")
     ctx = make_ctx()
@@ -191,5 +220,7 @@ if __name__ == "__main__":
         allok &= check_render(C_feat=16, n_fine=16)
     if "unet" in what:
         allok &= check_unet()
+    if "unet_wide" in what:
+        allok &= check_unet_wide()
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)

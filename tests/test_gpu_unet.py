@@ -77,6 +77,36 @@ def test_cond_features_concat(gu):
     assert gu.rel_err(y, ref) < TOL
 
 
+@pytest.mark.parametrize("image,mc,mult,attn,batch", [
+    (8, 64, (1, 2), (2,), 1),      # fused 1x1x1 skip + split-K on the LDS-halo kernel, small-M kernel below
+    (16, 64, (1, 2, 2), (4,), 2),  # 64-voxel halo tiles, stride-2 gather kernel, batch 2
+    (16, 32, (1, 1), (), 1),       # 32-wide Cout tiles (NWN=2) on both halo tile depths
+])
+def test_mid_size_unet_vs_oracle_blockwise(gu, image, mc, mult, attn, batch):
+    """Sizes between the reference goldens: every block output against the pinned oracle (per-op tolerance of
+    SURVEY.md 8c: rtol 1e-4 of the tensor scale)."""
+    cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    import os
+    os.environ["HOLO_KEEP_INTERMEDIATES"] = "1"
+    try:
+        net, sd = gu.make_unet(cfg, seed=99)
+        from oracle.common import np_noise
+        x = torch.from_numpy(np_noise(11, (batch, 16, image, image, image)))
+        t = torch.tensor([321, 17][:batch], dtype=torch.int64)
+        trace = {}
+        ref = uo.unet_forward(sd, cfg, x, t, trace)
+        with torch.no_grad():
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+        assert gu.rel_err(y, ref) < 1e-4
+        for tag, r in trace.items():
+            if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
+                got = net.fetch_block(tag, tuple(r.shape))
+                assert gu.rel_err(got, r) < 1e-4, tag
+    finally:
+        del os.environ["HOLO_KEEP_INTERMEDIATES"]
+
+
 @pytest.mark.parametrize("tag,cfg", [("plumb32x16", PLUMB_CFG), ("north64x32", NORTH_CFG)])
 def test_full_size_unet_vs_reference_digest(gu, golden_dir, tag, cfg):
     """BASELINE configs[0] (32^3x16) and configs[1] (64^3x32): digests of the REFERENCE output."""
