@@ -198,22 +198,28 @@ def main():
         ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
         variants = {}
         for o in ops:
-            key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"]) if o["kernel"] == "conv_halo_kernel" \
-                else (o["kernel"], 0, False, 0)
+            key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"], 4 if o["cout"] >= 64 else 2) \
+                if o["kernel"] == "conv_halo_kernel" else (o["kernel"], 0, False, 0, 0)
             v = variants.setdefault(key, dict(ms=0.0, flops=0.0, n=0))
             v["ms"] += o["ms"]; v["flops"] += o["flops"]; v["n"] += 1
-        (kname, tz, sk, od), dom = max(variants.items(), key=lambda kv: kv[1]["ms"])
+        for o in ops:  # algorithmic bytes of a launch: input (+ fused skip input) + output + weights, each touched once
+            vin = o["out_dim"] ** 3 * (o["stride"] ** 3) / (8 if o["upsample"] else 1)
+            o["bytes"] = 4.0 * (vin * o["cin"] + o["out_dim"] ** 3 * o["cout"] + 27 * o["cin"] * o["cout"])
+        (kname, tz, sk, od, nwn), dom = max(variants.items(), key=lambda kv: kv[1]["ms"])
+        dom_ops = [o for o in ops if o["kernel"] == kname and o["tile_depth"] == tz and o["fused_skip"] == sk
+                   and o["out_dim"] == od and (4 if o["cout"] >= 64 else 2) == nwn]
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         all_ms = sum(o["ms"] for o in ops)
         all_fl = sum(o["flops"] for o in ops)
-        label = f"{kname}<4, {tz}, {'true' if sk else 'false'}> at {od}^3 output" if kname == "conv_halo_kernel" else kname
+        label = f"{kname}<{nwn}, {tz}, {'true' if sk else 'false'}> at {od}^3 output" if kname == "conv_halo_kernel" else kname
         traffic = None
         try:  # HBM bytes per launch of this kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
             pmc = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
             ent = pmc.get(label)
             if ent and args.workload == "north":
                 traffic = {"bytes_per_launch": ent["fetch_bytes"] + ent["write_bytes"], "fetch_bytes": ent["fetch_bytes"],
-                           "write_bytes": ent["write_bytes"], "algorithmic_bytes_per_launch": ent.get("algorithmic_bytes"),
+                           "write_bytes": ent["write_bytes"],
+                           "algorithmic_bytes_per_launch": sum(o["bytes"] for o in dom_ops) / len(dom_ops),
                            "source": ent.get("source")}
         except (OSError, ValueError):
             pass
@@ -226,7 +232,7 @@ def main():
                                       "algorithmic_gflop_per_forward": all_fl / 1e9,
                                       "achieved": all_fl / (all_ms * 1e-3) / 1e12,
                                       "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
-                "by_variant": [{"kernel": k[0], "tile_depth": k[1], "fused_skip": k[2], "out_dim": k[3],
+                "by_variant": [{"kernel": k[0], "wave_cols": k[4], "tile_depth": k[1], "fused_skip": k[2], "out_dim": k[3],
                                 "launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12}
                                for k, v in sorted(variants.items(), key=lambda kv: -kv[1]["ms"])]}
         if os.environ.get("HOLO_BENCH_OPS"):

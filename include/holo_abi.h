@@ -80,8 +80,8 @@ int holo_unet_destroy(HoloUnet* net);
 int holo_unet_num_params(const HoloUnet* net);
 int holo_unet_param_info(const HoloUnet* net, int index, char* name, int name_cap, int64_t shape[8], int* ndim);
 
-/* Bind one parameter.  The library keeps a repacked private copy (conv weights
- * [tap][Cout][Cin], concatenated embedding linears); call again after the caller's tensor changes. */
+/* Bind one parameter.  The library keeps a repacked private copy (conv weights in an MFMA-fragment-packed
+ * [tap][Cin/32][Cout/16][...] layout, concatenated embedding linears); call again after the caller's tensor changes. */
 int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, int dtype, int ndim,
                         const int64_t* shape, void* stream);
 

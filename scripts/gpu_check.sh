@@ -14,4 +14,5 @@ echo "== rocprofv3 kernel trace"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --frames 2 --no-cpu-baseline --conv-iters 1 > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err ; echo "rocprof rc=$?" )
 find /tmp/prof_$TAG -name "*stats*" | head ; 
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
-head -30 $OUT/kernel_stats.csv 2>/dev/null
+for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv"); do python3 scripts/trace_by_grid.py "$f" "$OUT/kernel_trace_by_grid.csv"; done
+head -12 $OUT/kernel_stats.csv 2>/dev/null | cut -c1-200

@@ -13,7 +13,7 @@ run_pass () {
 import csv, sys, collections
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r["Kernel_Name"][:70], r.get("Grid_Size", r.get("Grid_Size_X", "")), r["Counter_Name"])
+    k = (r["Kernel_Name"][:110], r.get("Grid_Size", r.get("Grid_Size_X", "")), r["Counter_Name"])
     a = agg.setdefault(k, [0, 0.0])
     a[0] += 1; a[1] += float(r["Counter_Value"])
 with open(sys.argv[2], "w") as f:
