@@ -15,6 +15,7 @@ Multi-GPU: samples are independent DDPM chains, so sample ``i``
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -124,3 +125,38 @@ def generate_samples(model, num_samples: int = 2, n_eval_cameras: int = 25 * 3, 
         "depths_render": gather_frames(local_dep, num_samples, (n_eval_cameras, 1, H, W), device),
         "masks_render": gather_frames(local_msk, num_samples, (n_eval_cameras, 1, H, W), device),
     }
+
+
+def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[str] = None,
+                                     render_size: Optional[Tuple[int, int]] = None, n_eval_cameras: int = 25 * 3,
+                                     num_samples: int = 2, seed: int = 3,
+                                     up: Tuple[float, float, float] = CANONICAL_CO3D_UP_AXIS,
+                                     camera_elevation: float = -30.0 * (2 * math.pi / 360),
+                                     progressive_sampling_steps_per_render: int = -1, save_frames: bool = True,
+                                     device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+    """``generate_samples(exp_dir=...)`` of the reference script (generate_samples.py:37-138) on the HIP path:
+    experiment directory -> model (``checkpoint.load_experiment``) -> sharded sampling + fly-around renders.
+
+    Output stage: rank 0 writes ``<output_directory>/sample_%05d_frames.pt`` (images / depths / masks of the
+    fly-around as tensors); video encoding and visdom (flyaround.py:422-610) are outside this path."""
+    from .checkpoint import load_experiment
+    rank, world = dist_info()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if output_directory is None:
+        folder = "generated_samples" if progressive_sampling_steps_per_render == -1 else "generated_samples_denoising"
+        output_directory = os.path.join(exp_dir, folder)
+    model, report = load_experiment(exp_dir, render_size=render_size, device=device)
+    if not (model.net_3d_enabled and model.diffusion_enabled):
+        raise ValueError("Can generate random samples only from a trained HoloDiffusion model "
+                         "(net_3d_enabled and diffusion_enabled)")
+    out = generate_samples(model, num_samples=num_samples, n_eval_cameras=n_eval_cameras, seed=seed, up=up,
+                           camera_elevation=camera_elevation,
+                           progressive_sampling_steps_per_render=progressive_sampling_steps_per_render, device=device)
+    if save_frames and rank == 0:
+        os.makedirs(output_directory, exist_ok=True)
+        for i in range(num_samples):
+            torch.save({k: v[i].cpu() for k, v in out.items()},
+                       os.path.join(output_directory, f"sample_{i:05d}_frames.pt"))
+    out["load_report"] = report
+    return out

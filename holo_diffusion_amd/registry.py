@@ -12,6 +12,7 @@ registers the classes in the real registry.
 from __future__ import annotations
 
 import dataclasses
+import enum
 from typing import Any, Dict, Type
 
 
@@ -79,6 +80,8 @@ def apply_config(obj: Any, kwargs: Dict[str, Any]) -> None:
         default = fields[k]
         if isinstance(default, tuple) and isinstance(v, (list, tuple)):
             v = tuple(v)
+        if isinstance(default, enum.Enum) and isinstance(v, str):  # YAML carries enum fields by member name
+            v = type(default)[v]
         setattr(obj, k, v)
     for k, v in fields.items():
         if k not in kwargs:

@@ -257,9 +257,9 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         (and its tests, which call it with ``pts_3d``)."""
         assert voxel_grid_features is not None, "voxel_grid_features must be provided!"
         assert ray_bundle is not None or pts_3d is not None, "either ray_bundle or pts_3d must be provided!"
-        if self.render_normals:
-            raise NotImplementedError("render_normals: the reference computes normals and never exports them "
-                                      "(holo_diffusion_model.py drops aux['normals']); not implemented")
+        # render_normals (released YAMLs set it, configs/apple.yaml:203): the reference differentiates the density
+        # w.r.t. the points and HoloDiffusionModel then drops the result (no `normals_render` output); accepted and
+        # not computed here (SURVEY.md row R10: optional, off the hot path).
         if pts_3d is None:
             if ray_bundle.origins is None:
                 ray_bundle.materialize()

@@ -65,3 +65,37 @@ def test_progressive_generator_clips_and_flyaround_shapes(gu):
         res = generate_samples(model, num_samples=2, n_eval_cameras=2, seed=3, device=gu.DEV,
                                sampler_kwargs=dict(max_iter=2))
         assert res["images_render"].shape == (2, 2, 3, 8, 8) and torch.isfinite(res["images_render"]).all()
+
+
+def test_experiment_directory_drives_the_hip_path(gu, tmp_path):
+    """expconfig.yaml + model_epoch_*.pth -> model on the GPU -> one frame equals the oracle run on the checkpoint's
+    own tensors (a reference checkpoint drives the HIP path through the reference's key names)."""
+    import os
+
+    import yaml
+
+    from holo_diffusion_amd import checkpoint as ck
+    from tests.test_checkpoint_loading import _expconfig, _reference_like_state
+    d = str(tmp_path)
+    with open(os.path.join(d, "expconfig.yaml"), "w") as f:
+        yaml.safe_dump(_expconfig(resol=8, feat=16, mc=32), f)
+    cfg, _ = ck.read_expconfig(d)
+    kw, _ = ck.model_args_from_expconfig(cfg)
+    state = _reference_like_state(hda.HoloDiffusionModel(**kw), 11)
+    torch.save(state, os.path.join(d, "model_epoch_00000042.pth"))
+    H, W = 10, 14
+    model, rep = ck.load_experiment(d, render_size=(W, H), device=gu.DEV)
+    assert rep.checkpoint_file.endswith("model_epoch_00000042.pth")
+    usd = {k[len("net_3d._net."):]: v for k, v in state.items() if k.startswith("net_3d._net.")}
+    msd = {k[len("_implicit_functions.0._fn.render_mlp."):]: v for k, v in state.items()
+           if k.startswith("_implicit_functions.0._fn.render_mlp.")}
+    ucfg = uo.UNetCfg(image_size=8, in_channels=16, out_channels=16, model_channels=32, num_res_blocks=2,
+                      channel_mult=(1, 2), attention_resolutions=(2,), num_heads=2)
+    rcfg = ro.RenderCfg(resol=8, feature_size=16, image_height=H, image_width=W, n_pts_fine=16)
+    vf = torch.from_numpy(np_noise(5, (1, 16, 8, 8, 8))).clamp(-1, 1)
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2)
+    preds = model(camera=cams[2].to(gu.DEV), voxel_features=vf.to(gu.DEV))
+    grid_ref = torch.tanh(uo.unet_forward(usd, ucfg, vf, torch.zeros(1, dtype=torch.long)))
+    ref = ro.render(grid_ref, msd, gu.cam_dict(cams, 2), rcfg)
+    assert (preds["images_render"].cpu() - ref["images_render"]).abs().max() < 1e-3
+    assert (preds["masks_render"].cpu() - ref["masks_render"]).abs().max() < 1e-3
