@@ -171,6 +171,7 @@ struct RenderKernelParams {
   float* rgb_c;  // may be null
   float* depth_c;
   float* mask_c;
+  unsigned long long* dbg;  // optional per-wave phase timestamps [wave][8] (HOLO_RENDER_TIMELINE=1); null in production
 };
 
 // stand-alone implicit function: densities[P], colours[P][3] at world points pts[P][3];

@@ -56,7 +56,8 @@ struct MlpLds {
   static constexpr int C = 2 * CH;
   static constexpr int LDW = C + 4;
   float w[HD * LDW];              // W_eff rows (hidden features), padded rows
-  float aux[NTILE * 2 * 16 * 4];  // per D row {b_feat, 0.4*wr0, 0.4*wr1, 0.4*wr2}
+  float bias[NTILE * 2 * 16];     // b_feat in D-row order: [tile][lane half][r] (the 16 rows a lane owns per tile)
+  float wr[3][NTILE * 2 * 16];    // 0.4 * w_rad[colour] in the same order
   float u[2 * 4 * CH];            // per half: {w_dens, u_rad0, u_rad1, u_rad2} slices of CH floats
 };
 
@@ -71,10 +72,10 @@ __device__ __forceinline__ void stage_mlp(MlpLds<CH>& L, const MlpParams& m, int
   for (int i = tid; i < NTILE * 2 * 16; i += 256) {
     const int r = i & 15, h = (i >> 4) & 1, t = i >> 5;
     const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    L.aux[i * 4 + 0] = m.b_feat[row];
-    L.aux[i * 4 + 1] = 0.4f * m.w_rad[0 * HD + row];
-    L.aux[i * 4 + 2] = 0.4f * m.w_rad[1 * HD + row];
-    L.aux[i * 4 + 3] = 0.4f * m.w_rad[2 * HD + row];
+    L.bias[i] = m.b_feat[row];
+    L.wr[0][i] = 0.4f * m.w_rad[0 * HD + row];
+    L.wr[1][i] = 0.4f * m.w_rad[1 * HD + row];
+    L.wr[2][i] = 0.4f * m.w_rad[2 * HD + row];
   }
   for (int i = tid; i < 2 * 4 * CH; i += 256) {
     const int k = i % CH, j = (i / CH) & 3, h = i / (4 * CH);
@@ -113,9 +114,12 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
                                            float& cb) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
-  float f[CH];
+  // On gfx950 the fp32 MFMA runs on the same FMA lanes as ordinary vector instructions (tools/coexec_probe.cpp:
+  // MFMA waves and VALU waves of one SIMD do not overlap), so every VALU instruction here costs MFMA time.  All
+  // per-channel / per-row arithmetic is therefore written on register PAIRS (v_pk_fma_f32: two fmaf per instruction).
+  f32x2 fv[CH / 2];  // interpolated features, channel pairs
 #pragma unroll
-  for (int k = 0; k < CH; ++k) f[k] = 0.f;
+  for (int k = 0; k < CH / 2; ++k) fv[k] = f32x2{0.f, 0.f};
   {
     const float lx = px / half_extent, ly = py / half_extent, lz = pz / half_extent;
     const float ix = ((lx + 1.f) * 0.5f) * Rm1, iy = ((ly + 1.f) * 0.5f) * Rm1, iz = ((lz + 1.f) * 0.5f) * Rm1;
@@ -140,27 +144,33 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
       const float w = ((dx ? wxb : wxa) * (dy ? wyb : wya)) * (dz ? wzb : wza);
       const int xx = dx ? xb : xa, yy = dy ? yb : ya, zz = dz ? zb : za;
       const float4* g = reinterpret_cast<const float4*>(gbase + ((int64_t)(zz * R + yy) * R + xx) * C);
+      const f32x2 w2 = f32x2{w, w};
 #pragma unroll
       for (int v = 0; v < CH / 4; ++v) {
         const float4 t = g[v];
-        f[4 * v + 0] = fmaf(w, t.x, f[4 * v + 0]);
-        f[4 * v + 1] = fmaf(w, t.y, f[4 * v + 1]);
-        f[4 * v + 2] = fmaf(w, t.z, f[4 * v + 2]);
-        f[4 * v + 3] = fmaf(w, t.w, f[4 * v + 3]);
+        fv[2 * v + 0] = pk_fma(w2, f32x2{t.x, t.y}, fv[2 * v + 0]);
+        fv[2 * v + 1] = pk_fma(w2, f32x2{t.z, t.w}, fv[2 * v + 1]);
       }
     }
   }
-  // lane-local half dot products: density row and the linear (0.6 h) part of the three radiance sums
-  float dpart = 0.f, rp0 = 0.f, rp1 = 0.f, rp2 = 0.f;
+  // lane-local half dot products: density row and the linear (0.6 h) part of the three radiance sums, each as an
+  // (even channel, odd channel) pair of partial sums
+  f32x2 dp2 = f32x2{0.f, 0.f}, r0 = dp2, r1 = dp2, r2 = dp2;
   {
-    const float4* up = reinterpret_cast<const float4*>(L.u + lh * 4 * CH);
+    int lhl = lh;
+    HOLO_LAUNDER(lhl);  // reloaded per sample: hoisted out of the march loops these rows would pin 4*CH VGPRs
+    const float4* up = reinterpret_cast<const float4*>(L.u + lhl * 4 * CH);
 #pragma unroll
     for (int v = 0; v < CH / 4; ++v) {
       const float4 a = up[v], b = up[CH / 4 + v], c = up[2 * (CH / 4) + v], d = up[3 * (CH / 4) + v];
-      dpart = fmaf(a.x, f[4 * v], fmaf(a.y, f[4 * v + 1], fmaf(a.z, f[4 * v + 2], fmaf(a.w, f[4 * v + 3], dpart))));
-      rp0 = fmaf(b.x, f[4 * v], fmaf(b.y, f[4 * v + 1], fmaf(b.z, f[4 * v + 2], fmaf(b.w, f[4 * v + 3], rp0))));
-      rp1 = fmaf(c.x, f[4 * v], fmaf(c.y, f[4 * v + 1], fmaf(c.z, f[4 * v + 2], fmaf(c.w, f[4 * v + 3], rp1))));
-      rp2 = fmaf(d.x, f[4 * v], fmaf(d.y, f[4 * v + 1], fmaf(d.z, f[4 * v + 2], fmaf(d.w, f[4 * v + 3], rp2))));
+      dp2 = pk_fma(f32x2{a.x, a.y}, fv[2 * v], dp2);
+      dp2 = pk_fma(f32x2{a.z, a.w}, fv[2 * v + 1], dp2);
+      r0 = pk_fma(f32x2{b.x, b.y}, fv[2 * v], r0);
+      r0 = pk_fma(f32x2{b.z, b.w}, fv[2 * v + 1], r0);
+      r1 = pk_fma(f32x2{c.x, c.y}, fv[2 * v], r1);
+      r1 = pk_fma(f32x2{c.z, c.w}, fv[2 * v + 1], r1);
+      r2 = pk_fma(f32x2{d.x, d.y}, fv[2 * v], r2);
+      r2 = pk_fma(f32x2{d.z, d.w}, fv[2 * v + 1], r2);
     }
   }
   // hidden features on the matrix cores, tile by tile
@@ -169,7 +179,7 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
     // the LDS-resident weights are loop invariant across march steps: keep the compiler from hoisting
     // (and spilling) 8 tiles of operands out of the sample loops
     asm volatile("" ::: "memory");
-    const float4* aux = reinterpret_cast<const float4*>(L.aux + ((t * 2 + lh) * 16) * 4);
+    const int ro = (t * 2 + lh) * 16;  // this lane's 16 D rows of the tile
     const float4* ap = reinterpret_cast<const float4*>(L.w + (t * 32 + li) * LDW + lh * CH);
     float a[CH];
 #pragma unroll
@@ -180,21 +190,36 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
       a[4 * v + 2] = t4.z;
       a[4 * v + 3] = t4.w;
     }
-    f32x16 acc;
+    f32x16 acc;  // starts at the bias of the lane's own rows (four 16-byte LDS reads straight into the tuple)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = aux[r].x;  // accumulator starts at the bias of the lane's own rows
+    for (int v = 0; v < 4; ++v) {
+      const float4 b4 = *reinterpret_cast<const float4*>(L.bias + ro + 4 * v);
+      acc[4 * v + 0] = b4.x;
+      acc[4 * v + 1] = b4.y;
+      acc[4 * v + 2] = b4.z;
+      acc[4 * v + 3] = b4.w;
+    }
 #pragma unroll
-    for (int k = 0; k < CH; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], f[k], acc, 0, 0, 0);
-    // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units
+    for (int k = 0; k < CH; ++k)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], (k & 1) ? fv[k >> 1].y : fv[k >> 1].x, acc, 0, 0, 0);
+    // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units:
+    // radiance sums  r_c += 0.4 w_c[row] |h[row]|  on row pairs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float4 w4 = aux[r];
-      const float ah = fabsf(acc[r]);
-      rp0 = fmaf(w4.y, ah, rp0);
-      rp1 = fmaf(w4.z, ah, rp1);
-      rp2 = fmaf(w4.w, ah, rp2);
+    for (int v = 0; v < 4; ++v) {
+      const float4 w0 = *reinterpret_cast<const float4*>(L.wr[0] + ro + 4 * v);
+      const float4 w1 = *reinterpret_cast<const float4*>(L.wr[1] + ro + 4 * v);
+      const float4 w2 = *reinterpret_cast<const float4*>(L.wr[2] + ro + 4 * v);
+      const f32x2 h01 = f32x2{fabsf(acc[4 * v + 0]), fabsf(acc[4 * v + 1])};
+      const f32x2 h23 = f32x2{fabsf(acc[4 * v + 2]), fabsf(acc[4 * v + 3])};
+      r0 = pk_fma(f32x2{w0.x, w0.y}, h01, r0);
+      r1 = pk_fma(f32x2{w1.x, w1.y}, h01, r1);
+      r2 = pk_fma(f32x2{w2.x, w2.y}, h01, r2);
+      r0 = pk_fma(f32x2{w0.z, w0.w}, h23, r0);
+      r1 = pk_fma(f32x2{w1.z, w1.w}, h23, r1);
+      r2 = pk_fma(f32x2{w2.z, w2.w}, h23, r2);
     }
   }
+  float dpart = dp2.x + dp2.y, rp0 = r0.x + r0.y, rp1 = r1.x + r1.y, rp2 = r2.x + r2.y;
   dpart += __shfl_xor(dpart, 32);
   rp0 += __shfl_xor(rp0, 32);
   rp1 += __shfl_xor(rp1, 32);
@@ -267,6 +292,8 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   float4* fval = cval + MAXC * 32;
   float* fz = p.fz_ws + wslot * ((int64_t)p.n_fine * 32) + li;
 
+  unsigned long long* dbg = p.dbg ? p.dbg + wslot * 8 : nullptr;
+  if (dbg && lane == 0) dbg[0] = HOLO_PROBE_CLOCK();
   // ---- coarse pass (all rays of the wave in lock step): evaluate, composite, keep weights + values
   {
     float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
       ag = fmaf(w, cg, ag);
       ab = fmaf(w, cb, ab);
       ad = fmaf(w, zi, ad);
-      cdf[i * 64] = w;  // weights for now; turned into the cdf below (each lane keeps its own copy)
+      if (lh == 0) cdf[i * 64] = w;  // weights for now; turned into the cdf below (private column of the ray)
       Tr = 1.f - O;
       zi = zn;
     }
@@ -299,52 +326,113 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
     }
   }
 
-  // ---- weights[1:-1] -> pdf -> cdf (in place in the lane's private column)
-  // cdf has nb = nc-1 entries, cdf[0] = 0;  bins (interval mid points) also nb entries
+  // ---- weights[1:-1] -> pdf -> cdf (in place in the ray's private column; lane half 0 only)
+  // cdf has nb = nc-1 entries, cdf[0] = 0;  bins (interval mid points) also nb entries.  The finished CDF is also
+  // written ray-major into the unused half-1 columns of the wave's region (T[ray][j], two 128-byte runs per ray)
+  // for the cooperative inverse-CDF phase below.
+  if (dbg && lane == 0) dbg[1] = HOLO_PROBE_CLOCK();
   const int nb = nc - 1;
-  {
+  float* cdfT = p.cdf_ws + wslot * (MAXC * 64) + 32;  // T[r][j] at cdfT[(2*r + (j>>5))*64 + (j&31)]
+  if (lh == 0) {
+    // loads go out in batches of 8 (a plain loop makes every load a full L2 round trip); the additions keep
+    // their sequential order
     float S = 0.f;
-    for (int m = 1; m < nc - 1; ++m) S += cdf[m * 64] + p.pdf_eps;
+    for (int m0 = 1; m0 < nc - 1; m0 += 8) {
+      float wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = cdf[min(m0 + q, nc - 2) * 64];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (m0 + q < nc - 1) S += wv[q] + p.pdf_eps;
+    }
     float run = 0.f;
     cdf[0] = 0.f;
-    for (int j = 1; j < nb; ++j) {  // cdf[j] = cdf[j-1] + (w[j] + eps)/S ; slot j still holds w[j] here
-      run += (cdf[j * 64] + p.pdf_eps) / S;
-      cdf[j * 64] = run;
+    cdfT[(2 * li) * 64] = 0.f;
+    for (int j0 = 1; j0 < nb; j0 += 8) {  // cdf[j] = cdf[j-1] + (w[j] + eps)/S ; slot j still holds w[j] here
+      float wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = cdf[min(j0 + q, nb - 1) * 64];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = j0 + q;
+        if (j < nb) {
+          run += (wv[q] + p.pdf_eps) / S;
+          cdf[j * 64] = run;
+          cdfT[(2 * li + (j >> 5)) * 64 + (j & 31)] = run;
+        }
+      }
     }
   }
+  __threadfence();  // the T rows are read by OTHER lanes of this wave below
+  __builtin_amdgcn_wave_barrier();
 
+  if (dbg && lane == 0) dbg[2] = HOLO_PROBE_CLOCK();
   auto zcoarse = [&](int i) { return lin_space(p.zmin, p.zmax, zstep, i, nc); };
 
-  // ---- importance samples: inverse CDF at u = linspace(0,1,nf) (monotone, so the bin pointer only advances),
-  //      evaluated in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
-  //      those values are bit-identical to the coarse pass, so only the nf NEW points are evaluated here.
+  // ---- importance-sample depths of all 32 rays, cooperatively: for one ray at a time lane j holds cdf[j] and lane
+  //      kk computes the inverse CDF at u_kk = linspace(0,1,nf)[kk] with a binary search over the lanes' values
+  //      (ds_bpermute): searchsorted(right=True), then the lerp of sample_pdf.  Replaces a per-ray serial walk whose
+  //      every step was three dependent L2 round trips in the middle of the evaluation loop.
   {
     const float ustep = 1.0f / (float)(nf - 1);
-    int ind = 0;
     auto mid = [&](int i) {
       const float a0 = zcoarse(i), a1 = zcoarse(i + 1);
       return a0 - (a0 - a1) * 0.5f;  // torch.lerp(z[1:], z[:-1], 0.5)
     };
-    for (int kk = 0; kk < nf; ++kk) {
-      const float u = lin_space(0.f, 1.f, ustep, kk, nf);
-      while (ind < nb && cdf[ind * 64] <= u) ++ind;  // searchsorted(right=True)
-      const int below = ind - 1 > 0 ? ind - 1 : 0;
-      const int above = ind < nb - 1 ? ind : nb - 1;
-      const float cb_ = cdf[below * 64], ca_ = cdf[above * 64];
-      float den = ca_ - cb_;
-      if (den < p.pdf_eps) den = 1.f;
-      const float tt = (u - cb_) / den;
-      const float bb = mid(below), ba = mid(above);
-      const float zf = bb + tt * (ba - bb);
-      float sg, cr, cg, cb;
-      eval(zf, sg, cr, cg, cb);
-      if (lh == 0) {
-        fz[kk * 32] = zf;
-        fval[kk * 32] = make_float4(sg, cr, cg, cb);
+    float* fzw = p.fz_ws + wslot * ((int64_t)p.n_fine * 32);
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      float cv[8];  // the CDF rows of 8 rays are requested together
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        cv[q] = lane < nb ? cdfT[(2 * (r0 + q) + (lane >> 5)) * 64 + (lane & 31)] : 3.0e38f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = r0 + q;
+        const float c = cv[q];
+        for (int kb = 0; kb < nf; kb += 64) {
+          const int kk = kb + lane;
+          const float u = lin_space(0.f, 1.f, ustep, kk < nf ? kk : nf - 1, nf);
+          int lo = 0, hi = nb;  // ind = #{j < nb : cdf[j] <= u}
+#pragma unroll
+          for (int it = 0; it < 7; ++it) {  // nb <= 63 < 2^6 (+1 closing step); every lane runs all steps (shuffles)
+            const int md = (lo + hi) >> 1;
+            const float cm = __shfl(c, md < nb ? md : nb - 1);
+            const bool go = lo < hi && cm <= u;
+            const bool stay = lo < hi && !(cm <= u);
+            if (go) lo = md + 1;
+            if (stay) hi = md;
+          }
+          const int ind = lo;
+          const int below = ind - 1 > 0 ? ind - 1 : 0;
+          const int above = ind < nb - 1 ? ind : nb - 1;
+          const float cb_ = __shfl(c, below), ca_ = __shfl(c, above);
+          float den = ca_ - cb_;
+          if (den < p.pdf_eps) den = 1.f;
+          const float tt = (u - cb_) / den;
+          const float bb = mid(below), ba = mid(above);
+          if (kk < nf) fzw[kk * 32 + r] = bb + tt * (ba - bb);
+        }
       }
     }
   }
+  __threadfence();
+  __builtin_amdgcn_wave_barrier();
 
+  if (dbg && lane == 0) dbg[3] = HOLO_PROBE_CLOCK();
+  // ---- fine pass, in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
+  //      those values are bit-identical to the coarse pass, so only the nf NEW points are evaluated here.
+  {
+    float zf = fz[0];
+    for (int kk = 0; kk < nf; ++kk) {
+      const float zf_next = fz[(kk + 1 < nf ? kk + 1 : kk) * 32];  // requested a whole evaluation ahead
+      float sg, cr, cg, cb;
+      eval(zf, sg, cr, cg, cb);
+      if (lh == 0) fval[kk * 32] = make_float4(sg, cr, cg, cb);
+      zf = zf_next;
+    }
+  }
+
+  if (dbg && lane == 0) dbg[4] = HOLO_PROBE_CLOCK();
   // ---- fine composite: merge of the two sorted depth lists (== torch.sort of their concatenation), per ray,
   //      no evaluation.  One lane per ray (half 0); no wave-collective operations below this point.
   if (lh == 0) {
@@ -395,6 +483,7 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
       p.mask[ray] = O;
     }
   }
+  if (dbg && lane == 0) dbg[5] = HOLO_PROBE_CLOCK();
 }
 
 // radiance direction term per ray direction (one thread per direction)

@@ -8,6 +8,7 @@
 //   HoloDiffusionModel.forward render section  holo_diffusion_model.py:431-457,515-523
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -319,8 +320,38 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
       p.depth_c = depths_coarse + (size_t)ci * npix;
       p.mask_c = masks_coarse + (size_t)ci * npix;
     }
+#ifndef HOLO_EMU
+    static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
+#else
+    const bool timeline = false;
+#endif
+    const int nwaves = 4 * ((npix + 127) / 128);
+#ifndef HOLO_EMU
+    if (timeline) {
+      HIP_TRY(hipMalloc((void**)&p.dbg, (size_t)nwaves * 64));
+      HIP_TRY(hipMemsetAsync(p.dbg, 0, (size_t)nwaves * 64, (hipStream_t)stream));
+    }
+#endif
     rc = render_launch(p, stream);
     if (rc) return HOLO_E_INVALID;
+#ifndef HOLO_EMU
+    if (timeline) {
+      std::vector<unsigned long long> d((size_t)nwaves * 8);
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      HIP_TRY(hipMemcpy(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost));
+      (void)hipFree(p.dbg);
+      double ph[5] = {0, 0, 0, 0, 0};
+      unsigned long long t0 = ~0ull, t1 = 0;
+      for (int w = 0; w < nwaves; ++w) {
+        for (int k = 0; k < 5; ++k) ph[k] += (double)(d[w * 8 + k + 1] - d[w * 8 + k]);
+        if (d[w * 8] < t0) t0 = d[w * 8];
+        if (d[w * 8 + 5] > t1) t1 = d[w * 8 + 5];
+      }
+      fprintf(stderr, "[render timeline] waves %d span %.1f us | per wave: coarse %.1f  cdf %.1f  inverse-cdf %.1f  fine %.1f  "
+              "composite %.1f us\n", nwaves, (t1 - t0) * 0.01, ph[0] / nwaves * 0.01, ph[1] / nwaves * 0.01,
+              ph[2] / nwaves * 0.01, ph[3] / nwaves * 0.01, ph[4] / nwaves * 0.01);
+    }
+#endif
   }
   return 0;
 }

@@ -186,6 +186,7 @@ static inline float __fadd_rn(float a, float b) {
 static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 
+static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 static inline void emu_wave_barrier() { emu_wave().bar.wait(); }
