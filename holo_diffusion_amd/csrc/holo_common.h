@@ -15,6 +15,7 @@ struct f32x2 {
   float x, y;
 };
 static inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
+static inline f32x2 pk_mul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
 #define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
@@ -26,6 +27,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fused multiply-adds in one v_pk_fma_f32 (each element rounds exactly like fmaf)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 // Passes a per-lane value through an empty asm: the optimiser can no longer prove it loop-invariant, so index

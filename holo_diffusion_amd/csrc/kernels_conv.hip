@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   const int lj = lane & 15;
   const int kq = lane >> 4;
   const int wn = wave % NWN;
-  const int wm = wave / NWN;
+  const int wm = NWN == 4 ? 0 : wave / NWN;  // (4 waves: compile-time 0, so the A addresses fold into immediates)
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
   // Spatial tiles: the workgroup is PERSISTENT over blockIdx.x (conv_plan sizes gridDim.x to the resident slots
@@ -344,9 +344,39 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 
   // ---- halo staging, split in "issue the loads" / "transform + write LDS"
   float4 hreg[HALO_IT];
-  unsigned hmask = 0;  // bit i: element i is inside the volume (zero padding otherwise)
+  unsigned hmask = 0;   // bit i: element i is inside the volume and a real channel (zero padding otherwise)
+  unsigned hvalid = 0;  // spatial part of hmask, per tile
+  // clamped source voxel of every halo row this thread stages, per tile: parked in LDS ([i][thread], conflict
+  // free) - in registers the 13 values push the 128-voxel variant past 256 VGPRs under the last tap
+  __shared__ int s_hvox[HALO_IT * 256];
   int hcoef_c = 0;
   bool h_is_skip = false;
+  // On gfx950 the fp32 MFMA runs on the vector FMA lanes (tools/coexec_probe.cpp), so every VALU instruction of the
+  // staging path costs matrix time: the halo coordinates are worked out ONCE per tile (halo_prepare), a chunk's
+  // loads are then one multiply-add each, and the activation runs on register pairs (v_pk_fma / v_pk_mul).
+  auto halo_prepare = [&]() {
+    hvalid = 0;
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int hv = min(r0 + 32 * i, HALO_VOX - 1);
+      const int hz = hv / (HY * HX);
+      const int rem = hv - hz * (HY * HX);
+      const int hy = rem / HX;
+      const int hx = rem - hy * HX;
+      int z = tz0 + hz - 1, y = ty0 + hy - 1, x = tx0 + hx - 1;
+      const bool ok = z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+      z = min(max(z, 0), p.ID - 1);
+      y = min(max(y, 0), p.IH - 1);
+      x = min(max(x, 0), p.IW - 1);
+      if (p.ups) {  // (never set together with a fused skip: ResBlocks do not resample)
+        z >>= 1;
+        y >>= 1;
+        x >>= 1;
+      }
+      s_hvox[i * 256 + tid] = (z * SH + y) * SW + x;
+      hvalid |= (ok ? 1u : 0u) << i;
+    }
+  };
   auto halo_issue = [&](int cc) {
     h_is_skip = SKIP && cc >= ncc;
     int c = (h_is_skip ? cc - ncc : cc) * BK + q * 4;
@@ -361,65 +391,47 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
       Cs = h_is_skip ? p.skip_C1 : p.C1;
       cs = c - C0s;
     }
-    hmask = 0;
+    hmask = cvalid ? hvalid : 0u;
     // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards:
     // a "load or zero" branch would make the compiler wait for each load before the next one is issued.
-    // (r0 is laundered through an empty asm so that the per-row halo coordinates below are recomputed at every
-    //  call: hoisted out of the persistent tile loop they would pin ~40 VGPRs and push the kernel into scratch)
-    int r0l = r0;
-    HOLO_LAUNDER(r0l);
+    // uniform 64-bit base + one 32-bit byte offset per load (conv_plan keeps a source volume below 4 GB on this path)
+    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)n * SD * SH * SW * Cs);
+    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
+    int tl = tid;
+    HOLO_LAUNDER(tl);  // (otherwise the compiler forwards the values stored by halo_prepare and keeps them in VGPRs)
 #pragma unroll
-    for (int i = 0; i < HALO_IT; ++i) {
-      const int hv = min(r0l + 32 * i, HALO_VOX - 1);
-      const int hz = hv / (HY * HX);
-      const int rem = hv - hz * (HY * HX);
-      const int hy = rem / HX;
-      const int hx = rem - hy * HX;
-      int z = tz0 + hz - 1, y = ty0 + hy - 1, x = tx0 + hx - 1;
-      const bool ok = cvalid && z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
-      z = min(max(z, 0), p.ID - 1);
-      y = min(max(y, 0), p.IH - 1);
-      x = min(max(x, 0), p.IW - 1);
-      if (p.ups) {  // (never set together with a fused skip: ResBlocks do not resample)
-        z >>= 1;
-        y >>= 1;
-        x >>= 1;
-      }
-      hreg[i] = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + y) * SW + x) * Cs + cs);
-      hmask |= (ok ? 1u : 0u) << i;
-    }
+    for (int i = 0; i < HALO_IT; ++i)
+      hreg[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs));
   };
   auto halo_commit = [&]() {
-    float4 c01 = make_float4(1.f, 0.f, 1.f, 0.f), c23 = c01;
+    f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
     const bool xform = p.coef && !h_is_skip;  // the skip path reads the raw block input
     if (xform) {
       const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
       const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
-      c01 = cf[0];
-      c23 = cf[1];
+      const float4 c01 = cf[0], c23 = cf[1];  // (a,b) interleaved per channel
+      a01 = f32x2{c01.x, c01.z};
+      b01 = f32x2{c01.y, c01.w};
+      a23 = f32x2{c23.x, c23.z};
+      b23 = f32x2{c23.y, c23.w};
     }
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
       const int hv = r0 + 32 * i;
-      float4 v = hreg[i];
+      f32x2 v01 = f32x2{hreg[i].x, hreg[i].y}, v23 = f32x2{hreg[i].z, hreg[i].w};
       if (xform) {
-        v.x = v.x * c01.x + c01.y;
-        v.y = v.y * c01.z + c01.w;
-        v.z = v.z * c23.x + c23.y;
-        v.w = v.w * c23.z + c23.w;
+        v01 = pk_fma(v01, a01, b01);
+        v23 = pk_fma(v23, a23, b23);
         if (p.act) {
-          v.x = silu_f(v.x);
-          v.y = silu_f(v.y);
-          v.z = silu_f(v.z);
-          v.w = silu_f(v.w);
+          v01 = f32x2{silu_f(v01.x), silu_f(v01.y)};
+          v23 = f32x2{silu_f(v23.x), silu_f(v23.y)};
         }
       }
       const float keep = ((hmask >> i) & 1u) ? 1.f : 0.f;  // zero padding is applied AFTER the activation
-      v.x *= keep;
-      v.y *= keep;
-      v.z *= keep;
-      v.w *= keep;
-      if (hv < HALO_VOX) *reinterpret_cast<float4*>(s_halo + hv * LDK + q * 4) = v;
+      const f32x2 k2 = f32x2{keep, keep};
+      v01 = pk_mul(v01, k2);
+      v23 = pk_mul(v23, k2);
+      if (hv < HALO_VOX) *reinterpret_cast<float4*>(s_halo + hv * LDK + q * 4) = make_float4(v01.x, v01.y, v23.x, v23.y);
     }
   };
 
@@ -484,6 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   // instantiation requests and commits back to back instead: measured on MI355X the prefetch makes it 7% SLOWER
   // (225 instead of 171 VGPRs, and its chunks are short).
   decode_tile(blockIdx.x);
+  halo_prepare();
   if (!SKIP) halo_issue(cc_begin);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   ctx0 = tx0, cty0 = ty0, ctz0 = tz0, cn = n;
@@ -511,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
         halo_issue(cc + 1);
       } else if (more_tiles) {
         decode_tile(tile + gridDim.x);
+        halo_prepare();
         halo_issue(cc_begin);
       }
     }
@@ -612,7 +626,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     dbg[4] = hw;
     dbg[5] = xcc;
   }
-  if (SKIP && more_tiles) decode_tile(tile + gridDim.x);
+  if (SKIP && more_tiles) {
+    decode_tile(tile + gridDim.x);
+    halo_prepare();
+  }
   }  // tile loop
 }
 
@@ -989,8 +1006,12 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   const int64_t tiles = cdiv(M, BM) * cdiv(p.Cout, bn);
   int nsplit = 1;
   const int64_t target = 2 * (int64_t)num_cus;
+  const int64_t src_vox = (int64_t)p.ID * p.IH * p.IW;  // the halo kernel addresses a source sample with 32-bit byte offsets
+  const int cmax = p.C0 > p.C1 ? p.C0 : p.C1;
+  const int skmax = p.skip_C0 > p.skip_C1 ? p.skip_C0 : p.skip_C1;
+  const bool fits32 = src_vox * (cmax > skmax ? cmax : skmax) * 4 < ((int64_t)1 << 32);
   p.mode = (p.ksz == 3 && p.stride == 1 && p.pad == 1 && (p.OD % 2) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 &&  // (TZ=1 tiles need no z divisibility)
-            p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0)
+            p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1
                : 0;
   if (p.mode == 0 && p.Cout >= 64) {  // 1x1x1, strided and deepest-level convs: row-tile kernel
