@@ -41,6 +41,8 @@ UNET_FLOPS_PER_STEP = 1180.8e9  # BASELINE.md §2 (reference module trace, 2*MAC
 
 NORTH = dict(resol=64, feature_size=32, model_channels=64, channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8))
 SMALL = dict(resol=32, feature_size=16, model_channels=64, channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8))
+DONUT = dict(resol=128, feature_size=32, model_channels=64, channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8))
+FLOPS_PER_STEP = {64: 1180.8e9, 32: 139.1e9, 128: 11926.9e9}  # BASELINE.md / SURVEY.md 8d (reference module trace)
 
 
 def build_model(w, H, W, device, n_fine=64):
@@ -126,7 +128,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=5, help="timed 400x400 frames in the render leg")
     ap.add_argument("--image-size", type=int, default=400)
-    ap.add_argument("--workload", choices=["north", "small"], default="north")
+    ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
+                    help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "
+                         "sizes on the same fp32 path (side measurements, never the reported line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-iters", type=int, default=3)
     args = ap.parse_args()
@@ -141,7 +145,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
-    w = NORTH if args.workload == "north" else SMALL
+    w = {"north": NORTH, "small": SMALL, "donut128": DONUT}[args.workload]
     H = W = args.image_size
     warnings.simplefilter("ignore")
     model, usd, msd = build_model(w, H, W, device)
@@ -258,12 +262,13 @@ def main():
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; "
-                                    if args.workload == "north" else "32^3x16 plumbing grid; ")
+            "config": {"workload": ({"north": "apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; ",
+                                     "small": "32^3x16 plumbing grid; ",
+                                     "donut128": "128^3x32 grid (donut.yaml size) on the fp32 path; "}[args.workload])
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
-            "unet_tflops": UNET_FLOPS_PER_STEP * steps_per_s / world / 1e12 if args.workload == "north" else None,
+            "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "kernel": "render_kernel<16> (one launch per frame)",
                                 "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,

@@ -143,3 +143,22 @@ def test_wrong_shape_and_unset_errors(gu):
     net, _ = gu.make_unet(TINY_CFG)
     with pytest.raises(_lib.HoloError):
         net(torch.zeros(1, 32, 4, 4, 4, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
+
+
+def test_128_cubed_forward_vs_oracle(gu):
+    """BASELINE configs[4] grid size (128^3 x 32) on the fp32 path: full forward against the pinned oracle run on the
+    host cores (the oracle takes ~1 min at this size); tolerance of SURVEY.md 8c for a full forward."""
+    cfg = uo.UNetCfg(image_size=128, in_channels=32, out_channels=32, model_channels=64, num_res_blocks=2,
+                     channel_mult=(1, 1, 2, 4, 8), attention_resolutions=(4, 8), num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=1234)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(31, (1, 32, 128, 128, 128)))
+    t = torch.tensor([500], dtype=torch.int64)
+    with torch.no_grad():
+        y = net(x.to(gu.DEV), t.to(gu.DEV))
+        y2 = net(x.to(gu.DEV), t.to(gu.DEV))
+    assert torch.equal(y, y2)  # deterministic (no atomics anywhere on the path)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = uo.unet_forward(sd, cfg, x, t)
+    assert torch.isfinite(y).all()
+    assert (y.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max()
