@@ -36,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2516.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
 UNET_FLOPS_PER_STEP = 1180.8e9  # BASELINE.md §2 (reference module trace, 2*MACs) at 64^3x32
 
@@ -45,14 +46,14 @@ DONUT = dict(resol=128, feature_size=32, model_channels=64, channel_mult=(1, 1, 
 FLOPS_PER_STEP = {64: 1180.8e9, 32: 139.1e9, 128: 11926.9e9}  # BASELINE.md / SURVEY.md 8d (reference module trace)
 
 
-def build_model(w, H, W, device, n_fine=64):
+def build_model(w, H, W, device, n_fine=64, compute_dtype="f32"):
     import holo_diffusion_amd as hda
     from holo_diffusion_amd.structure import unet_param_shapes
     from holo_diffusion_amd.weights import synth_state_dict
     model = hda.HoloDiffusionModel(
         resol=w["resol"], feature_size=w["feature_size"], render_image_width=W, render_image_height=H,
         net_3d_SimpleUnet3D_args=dict(model_channels=w["model_channels"], channel_mult=w["channel_mult"],
-                                      attention_resolutions=w["attention_resolutions"]),
+                                      attention_resolutions=w["attention_resolutions"], compute_dtype=compute_dtype),
         diffusion_args=dict(num_steps=1000),
         renderer_HoloMultiPassEmissionAbsorptionRenderer_args=dict(n_pts_per_ray_fine_evaluation=n_fine))
     usd = synth_state_dict(unet_param_shapes(w["resol"], w["feature_size"], w["feature_size"], w["model_channels"], 2,
@@ -131,6 +132,9 @@ def main():
     ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
                     help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "
                          "sizes on the same fp32 path (side measurements, never the reported line)")
+    ap.add_argument("--compute-dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reported line (reference arithmetic); bf16 = opt-in bf16 products / fp32 accumulate in "
+                         "the 3x3x3 convolutions (side measurement for the bf16 configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-iters", type=int, default=3)
     args = ap.parse_args()
@@ -148,7 +152,7 @@ def main():
     w = {"north": NORTH, "small": SMALL, "donut128": DONUT}[args.workload]
     H = W = args.image_size
     warnings.simplefilter("ignore")
-    model, usd, msd = build_model(w, H, W, device)
+    model, usd, msd = build_model(w, H, W, device, compute_dtype=args.compute_dtype)
     net, diff = model.net_3d, model.diffusion
     shape = (1, w["feature_size"]) + (w["resol"],) * 3
     torch.manual_seed(42 + rank)
@@ -227,8 +231,9 @@ def main():
                            "source": ent.get("source")}
         except (OSError, ValueError):
             pass
-        roof = {"bound": "mfma", "kernel": label + " (3x3x3 conv3d, LDS voxel-halo implicit GEMM, fp32 MFMA)",
-                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+        peak = PEAK_FP32_MFMA_TFLOPS if args.compute_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": label + f" (3x3x3 conv3d, LDS voxel-halo implicit GEMM, {args.compute_dtype} MFMA)",
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "launches_per_forward": dom["n"], "avg_launch_ms": dom["ms"] / dom["n"],
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["n"] / 1e9,
                 "share_of_conv_time": dom["ms"] / all_ms,
@@ -261,7 +266,8 @@ def main():
             "metric": "denoise-steps/sec + rendered-rays/sec, 64^3x32 grid @400^2 render",
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.compute_dtype == "f32" else "bf16 products / f32 accumulate in the 3x3x3 convs, f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": ({"north": "apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; ",
                                      "small": "32^3x16 plumbing grid; ",
                                      "donut128": "128^3x32 grid (donut.yaml size) on the fp32 path; "}[args.workload])

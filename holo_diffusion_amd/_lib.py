@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 
 HOLO_DTYPE_F32 = 0
+HOLO_DTYPE_BF16 = 1
 
 
 class HoloError(RuntimeError):
@@ -67,6 +68,7 @@ SIGNATURES = {
     "holo_unet_num_params": (C.c_int, [_vp]),
     "holo_unet_param_info": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _i64p, C.POINTER(C.c_int)]),
     "holo_unet_set_param": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, C.c_int, _i64p, _vp]),
+    "holo_unet_set_compute_dtype": (C.c_int, [_vp, C.c_int]),
     "holo_unet_workspace_bytes": (C.c_size_t, [_vp, C.c_int]),
     "holo_unet_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_unet_fetch_block": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _i64p, _vp, _vp]),

@@ -16,6 +16,8 @@ struct f32x2 {
 };
 static inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
 static inline f32x2 pk_mul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+static inline uint32_t pack_bf16x2(float lo, float hi) { return emu_bf16_bits(lo) | (emu_bf16_bits(hi) << 16); }
+static inline f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
 #define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
@@ -28,6 +30,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fused multiply-adds in one v_pk_fma_f32 (each element rounds exactly like fmaf)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
+// two floats -> two bf16 (round to nearest even, v_cvt_pk_bf16_f32), `lo` in the low half
+typedef __bf16 holo_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 holo_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const holo_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// v_mfma_f32_16x16x32_bf16 on raw 16-byte operands (8 bf16 per lane: A row / B column lane&15, k-group lane>>4)
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(holo_bf16x8, a), __builtin_bit_cast(holo_bf16x8, b), c,
+                                                 0, 0, 0);
+}
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 // Passes a per-lane value through an empty asm: the optimiser can no longer prove it loop-invariant, so index

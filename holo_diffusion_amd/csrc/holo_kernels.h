@@ -36,6 +36,12 @@ struct ConvParams {
   const float* skip_src1;
   int skip_C0, skip_C1;
   const float* skip_w;    // packed like w with one tap
+  // bf16-multiply variant of the halo kernel (opt-in, holo_unet_set_compute_dtype): the same weights rounded to
+  // bf16 (RNE), packed [ksz^3][CinP/32][CoutP/16][lane 64][8 bf16] = one 1 KB block of B operands of
+  // v_mfma_f32_16x16x32_bf16 per (tap, chunk, 16-Cout slice).  Used when bf16 != 0 and the launch is on the halo path.
+  const uint16_t* w_bf;
+  const uint16_t* skip_w_bf;
+  int bf16;
   int skip_CinP;
   const float* skip_bias;
   double* stats;          // optional: GroupNorm partial sums of `out`, [N][conv_stats_slabs(p)][Cout][2]
@@ -124,6 +130,8 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
 int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
 
+int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int Cin, int taps, int CoutP, int CinP,
+                                   void* stream);
 // OIDHW [Cout][Cin][taps] -> zero padded MFMA-fragment-packed layout (see ConvParams::w)
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
                               void* stream);

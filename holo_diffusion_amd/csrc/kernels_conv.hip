@@ -289,14 +289,19 @@ constexpr int HY = 10, HX = 10;
 // NWN: waves along Cout (4 -> 64 channels per block, 2 -> 32).  TZ: tile depth in voxels (2 -> 128-voxel tiles
 // for the 64^3 level; 1 -> 64-voxel tiles so that the 32^3..8^3 levels launch twice the workgroups and the 32^3
 // level needs no split-K)
-template <int NWN, int TZ, bool SKIP>  // SKIP: a 1x1x1 skip connection is fused as extra K chunks
+// BF: multiply in bf16 on the matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate): the halo is rounded to bf16
+// (RNE) when it is committed to LDS (80-byte rows: 32 channels + 16 bytes of padding, conflict free for the
+// 16-byte A reads), the weights come pre-rounded and packed per lane, and one MFMA covers the 32 channels of a
+// chunk for a tap (eight v_mfma_f32_16x16x4_f32 in the fp32 form).  Opt-in (ConvParams::bf16).
+template <int NWN, int TZ, bool SKIP, bool BF = false>  // SKIP: a 1x1x1 skip connection is fused as extra K chunks
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
+  constexpr int RS = BF ? 20 : LDK;  // LDS row stride of one halo voxel, in 4-byte words
   constexpr int BN = 16 * NWN;
   constexpr int MT = TZ * NWN;  // 16-voxel tiles per wave
   constexpr int HZ = TZ + 2;
   constexpr int HALO_VOX = HZ * HY * HX;
   constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // halo rows per thread (8 threads cover one row's 32 channels)
-  __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * LDK];
+  __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * RS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -431,7 +436,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
       const f32x2 k2 = f32x2{keep, keep};
       v01 = pk_mul(v01, k2);
       v23 = pk_mul(v23, k2);
-      if (hv < HALO_VOX) *reinterpret_cast<float4*>(s_halo + hv * LDK + q * 4) = make_float4(v01.x, v01.y, v23.x, v23.y);
+      if (BF) {
+        if (hv < HALO_VOX)
+          *reinterpret_cast<uint2*>(s_halo + hv * RS + q * 2) = make_uint2(pack_bf16x2(v01.x, v01.y), pack_bf16x2(v23.x, v23.y));
+      } else {
+        if (hv < HALO_VOX) *reinterpret_cast<float4*>(s_halo + hv * RS + q * 4) = make_float4(v01.x, v01.y, v23.x, v23.y);
+      }
     }
   };
 
@@ -445,25 +455,33 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int T = wm * MT + t;
-    a_off[t] = (((T >> 2) * HY + (T & 3) + 4 * (lj >> 3)) * HX + (lj & 7)) * LDK + kq * 8;
+    a_off[t] = (((T >> 2) * HY + (T & 3) + 4 * (lj >> 3)) * HX + (lj & 7)) * RS + kq * (BF ? 4 : 8);
   }
   // B addressing: weight row of this lane's output channel, 8 channels starting at 8*kq of the chunk
-  // (packed layout: the two 16-byte B fragments of a lane for one (tap, chunk) sit at lane*16 B in two 1 KB planes)
+  // (packed layout: the two 16-byte B fragments of a lane for one (tap, chunk) sit at lane*16 B in two 1 KB planes;
+  //  bf16: one 16-byte fragment per lane, 1 KB per block)
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
-  const float* w_lane = p.w + (int64_t)((n0 >> 4) + wn) * 512 + lane * 4;
+  constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, slice) block
+  const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wn) * WBLK + lane * 4;
+  const float* skw = BF ? reinterpret_cast<const float*>(p.skip_w_bf) : p.skip_w;
 
   auto load_a = [&](float4 (&a)[MT], int tap, int half) {
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
-    const int toff = ((kd * HY + kh) * HX + kw) * LDK + half * 4;
+    const int toff = ((kd * HY + kh) * HX + kw) * RS + half * 4;
 #pragma unroll
     for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(s_halo + a_off[t] + toff);
   };
   auto load_b = [&](float4 (&b)[2], int cc, int tap) {
-    const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 512;
+    const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
     b[0] = *reinterpret_cast<const float4*>(wp);
-    b[1] = *reinterpret_cast<const float4*>(wp + 256);
+    if (!BF) b[1] = *reinterpret_cast<const float4*>(wp + 256);
   };
   auto mfma_half = [&](const float4 (&a)[MT], const float4& b) {
+    if (BF) {  // one instruction covers the chunk's 32 channels
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[t], b, acc[t]);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -480,6 +498,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   // one tap: on entry `cur` holds the first-half A operands of `tap` and `bc` its weights
   auto tap_body = [&](float4 (&cur)[MT], float4 (&nxt)[MT], float4 (&bc)[2], float4 (&bn)[2], int cc, int tap,
                       bool prefetch) {
+    if (BF) {  // whole tap = MT instructions; the next tap's operands are requested ahead of them
+      if (prefetch) {
+        load_a(nxt, tap + 1, 0);
+        load_b(bn, cc, tap + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(cur, bc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
     load_a(aB, tap, 1);
     if (prefetch) load_b(bn, cc, tap + 1);
     __builtin_amdgcn_sched_barrier(0);  // keep the requests above AHEAD of the MFMAs that hide their latency
@@ -536,14 +564,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     for (int cc = sk_begin; cc < sk_end; ++cc) {
       halo_issue(cc);
       halo_commit();
-      const float* wp = p.skip_w + ((int64_t)(cc - ncc) * wnsl + (n0 >> 4) + wn) * 512 + lane * 4;
+      const float* wp = skw + ((int64_t)(cc - ncc) * wnsl + (n0 >> 4) + wn) * WBLK + lane * 4;
       b0[0] = *reinterpret_cast<const float4*>(wp);
-      b0[1] = *reinterpret_cast<const float4*>(wp + 256);
+      if (!BF) b0[1] = *reinterpret_cast<const float4*>(wp + 256);
       __syncthreads();
       load_a(aA, 13, 0);
-      load_a(aB, 13, 1);
+      if (!BF) load_a(aB, 13, 1);
       mfma_half(aA, b0[0]);
-      mfma_half(aB, b0[1]);
+      if (!BF) mfma_half(aB, b0[1]);
       __syncthreads();
     }
   }
@@ -1101,22 +1129,33 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (wide && p.tz == 2 && sk) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 2, true>), hgrid, block, stream, p);
-    } else if (wide && p.tz == 2) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 2, false>), hgrid, block, stream, p);
-    } else if (wide && sk) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 1, true>), hgrid, block, stream, p);
-    } else if (wide) {
-      HOLO_LAUNCH((conv_halo_kernel<4, 1, false>), hgrid, block, stream, p);
-    } else if (sk) {
+    const bool bf = p.bf16 && p.w_bf && (!sk || p.skip_w_bf);
+    if (!wide && sk) {
       set_error("conv_launch: fused skip needs Cout >= 64");
       return -1;
-    } else if (p.tz == 2) {
-      HOLO_LAUNCH((conv_halo_kernel<2, 2, false>), hgrid, block, stream, p);
-    } else {
-      HOLO_LAUNCH((conv_halo_kernel<2, 1, false>), hgrid, block, stream, p);
     }
+#define HOLO_HALO(NWN_, TZ_, SK_)                                                                 \
+  do {                                                                                            \
+    if (bf) {                                                                                     \
+      HOLO_LAUNCH((conv_halo_kernel<NWN_, TZ_, SK_, true>), hgrid, block, stream, p);             \
+    } else {                                                                                      \
+      HOLO_LAUNCH((conv_halo_kernel<NWN_, TZ_, SK_, false>), hgrid, block, stream, p);            \
+    }                                                                                             \
+  } while (0)
+    if (wide && p.tz == 2 && sk) {
+      HOLO_HALO(4, 2, true);
+    } else if (wide && p.tz == 2) {
+      HOLO_HALO(4, 2, false);
+    } else if (wide && sk) {
+      HOLO_HALO(4, 1, true);
+    } else if (wide) {
+      HOLO_HALO(4, 1, false);
+    } else if (p.tz == 2) {
+      HOLO_HALO(2, 2, false);
+    } else {
+      HOLO_HALO(2, 1, false);
+    }
+#undef HOLO_HALO
   } else if (p.mode == 2) {
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
     HOLO_LAUNCH(conv_small_kernel, sgrid, block, stream, p);

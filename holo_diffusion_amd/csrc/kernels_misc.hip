@@ -332,6 +332,30 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
   }
 }
 
+// OIDHW [Cout][Cin][taps] -> bf16 (RNE) packed [tap][CinP/32][CoutP/16][lane = 16*kq + lj][8]: lane's 8 values are
+// channels 8*kq .. 8*kq+7 of the chunk for output channel 16*slice + lj (B operand of v_mfma_f32_16x16x32_bf16)
+__global__ __launch_bounds__(256) void repack_conv_weight_bf16_kernel(const float* __restrict__ w,
+                                                                      uint16_t* __restrict__ out, int Cout, int Cin,
+                                                                      int taps, int CoutP, int CinP) {
+  const int64_t total = (int64_t)CoutP * CinP * taps / 2;  // pairs
+  const int ncc = CinP >> 5, nsl = CoutP >> 4;
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e2 = (int)(i & 3);  // pair index inside the lane's 8 values
+    const int lane = (int)((i >> 2) & 63);
+    int64_t blk = i >> 8;
+    const int slice = (int)(blk % nsl);
+    blk /= nsl;
+    const int cc = (int)(blk % ncc);
+    const int tap = (int)(blk / ncc);
+    const int co = slice * 16 + (lane & 15);
+    const int ci = cc * 32 + (lane >> 4) * 8 + e2 * 2;
+    const float v0 = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
+    const float v1 = (ci + 1 < Cin && co < Cout) ? w[((int64_t)co * Cin + ci + 1) * taps + tap] : 0.f;
+    o32[i] = pack_bf16x2(v0, v1);
+  }
+}
+
 }  // namespace
 
 int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream) {
@@ -422,6 +446,15 @@ int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* s
   int64_t blocks = cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
   HOLO_LAUNCH(clip_kernel, dim3((unsigned)blocks), dim3(256), stream, x, y, lo, hi, n);
+  return 0;
+}
+int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int Cin, int taps, int CoutP, int CinP,
+                                   void* stream) {
+  int64_t total = (int64_t)CoutP * CinP * taps / 2;
+  int64_t blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  HOLO_LAUNCH(repack_conv_weight_bf16_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, taps, CoutP,
+              CinP);
   return 0;
 }
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,

@@ -72,6 +72,7 @@ struct ParamSlot {
   int64_t numel;
   ParamKind kind;
   float* priv;  // private (repacked) device copy
+  uint16_t* priv_bf = nullptr;  // conv weights: bf16 (RNE) copy packed for v_mfma_f32_16x16x32_bf16
   bool set;
 };
 
@@ -163,6 +164,9 @@ struct HoloUnet {
   std::vector<ParamSlot> params;
   std::map<std::string, int> pindex;
   float* pstore = nullptr;  // one allocation for all private parameter copies
+  uint16_t* pstore_bf = nullptr;                       // bf16 copies of the conv weights
+  std::map<const float*, const uint16_t*> bf_of;       // fp32 private copy -> bf16 copy
+  bool compute_bf16 = false;                           // holo_unet_set_compute_dtype
   // concatenated emb_layers
   int emb_rows = 0;
   std::map<std::string, int> emb_row_off;  // resblock prefix -> first row
@@ -444,6 +448,11 @@ struct Planner {
     p.CoutP = pad_cout(Cout);
     p.CinP = pad_cin(p.C0 + p.C1);
     p.w = w;
+    if (u->compute_bf16) {  // halo-path launches multiply in bf16 (conv_launch checks the pointers)
+      auto it = u->bf_of.find(w);
+      p.w_bf = it == u->bf_of.end() ? nullptr : it->second;
+      p.bf16 = 1;
+    }
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
     p.bias = bias;
@@ -455,6 +464,10 @@ struct Planner {
       p.skip_C0 = skip0->C;
       p.skip_C1 = skip1 ? skip1->C : 0;
       p.skip_w = skip_w;
+      if (u->compute_bf16) {
+        auto it = u->bf_of.find(skip_w);
+        p.skip_w_bf = it == u->bf_of.end() ? nullptr : it->second;
+      }
       p.skip_CinP = pad_cin(p.skip_C0 + p.skip_C1);
       p.skip_bias = skip_bias;
     }
@@ -857,6 +870,24 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
       s.priv = cur;
       cur += (priv_numel(s) + 63) & ~(int64_t)63;
     }
+  {  // bf16 copies of the conv weights (same padded element counts, 2 bytes each)
+    int64_t tb = 0;
+    for (auto& s : u->params)
+      if (s.kind == P_CONV3 || s.kind == P_CONV1) tb += (priv_numel(s) + 63) & ~(int64_t)63;
+    if (hipMalloc((void**)&u->pstore_bf, (size_t)tb * sizeof(uint16_t)) != hipSuccess) {
+      set_error("holo_unet_create: hipMalloc of %lld bf16 weights failed", (long long)tb);
+      (void)hipFree(u->pstore);
+      delete u;
+      return HOLO_E_HIP;
+    }
+    uint16_t* cb = u->pstore_bf;
+    for (auto& s : u->params)
+      if (s.kind == P_CONV3 || s.kind == P_CONV1) {
+        s.priv_bf = cb;
+        u->bf_of[s.priv] = cb;
+        cb += (priv_numel(s) + 63) & ~(int64_t)63;
+      }
+  }
   u->emb_w = cur;
   cur += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
   u->emb_b = cur;
@@ -874,6 +905,7 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
 int holo_unet_destroy(HoloUnet* net) {
   if (!net) return 0;
   if (net->pstore) (void)hipFree(net->pstore);
+  if (net->pstore_bf) (void)hipFree(net->pstore_bf);
   delete net;
   return 0;
 }
@@ -923,11 +955,28 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
                                        s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]),
                                        stream);
     if (rc) return rc;
+    rc = repack_conv_weight_bf16_launch((const float*)dev_ptr, s.priv_bf, (int)s.shape[0], (int)s.shape[1],
+                                        s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]),
+                                        stream);
+    if (rc) return rc;
   } else {
     HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
   }
   s.set = true;
+  return 0;
+}
+
+int holo_unet_set_compute_dtype(HoloUnet* net, int dtype) {
+  if (!net || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_BF16)) {
+    set_error("holo_unet_set_compute_dtype: HOLO_DTYPE_F32 or HOLO_DTYPE_BF16");
+    return HOLO_E_INVALID;
+  }
+  const bool bf = dtype == HOLO_DTYPE_BF16;
+  if (bf != net->compute_bf16) {
+    net->compute_bf16 = bf;
+    net->plan_batch = -1;  // re-plan: the conv ops carry the choice
+  }
   return 0;
 }
 

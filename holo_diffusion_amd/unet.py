@@ -77,6 +77,10 @@ class SimpleUnet3D(Unet3DBase):
     dropout: float = 0.0
     # 3d down/upsamples have the same size in all 3 dims
     homogeneous_resample: bool = True
+    # build-side extension (not a reference field): arithmetic of the stride-1 3x3x3 convolutions, "f32" (exact fp32
+    # MFMA, the reference's arithmetic) or "bf16" (bf16 products on the matrix cores, fp32 accumulation; opt-in for
+    # the bf16 configurations, tolerance rtol 2e-2) - holo_unet_set_compute_dtype
+    compute_dtype: str = "f32"
 
     def __init__(self, **kwargs):
         torch.nn.Module.__init__(self)
@@ -142,6 +146,10 @@ class SimpleUnet3D(Unet3DBase):
                 if tuple(shp[:nd.value]) != tuple(shapes.get(k, ())):
                     raise _lib.HoloError(f"parameter '{k}': library shape {tuple(shp[:nd.value])} != {shapes.get(k)}")
             self._handle, self._handle_device, self._dirty = h, device, True
+        code = {"f32": _lib.HOLO_DTYPE_F32, "bf16": _lib.HOLO_DTYPE_BF16}.get(self.compute_dtype)
+        if code is None:
+            raise _lib.HoloError(f"SimpleUnet3D.compute_dtype must be 'f32' or 'bf16' (got {self.compute_dtype!r})")
+        _lib.check(L, L.holo_unet_set_compute_dtype(self._handle, code), "holo_unet_set_compute_dtype")
         if self._dirty:
             sd = dict(self._net.named_parameters())
             st = runtime.stream_ptr(device)

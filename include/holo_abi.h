@@ -39,7 +39,7 @@ enum {
   HOLO_E_UNSUPPORTED = -5
 };
 
-enum { HOLO_DTYPE_F32 = 0 };
+enum { HOLO_DTYPE_F32 = 0, HOLO_DTYPE_BF16 = 1 };
 
 typedef struct HoloCtx HoloCtx;
 typedef struct HoloUnet HoloUnet;
@@ -84,6 +84,14 @@ int holo_unet_param_info(const HoloUnet* net, int index, char* name, int name_ca
  * [tap][Cin/32][Cout/16][...] layout, concatenated embedding linears); call again after the caller's tensor changes. */
 int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, int dtype, int ndim,
                         const int64_t* shape, void* stream);
+
+/* Arithmetic of the stride-1 3x3x3 convolutions (95% of the FLOPs):
+ *   HOLO_DTYPE_F32  (default) exact-fp32 MFMA, the reference's arithmetic (unet.py:639)
+ *   HOLO_DTYPE_BF16 operands rounded to bf16 (RNE) at the LDS halo / weight pack, products on the bf16 matrix
+ *                   cores, fp32 accumulation; activations in HBM, GroupNorm, attention, 1x1x1 and strided convs
+ *                   stay fp32.  Opt-in for the bf16 configurations (BASELINE configs[4]); tolerance rtol 2e-2.
+ * May be called at any time; takes effect at the next forward. */
+int holo_unet_set_compute_dtype(HoloUnet* net, int dtype);
 
 size_t holo_unet_workspace_bytes(HoloUnet* net, int batch);
 

@@ -107,7 +107,7 @@ def check_unet():
     return ok
 
 
-def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16):
+def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16, bf16=False):
     """Wider tiny net: model_channels 64 puts the ResBlocks of the top level on the LDS-halo kernel with the fused
     1x1x1 skip connection and split-K (no reference golden at this size: compared with the pinned oracle)."""
     print(f"== wide tiny UNet (image {image}, mc {mc}, mult {mult}) through the emulated kernels vs oracle")
@@ -116,6 +116,9 @@ def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16):
     sd = synth_state_dict(uo.unet_param_shapes(cfg), 99)
     ctx = make_ctx()
     net = make_unet(ctx, cfg, sd)
+    if bf16:
+        print("  (bf16 products in the halo convolutions, fp32 accumulate: tolerance 2e-2)")
+        _lib.check(lib, lib.holo_unet_set_compute_dtype(net, _lib.HOLO_DTYPE_BF16), "set_compute_dtype")
     x = torch.from_numpy(np_noise(11, (1, in_ch, image, image, image)))
     t = torch.tensor([321], dtype=torch.int64)
     trace = {}
@@ -131,8 +134,8 @@ def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16):
         numel = C.c_int64()
         _lib.check(lib, lib.holo_unet_fetch_block(net, tag.encode(), ptr(dst), dst.numel(), C.byref(numel), ptr(ws),
                                                   None), f"fetch {tag}")
-        ok &= report(tag, dst, r)
-    ok &= report("y", y, ref)
+        ok &= report(tag, dst, r, 2e-2 if bf16 else 1e-4)
+    ok &= report("y", y, ref, 2e-2 if bf16 else 1e-4)
     return ok
 
 
@@ -222,5 +225,7 @@ if __name__ == "__main__":
         allok &= check_unet()
     if "unet_wide" in what:
         allok &= check_unet_wide()
+    if "unet_wide_bf16" in what:
+        allok &= check_unet_wide(bf16=True)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)

@@ -25,6 +25,10 @@ struct float4 {
   float x, y, z, w;
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct uint2 {
+  uint32_t x, y;
+};
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct float2 {
   float x, y;
 };
@@ -84,6 +88,7 @@ struct SpinBarrier {
 struct WaveCtx {
   SpinBarrier bar;
   float a[64], b[64];
+  float a4[64][4], b4[64][4];  // 16-byte operands of the bf16 MFMA
 };
 
 struct BlockCtx {
@@ -140,6 +145,47 @@ static inline f32x4 emu_mfma_f32_16x16x4f32(float a, float b, f32x4 c) {
   return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
+
+// bf16 helpers (round-to-nearest-even, like v_cvt_pk_bf16_f32)
+static inline uint32_t emu_bf16_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+static inline float emu_bf16_to_f32(uint32_t h) {
+  uint32_t u = h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+// v_mfma_f32_16x16x32_bf16: lane l holds 8 bf16 of A row l&15 / B column l&15 for k-group l>>4;
+// D col = l&15, row = 4*(l>>4)+r.  Operands are passed as raw 16-byte registers.
+static inline f32x4 emu_mfma_f32_16x16x32_bf16(float4 a, float4 b, f32x4 c) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  std::memcpy(w.a4[lane], &a, 16);
+  std::memcpy(w.b4[lane], &b, 16);
+  w.bar.wait();
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    const int col = lane & 15;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      uint32_t aw[4], bw[4];
+      std::memcpy(aw, w.a4[row + 16 * g], 16);
+      std::memcpy(bw, w.b4[col + 16 * g], 16);
+      for (int e = 0; e < 8; ++e) {
+        const float av = emu_bf16_to_f32((aw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        const float bv = emu_bf16_to_f32((bw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        acc = std::fma(av, bv, acc);
+      }
+    }
+    c[r] = acc;
+  }
+  w.bar.wait();
+  return c;
+}
 
 static inline float __shfl_xor(float v, int mask) {
   emu::WaveCtx& w = emu_wave();

@@ -9,13 +9,13 @@ from oracle import unet_oracle as uo
 DEV = torch.device("cuda", 0)
 
 
-def make_unet(cfg: uo.UNetCfg, seed: int = 1234):
+def make_unet(cfg: uo.UNetCfg, seed: int = 1234, compute_dtype: str = "f32"):
     """SimpleUnet3D on the GPU + the identical CPU state dict (reference names)."""
     sd = synth_state_dict(uo.unet_param_shapes(cfg), seed)
     net = hda.SimpleUnet3D(image_size=cfg.image_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                            model_channels=cfg.model_channels, num_res_blocks=cfg.num_res_blocks,
                            channel_mult=cfg.channel_mult, attention_resolutions=cfg.attention_resolutions,
-                           num_heads=cfg.num_heads)
+                           num_heads=cfg.num_heads, compute_dtype=compute_dtype)
     net.load_state_dict({"_net." + k: v for k, v in sd.items()})
     return net.to(DEV), sd
 

@@ -162,3 +162,38 @@ def test_128_cubed_forward_vs_oracle(gu):
     ref = uo.unet_forward(sd, cfg, x, t)
     assert torch.isfinite(y).all()
     assert (y.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("image,mc,mult,attn", [(8, 64, (1, 2), (2,)), (16, 64, (1, 2, 2), (4,)), (16, 32, (1, 1), ())])
+def test_bf16_compute_mode_vs_oracle(gu, image, mc, mult, attn):
+    """Opt-in bf16 products (fp32 accumulate) in the halo convolutions against the fp32 oracle: tolerance of
+    SURVEY.md 8c for the bf16 path (rtol 2e-2 of the tensor scale); the error must also be bf16-sized, not zero."""
+    cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=99, compute_dtype="bf16")
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(11, (2, 16, image, image, image)))
+    t = torch.tensor([321, 17], dtype=torch.int64)
+    ref = uo.unet_forward(sd, cfg, x, t)
+    with torch.no_grad():
+        y = net(x.to(gu.DEV), t.to(gu.DEV))
+    err = gu.rel_err(y, ref)
+    assert 1e-5 < err < 2e-2, err
+
+
+def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
+    """64^3 x 32 north-star net: bf16-product mode against the (oracle-pinned) fp32 path on the same device."""
+    n32, _ = gu.make_unet(NORTH_CFG)
+    nbf, _ = gu.make_unet(NORTH_CFG, compute_dtype="bf16")
+    x = seeded_input(NORTH_CFG, 7 + 500).to(gu.DEV)
+    t = torch.tensor([500], device=gu.DEV)
+    with torch.no_grad():
+        y32 = n32(x, t)
+        ybf = nbf(x, t)
+    err = ((ybf - y32).abs().max() / y32.abs().max()).item()
+    assert 1e-5 < err < 2e-2, err
+    # switching back restores the exact fp32 arithmetic
+    nbf.compute_dtype = "f32"
+    with torch.no_grad():
+        y2 = nbf(x, t)
+    assert torch.equal(y2, y32)
