@@ -94,6 +94,9 @@ struct AttnParams {
 };
 bool flash_attn_supported(int T, int head_channels);
 int flash_attn_launch(const AttnParams& p, void* stream);
+// bf16-product variant (shared K/V tiles in LDS, v_mfma_f32_16x16x32_bf16), for the opt-in bf16 mode
+bool flash_attn_bf16_supported(int T, int head_channels);
+int flash_attn_bf16_launch(const AttnParams& p, void* stream);
 
 // in-place row softmax over `rows` rows of length `cols` (unet.py:453, fp32)
 int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);

@@ -550,6 +550,14 @@ struct Planner {
       op.attn.H = H;
       const double sc = 1.0 / sqrt(sqrt((double)ch));
       op.attn.scale2 = (float)(sc * sc);
+      // bf16 mode, long sequences: shared-tile bf16 kernel (below ~8k tokens its 128-query tiles under-fill the chip
+      // and the fp32 kernel is as fast); HOLO_BF16_FLASH_MIN_T overrides the threshold (tests)
+      const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
+      const int64_t min_t = mt ? atoll(mt) : 8192;
+      op.i0 = (u->compute_bf16 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
+      if (getenv("HOLO_DEBUG_PLAN"))
+        fprintf(stderr, "[plan] attention %s: T=%lld C=%d heads=%d -> %s flash kernel\n", p.c_str(), (long long)T, C, H,
+                op.i0 ? "bf16" : "fp32");
       ops.push_back(op);
     } else {
       size_t S = scratch_alloc(s_bytes);
@@ -786,7 +794,7 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
     case OP_SOFTMAX:
       return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
     case OP_FLASH:
-      return flash_attn_launch(op.attn, stream);
+      return op.i0 ? flash_attn_bf16_launch(op.attn, stream) : flash_attn_launch(op.attn, stream);
     case OP_OUT:
       return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
   }

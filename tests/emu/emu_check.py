@@ -227,5 +227,8 @@ if __name__ == "__main__":
         allok &= check_unet_wide()
     if "unet_wide_bf16" in what:
         allok &= check_unet_wide(bf16=True)
+    if "unet_attn_bf16" in what:  # attention at T = 512 through the bf16 flash kernel (HOLO_BF16_FLASH_MIN_T=0)
+        os.environ["HOLO_BF16_FLASH_MIN_T"] = "0"
+        allok &= check_unet_wide(attn=(1,), bf16=True)
     print("ALL OK" if allok else "FAILURES")
     sys.exit(0 if allok else 1)

@@ -197,3 +197,21 @@ def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
     with torch.no_grad():
         y2 = nbf(x, t)
     assert torch.equal(y2, y32)
+
+
+@pytest.mark.parametrize("image,mc,mult,attn", [(16, 64, (1, 2, 2), (1, 2)), (16, 128, (1, 2), (2,))])
+def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
+    """The shared-tile bf16 attention kernel (normally used from 8k tokens) forced on at T = 4096 / 512 with head
+    channels 32, 64 and 128, inside the bf16-product mode, against the fp32 oracle (rtol 2e-2 of the scale)."""
+    monkeypatch.setenv("HOLO_BF16_FLASH_MIN_T", "0")
+    cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=7, compute_dtype="bf16")
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(13, (1, 16, image, image, image)))
+    t = torch.tensor([77], dtype=torch.int64)
+    ref = uo.unet_forward(sd, cfg, x, t)
+    with torch.no_grad():
+        y = net(x.to(gu.DEV), t.to(gu.DEV))
+    err = gu.rel_err(y, ref)
+    assert 1e-5 < err < 2e-2, err
