@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
                     help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "
                          "sizes on the same fp32 path (side measurements, never the reported line)")
-    ap.add_argument("--compute-dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--compute-dtype", choices=["f32", "bf16", "f32_bf16x3"], default="f32",
                     help="f32 = the reported line (reference arithmetic); bf16 = opt-in bf16 products / fp32 accumulate in "
                          "the 3x3x3 convolutions (side measurement for the bf16 configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,6 +247,30 @@ def main():
         if os.environ.get("HOLO_BENCH_OPS"):
             for o in all_ops:
                 print("# op", json.dumps({**o, "tflops": o["flops"] / (o["ms"] * 1e-3) / 1e12}), file=sys.stderr)
+    # ---------------- side measurements (N=1 only, never the reported value): the opt-in matrix-core modes
+    alt = None
+    if world == 1 and args.compute_dtype == "f32" and args.workload == "north":
+        alt = {}
+        for mode in ("f32_bf16x3", "bf16"):
+            net.compute_dtype = mode
+            x2 = torch.randn(*shape, device=device)
+            with torch.no_grad():
+                for k in range(2):
+                    x2 = one_step(x2, k)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(2, 12):
+                    x2 = one_step(x2, k)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+            alt[mode] = {"denoise_steps_per_s": 10 / dt2, "ms_per_step": 1e3 * dt2 / 10,
+                         "arithmetic": {"f32_bf16x3": "3x3x3 convs: fp32 operands split exactly into 3 bf16 terms, 6 bf16 "
+                                                      "MFMAs per product, fp32 accumulate (meets the fp32 parity "
+                                                      "tolerances); everything else fp32",
+                                        "bf16": "3x3x3 convs: bf16 products, fp32 accumulate (rtol 2e-2); everything "
+                                                "else fp32"}[mode]}
+        net.compute_dtype = "f32"
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, usd, msd)
@@ -266,7 +290,10 @@ def main():
             "metric": "denoise-steps/sec + rendered-rays/sec, 64^3x32 grid @400^2 render",
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.compute_dtype == "f32" else "bf16 products / f32 accumulate in the 3x3x3 convs, f32 elsewhere",
+            "dtype": {"f32": "f32",
+                      "bf16": "bf16 products / f32 accumulate in the 3x3x3 convs, f32 elsewhere",
+                      "f32_bf16x3": "f32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate "
+                                    "(3x3x3 convs); f32 elsewhere"}[args.compute_dtype],
             "data": "synthetic",
             "config": {"workload": ({"north": "apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; ",
                                      "small": "32^3x16 plumbing grid; ",
@@ -284,6 +311,7 @@ def main():
                                 "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
                                 "frac_mfma": mlp_flops_per_ray * rays_per_s / world / 1e12 / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
+            "opt_in_modes_not_reported": alt,
         }
         print(json.dumps(line))
 

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
+HOLO_DTYPE_F32_BF16X3 = 2
 
 
 class HoloError(RuntimeError):

@@ -39,6 +39,8 @@ struct ConvParams {
   // bf16-multiply variant of the halo kernel (opt-in, holo_unet_set_compute_dtype): the same weights rounded to
   // bf16 (RNE), packed [ksz^3][CinP/32][CoutP/16][lane 64][8 bf16] = one 1 KB block of B operands of
   // v_mfma_f32_16x16x32_bf16 per (tap, chunk, 16-Cout slice).  Used when bf16 != 0 and the launch is on the halo path.
+  // The buffer holds THREE such planes (hi, mid, lo: w = hi + mid + lo exactly); bf16 == 1 uses plane 0 only,
+  // bf16 == 2 the fp32-accurate bf16x3 kernel (conv_halo_split_kernel) all three.
   const uint16_t* w_bf;
   const uint16_t* skip_w_bf;
   int bf16;

@@ -662,6 +662,281 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 }
 
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32-accurate convolution on the bf16 matrix cores ("bf16x3 split", opt-in: ConvParams::bf16 == 2).
+//
+// On gfx950 the exact-fp32 MFMA runs on the vector FMA lanes (157 TF, shared with every VALU instruction); the bf16
+// MFMA is a separate unit 16x faster.  Every fp32 operand is split EXACTLY into three bf16 terms
+//     x = hi + mid + lo,   hi = rne_bf16(x), mid = rne_bf16(x - hi), lo = rne_bf16(x - hi - mid)
+// (24 = 3 x 8 mantissa bits; the two subtractions are exact in fp32) and the product x*w is assembled from the six
+// leading cross terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (each a bf16 x bf16 product, exact in the
+// fp32 accumulator); the dropped terms are <= 2^-23 |x w| relative, i.e. the size of ONE fp32 rounding of the
+// product.  Six bf16 MFMAs cost 6/16 of the fp32 MFMA they replace and leave the vector lanes to the staging work.
+// The activations are split as the halo is committed to LDS (three copies, 64-byte rows, XOR-swizzled 16-byte slots
+// so that the A reads are conflict free without padding); the weights are split once at set_param.
+// Structure = conv_halo_kernel with 64-voxel tiles (1 x 8 x 8), 4 waves x 16 Cout, no fused skip.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf_lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf_hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// two floats -> packed (hi, mid, lo) bf16 pairs
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = pack_bf16x2(x0, x1);
+  const float r0 = x0 - bf_lo_f32(h), r1 = x1 - bf_hi_f32(h);
+  m = pack_bf16x2(r0, r1);
+  l = pack_bf16x2(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
+  constexpr int MT = 4;                         // 16-voxel tiles per wave (tile = 1 x 8 x 8 voxels)
+  constexpr int HALO_VOX = 3 * HY * HX;         // 300
+  constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // 10
+  constexpr int RW = 16;                        // words per halo row (32 bf16), no padding: swizzled slots
+  constexpr int PLANE = HALO_VOX * RW;          // words per copy
+  __shared__ __attribute__((aligned(16))) uint32_t s_halo[3 * PLANE];
+  __shared__ int s_hvox[HALO_IT * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = tid >> 6;  // wave = 16-Cout slice
+  const int lj = lane & 15;
+  const int kq = lane >> 4;
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + BK - 1) / BK;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD;
+  int bt = blockIdx.x;
+  const int tx0 = (bt % ntx) << 3;
+  bt /= ntx;
+  const int ty0 = (bt % nty) << 3;
+  bt /= nty;
+  const int tz0 = bt % ntz;
+  const int n = bt / ntz;
+  const int n0 = blockIdx.y * 64;
+  const int cc_begin = blockIdx.z * p.chunks_per_split;
+  int cc_end = cc_begin + p.chunks_per_split;
+  if (cc_end > ncc) cc_end = ncc;
+  const int SD = p.ups ? (p.ID >> 1) : p.ID;
+  const int SH = p.ups ? (p.IH >> 1) : p.IH;
+  const int SW = p.ups ? (p.IW >> 1) : p.IW;
+  const int q = tid & 7;
+  const int r0 = tid >> 3;
+
+  // ---- halo coordinates once per tile (parked in LDS), loads from clamped addresses, see conv_halo_kernel
+  unsigned hvalid = 0, hmask = 0;
+#pragma unroll
+  for (int i = 0; i < HALO_IT; ++i) {
+    const int hv = min(r0 + 32 * i, HALO_VOX - 1);
+    const int hz = hv / (HY * HX);
+    const int rem = hv - hz * (HY * HX);
+    const int hy = rem / HX;
+    const int hx = rem - hy * HX;
+    int z = tz0 + hz - 1, y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+    z = min(max(z, 0), p.ID - 1);
+    y = min(max(y, 0), p.IH - 1);
+    x = min(max(x, 0), p.IW - 1);
+    if (p.ups) {
+      z >>= 1;
+      y >>= 1;
+      x >>= 1;
+    }
+    s_hvox[i * 256 + tid] = (z * SH + y) * SW + x;
+    hvalid |= (ok ? 1u : 0u) << i;
+  }
+  float4 hreg[HALO_IT];
+  int hcoef_c = 0;
+  auto halo_issue = [&](int cc) {
+    int c = cc * BK + q * 4;
+    hcoef_c = c;
+    const bool cvalid = c < Cin;
+    if (!cvalid) c = 0;
+    const float* src = p.src0;
+    int Cs = p.C0, cs = c;
+    if (c >= p.C0) {
+      src = p.src1;
+      Cs = p.C1;
+      cs = c - p.C0;
+    }
+    hmask = cvalid ? hvalid : 0u;
+    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)n * SD * SH * SW * Cs);
+    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
+    int tl = tid;
+    HOLO_LAUNDER(tl);
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i)
+      hreg[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs));
+  };
+  auto halo_commit = [&]() {
+    f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
+    if (p.coef) {
+      const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
+      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
+      const float4 c01 = cf[0], c23 = cf[1];
+      a01 = f32x2{c01.x, c01.z};
+      b01 = f32x2{c01.y, c01.w};
+      a23 = f32x2{c23.x, c23.z};
+      b23 = f32x2{c23.y, c23.w};
+    }
+#pragma unroll
+    for (int i = 0; i < HALO_IT; ++i) {
+      const int hv = r0 + 32 * i;
+      f32x2 v01 = f32x2{hreg[i].x, hreg[i].y}, v23 = f32x2{hreg[i].z, hreg[i].w};
+      if (p.coef) {
+        v01 = pk_fma(v01, a01, b01);
+        v23 = pk_fma(v23, a23, b23);
+        if (p.act) {
+          v01 = f32x2{silu_f(v01.x), silu_f(v01.y)};
+          v23 = f32x2{silu_f(v23.x), silu_f(v23.y)};
+        }
+      }
+      const float keep = ((hmask >> i) & 1u) ? 1.f : 0.f;  // zero padding AFTER the activation
+      const f32x2 k2 = f32x2{keep, keep};
+      v01 = pk_mul(v01, k2);
+      v23 = pk_mul(v23, k2);
+      uint32_t h0, m0, l0, h1, m1, l1;
+      split3_pair(v01.x, v01.y, h0, m0, l0);
+      split3_pair(v23.x, v23.y, h1, m1, l1);
+      if (hv < HALO_VOX) {
+        // channel quad q -> 16-byte slot q>>1 (8 channels), half q&1; slot XOR-swizzled by the row
+        uint32_t* row = s_halo + hv * RW + (((q >> 1) ^ ((hv >> 2) & 3)) << 2) + ((q & 1) << 1);
+        *reinterpret_cast<uint2*>(row) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(row + PLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(row + 2 * PLANE) = make_uint2(l0, l1);
+      }
+    }
+  };
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+
+  // A rows: MFMA tile t = x 0..7 of rows y = t and t+4 (see conv_halo_kernel); halo row index of the lane's voxel
+  int a_row[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_row[t] = (t + 4 * (lj >> 3)) * HX + (lj & 7);
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
+  const int64_t wplane = (int64_t)p.ksz * p.ksz * p.ksz * wncc * wnsl * 256;  // words per weight copy
+  const float* w_lane = reinterpret_cast<const float*>(p.w_bf) + (int64_t)((n0 >> 4) + wn) * 256 + lane * 4;
+
+  auto load_a = [&](float4 (&a)[3][MT], int tap) {
+    const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+    const int trow = (kd * HY + kh) * HX + kw;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int row = a_row[t] + trow;
+      const uint32_t* ap = s_halo + row * RW + ((kq ^ ((row >> 2) & 3)) << 2);
+      a[0][t] = *reinterpret_cast<const float4*>(ap);
+      a[1][t] = *reinterpret_cast<const float4*>(ap + PLANE);
+      a[2][t] = *reinterpret_cast<const float4*>(ap + 2 * PLANE);
+    }
+  };
+  auto load_b = [&](float4 (&b)[3], int cc, int tap) {
+    const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 256;
+    b[0] = *reinterpret_cast<const float4*>(wp);
+    b[1] = *reinterpret_cast<const float4*>(wp + wplane);
+    b[2] = *reinterpret_cast<const float4*>(wp + 2 * wplane);
+  };
+  auto mfma_tap = [&](const float4 (&a)[3][MT], const float4 (&b)[3]) {
+    // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[2][t], b[0], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[2], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[1][t], b[1], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[1][t], b[0], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[1], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[0], acc[t]);
+  };
+
+  float4 aA[3][MT] = {}, aB[3][MT] = {};
+  float4 bA[3] = {}, bB[3] = {};
+  auto tap_body = [&](float4 (&cur)[3][MT], float4 (&nxt)[3][MT], float4 (&bc)[3], float4 (&bn)[3], int cc, int tap,
+                      bool prefetch) {
+    if (prefetch) {
+      load_a(nxt, tap + 1);
+      load_b(bn, cc, tap + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap(cur, bc);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  halo_issue(cc_begin);
+  for (int cc = cc_begin; cc < cc_end; ++cc) {
+    halo_commit();
+    load_b(bA, cc, 0);
+    __syncthreads();
+    load_a(aA, 0);
+    for (int tap = 0; tap < 26; tap += 2) {
+      tap_body(aA, aB, bA, bB, cc, tap, true);
+      tap_body(aB, aA, bB, bA, cc, tap + 1, true);
+    }
+    if (cc + 1 < cc_end) halo_issue(cc + 1);
+    tap_body(aA, aB, bA, bB, cc, 26, false);
+    __syncthreads();
+  }
+
+  // ---- epilogue (as conv_halo_kernel with MT = 4, TZ = 1)
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int co = n0 + wn * 16 + lj;
+  const int coc = co < p.Cout ? co : p.Cout - 1;
+  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+  const int64_t tbase = ((((int64_t)n * p.OD + tz0) * p.OH + ty0) * p.OW + tx0) * p.Cout;
+  int off[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) off[t] = ((t + 4 * (kq >> 1)) * p.OW + 4 * (kq & 1)) * p.Cout;
+  if (p.nsplit == 1) {
+    if (p.residual) {
+      const float* rp = p.residual + tbase + coc;
+      float res[MT][4];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += res[t][r];
+    }
+    float* op = p.out + tbase + coc;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[t][r] + bv;
+        if (co < p.Cout) op[off[t] + r * p.Cout] = v;
+        ssum += v;
+        ssq += v * v;
+      }
+  } else if (co < p.Cout) {
+    float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + co;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pp[off[t] + r * p.Cout] = acc[t][r];
+  }
+  if (p.stats && p.nsplit == 1) {
+    ssum += __shfl_xor(ssum, 16);
+    ssq += __shfl_xor(ssq, 16);
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (kq == 0 && co < p.Cout) {
+      const int tiles_per_sample = ntx * nty * ntz;
+      const int slab = (int)(blockIdx.x % tiles_per_sample);
+      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
+      d[0] = (double)ssum;
+      d[1] = (double)ssq;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-tile kernel for the latency-bound launches: the deepest UNet levels (4^3 / 2^3 voxels: M = 64 rows, K up
 // to 27*1024, pure weight streaming: 28-56 MB of weights for ~1 GFLOP) and every 1x1x1 convolution (attention
@@ -1059,7 +1334,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
     p.tz = 2;
     int64_t htiles = tiles;
-    if (tiles < target) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
+    const bool split3 = p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w;  // bf16x3 kernel: 64-voxel tiles only
+    if (tiles < target || split3) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
@@ -1129,7 +1405,10 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    const bool bf = p.bf16 && p.w_bf && (!sk || p.skip_w_bf);
+    if (p.bf16 == 2 && p.w_bf && wide && !sk && p.tz == 1) {
+      HOLO_LAUNCH(conv_halo_split_kernel, hgrid, block, stream, p);
+    } else {
+    const bool bf = p.bf16 == 1 && p.w_bf && (!sk || p.skip_w_bf);
     if (!wide && sk) {
       set_error("conv_launch: fused skip needs Cout >= 64");
       return -1;
@@ -1156,6 +1435,7 @@ int conv_launch(const ConvParams& p, void* stream) {
       HOLO_HALO(2, 1, false);
     }
 #undef HOLO_HALO
+    }
   } else if (p.mode == 2) {
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
     HOLO_LAUNCH(conv_small_kernel, sgrid, block, stream, p);

@@ -332,12 +332,14 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
   }
 }
 
-// OIDHW [Cout][Cin][taps] -> bf16 (RNE) packed [tap][CinP/32][CoutP/16][lane = 16*kq + lj][8]: lane's 8 values are
-// channels 8*kq .. 8*kq+7 of the chunk for output channel 16*slice + lj (B operand of v_mfma_f32_16x16x32_bf16)
+// OIDHW [Cout][Cin][taps] -> THREE bf16 planes (hi, mid, lo with w = hi + mid + lo exactly: hi = rne(w),
+// mid = rne(w - hi), lo = rne(w - hi - mid)), each packed [tap][CinP/32][CoutP/16][lane = 16*kq + lj][8]: lane's 8
+// values are channels 8*kq .. 8*kq+7 of the chunk for output channel 16*slice + lj (B operand of
+// v_mfma_f32_16x16x32_bf16).  Plane 0 alone is the plain bf16 rounding used by the bf16 mode.
 __global__ __launch_bounds__(256) void repack_conv_weight_bf16_kernel(const float* __restrict__ w,
                                                                       uint16_t* __restrict__ out, int Cout, int Cin,
                                                                       int taps, int CoutP, int CinP) {
-  const int64_t total = (int64_t)CoutP * CinP * taps / 2;  // pairs
+  const int64_t total = (int64_t)CoutP * CinP * taps / 2;  // pairs per plane
   const int ncc = CinP >> 5, nsl = CoutP >> 4;
   uint32_t* o32 = reinterpret_cast<uint32_t*>(out);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -352,7 +354,13 @@ __global__ __launch_bounds__(256) void repack_conv_weight_bf16_kernel(const floa
     const int ci = cc * 32 + (lane >> 4) * 8 + e2 * 2;
     const float v0 = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
     const float v1 = (ci + 1 < Cin && co < Cout) ? w[((int64_t)co * Cin + ci + 1) * taps + tap] : 0.f;
-    o32[i] = pack_bf16x2(v0, v1);
+    const uint32_t h = pack_bf16x2(v0, v1);
+    const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
+    const uint32_t m = pack_bf16x2(r0, r1);
+    const uint32_t l = pack_bf16x2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+    o32[i] = h;
+    o32[total + i] = m;
+    o32[2 * total + i] = l;
   }
 }
 

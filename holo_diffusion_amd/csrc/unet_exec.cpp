@@ -166,7 +166,7 @@ struct HoloUnet {
   float* pstore = nullptr;  // one allocation for all private parameter copies
   uint16_t* pstore_bf = nullptr;                       // bf16 copies of the conv weights
   std::map<const float*, const uint16_t*> bf_of;       // fp32 private copy -> bf16 copy
-  bool compute_bf16 = false;                           // holo_unet_set_compute_dtype
+  int compute_mode = 0;  // holo_unet_set_compute_dtype: 0 exact fp32 MFMA, 1 bf16 products, 2 bf16x3 split (fp32-accurate)
   // concatenated emb_layers
   int emb_rows = 0;
   std::map<std::string, int> emb_row_off;  // resblock prefix -> first row
@@ -448,10 +448,10 @@ struct Planner {
     p.CoutP = pad_cout(Cout);
     p.CinP = pad_cin(p.C0 + p.C1);
     p.w = w;
-    if (u->compute_bf16) {  // halo-path launches multiply in bf16 (conv_launch checks the pointers)
+    if (u->compute_mode) {  // halo-path launches multiply on the bf16 matrix cores (conv_launch checks the pointers)
       auto it = u->bf_of.find(w);
       p.w_bf = it == u->bf_of.end() ? nullptr : it->second;
-      p.bf16 = 1;
+      p.bf16 = u->compute_mode;
     }
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
@@ -464,7 +464,7 @@ struct Planner {
       p.skip_C0 = skip0->C;
       p.skip_C1 = skip1 ? skip1->C : 0;
       p.skip_w = skip_w;
-      if (u->compute_bf16) {
+      if (u->compute_mode) {
         auto it = u->bf_of.find(skip_w);
         p.skip_w_bf = it == u->bf_of.end() ? nullptr : it->second;
       }
@@ -502,7 +502,8 @@ struct Planner {
     const float* residual;
     const bool has_skip = b.cin != b.cout;
     // the 1x1x1 skip conv rides inside the second 3x3x3 conv (halo kernel) wherever that kernel applies
-    const bool fuse_skip = has_skip && (R % 8) == 0 && b.cout >= 64 && !getenv("HOLO_NO_SKIP_FUSION");
+    // (the bf16x3 kernel has no fused-skip variant: its skip connection runs as a separate fp32 1x1x1 conv)
+    const bool fuse_skip = has_skip && (R % 8) == 0 && b.cout >= 64 && u->compute_mode != 2 && !getenv("HOLO_NO_SKIP_FUSION");
     if (has_skip && !fuse_skip) {
       s = new_act(b.cout, R);
       emit_conv(x0, x1, R, 0, R, 1, 1, P(u, p + ".skip_connection.weight"), P(u, p + ".skip_connection.bias"), 0,
@@ -554,7 +555,7 @@ struct Planner {
       // and the fp32 kernel is as fast); HOLO_BF16_FLASH_MIN_T overrides the threshold (tests)
       const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
       const int64_t min_t = mt ? atoll(mt) : 8192;
-      op.i0 = (u->compute_bf16 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
+      op.i0 = (u->compute_mode == 1 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
       if (getenv("HOLO_DEBUG_PLAN"))
         fprintf(stderr, "[plan] attention %s: T=%lld C=%d heads=%d -> %s flash kernel\n", p.c_str(), (long long)T, C, H,
                 op.i0 ? "bf16" : "fp32");
@@ -881,7 +882,7 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
   {  // bf16 copies of the conv weights (same padded element counts, 2 bytes each)
     int64_t tb = 0;
     for (auto& s : u->params)
-      if (s.kind == P_CONV3 || s.kind == P_CONV1) tb += (priv_numel(s) + 63) & ~(int64_t)63;
+      if (s.kind == P_CONV3 || s.kind == P_CONV1) tb += 3 * ((priv_numel(s) + 63) & ~(int64_t)63);  // hi, mid, lo planes
     if (hipMalloc((void**)&u->pstore_bf, (size_t)tb * sizeof(uint16_t)) != hipSuccess) {
       set_error("holo_unet_create: hipMalloc of %lld bf16 weights failed", (long long)tb);
       (void)hipFree(u->pstore);
@@ -893,7 +894,7 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
       if (s.kind == P_CONV3 || s.kind == P_CONV1) {
         s.priv_bf = cb;
         u->bf_of[s.priv] = cb;
-        cb += (priv_numel(s) + 63) & ~(int64_t)63;
+        cb += 3 * ((priv_numel(s) + 63) & ~(int64_t)63);
       }
   }
   u->emb_w = cur;
@@ -976,13 +977,13 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
 }
 
 int holo_unet_set_compute_dtype(HoloUnet* net, int dtype) {
-  if (!net || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_BF16)) {
-    set_error("holo_unet_set_compute_dtype: HOLO_DTYPE_F32 or HOLO_DTYPE_BF16");
+  if (!net || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_BF16 && dtype != HOLO_DTYPE_F32_BF16X3)) {
+    set_error("holo_unet_set_compute_dtype: HOLO_DTYPE_F32, HOLO_DTYPE_BF16 or HOLO_DTYPE_F32_BF16X3");
     return HOLO_E_INVALID;
   }
-  const bool bf = dtype == HOLO_DTYPE_BF16;
-  if (bf != net->compute_bf16) {
-    net->compute_bf16 = bf;
+  const int mode = dtype == HOLO_DTYPE_BF16 ? 1 : dtype == HOLO_DTYPE_F32_BF16X3 ? 2 : 0;
+  if (mode != net->compute_mode) {
+    net->compute_mode = mode;
     net->plan_batch = -1;  // re-plan: the conv ops carry the choice
   }
   return 0;

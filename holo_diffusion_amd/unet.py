@@ -79,7 +79,8 @@ class SimpleUnet3D(Unet3DBase):
     homogeneous_resample: bool = True
     # build-side extension (not a reference field): arithmetic of the stride-1 3x3x3 convolutions, "f32" (exact fp32
     # MFMA, the reference's arithmetic) or "bf16" (bf16 products on the matrix cores, fp32 accumulation; opt-in for
-    # the bf16 configurations, tolerance rtol 2e-2) - holo_unet_set_compute_dtype
+    # the bf16 configurations, tolerance rtol 2e-2) or "f32_bf16x3" (fp32 operands split exactly into three bf16
+    # terms, six bf16 MFMAs per product: fp32-accurate on the bf16 matrix cores) - holo_unet_set_compute_dtype
     compute_dtype: str = "f32"
 
     def __init__(self, **kwargs):
@@ -146,9 +147,11 @@ class SimpleUnet3D(Unet3DBase):
                 if tuple(shp[:nd.value]) != tuple(shapes.get(k, ())):
                     raise _lib.HoloError(f"parameter '{k}': library shape {tuple(shp[:nd.value])} != {shapes.get(k)}")
             self._handle, self._handle_device, self._dirty = h, device, True
-        code = {"f32": _lib.HOLO_DTYPE_F32, "bf16": _lib.HOLO_DTYPE_BF16}.get(self.compute_dtype)
+        code = {"f32": _lib.HOLO_DTYPE_F32, "bf16": _lib.HOLO_DTYPE_BF16,
+                "f32_bf16x3": _lib.HOLO_DTYPE_F32_BF16X3}.get(self.compute_dtype)
         if code is None:
-            raise _lib.HoloError(f"SimpleUnet3D.compute_dtype must be 'f32' or 'bf16' (got {self.compute_dtype!r})")
+            raise _lib.HoloError("SimpleUnet3D.compute_dtype must be 'f32', 'bf16' or 'f32_bf16x3' "
+                                 f"(got {self.compute_dtype!r})")
         _lib.check(L, L.holo_unet_set_compute_dtype(self._handle, code), "holo_unet_set_compute_dtype")
         if self._dirty:
             sd = dict(self._net.named_parameters())

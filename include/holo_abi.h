@@ -39,7 +39,7 @@ enum {
   HOLO_E_UNSUPPORTED = -5
 };
 
-enum { HOLO_DTYPE_F32 = 0, HOLO_DTYPE_BF16 = 1 };
+enum { HOLO_DTYPE_F32 = 0, HOLO_DTYPE_BF16 = 1, HOLO_DTYPE_F32_BF16X3 = 2 };
 
 typedef struct HoloCtx HoloCtx;
 typedef struct HoloUnet HoloUnet;
@@ -90,6 +90,10 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
  *   HOLO_DTYPE_BF16 operands rounded to bf16 (RNE) at the LDS halo / weight pack, products on the bf16 matrix
  *                   cores, fp32 accumulation; activations in HBM, GroupNorm, attention, 1x1x1 and strided convs
  *                   stay fp32.  Opt-in for the bf16 configurations (BASELINE configs[4]); tolerance rtol 2e-2.
+ *   HOLO_DTYPE_F32_BF16X3  fp32-accurate arithmetic on the bf16 matrix cores: every fp32 operand is split exactly
+ *                   into three bf16 terms and each product is assembled from the six leading cross terms (dropped
+ *                   terms <= 2^-23 relative, the size of one fp32 rounding), fp32 accumulation.  Opt-in; meets the
+ *                   fp32 tolerances of the parity tests.
  * May be called at any time; takes effect at the next forward. */
 int holo_unet_set_compute_dtype(HoloUnet* net, int dtype);
 

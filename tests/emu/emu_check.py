@@ -107,7 +107,7 @@ def check_unet():
     return ok
 
 
-def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16, bf16=False):
+def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16, bf16=False, split=False):
     """Wider tiny net: model_channels 64 puts the ResBlocks of the top level on the LDS-halo kernel with the fused
     1x1x1 skip connection and split-K (no reference golden at this size: compared with the pinned oracle)."""
     print(f"== wide tiny UNet (image {image}, mc {mc}, mult {mult}) through the emulated kernels vs oracle")
@@ -119,6 +119,9 @@ def check_unet_wide(image=8, mc=64, mult=(1, 2), attn=(2,), in_ch=16, bf16=False
     if bf16:
         print("  (bf16 products in the halo convolutions, fp32 accumulate: tolerance 2e-2)")
         _lib.check(lib, lib.holo_unet_set_compute_dtype(net, _lib.HOLO_DTYPE_BF16), "set_compute_dtype")
+    if split:
+        print("  (fp32 operands split into three bf16 terms, six bf16 MFMAs per product: fp32 tolerance)")
+        _lib.check(lib, lib.holo_unet_set_compute_dtype(net, _lib.HOLO_DTYPE_F32_BF16X3), "set_compute_dtype")
     x = torch.from_numpy(np_noise(11, (1, in_ch, image, image, image)))
     t = torch.tensor([321], dtype=torch.int64)
     trace = {}
@@ -227,6 +230,8 @@ if __name__ == "__main__":
         allok &= check_unet_wide()
     if "unet_wide_bf16" in what:
         allok &= check_unet_wide(bf16=True)
+    if "unet_wide_split" in what:
+        allok &= check_unet_wide(split=True)
     if "unet_attn_bf16" in what:  # attention at T = 512 through the bf16 flash kernel (HOLO_BF16_FLASH_MIN_T=0)
         os.environ["HOLO_BF16_FLASH_MIN_T"] = "0"
         allok &= check_unet_wide(attn=(1,), bf16=True)

@@ -146,6 +146,11 @@ static inline f32x4 emu_mfma_f32_16x16x4f32(float a, float b, f32x4 c) {
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
 
+static inline float __uint_as_float(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
 // bf16 helpers (round-to-nearest-even, like v_cvt_pk_bf16_f32)
 static inline uint32_t emu_bf16_bits(float f) {
   uint32_t u;

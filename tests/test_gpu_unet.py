@@ -107,11 +107,13 @@ def test_mid_size_unet_vs_oracle_blockwise(gu, image, mc, mult, attn, batch):
         del os.environ["HOLO_KEEP_INTERMEDIATES"]
 
 
-@pytest.mark.parametrize("tag,cfg", [("plumb32x16", PLUMB_CFG), ("north64x32", NORTH_CFG)])
-def test_full_size_unet_vs_reference_digest(gu, golden_dir, tag, cfg):
-    """BASELINE configs[0] (32^3x16) and configs[1] (64^3x32): digests of the REFERENCE output."""
+@pytest.mark.parametrize("tag,cfg,compute", [("plumb32x16", PLUMB_CFG, "f32"), ("north64x32", NORTH_CFG, "f32"),
+                                             ("north64x32", NORTH_CFG, "f32_bf16x3")])
+def test_full_size_unet_vs_reference_digest(gu, golden_dir, tag, cfg, compute):
+    """BASELINE configs[0] (32^3x16) and configs[1] (64^3x32): digests of the REFERENCE output; the fp32-accurate
+    bf16x3 mode is held to the same tolerance as the exact-fp32 path."""
     g = np.load(os.path.join(golden_dir, "full_unet_digests.npz"))
-    net, _ = gu.make_unet(cfg)
+    net, _ = gu.make_unet(cfg, compute_dtype=compute)
     for t in (0, 500, 999):
         y = net(seeded_input(cfg, 7 + t).to(gu.DEV), torch.tensor([t], device=gu.DEV)).cpu()
         assert torch.isfinite(y).all()
@@ -215,3 +217,28 @@ def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
         y = net(x.to(gu.DEV), t.to(gu.DEV))
     err = gu.rel_err(y, ref)
     assert 1e-5 < err < 2e-2, err
+
+
+@pytest.mark.parametrize("image,mc,mult,attn,batch", [(8, 64, (1, 2), (2,), 1), (16, 64, (1, 2, 2), (4,), 2)])
+def test_f32_bf16x3_mode_meets_the_fp32_tolerance(gu, image, mc, mult, attn, batch):
+    """fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per product: every block output against the
+    pinned oracle at the SAME per-op tolerance as the exact-fp32 path (rtol 1e-4 of the tensor scale)."""
+    import os
+    cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    os.environ["HOLO_KEEP_INTERMEDIATES"] = "1"
+    try:
+        net, sd = gu.make_unet(cfg, seed=99, compute_dtype="f32_bf16x3")
+        from oracle.common import np_noise
+        x = torch.from_numpy(np_noise(11, (batch, 16, image, image, image)))
+        t = torch.tensor([321, 17][:batch], dtype=torch.int64)
+        trace = {}
+        ref = uo.unet_forward(sd, cfg, x, t, trace)
+        with torch.no_grad():
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+        assert gu.rel_err(y, ref) < 1e-4
+        for tag, r in trace.items():
+            if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
+                assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 1e-4, tag
+    finally:
+        del os.environ["HOLO_KEEP_INTERMEDIATES"]
