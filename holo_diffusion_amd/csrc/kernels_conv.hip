@@ -687,29 +687,39 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uin
   l = pack_bf16x2(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
 }
 
-__global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
-  constexpr int MT = 4;                         // 16-voxel tiles per wave (tile = 1 x 8 x 8 voxels)
-  constexpr int HALO_VOX = 3 * HY * HX;         // 300
-  constexpr int HALO_IT = (HALO_VOX + 31) / 32;  // 10
+// TZ = 1: 64-voxel tiles, 4 waves (2 workgroups per CU).  TZ = 2: 128-voxel tiles, 8 waves (wave = 16-Cout slice x
+// z-slab; one workgroup per CU, same 8 waves per CU): each weight block is then fetched by two waves of ONE
+// workgroup (the second hits L1), halving the L2 -> CU weight traffic that bounds the 64-voxel form at 64^3.
+template <int TZ>
+__global__ __launch_bounds__(256 * TZ, 2 / TZ) void conv_halo_split_kernel(ConvParams p) {
+  constexpr int NT = 256 * TZ;                  // threads per workgroup
+  constexpr int MT = 2;                         // 16-voxel tiles per wave   } 2 x 2 register blocking: every A fragment
+  constexpr int NS = 2;                         // 16-Cout slices per wave   } feeds two MFMAs, every B fragment two
+  constexpr int HALO_VOX = (TZ + 2) * HY * HX;  // 300 / 400
+  constexpr int RPT = NT / 8;                   // halo rows staged per pass (8 threads per row)
+  constexpr int HALO_IT = (HALO_VOX + RPT - 1) / RPT;
   constexpr int RW = 16;                        // words per halo row (32 bf16), no padding: swizzled slots
   constexpr int PLANE = HALO_VOX * RW;          // words per copy
   __shared__ __attribute__((aligned(16))) uint32_t s_halo[3 * PLANE];
-  __shared__ int s_hvox[HALO_IT * 256];
+  __shared__ int s_hvox[HALO_IT * NT];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wn = tid >> 6;  // wave = 16-Cout slice
+  const int wave = tid >> 6;
+  const int wc = wave & 1;         // Cout half of the 64-wide block: slices 2*wc, 2*wc+1
+  const int wv = (wave >> 1) & 1;  // voxel half of the 8 x 8 slab: MFMA tiles 2*wv, 2*wv+1
+  const int wz = wave >> 2;        // z-slab of the tile (TZ = 2)
   const int lj = lane & 15;
   const int kq = lane >> 4;
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
-  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD / TZ;
   int bt = blockIdx.x;
   const int tx0 = (bt % ntx) << 3;
   bt /= ntx;
   const int ty0 = (bt % nty) << 3;
   bt /= nty;
-  const int tz0 = bt % ntz;
+  const int tz0 = (bt % ntz) * TZ;
   const int n = bt / ntz;
   const int n0 = blockIdx.y * 64;
   const int cc_begin = blockIdx.z * p.chunks_per_split;
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
   unsigned hvalid = 0, hmask = 0;
 #pragma unroll
   for (int i = 0; i < HALO_IT; ++i) {
-    const int hv = min(r0 + 32 * i, HALO_VOX - 1);
+    const int hv = min(r0 + RPT * i, HALO_VOX - 1);
     const int hz = hv / (HY * HX);
     const int rem = hv - hz * (HY * HX);
     const int hy = rem / HX;
@@ -740,7 +750,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
       y >>= 1;
       x >>= 1;
     }
-    s_hvox[i * 256 + tid] = (z * SH + y) * SW + x;
+    s_hvox[i * NT + tid] = (z * SH + y) * SW + x;
     hvalid |= (ok ? 1u : 0u) << i;
   }
   float4 hreg[HALO_IT];
@@ -764,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
     HOLO_LAUNDER(tl);
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i)
-      hreg[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs));
+      hreg[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)s_hvox[i * NT + tl] * cbytes + cofs));
   };
   auto halo_commit = [&]() {
     f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < HALO_IT; ++i) {
-      const int hv = r0 + 32 * i;
+      const int hv = r0 + RPT * i;
       f32x2 v01 = f32x2{hreg[i].x, hreg[i].y}, v23 = f32x2{hreg[i].z, hreg[i].w};
       if (p.coef) {
         v01 = pk_fma(v01, a01, b01);
@@ -806,133 +816,143 @@ __global__ __launch_bounds__(256, 2) void conv_halo_split_kernel(ConvParams p) {
     }
   };
 
-  f32x4 acc[MT];
+  f32x4 acc[MT][NS];
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][s2][r] = 0.f;
 
   // A rows: MFMA tile t = x 0..7 of rows y = t and t+4 (see conv_halo_kernel); halo row index of the lane's voxel
   int a_row[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) a_row[t] = (t + 4 * (lj >> 3)) * HX + (lj & 7);
+  for (int t = 0; t < MT; ++t) a_row[t] = ((wz * HY) + 2 * wv + t + 4 * (lj >> 3)) * HX + (lj & 7);
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
   const int64_t wplane = (int64_t)p.ksz * p.ksz * p.ksz * wncc * wnsl * 256;  // words per weight copy
-  const float* w_lane = reinterpret_cast<const float*>(p.w_bf) + (int64_t)((n0 >> 4) + wn) * 256 + lane * 4;
+  const float* w_lane = reinterpret_cast<const float*>(p.w_bf) + (int64_t)((n0 >> 4) + 2 * wc) * 256 + lane * 4;
 
-  auto load_a = [&](float4 (&a)[3][MT], int tap) {
+  auto load_a = [&](float4 (&a)[MT], int plane, int tap) {  // one bf16 plane (0 hi, 1 mid, 2 lo) of a tap's A operands
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
     const int trow = (kd * HY + kh) * HX + kw;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int row = a_row[t] + trow;
-      const uint32_t* ap = s_halo + row * RW + ((kq ^ ((row >> 2) & 3)) << 2);
-      a[0][t] = *reinterpret_cast<const float4*>(ap);
-      a[1][t] = *reinterpret_cast<const float4*>(ap + PLANE);
-      a[2][t] = *reinterpret_cast<const float4*>(ap + 2 * PLANE);
+      a[t] = *reinterpret_cast<const float4*>(s_halo + plane * PLANE + row * RW + ((kq ^ ((row >> 2) & 3)) << 2));
     }
   };
-  auto load_b = [&](float4 (&b)[3], int cc, int tap) {
+  auto load_b = [&](float4 (&b)[3][NS], int cc, int tap) {  // [plane][slice]; the two slices are adjacent 1 KB blocks
     const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 256;
-    b[0] = *reinterpret_cast<const float4*>(wp);
-    b[1] = *reinterpret_cast<const float4*>(wp + wplane);
-    b[2] = *reinterpret_cast<const float4*>(wp + 2 * wplane);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) b[pl][s2] = *reinterpret_cast<const float4*>(wp + pl * wplane + s2 * 256);
   };
-  auto mfma_tap = [&](const float4 (&a)[3][MT], const float4 (&b)[3]) {
-    // smallest terms first: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi
+  auto mfma4 = [&](const float4 (&a)[MT], const float4 (&b)[NS]) {  // four independent accumulators
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[2][t], b[0], acc[t]);
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[2], acc[t]);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[1][t], b[1], acc[t]);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[1][t], b[0], acc[t]);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[1], acc[t]);
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = mfma_bf16_16x16x32(a[0][t], b[0], acc[t]);
+      for (int s2 = 0; s2 < NS; ++s2) acc[t][s2] = mfma_bf16_16x16x32(a[t], b[s2], acc[t][s2]);
   };
 
-  float4 aA[3][MT] = {}, aB[3][MT] = {};
-  float4 bA[3] = {}, bB[3] = {};
-  auto tap_body = [&](float4 (&cur)[3][MT], float4 (&nxt)[3][MT], float4 (&bc)[3], float4 (&bn)[3], int cc, int tap,
-                      bool prefetch) {
-    if (prefetch) {
-      load_a(nxt, tap + 1);
-      load_b(bn, cc, tap + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_tap(cur, bc);
-    __builtin_amdgcn_sched_barrier(0);
-  };
+  // Operand pipeline.  A tap is only 24 MFMAs (~400 cycles), shorter than an L2 round trip, so the weights run
+  // through a 4-deep register ring (requested THREE taps ahead).  The A planes of the next tap are requested inside
+  // the current tap as soon as their registers die (lo after the first product group, mid after the fourth), so
+  // only the hi plane is double buffered: 64 instead of 96 VGPRs of A operands.
+  // Product order (smallest terms first): lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.
+  float4 aHi[2][MT] = {}, aMid[MT] = {}, aLo[MT] = {};
+  float4 bRing[4][3][NS] = {};
 
   halo_issue(cc_begin);
   for (int cc = cc_begin; cc < cc_end; ++cc) {
     halo_commit();
-    load_b(bA, cc, 0);
+    load_b(bRing[0], cc, 0);
+    load_b(bRing[1], cc, 1);
+    load_b(bRing[2], cc, 2);
     __syncthreads();
-    load_a(aA, 0);
-    for (int tap = 0; tap < 26; tap += 2) {
-      tap_body(aA, aB, bA, bB, cc, tap, true);
-      tap_body(aB, aA, bB, bA, cc, tap + 1, true);
+    load_a(aHi[0], 0, 0);
+    load_a(aMid, 1, 0);
+    load_a(aLo, 2, 0);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const float4(&b)[3][NS] = bRing[tap & 3];
+      const float4(&hi)[MT] = aHi[tap & 1];
+      if (tap + 1 < 27) load_a(aHi[(tap + 1) & 1], 0, tap + 1);
+      if (tap + 3 < 27) load_b(bRing[(tap + 3) & 3], cc, tap + 3);
+      if (tap == 26 && cc + 1 < cc_end) halo_issue(cc + 1);  // next chunk's halo flies under the last tap
+      __builtin_amdgcn_sched_barrier(0);
+      mfma4(aLo, b[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) load_a(aLo, 2, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma4(hi, b[2]);
+      mfma4(aMid, b[1]);
+      mfma4(aMid, b[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) load_a(aMid, 1, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma4(hi, b[1]);
+      mfma4(hi, b[0]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (cc + 1 < cc_end) halo_issue(cc + 1);
-    tap_body(aA, aB, bA, bB, cc, 26, false);
     __syncthreads();
   }
 
-  // ---- epilogue (as conv_halo_kernel with MT = 4, TZ = 1)
+  // ---- epilogue: per (tile t, slice s2): D col = lane&15 (Cout), row = 4*(lane>>4) + r (voxel of the tile)
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
-  const int co = n0 + wn * 16 + lj;
-  const int coc = co < p.Cout ? co : p.Cout - 1;
-  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
-  float ssum = 0.f, ssq = 0.f;
-  const int64_t tbase = ((((int64_t)n * p.OD + tz0) * p.OH + ty0) * p.OW + tx0) * p.Cout;
+  const int64_t tbase = ((((int64_t)n * p.OD + tz0 + wz) * p.OH + ty0) * p.OW + tx0) * p.Cout;
   int off[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) off[t] = ((t + 4 * (kq >> 1)) * p.OW + 4 * (kq & 1)) * p.Cout;
-  if (p.nsplit == 1) {
-    if (p.residual) {
-      const float* rp = p.residual + tbase + coc;
-      float res[MT][4];
+  for (int t = 0; t < MT; ++t) off[t] = ((2 * wv + t + 4 * (kq >> 1)) * p.OW + 4 * (kq & 1)) * p.Cout;
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+  for (int s2 = 0; s2 < NS; ++s2) {
+    const int co = n0 + (2 * wc + s2) * 16 + lj;
+    const int coc = co < p.Cout ? co : p.Cout - 1;
+    const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+    float ssum = 0.f, ssq = 0.f;
+    if (p.nsplit == 1) {
+      if (p.residual) {  // one batch of loads under a uniform branch (see conv_halo_kernel)
+        const float* rp = p.residual + tbase + coc;
+        float res[MT][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+          for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r] += res[t][r];
-    }
-    float* op = p.out + tbase + coc;
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[t][r] + bv;
-        if (co < p.Cout) op[off[t] + r * p.Cout] = v;
-        ssum += v;
-        ssq += v * v;
+          for (int r = 0; r < 4; ++r) acc[t][s2][r] += res[t][r];
       }
-  } else if (co < p.Cout) {
-    float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + co;
+      float* op = p.out + tbase + coc;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+      for (int t = 0; t < MT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pp[off[t] + r * p.Cout] = acc[t][r];
-  }
-  if (p.stats && p.nsplit == 1) {
-    ssum += __shfl_xor(ssum, 16);
-    ssq += __shfl_xor(ssq, 16);
-    ssum += __shfl_xor(ssum, 32);
-    ssq += __shfl_xor(ssq, 32);
-    if (kq == 0 && co < p.Cout) {
-      const int tiles_per_sample = ntx * nty * ntz;
-      const int slab = (int)(blockIdx.x % tiles_per_sample);
-      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
-      d[0] = (double)ssum;
-      d[1] = (double)ssq;
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[t][s2][r] + bv;
+          if (co < p.Cout) op[off[t] + r * p.Cout] = v;
+          ssum += v;
+          ssq += v * v;
+        }
+    } else if (co < p.Cout) {
+      float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + co;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[off[t] + r * p.Cout] = acc[t][s2][r];
+    }
+    // GroupNorm statistics of the output: one slab per (workgroup, z-slab, voxel half) -> stats[n][slab][Cout][2]
+    if (p.stats && p.nsplit == 1) {
+      ssum += __shfl_xor(ssum, 16);
+      ssq += __shfl_xor(ssq, 16);
+      ssum += __shfl_xor(ssum, 32);
+      ssq += __shfl_xor(ssq, 32);
+      if (kq == 0 && co < p.Cout) {
+        const int tiles_per_sample = ntx * nty * ntz;
+        const int slab = ((int)(blockIdx.x % tiles_per_sample) * TZ + wz) * 2 + wv;
+        double* d = p.stats + (((int64_t)n * tiles_per_sample * TZ * 2 + slab) * p.Cout + co) * 2;
+        d[0] = (double)ssum;
+        d[1] = (double)ssq;
+      }
     }
   }
 }
@@ -1334,8 +1354,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
     p.tz = 2;
     int64_t htiles = tiles;
-    const bool split3 = p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w;  // bf16x3 kernel: 64-voxel tiles only
-    if (tiles < target || split3) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
+    if (tiles < target) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
@@ -1377,6 +1396,7 @@ int conv_stats_slabs(const ConvParams& p) {
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     return B;
   }
+  if (p.mode == 1 && p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w) return (int)(V / 32);  // bf16x3 kernel: per half 8x8 slab
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
   return 0;
@@ -1405,8 +1425,12 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (p.bf16 == 2 && p.w_bf && wide && !sk && p.tz == 1) {
-      HOLO_LAUNCH(conv_halo_split_kernel, hgrid, block, stream, p);
+    if (p.bf16 == 2 && p.w_bf && wide && !sk) {
+      if (p.tz == 2) {
+        HOLO_LAUNCH(conv_halo_split_kernel<2>, hgrid, dim3(512), stream, p);
+      } else {
+        HOLO_LAUNCH(conv_halo_split_kernel<1>, hgrid, block, stream, p);
+      }
     } else {
     const bool bf = p.bf16 == 1 && p.w_bf && (!sk || p.skip_w_bf);
     if (!wide && sk) {

@@ -1,8 +1,8 @@
 export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --frames 1 --no-cpu-baseline --conv-iters 1"
+CMD="python $GRAFT_REPO_ROOT/bench.py --compute-dtype f32_bf16x3 --steps 1 --warmup 1 --frames 1 --no-cpu-baseline --conv-iters 1"
 pass () { n=$1; shift; ( cd /tmp && timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/px_$n -o p -- $CMD > /dev/null 2>&1 ); }
-pass a SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES
-pass b GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU
+pass a SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY
+pass b GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD TCP_PENDING_STALL_CYCLES_sum SQ_LDS_ADDR_CONFLICT
 python3 - <<'PY'
 import csv, glob, collections
 for n in 'ab':
@@ -11,8 +11,9 @@ for n in 'ab':
     agg = collections.OrderedDict()
     for r in csv.DictReader(open(f[0])):
         kn = r['Kernel_Name']
-        if 'render_kernel' not in kn and 'conv_halo_kernel<4, 2, false>' not in kn: continue
-        k = (kn[34:66], r['Counter_Name'])
+        if 'conv_halo_split_kernel<2>' not in kn: continue
+        if int(r.get('Grid_Size', r.get('Grid_Size_X', 0))) != 2048*512: continue
+        k = ('split<2> 64^3', r['Counter_Name'])
         a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r['Counter_Value'])
     for k, a in agg.items(): print(k[0], k[1], 'n', a[0], 'avg %.4g' % (a[1]/a[0]))
 PY
