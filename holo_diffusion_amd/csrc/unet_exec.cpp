@@ -984,7 +984,8 @@ int holo_unet_set_compute_dtype(HoloUnet* net, int dtype) {
   const int mode = dtype == HOLO_DTYPE_BF16 ? 1 : dtype == HOLO_DTYPE_F32_BF16X3 ? 2 : 0;
   if (mode != net->compute_mode) {
     net->compute_mode = mode;
-    net->plan_batch = -1;  // re-plan: the conv ops carry the choice
+    net->plan_batch = -1;   // re-plan: the conv ops carry the choice
+    net->ws_cache.clear();  // ... and the plan's workspace differs between modes (fused skips, statistics slabs)
   }
   return 0;
 }

@@ -199,6 +199,12 @@ def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
     with torch.no_grad():
         y2 = nbf(x, t)
     assert torch.equal(y2, y32)
+    # and every mode can be entered from every other on a live net (the plan and its workspace are rebuilt)
+    for mode, tol in (("f32_bf16x3", 1e-4), ("bf16", 2e-2), ("f32_bf16x3", 1e-4), ("f32", 0.0)):
+        n32.compute_dtype = mode
+        with torch.no_grad():
+            ym = n32(x, t)
+        assert ((ym - y32).abs().max() / y32.abs().max()).item() <= tol, mode
 
 
 @pytest.mark.parametrize("image,mc,mult,attn", [(16, 64, (1, 2, 2), (1, 2)), (16, 128, (1, 2), (2,))])
