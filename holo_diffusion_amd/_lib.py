@@ -84,6 +84,7 @@ SIGNATURES = {
     "holo_renderer_destroy": (C.c_int, [_vp]),
     "holo_renderer_set_param": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, C.c_int, _i64p, _vp]),
     "holo_renderer_commit": (C.c_int, [_vp, _vp]),
+    "holo_renderer_set_compute_dtype": (C.c_int, [_vp, C.c_int]),
     "holo_render_workspace_bytes": (C.c_size_t, [_vp, C.c_int]),
     "holo_render": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, _vp]),

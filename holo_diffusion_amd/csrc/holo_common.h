@@ -18,6 +18,7 @@ static inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fma(a.
 static inline f32x2 pk_mul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
 static inline uint32_t pack_bf16x2(float lo, float hi) { return emu_bf16_bits(lo) | (emu_bf16_bits(hi) << 16); }
 static inline f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
+static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return emu_mfma_f32_32x32x16_bf16(a, b, c); }
 #define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
@@ -40,6 +41,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // v_mfma_f32_16x16x32_bf16 on raw 16-byte operands (8 bf16 per lane: A row / B column lane&15, k-group lane>>4)
 __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(holo_bf16x8, a), __builtin_bit_cast(holo_bf16x8, b), c,
+                                                 0, 0, 0);
+}
+// v_mfma_f32_32x32x16_bf16 on raw 16-byte operands (8 bf16 per lane: A row / B column lane&31, k-group lane>>5)
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(holo_bf16x8, a), __builtin_bit_cast(holo_bf16x8, b), c,
                                                  0, 0, 0);
 }
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
@@ -66,6 +72,17 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c)
 #endif
 
 #define HOLO_WAVE 64
+
+// ---- exact three-term bf16 split of fp32 values (x = hi + mid + lo, the two subtractions are exact in fp32)
+__device__ __forceinline__ float bf_lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float bf_hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+// two floats -> packed (hi, mid, lo) bf16 pairs
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = pack_bf16x2(x0, x1);
+  const float r0 = x0 - bf_lo_f32(h), r1 = x1 - bf_hi_f32(h);
+  m = pack_bf16x2(r0, r1);
+  l = pack_bf16x2(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
+}
 
 namespace holo {
 

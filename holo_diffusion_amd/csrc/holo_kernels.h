@@ -185,6 +185,7 @@ struct RenderKernelParams {
   float* depth_c;
   float* mask_c;
   unsigned long long* dbg;  // optional per-wave phase timestamps [wave][8] (HOLO_RENDER_TIMELINE=1); null in production
+  int split3;  // 1: RenderMLP products on the bf16 matrix cores from an exact 3-term bf16 split (feature_size 32 only)
 };
 
 // stand-alone implicit function: densities[P], colours[P][3] at world points pts[P][3];

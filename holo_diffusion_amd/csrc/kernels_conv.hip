@@ -677,16 +677,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 // so that the A reads are conflict free without padding); the weights are split once at set_param.
 // Structure = conv_halo_kernel with 64-voxel tiles (1 x 8 x 8), 4 waves x 16 Cout, no fused skip.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf_lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
-__device__ __forceinline__ float bf_hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
-// two floats -> packed (hi, mid, lo) bf16 pairs
-__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-  h = pack_bf16x2(x0, x1);
-  const float r0 = x0 - bf_lo_f32(h), r1 = x1 - bf_hi_f32(h);
-  m = pack_bf16x2(r0, r1);
-  l = pack_bf16x2(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
-}
-
 // TZ = 1: 64-voxel tiles, 4 waves (2 workgroups per CU).  TZ = 2: 128-voxel tiles, 8 waves (wave = 16-Cout slice x
 // z-slab; one workgroup per CU, same 8 waves per CU): each weight block is then fetched by two waves of ONE
 // workgroup (the second hits L1), halving the L2 -> CU weight traffic that bounds the 64-voxel form at 64^3.

@@ -33,6 +33,8 @@
 // The voxel grid is channels-last so a corner is CH*4 contiguous bytes per lane; the 33.5 MB grid stays
 // resident in the 256 MB Infinity Cache / L2 across the frame.  All eight corner fetches of a sample are
 // issued unconditionally from clamped addresses (zeros padding = zero weight).
+#include <string.h>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -51,23 +53,51 @@ __device__ __forceinline__ float leaky02(float v) { return fmaxf(v, 0.2f * v); }
 __device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // LDS image of the packed MLP shared by the block
-template <int CH>
+// SP (fp32-accurate bf16x3 split, opt-in): W_eff is held as three bf16 planes (hi, mid, lo; 64-byte rows of 4
+// XOR-swizzled 16-byte slots, slot = 2*kstep + lane half) and a lane half owns channels 16s + 8g + (0..7) of every
+// 16-channel k-step s, which is the operand layout of v_mfma_f32_32x32x16_bf16.
+template <int CH, bool SP = false>
 struct MlpLds {
   static constexpr int C = 2 * CH;
   static constexpr int LDW = C + 4;
-  float w[HD * LDW];              // W_eff rows (hidden features), padded rows
+  static constexpr int WPLANE = HD * (C / 2);  // words per bf16 plane
+  float w[SP ? 3 * WPLANE : HD * LDW];  // W_eff rows (hidden features): padded fp32 rows, or the three bf16 planes
   float bias[NTILE * 2 * 16];     // b_feat in D-row order: [tile][lane half][r] (the 16 rows a lane owns per tile)
   float wr[3][NTILE * 2 * 16];    // 0.4 * w_rad[colour] in the same order
-  float u[2 * 4 * CH];            // per half: {w_dens, u_rad0, u_rad1, u_rad2} slices of CH floats
+  float u[2 * 4 * CH];            // per half: {w_dens, u_rad0, u_rad1, u_rad2} slices of CH floats (lane channel order)
 };
 
-template <int CH>
-__device__ __forceinline__ void stage_mlp(MlpLds<CH>& L, const MlpParams& m, int tid) {
+// channel owned by lane half h at position k of its CH channels
+template <int CH, bool SP>
+__device__ __forceinline__ int lane_channel(int h, int k) {
+  return SP ? 16 * (k >> 3) + 8 * h + (k & 7) : h * CH + k;
+}
+
+template <int CH, bool SP>
+__device__ __forceinline__ void stage_mlp(MlpLds<CH, SP>& L, const MlpParams& m, int tid) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
-  for (int i = tid; i < HD * (C / 4); i += 256) {
-    const int row = i / (C / 4), c4 = i - row * (C / 4);
-    *reinterpret_cast<float4*>(L.w + row * LDW + c4 * 4) = *reinterpret_cast<const float4*>(m.w_feat + row * C + c4 * 4);
+  if (SP) {
+    static_assert(!SP || CH == 16, "the split renderer is built for feature_size 32");
+    uint32_t* wb = reinterpret_cast<uint32_t*>(L.w);
+    constexpr int WPL = HD * (C / 2);
+    for (int i = tid; i < HD * (C / 2); i += 256) {  // one channel pair per step
+      const int row = i / (C / 2), cp = i - row * (C / 2);
+      const int c = 2 * cp;
+      const float x0 = m.w_feat[row * C + c], x1 = m.w_feat[row * C + c + 1];
+      uint32_t h, md, l;
+      split3_pair(x0, x1, h, md, l);
+      const int slot = 2 * (c >> 4) + ((c >> 3) & 1);  // k-step, lane half
+      const int word = row * (C / 2) + ((slot ^ ((row >> 2) & 3)) << 2) + ((c & 7) >> 1);
+      wb[word] = h;
+      wb[WPL + word] = md;
+      wb[2 * WPL + word] = l;
+    }
+  } else {
+    for (int i = tid; i < HD * (C / 4); i += 256) {
+      const int row = i / (C / 4), c4 = i - row * (C / 4);
+      *reinterpret_cast<float4*>(L.w + row * LDW + c4 * 4) = *reinterpret_cast<const float4*>(m.w_feat + row * C + c4 * 4);
+    }
   }
   for (int i = tid; i < NTILE * 2 * 16; i += 256) {
     const int r = i & 15, h = (i >> 4) & 1, t = i >> 5;
@@ -79,7 +109,8 @@ __device__ __forceinline__ void stage_mlp(MlpLds<CH>& L, const MlpParams& m, int
   }
   for (int i = tid; i < 2 * 4 * CH; i += 256) {
     const int k = i % CH, j = (i / CH) & 3, h = i / (4 * CH);
-    L.u[i] = (j == 0) ? m.w_dens[h * CH + k] : m.u_rad[(j - 1) * C + h * CH + k];
+    const int ch = lane_channel<CH, SP>(h, k);
+    L.u[i] = (j == 0) ? m.w_dens[ch] : m.u_rad[(j - 1) * C + ch];
   }
 }
 
@@ -107,8 +138,9 @@ __device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy,
 }
 
 // One sample of the implicit function for the lane's item: world point -> raw density, colour.
-template <int CH>
-__device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __restrict__ gbase, int R, float Rm1,
+// gbase already points at the lane half's first channel (grid + lane_channel(lh, 0)).
+template <int CH, bool SP = false>
+__device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ gbase, int R, float Rm1,
                                            float half_extent, float b_dens, int li, int lh, float px, float py,
                                            float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
                                            float& cb) {
@@ -147,7 +179,7 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
       const f32x2 w2 = f32x2{w, w};
 #pragma unroll
       for (int v = 0; v < CH / 4; ++v) {
-        const float4 t = g[v];
+        const float4 t = g[SP ? 4 * (v >> 1) + (v & 1) : v];  // SP: 8 channels of every 16-channel k-step
         fv[2 * v + 0] = pk_fma(w2, f32x2{t.x, t.y}, fv[2 * v + 0]);
         fv[2 * v + 1] = pk_fma(w2, f32x2{t.z, t.w}, fv[2 * v + 1]);
       }
@@ -173,6 +205,19 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
       r2 = pk_fma(f32x2{d.z, d.w}, fv[2 * v + 1], r2);
     }
   }
+  // SP: the lane's features split exactly into three bf16 terms, packed as B operands [plane][k-step]
+  float4 fb[3][SP ? CH / 8 : 1];
+  if (SP) {
+#pragma unroll
+    for (int ks = 0; ks < CH / 8; ++ks) {
+      uint32_t h[4], md[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3_pair(fv[4 * ks + e].x, fv[4 * ks + e].y, h[e], md[e], l[e]);
+      memcpy(&fb[0][ks], h, 16);
+      memcpy(&fb[1][ks], md, 16);
+      memcpy(&fb[2][ks], l, 16);
+    }
+  }
   // hidden features on the matrix cores, tile by tile
 #pragma unroll 1
   for (int t = 0; t < NTILE; ++t) {
@@ -180,16 +225,6 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
     // (and spilling) 8 tiles of operands out of the sample loops
     asm volatile("" ::: "memory");
     const int ro = (t * 2 + lh) * 16;  // this lane's 16 D rows of the tile
-    const float4* ap = reinterpret_cast<const float4*>(L.w + (t * 32 + li) * LDW + lh * CH);
-    float a[CH];
-#pragma unroll
-    for (int v = 0; v < CH / 4; ++v) {
-      const float4 t4 = ap[v];
-      a[4 * v + 0] = t4.x;
-      a[4 * v + 1] = t4.y;
-      a[4 * v + 2] = t4.z;
-      a[4 * v + 3] = t4.w;
-    }
     f32x16 acc;  // starts at the bias of the lane's own rows (four 16-byte LDS reads straight into the tuple)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -199,9 +234,45 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
       acc[4 * v + 2] = b4.z;
       acc[4 * v + 3] = b4.w;
     }
+    if (SP) {
+      // six leading cross terms of every product on v_mfma_f32_32x32x16_bf16 (smallest first); one accumulator chain
+      // per k-step, summed at the end, so that consecutive MFMAs are independent
+      constexpr int WPL = HD * (C / 2);
+      const int row = t * 32 + li;
+      f32x16 acc1;
 #pragma unroll
-    for (int k = 0; k < CH; ++k)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], (k & 1) ? fv[k >> 1].y : fv[k >> 1].x, acc, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      float4 aw[3][2];  // [plane][k-step]: every plane's fragments are read once and used in 3 / 2 / 1 products
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const float* wp = L.w + pl * WPL + row * (C / 2);
+        aw[pl][0] = *reinterpret_cast<const float4*>(wp + (((0 + lh) ^ ((row >> 2) & 3)) << 2));
+        aw[pl][1] = *reinterpret_cast<const float4*>(wp + (((2 + lh) ^ ((row >> 2) & 3)) << 2));
+      }
+#pragma unroll
+      for (int pr = 0; pr < 6; ++pr) {
+        const int pa = (pr == 0) ? 2 : (pr == 2 || pr == 3) ? 1 : 0;  // A plane: lo, hi, mid, mid, hi, hi
+        const int pb = (pr == 1) ? 2 : (pr == 2 || pr == 4) ? 1 : 0;  // B plane: hi, lo, mid, hi, mid, hi
+        acc = mfma_bf16_32x32x16(aw[pa][0], fb[pb][0], acc);
+        acc1 = mfma_bf16_32x32x16(aw[pa][1], fb[pb][SP ? 1 : 0], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+    } else {
+      const float4* ap = reinterpret_cast<const float4*>(L.w + (t * 32 + li) * LDW + lh * CH);
+      float a[CH];
+#pragma unroll
+      for (int v = 0; v < CH / 4; ++v) {
+        const float4 t4 = ap[v];
+        a[4 * v + 0] = t4.x;
+        a[4 * v + 1] = t4.y;
+        a[4 * v + 2] = t4.z;
+        a[4 * v + 3] = t4.w;
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], (k & 1) ? fv[k >> 1].y : fv[k >> 1].x, acc, 0, 0, 0);
+    }
     // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units:
     // radiance sums  r_c += 0.4 w_c[row] |h[row]|  on row pairs
 #pragma unroll
@@ -234,9 +305,9 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH>& L, const float* __r
 // ([workgroup][wave][j][lane], L2-resident, coalesced when the lanes share j): keeping them in LDS (32 KB per
 // workgroup) capped the kernel at two workgroups per CU and left the matrix pipe idle whenever both resident
 // waves of a SIMD were in their gather / VALU phases.
-template <int CH>
+template <int CH, bool SP = false>
 __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderKernelParams p) {
-  __shared__ __attribute__((aligned(16))) MlpLds<CH> s_mlp;
+  __shared__ __attribute__((aligned(16))) MlpLds<CH, SP> s_mlp;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -244,7 +315,7 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  stage_mlp<CH>(s_mlp, p.mlp, tid);
+  stage_mlp<CH, SP>(s_mlp, p.mlp, tid);
   __syncthreads();
 
   // ---- ray setup (pytorch3d NDC grid: +x left, +y up; pixel centres)
@@ -273,10 +344,10 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
 
   const int R = p.R;
   const float Rm1 = (float)(R - 1);
-  const float* gbase = p.grid_cl + lh * CH;
+  const float* gbase = p.grid_cl + lane_channel<CH, SP>(lh, 0);
 
   auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb) {
-    eval_point<CH>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0], org[1] + z * dir[1],
+    eval_point<CH, SP>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0], org[1] + z * dir[1],
                    org[2] + z * dir[2], rdir, sigma, cr, cg, cb);
   };
 
@@ -501,13 +572,13 @@ __global__ __launch_bounds__(256) void dir_term_kernel(MlpParams m, const float*
 // (densities, colours) for arbitrary points: grid-stride over groups of 128 points per block
 template <int CH>
 __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParams p) {
-  __shared__ __attribute__((aligned(16))) MlpLds<CH> s_mlp;
+  __shared__ __attribute__((aligned(16))) MlpLds<CH, false> s_mlp;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int li = lane & 31;
   const int lh = lane >> 5;
-  stage_mlp<CH>(s_mlp, p.mlp, tid);
+  stage_mlp<CH, false>(s_mlp, p.mlp, tid);
   __syncthreads();
   const float Rm1 = (float)(p.R - 1);
   const float* gbase = p.grid_cl + lh * CH;
@@ -520,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParam
     const int64_t di = ii / p.pts_per_dir;
     const float rdir[3] = {p.rdir[di * 3 + 0], p.rdir[di * 3 + 1], p.rdir[di * 3 + 2]};
     float sg, cr, cg, cb;
-    eval_point<CH>(s_mlp, gbase, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg, cr, cg, cb);
+    eval_point<CH, false>(s_mlp, gbase, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg, cr, cg, cb);
     if (active && lh == 0) {
       p.densities[i] = sg;
       p.colours[i * 3 + 0] = cr;
@@ -548,7 +619,11 @@ int render_launch(const RenderKernelParams& p, void* stream) {
       HOLO_LAUNCH(render_kernel<8>, grid, dim3(256), stream, p);
       break;
     case 32:
-      HOLO_LAUNCH(render_kernel<16>, grid, dim3(256), stream, p);
+      if (p.split3) {
+        HOLO_LAUNCH((render_kernel<16, true>), grid, dim3(256), stream, p);
+      } else {
+        HOLO_LAUNCH((render_kernel<16, false>), grid, dim3(256), stream, p);
+      }
       break;
     case 64:
       HOLO_LAUNCH(render_kernel<32>, grid, dim3(256), stream, p);

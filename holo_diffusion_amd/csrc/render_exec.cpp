@@ -40,6 +40,7 @@ struct HoloRenderer {
   float b_dens = 0.f;
   float b_rad[3] = {0, 0, 0};
   bool committed = false;
+  int split3 = 0;  // holo_renderer_set_compute_dtype
 };
 
 static int dir_emb(const HoloRenderCfg& c) { return 3 * (2 * c.dir_emb_dims + 1); }
@@ -239,6 +240,15 @@ static size_t fz_ws_bytes(const HoloRenderer* r) {
   return ((n_render_waves(r) * (size_t)r->cfg.n_pts_fine * 32 * sizeof(float)) + 255) & ~(size_t)255;
 }
 
+int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
+  if (!r || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_F32_BF16X3)) {
+    set_error("holo_renderer_set_compute_dtype: HOLO_DTYPE_F32 or HOLO_DTYPE_F32_BF16X3");
+    return HOLO_E_INVALID;
+  }
+  r->split3 = dtype == HOLO_DTYPE_F32_BF16X3 ? 1 : 0;
+  return 0;
+}
+
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
   (void)n_cameras;  // frames are rendered one after the other on the stream and share the scratch
   if (!r) return 0;
@@ -309,6 +319,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
     p.background_opacity = c.background_opacity;
     p.pdf_eps = c.sample_pdf_eps;
+    p.split3 = (r->split3 && c.feature_size == 32) ? 1 : 0;
     p.cdf_ws = (float*)((char*)workspace + grid_cl_bytes(r));
     p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r));
     p.fz_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r) + val_ws_bytes(r));

@@ -356,6 +356,9 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
     density_noise_std_train: float = 1.0
     return_weights: bool = False
     raymarcher_EmissionAbsorptionRaymarcher_args: Optional[dict] = None
+    # build-side extension (not a reference field): "f32" (exact-fp32 MFMA) or "f32_bf16x3" (RenderMLP products from an
+    # exact three-term bf16 split on the bf16 matrix cores, fp32 accumulation) - holo_renderer_set_compute_dtype
+    compute_dtype: str = "f32"
 
     _RAYMARCHER_DEFAULTS = dict(surface_thickness=1, bg_color=(0.0,), replicate_last_interval=False,
                                 background_opacity=1e10, density_relu=True, blend_output=False)
@@ -414,6 +417,10 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
                                                        t.dim(), _lib.shape_array(t.shape), st), f"set_param({k})")
             _lib.check(L, L.holo_renderer_commit(self._handle, st), "holo_renderer_commit")
             self._param_versions = versions
+        code = {"f32": _lib.HOLO_DTYPE_F32, "f32_bf16x3": _lib.HOLO_DTYPE_F32_BF16X3}.get(self.compute_dtype)
+        if code is None:
+            raise _lib.HoloError(f"renderer compute_dtype must be 'f32' or 'f32_bf16x3' (got {self.compute_dtype!r})")
+        _lib.check(L, L.holo_renderer_set_compute_dtype(self._handle, code), "holo_renderer_set_compute_dtype")
         return self._handle
 
     def __del__(self):

@@ -173,6 +173,11 @@ int holo_renderer_set_param(HoloRenderer* r, const char* name, const void* dev_p
  * float64 and uploads the packed weights.  Must be called after all set_param calls. */
 int holo_renderer_commit(HoloRenderer* r, void* stream);
 
+/* Arithmetic of the RenderMLP hidden layer inside holo_render: HOLO_DTYPE_F32 (default, exact-fp32 MFMA) or
+ * HOLO_DTYPE_F32_BF16X3 (weights and interpolated features split exactly into three bf16 terms, six bf16 MFMAs per
+ * product, fp32 accumulation; feature_size 32 only, other sizes keep the exact path).  Opt-in. */
+int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype);
+
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras);
 
 /* Render n_cameras full-grid frames of one voxel grid.

@@ -167,8 +167,8 @@ def check_ddpm():
     return ok
 
 
-def check_render(C_feat=32, R=8, H=8, W=16, n_fine=64):
-    print(f"== fused renderer vs oracle (R={R}, C={C_feat}, {H}x{W}, n_fine={n_fine})")
+def check_render(C_feat=32, R=8, H=8, W=16, n_fine=64, split=False):
+    print(f"== fused renderer vs oracle (R={R}, C={C_feat}, {H}x{W}, n_fine={n_fine}{', bf16x3 split' if split else ''})")
     ctx = make_ctx()
     rcfg = ro.RenderCfg(resol=R, feature_size=C_feat, image_height=H, image_width=W, n_pts_fine=n_fine)
     shapes = ro.render_mlp_param_shapes(rcfg)
@@ -187,6 +187,8 @@ def check_render(C_feat=32, R=8, H=8, W=16, n_fine=64):
         _lib.check(lib, lib.holo_renderer_set_param(r, k.encode(), ptr(v), 0, v.dim(), _lib.shape_array(v.shape), None),
                    f"set {k}")
     _lib.check(lib, lib.holo_renderer_commit(r, None), "commit")
+    if split:
+        _lib.check(lib, lib.holo_renderer_set_compute_dtype(r, _lib.HOLO_DTYPE_F32_BF16X3), "set_compute_dtype")
     hc = _lib.HoloCamera()
     for i, v in enumerate(cam["R"].reshape(-1).tolist()):
         hc.R[i] = v
@@ -222,6 +224,8 @@ if __name__ == "__main__":
         allok &= check_ddpm()
     if "render" in what:
         allok &= check_render()
+    if "render_split" in what:
+        allok &= check_render(split=True)
     if "render16" in what:
         allok &= check_render(C_feat=16, n_fine=16)
     if "unet" in what:

@@ -192,6 +192,34 @@ static inline f32x4 emu_mfma_f32_16x16x32_bf16(float4 a, float4 b, f32x4 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l holds 8 bf16 of A row l&31 / B column l&31 for k-group l>>5;
+// D col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+static inline f32x16 emu_mfma_f32_32x32x16_bf16(float4 a, float4 b, f32x16 c) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  std::memcpy(w.a4[lane], &a, 16);
+  std::memcpy(w.b4[lane], &b, 16);
+  w.bar.wait();
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int col = lane & 31;
+    float acc = c[r];
+    for (int g = 0; g < 2; ++g) {
+      uint32_t aw[4], bw[4];
+      std::memcpy(aw, w.a4[row + 32 * g], 16);
+      std::memcpy(bw, w.b4[col + 32 * g], 16);
+      for (int e = 0; e < 8; ++e) {
+        const float av = emu_bf16_to_f32((aw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        const float bv = emu_bf16_to_f32((bw[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+        acc = std::fma(av, bv, acc);
+      }
+    }
+    c[r] = acc;
+  }
+  w.bar.wait();
+  return c;
+}
+
 static inline float __shfl_xor(float v, int mask) {
   emu::WaveCtx& w = emu_wave();
   const int lane = emu::t_tid & 63;

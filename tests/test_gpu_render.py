@@ -26,8 +26,10 @@ def gu():
 TINY_UNET = dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2))
 
 
-def _render_pair(gu, resol, C, H, W, n_fine, density_bias, cam_index=1, n_cams=4, up=(0.0, -1.0, 0.0)):
+def _render_pair(gu, resol, C, H, W, n_fine, density_bias, cam_index=1, n_cams=4, up=(0.0, -1.0, 0.0),
+                 compute_dtype="f32"):
     model, _, _, rcfg, msd = gu.make_model(resol, C, H, W, TINY_UNET, n_fine=n_fine, density_bias=density_bias)
+    model.renderer.compute_dtype = compute_dtype
     model.net_3d_enabled = False  # render the grid as given (the UNet path has its own tests)
     grid = torch.tanh(torch.from_numpy(np_noise(7, (1, C, resol, resol, resol))))
     cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_cams, -30.0 * (2 * math.pi / 360), 10, up, 3.2)
@@ -43,8 +45,9 @@ def _render_pair(gu, resol, C, H, W, n_fine, density_bias, cam_index=1, n_cams=4
     (8, 16, 17, 13, 16, 0.1),      # 16 features, ragged image (partial last workgroup), 16 fine samples
     (8, 64, 16, 16, 64, 0.0),      # 64 features (released YAML feature_size)
 ])
-def test_render_vs_oracle(gu, resol, C, H, W, n_fine, bias):
-    preds, ref = _render_pair(gu, resol, C, H, W, n_fine, bias)
+@pytest.mark.parametrize("compute", ["f32", "f32_bf16x3"])  # the split mode is held to the same tolerances
+def test_render_vs_oracle(gu, resol, C, H, W, n_fine, bias, compute):
+    preds, ref = _render_pair(gu, resol, C, H, W, n_fine, bias, compute_dtype=compute)
     assert preds["images_render"].shape == (1, 3, H, W) and preds["masks_render"].shape == (1, 1, H, W)
     far = 14.0
     for k, tol in (("images_render", 2e-4), ("masks_render", 2e-4), ("depths_render", 2e-4 * far)):
