@@ -216,8 +216,8 @@ def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
                      channel_mult=mult, attention_resolutions=attn, num_heads=2)
     net, sd = gu.make_unet(cfg, seed=7, compute_dtype="bf16")
     from oracle.common import np_noise
-    x = torch.from_numpy(np_noise(13, (1, 16, image, image, image)))
-    t = torch.tensor([77], dtype=torch.int64)
+    x = torch.from_numpy(np_noise(13, (2, 16, image, image, image)))  # batch 2: (sample, head, query tile) decode
+    t = torch.tensor([77, 901], dtype=torch.int64)
     ref = uo.unet_forward(sd, cfg, x, t)
     with torch.no_grad():
         y = net(x.to(gu.DEV), t.to(gu.DEV))
