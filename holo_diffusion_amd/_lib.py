@@ -89,6 +89,7 @@ SIGNATURES = {
     "holo_render": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, _vp]),
     "holo_implicit_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_implicit_normals": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "holo_event_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "holo_event_timer_start": (C.c_int, [_vp, _vp]),
     "holo_event_timer_stop": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),

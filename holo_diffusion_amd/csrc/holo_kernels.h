@@ -204,6 +204,7 @@ struct ImplicitEvalParams {
   float* colours;
 };
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
+int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
 int render_launch(const RenderKernelParams& p, void* stream);
 
 }  // namespace holo

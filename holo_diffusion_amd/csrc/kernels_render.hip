@@ -601,6 +601,85 @@ __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParam
   }
 }
 
+
+// Normals of the density field at arbitrary points (RenderMLP.get_normals, holo_voxel_grid_implicit_function.py:
+// 131-145, 249-263): normalize(d density / d point), density = LeakyReLU(w_dens . f(p) + b_dens) with f the trilinear
+// fetch.  The density row is affine in the features (the folded density net), so the gradient is analytic: with
+// s_c = w_dens . F_c the scalar of corner c,  d/dx (sum_c w_c(p) s_c) follows from the derivatives of the per-axis
+// trilinear weights (zero for corners outside the grid, like grid_sample's backward).  One lane pair per point.
+template <int CH>
+__global__ __launch_bounds__(256) void implicit_normals_kernel(ImplicitEvalParams p, float* __restrict__ normals) {
+  constexpr int C = 2 * CH;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int R = p.R;
+  const float Rm1 = (float)(R - 1);
+  const float* gbase = p.grid_cl + lh * CH;
+  float wd[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) wd[k] = p.mlp.w_dens[lh * CH + k];
+  const int64_t ngroups = (p.n_points + 127) / 128;
+  for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int64_t i = g * 128 + wave * 32 + li;
+    const bool active = i < p.n_points;
+    const int64_t ii = active ? i : p.n_points - 1;
+    const float px = p.pts[ii * 3 + 0], py = p.pts[ii * 3 + 1], pz = p.pts[ii * 3 + 2];
+    const float lx = px / p.half_extent, ly = py / p.half_extent, lz = pz / p.half_extent;
+    const float ix = ((lx + 1.f) * 0.5f) * Rm1, iy = ((ly + 1.f) * 0.5f) * Rm1, iz = ((lz + 1.f) * 0.5f) * Rm1;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    const bool xa_in = fx0 >= 0.f && fx0 <= Rm1, xb_in = fx0 >= -1.f && fx0 <= Rm1 - 1.f;
+    const bool ya_in = fy0 >= 0.f && fy0 <= Rm1, yb_in = fy0 >= -1.f && fy0 <= Rm1 - 1.f;
+    const bool za_in = fz0 >= 0.f && fz0 <= Rm1, zb_in = fz0 >= -1.f && fz0 <= Rm1 - 1.f;
+    const float wx[2] = {xa_in ? (fx0 + 1.f) - ix : 0.f, xb_in ? ix - fx0 : 0.f};
+    const float wy[2] = {ya_in ? (fy0 + 1.f) - iy : 0.f, yb_in ? iy - fy0 : 0.f};
+    const float wz[2] = {za_in ? (fz0 + 1.f) - iz : 0.f, zb_in ? iz - fz0 : 0.f};
+    const float dwx[2] = {xa_in ? -1.f : 0.f, xb_in ? 1.f : 0.f};
+    const float dwy[2] = {ya_in ? -1.f : 0.f, yb_in ? 1.f : 0.f};
+    const float dwz[2] = {za_in ? -1.f : 0.f, zb_in ? 1.f : 0.f};
+    const int x0 = (int)fminf(fmaxf(fx0, -1.f), Rm1), y0 = (int)fminf(fmaxf(fy0, -1.f), Rm1),
+              z0 = (int)fminf(fmaxf(fz0, -1.f), Rm1);
+    const int xs[2] = {max(x0, 0), min(x0 + 1, R - 1)};
+    const int ys[2] = {max(y0, 0), min(y0 + 1, R - 1)};
+    const int zs[2] = {max(z0, 0), min(z0 + 1, R - 1)};
+    float sc[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+      const float4* gp = reinterpret_cast<const float4*>(gbase + ((int64_t)(zs[dz] * R + ys[dy]) * R + xs[dx]) * C);
+      float s = 0.f;
+#pragma unroll
+      for (int v = 0; v < CH / 4; ++v) {
+        const float4 t = gp[v];
+        s = fmaf(wd[4 * v], t.x, fmaf(wd[4 * v + 1], t.y, fmaf(wd[4 * v + 2], t.z, fmaf(wd[4 * v + 3], t.w, s))));
+      }
+      sc[corner] = s + __shfl_xor(s, 32);
+    }
+    float zval = p.mlp.b_dens, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+      zval = fmaf((wx[dx] * wy[dy]) * wz[dz], sc[corner], zval);
+      gx = fmaf((dwx[dx] * wy[dy]) * wz[dz], sc[corner], gx);
+      gy = fmaf((wx[dx] * dwy[dy]) * wz[dz], sc[corner], gy);
+      gz = fmaf((wx[dx] * wy[dy]) * dwz[dz], sc[corner], gz);
+    }
+    // chain rule: LeakyReLU'(z) * d(index)/d(point); both positive, kept so that F.normalize's eps acts as in torch
+    const float k = (zval > 0.f ? 1.f : 0.2f) * (0.5f * Rm1 / p.half_extent);
+    gx *= k;
+    gy *= k;
+    gz *= k;
+    const float nrm = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+    if (active && lh == 0) {
+      normals[i * 3 + 0] = gx / nrm;
+      normals[i * 3 + 1] = gy / nrm;
+      normals[i * 3 + 2] = gz / nrm;
+    }
+  }
+}
+
 }  // namespace
 
 int render_launch(const RenderKernelParams& p, void* stream) {
@@ -630,6 +709,28 @@ int render_launch(const RenderKernelParams& p, void* stream) {
       break;
     default:
       set_error("render: feature_size must be 16, 32 or 64 (got %d)", p.C);
+      return -1;
+  }
+  return 0;
+}
+
+int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream) {
+  if (p.n_points <= 0) return 0;
+  int64_t groups = cdiv(p.n_points, 128);
+  if (groups > 4096) groups = 4096;
+  dim3 grid((unsigned)groups);
+  switch (p.C) {
+    case 16:
+      HOLO_LAUNCH(implicit_normals_kernel<8>, grid, dim3(256), stream, p, normals);
+      break;
+    case 32:
+      HOLO_LAUNCH(implicit_normals_kernel<16>, grid, dim3(256), stream, p, normals);
+      break;
+    case 64:
+      HOLO_LAUNCH(implicit_normals_kernel<32>, grid, dim3(256), stream, p, normals);
+      break;
+    default:
+      set_error("implicit_normals: feature_size must be 16, 32 or 64 (got %d)", p.C);
       return -1;
   }
   return 0;

@@ -405,4 +405,35 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
   return implicit_eval_launch(p, stream) ? HOLO_E_INVALID : 0;
 }
 
+int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, int64_t n_points, float* normals,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (!r || !grid || !pts || !normals || !workspace || n_points < 0) {
+    set_error("holo_implicit_normals: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_implicit_normals: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  const size_t grid_bytes = grid_cl_bytes(r);
+  if (workspace_bytes < grid_bytes) {
+    set_error("holo_implicit_normals: workspace too small (need holo_render_workspace_bytes)");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  float* grid_cl = (float*)workspace;
+  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, c.feature_size, (int64_t)c.resol * c.resol * c.resol, 0, stream))
+    return HOLO_E_INVALID;
+  ImplicitEvalParams p;
+  memset(&p, 0, sizeof p);
+  p.grid_cl = grid_cl;
+  p.R = c.resol;
+  p.C = c.feature_size;
+  p.half_extent = 0.5f * (float)(c.resol - 1) * (c.volume_extent / (float)c.resol);
+  fill_mlp(r, p.mlp);
+  p.pts = pts;
+  p.n_points = n_points;
+  return implicit_normals_launch(p, normals, stream) ? HOLO_E_INVALID : 0;
+}
+
 }  // extern "C"

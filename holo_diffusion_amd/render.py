@@ -257,9 +257,9 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         (and its tests, which call it with ``pts_3d``)."""
         assert voxel_grid_features is not None, "voxel_grid_features must be provided!"
         assert ray_bundle is not None or pts_3d is not None, "either ray_bundle or pts_3d must be provided!"
-        # render_normals (released YAMLs set it, configs/apple.yaml:203): the reference differentiates the density
-        # w.r.t. the points and HoloDiffusionModel then drops the result (no `normals_render` output); accepted and
-        # not computed here (SURVEY.md row R10: optional, off the hot path).
+        # render_normals (released YAMLs set it, configs/apple.yaml:203): the stand-alone evaluation returns
+        # aux["normals"] (below); inside the fused renderer the normals are not rendered - HoloDiffusionModel drops them
+        # (no `normals_render` output, SURVEY.md row R10).
         if pts_3d is None:
             if ray_bundle.origins is None:
                 ray_bundle.materialize()
@@ -295,7 +295,14 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         _lib.check(L, L.holo_implicit_eval(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf),
                                            runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens), runtime.ptr(col),
                                            runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_implicit_eval")
-        return dens.reshape(*spatial, 1), col.reshape(*spatial, COLOUR_DIMS), {}
+        aux = {}
+        if self.render_normals:  # RenderMLP.get_normals (:131-145), evaluated analytically in the kernel
+            nrm = torch.empty(n, 3, device=dev)
+            _lib.check(L, L.holo_implicit_normals(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf), n,
+                                                  runtime.ptr(nrm), runtime.ptr(ws), ws.numel(),
+                                                  runtime.stream_ptr(dev)), "holo_implicit_normals")
+            aux["normals"] = nrm.reshape(*spatial, 3)
+        return dens.reshape(*spatial, 1), col.reshape(*spatial, COLOUR_DIMS), aux
 
 
 class ImplicitFunctionWrapper(torch.nn.Module):

@@ -199,6 +199,14 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
                        int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* Normals of the density field at world points.  Replaces RenderMLP.get_normals as used by
+ * HoloVoxelGridImplicitFunction.forward with render_normals=True (holo_voxel_grid_implicit_function.py:131-145,
+ * 249-263): normalize(d density / d point); the density net is affine up to its final LeakyReLU, so the gradient is
+ * evaluated analytically from the trilinear corner values instead of by autograd.
+ *   pts : (n_points, 3) world coordinates;  normals : (n_points, 3) */
+int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, int64_t n_points, float* normals,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
  * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).

@@ -216,6 +216,16 @@ def implicit_function(grid, sd, origins, dirs, lengths, cfg: RenderCfg, prefix: 
     return render_mlp(sd, feats, dn, cfg, prefix)
 
 
+def implicit_normals(grid, sd, pts, cfg: RenderCfg, prefix: str = ""):
+    """RenderMLP.get_normals (holo_voxel_grid_implicit_function.py:131-145) at world points pts (...,3): autograd of
+    the summed density (last output of the density net, after its LeakyReLU) w.r.t. the points, F.normalize'd."""
+    with torch.enable_grad():
+        x = pts.clone().requires_grad_(True)
+        dens, _ = render_mlp(sd, trilinear(grid, x, cfg), torch.zeros_like(x), cfg, prefix)
+        (g,) = torch.autograd.grad(dens.sum(), x)
+    return F.normalize(g, dim=-1)
+
+
 # ----------------------------------------------------------------------------
 # raymarcher + refiner
 # ----------------------------------------------------------------------------

@@ -180,3 +180,23 @@ def test_standalone_implicit_function_vs_oracle(gu):
     d_ref2, c_ref2 = ro.implicit_function(grid, msd, o, d, l, rcfg)
     assert (dens2.reshape(-1, 64, 1).cpu() - d_ref2).abs().max() < 1e-4
     assert (feats2.reshape(-1, 64, 3).cpu() - c_ref2).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("C", [16, 32, 64])
+def test_standalone_normals_vs_autograd_oracle(gu, C):
+    """render_normals=True (released YAMLs): aux["normals"] of the stand-alone implicit function against the oracle's
+    restatement of RenderMLP.get_normals (autograd of the summed density w.r.t. the points, F.normalize)."""
+    model, _, _, rcfg, msd = gu.make_model(8, C, 6, 10, TINY_UNET, density_bias=0.05)
+    fn = model._implicit_functions[0]._fn
+    fn.render_normals = True
+    grid = torch.tanh(torch.from_numpy(np_noise(23, (1, C, 8, 8, 8))))
+    pts = (torch.rand(3, 11, 5, 3, generator=torch.Generator().manual_seed(5)) - 0.5) * 12.0  # partly outside
+    _, _, aux = fn(pts_3d=pts.to(gu.DEV), voxel_grid_features=grid.to(gu.DEV))
+    got = aux["normals"].cpu()
+    assert got.shape == pts.shape
+    ref = ro.implicit_normals(grid, msd, pts, rcfg)
+    # a point outside the volume has zero gradient -> zero "normal" in both; elsewhere unit vectors
+    inside = ref.norm(dim=-1) > 0.5
+    assert 0.2 < inside.float().mean() < 0.98
+    assert (got[inside] - ref[inside]).abs().max() < 2e-4
+    assert got[~inside].abs().max() < 1e-6

@@ -110,3 +110,21 @@ def test_collapsed_density_net_matches_uncollapsed():
     be = W[p + "3.0.weight"] @ c2 + W[p + "3.0.bias"]
     o = F.leaky_relu(f.double() @ We.t() + be, 0.2)
     torch.testing.assert_close(o[:, -1:].float(), dens, rtol=1e-4, atol=1e-5)
+
+
+def test_normals_of_a_linear_density_field_are_constant():
+    """KAT for the oracle's get_normals restatement: a grid whose (single effective) feature is linear in x gives a
+    density with constant gradient direction +-x inside the volume."""
+    import torch
+    from oracle import render_oracle as ro
+    from holo_diffusion_amd.weights import synth_state_dict
+    R, C = 8, 16
+    cfg = ro.RenderCfg(resol=R, feature_size=C, image_height=4, image_width=4)
+    sd = synth_state_dict(ro.render_mlp_param_shapes(cfg), 11)
+    grid = torch.zeros(1, C, R, R, R)
+    grid[0, 0] = torch.linspace(-1, 1, R)[None, None, :].expand(R, R, R)  # varies along x (last axis) only
+    pts = (torch.rand(64, 3, generator=torch.Generator().manual_seed(1)) - 0.5) * 6.0  # well inside +-3.5
+    n = ro.implicit_normals(grid, sd, pts, cfg)
+    assert torch.allclose(n.norm(dim=-1), torch.ones(64), atol=1e-5)
+    assert n[:, 1:].abs().max() < 1e-5            # no y / z component
+    assert (n[:, 0] - n[0, 0]).abs().max() < 1e-5  # the same sign everywhere
