@@ -1,0 +1,85 @@
+"""Fly-around output stage: predictions -> displayable frames.
+
+Follows ``holo_diffusion/utils/render_utils/flyaround.py``:
+
+* ``_images_from_preds`` (:422-488): per key, masks / depths become 3-channel images; depth maps are normalised with
+  PyTorch3D's ``make_depth_image`` and composited over a white background with the (nearest-resized) render mask;
+* ``_generate_prediction_videos`` (:553-610): one clip per key, frames clipped to [0, 1].
+
+``make_depth_image`` lives in PyTorch3D 0.7.4 (``implicitron/tools/vis_utils.py``), which is not available here: its
+published algorithm is restated below (per-image 2 % / 98 % quantiles of the valid masked depths mapped to
+[0.1, 0.9]) — PARITY UNPINNED for that function.  Video encoding (ffmpeg via PyTorch3D's VideoWriter) and visdom are
+outside this path: frames are written as binary PPM files, one directory per key, ready for any encoder.
+Host-side torch code on small frame tensors; nothing here is on the measured hot path.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as Fu
+
+
+def make_depth_image(depths: torch.Tensor, masks: torch.Tensor, max_quantile: float = 0.98, min_quantile: float = 0.02,
+                     min_out_depth: float = 0.1, max_out_depth: float = 0.9) -> torch.Tensor:
+    """(N,1,H,W) depths + masks -> (N,1,H,W) in [0,1]: robust per-image normalisation of the foreground depths."""
+    normfacs = []
+    for d, m in zip(depths, masks):
+        ok = (d.reshape(-1) > 1e-6) & (m.reshape(-1) > 0.5)
+        if int(ok.sum()) <= 1:
+            normfacs.append(torch.zeros(2, dtype=depths.dtype, device=depths.device))
+            continue
+        dok = d.reshape(-1)[ok]
+        maxk = max(int(round((1 - max_quantile) * dok.numel())), 1)
+        mink = max(int(round(min_quantile * dok.numel())), 1)
+        nmax = dok.topk(k=maxk, dim=-1).values[-1]
+        nmin = dok.topk(k=mink, dim=-1, largest=False).values[-1]
+        normfacs.append(torch.stack([nmin, nmax]))
+    nf = torch.stack(normfacs)
+    lo, hi = nf[:, 0].reshape(-1, 1, 1, 1), nf[:, 1].reshape(-1, 1, 1, 1)
+    out = (depths - lo) / (hi - lo).clamp(1e-4)
+    return ((out * (max_out_depth - min_out_depth) + min_out_depth) * masks.float()).clamp(0.0, 1.0)
+
+
+def images_from_preds(preds: Dict[str, torch.Tensor],
+                      extract_keys: Sequence[str] = ("images_render", "masks_render", "depths_render")
+                      ) -> Dict[str, torch.Tensor]:
+    """``_images_from_preds`` for the keys the HIP path produces: every entry becomes an (N,3,H,W) CPU tensor."""
+    imout = {}
+    for k in extract_keys:
+        if k not in preds or preds[k] is None:
+            continue
+        v = preds[k].detach().float().cpu().clone()
+        if k.startswith("depth"):
+            mask = Fu.interpolate(preds["masks_render"].detach().float().cpu(), size=v.shape[2:], mode="nearest")
+            v = make_depth_image(v, mask)
+            v = v * mask + (1 - mask)  # white background
+        if v.shape[1] == 1:
+            v = v.repeat(1, 3, 1, 1)
+        imout[k] = v
+    return imout
+
+
+def write_ppm(path: str, image: torch.Tensor) -> None:
+    """(3,H,W) float image in [0,1] -> binary PPM (P6)."""
+    img = (image.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous()
+    h, w = img.shape[:2]
+    with open(path, "wb") as f:
+        f.write(f"P6\n{w} {h}\n255\n".encode())
+        f.write(img.numpy().tobytes())
+
+
+def export_flyaround_frames(frames: Dict[str, torch.Tensor], out_dir: str, sequence_name: str,
+                            keys: Optional[Sequence[str]] = None) -> Dict[str, str]:
+    """Frames of one fly-around ((F,C,H,W) per key, as ``render_flyaround`` returns them) -> one directory of PPM
+    frames per key, named like the reference's per-key clips (``<sequence_name>_<key>``).  Returns key -> directory."""
+    ims = images_from_preds(frames, tuple(keys) if keys else ("images_render", "masks_render", "depths_render"))
+    dirs = {}
+    for k, v in ims.items():
+        d = os.path.join(out_dir, f"{sequence_name}_{k}")
+        os.makedirs(d, exist_ok=True)
+        for i in range(v.shape[0]):
+            write_ppm(os.path.join(d, f"frame_{i:05d}.ppm"), v[i])
+        dirs[k] = d
+    return dirs

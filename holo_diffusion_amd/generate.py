@@ -138,7 +138,8 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
     experiment directory -> model (``checkpoint.load_experiment``) -> sharded sampling + fly-around renders.
 
     Output stage: rank 0 writes ``<output_directory>/sample_%05d_frames.pt`` (images / depths / masks of the
-    fly-around as tensors); video encoding and visdom (flyaround.py:422-610) are outside this path."""
+    fly-around as tensors) and, through ``flyaround_output``, one directory of displayable frames per key; video
+    encoding and visdom are outside this path."""
     from .checkpoint import load_experiment
     rank, world = dist_info()
     if device is None:
@@ -154,9 +155,12 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
                            camera_elevation=camera_elevation,
                            progressive_sampling_steps_per_render=progressive_sampling_steps_per_render, device=device)
     if save_frames and rank == 0:
+        from .flyaround_output import export_flyaround_frames
         os.makedirs(output_directory, exist_ok=True)
         for i in range(num_samples):
             torch.save({k: v[i].cpu() for k, v in out.items()},
                        os.path.join(output_directory, f"sample_{i:05d}_frames.pt"))
+            # displayable frames per key (flyaround.py:422-488,553-610), ready for a video encoder
+            export_flyaround_frames({k: v[i] for k, v in out.items()}, output_directory, f"sample_{i:05d}")
     out["load_report"] = report
     return out

@@ -107,3 +107,36 @@ def test_render_mlp_rejects_unsupported_structures():
     mlp = hda.RenderMLP(input_dims=32, output_vp_independent_feature_dims=0)
     assert {k: tuple(v.shape) for k, v in mlp.state_dict().items()} == ro.render_mlp_param_shapes(
         ro.RenderCfg(feature_size=32))
+
+
+def test_flyaround_output_stage(tmp_path):
+    """_images_from_preds semantics (flyaround.py:422-488): 3-channel outputs, depth normalised inside the mask to
+    [0.1, 0.9] and composited over white; frames land as one PPM directory per key."""
+    import torch
+    from holo_diffusion_amd import flyaround_output as fo
+    F, H, W = 3, 6, 8
+    g = torch.Generator().manual_seed(0)
+    mask = torch.zeros(F, 1, H, W)
+    mask[:, :, 1:5, 2:7] = 1.0
+    depth = (8.0 + 4.0 * torch.rand(F, 1, H, W, generator=g)) * mask
+    preds = {"images_render": torch.rand(F, 3, H, W, generator=g), "masks_render": mask, "depths_render": depth}
+    ims = fo.images_from_preds(preds)
+    assert set(ims) == {"images_render", "masks_render", "depths_render"}
+    for v in ims.values():
+        assert v.shape == (F, 3, H, W) and v.min() >= 0.0 and v.max() <= 1.0
+    assert torch.equal(ims["masks_render"][:, 0], mask[:, 0])
+    d = ims["depths_render"]
+    assert torch.all(d[:, :, 0, 0] == 1.0)                      # background composited to white
+    inside = d[:, 0][mask[:, 0] > 0.5]
+    assert inside.min() >= 0.0 and inside.max() <= 1.0 and 0.1 <= inside.median() <= 0.9
+    # monotone in depth inside one frame
+    f0 = depth[0, 0][mask[0, 0] > 0.5]
+    o0 = d[0, 0][mask[0, 0] > 0.5]
+    assert torch.all((o0[f0.argsort()][1:] - o0[f0.argsort()][:-1]) >= -1e-6)
+    dirs = fo.export_flyaround_frames(preds, str(tmp_path), "sample_00000")
+    import os
+    for k, p in dirs.items():
+        files = sorted(os.listdir(p))
+        assert len(files) == F and files[0] == "frame_00000.ppm"
+        head = open(os.path.join(p, files[0]), "rb").read(15)
+        assert head.startswith(b"P6\n8 6\n255\n")
