@@ -312,10 +312,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   const int wm = NWN == 4 ? 0 : wave / NWN;  // (4 waves: compile-time 0, so the A addresses fold into immediates)
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
-  // Spatial tiles: the workgroup is PERSISTENT over blockIdx.x (conv_plan sizes gridDim.x to the resident slots
-  // of the chip): it walks tiles blockIdx.x, +gridDim.x, ... so that workgroup dispatch, the exposed first halo
-  // load and the epilogue are paid once per slot instead of once per tile (the first halo of the next tile is
-  // requested under the last tap of the current one).
+  // Spatial tiles: one tile per workgroup (gridDim.x = tiles).  A persistent form - each workgroup walking tiles
+  // blockIdx.x, +gridDim.x, ... with the next tile's first halo requested under the last tap - was measured with
+  // tools/conv_timeline.cpp: it raises the slot occupancy from 1.6 to 1.8 of 2 but loses the natural phase stagger
+  // between the two resident workgroups and comes out even, and its cross-tile prefetch costs ~25 VGPRs (spills in
+  // the 128-voxel variant), so the loop below runs exactly once.
   const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD / TZ;
   const int ntiles = ntx * nty * ntz * p.N;
   int tx0 = 0, ty0 = 0, tz0 = 0, n = 0;      // tile whose halo is being STAGED (halo_issue)
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   decode_tile(blockIdx.x);
   halo_prepare();
   if (!SKIP) halo_issue(cc_begin);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += ntiles) {  // (one tile per workgroup, see below)
   ctx0 = tx0, cty0 = ty0, ctz0 = tz0, cn = n;
   unsigned long long* dbg = p.dbg ? p.dbg + ((int64_t)tile * gridDim.y + blockIdx.y) * 8 : nullptr;
   if (dbg && tid == 0) dbg[0] = HOLO_PROBE_CLOCK();
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   for (int t = 0; t < MT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
-  const bool more_tiles = tile + (int)gridDim.x < ntiles;
+  const bool more_tiles = false;
   for (int cc = cc_begin; cc < cc_end; ++cc) {
     if (SKIP) halo_issue(cc);
     halo_commit();

@@ -27,7 +27,9 @@ write = load(f"gpurun_out/{tag}/pmc_write.csv")
 res = {}
 for (k, grid), (n, f_kib) in fetch.items():
     w_kib = write.get((k, grid), (0, 0.0))[1]
-    m = re.search(r"conv_halo_kernel<(\d), (\d), (true|false)>", k)
+    m = re.search(r"conv_halo_kernel<(\d), (\d), (true|false)(?:, (true|false))?>", k)
+    if m and m.group(4) == "true":
+        continue  # bf16-product instantiation (opt-in mode): not the reported kernel
     if m:
         nwn, tz, sk = int(m.group(1)), int(m.group(2)), m.group(3)
         tiles = grid // 256  # Grid_Size is x*y*z threads: only single-Cout-block, un-split launches are unambiguous

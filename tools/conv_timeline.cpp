@@ -1,7 +1,7 @@
 // conv_timeline — per-workgroup timeline of one LDS-halo conv3d launch (development probe, not part of the library).
 // Build: hipcc -O2 --offload-arch=gfx950 tools/conv_timeline.cpp holo_diffusion_amd/csrc/kernels_conv.o \
 //              holo_diffusion_amd/csrc/kernels_misc.o holo_diffusion_amd/csrc/err.o -o tools/conv_timeline
-// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [grid_x=0 (planner)] [tile_depth=0 (planner)]
+// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [unused] [tile_depth=0 (planner)] [stagger_us=0]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,7 +28,7 @@ int main(int argc, char** argv) {
   p.Cout = Cout; p.w = w; p.CoutP = CoutP; p.CinP = CinP; p.out = out;
   conv_plan(p, 256);
   if (tzo > 0) { p.tz = tzo; p.grid_x = (int)(V / (64 * p.tz)); }
-  if (gx > 0) p.grid_x = gx;
+  (void)gx;  // (the persistent multi-tile form was removed from the kernel after these measurements; one tile per workgroup)
   p.stagger_ticks = stag * 100;
   const int ntile = (int)(V / (64 * p.tz));
   const int ny = (Cout + 63) / 64;
