@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=5, help="timed 400x400 frames in the render leg")
+    ap.add_argument("--frames", type=int, default=8,
+                    help="timed 400x400 frames in the render leg (one holo_render call; a fly-around is 40-75 frames, "
+                         "the library renders them 8 per kernel launch)")
     ap.add_argument("--image-size", type=int, default=400)
     ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
                     help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "

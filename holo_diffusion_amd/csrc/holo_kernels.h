@@ -163,16 +163,23 @@ struct RenderKernelParams {
   int R, C;
   float half_extent;  // 0.5*(R-1)*voxel_size (VolumeLocator local->world scale)
   MlpParams mlp;
-  // camera
-  float Rm[9], T[3], focal[2], pp[2];
-  float zmin, zmax;
+  // cameras of this launch: gridDim.y = n_cams frames are rendered by ONE launch (outputs of camera i at
+  // rgb + i*3*H*W, depth + i*H*W, ...): a single 400^2 frame is only 1.6 waves of workgroups on 256 CUs, so
+  // per-frame launches leave the chip half empty for the second half of every frame
+  struct Cam {
+    float Rm[9], T[3], focal[2], pp[2];
+    float zmin, zmax;
+  };
+  static constexpr int MAX_CAMS = 8;
+  Cam cams[MAX_CAMS];
+  int n_cams;
   int H, W;
   float range_x, range_y;  // NDC half ranges
   int n_coarse, n_fine;
   float bg[3];
   float background_opacity;
   float pdf_eps;
-  // scratch, per wave (4 * ceil(H*W/128) waves): cdf_ws 64*64 floats (per-lane coarse weights / CDF columns),
+  // scratch, per wave (n_cams * 4 * ceil(H*W/128) waves): cdf_ws 64*64 floats (per-lane coarse weights / CDF columns),
   // val_ws (64 + n_fine)*32 float4 (sigma, rgb of coarse and importance samples), fz_ws n_fine*32 floats
   float* cdf_ws;
   float* val_ws;

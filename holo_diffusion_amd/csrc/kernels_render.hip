@@ -320,6 +320,14 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
 
   // ---- ray setup (pytorch3d NDC grid: +x left, +y up; pixel centres)
   const int npix = p.H * p.W;
+  const int cam_i = blockIdx.y;  // frame of this workgroup
+  const RenderKernelParams::Cam& cam = p.cams[cam_i];
+  float* const o_rgb = p.rgb + (int64_t)cam_i * 3 * npix;
+  float* const o_depth = p.depth + (int64_t)cam_i * npix;
+  float* const o_mask = p.mask + (int64_t)cam_i * npix;
+  float* const o_rgb_c = p.rgb_c ? p.rgb_c + (int64_t)cam_i * 3 * npix : nullptr;
+  float* const o_depth_c = p.rgb_c ? p.depth_c + (int64_t)cam_i * npix : nullptr;
+  float* const o_mask_c = p.rgb_c ? p.mask_c + (int64_t)cam_i * npix : nullptr;
   const int ray = blockIdx.x * 128 + wave * 32 + li;
   const bool active = ray < npix;
   const int rr = active ? ray : npix - 1;
@@ -329,13 +337,13 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   const float miny = p.range_y - hy, maxy = -p.range_y + hy;
   const float xn = lin_space(minx, maxx, (maxx - minx) / (float)(p.W - 1), px, p.W);
   const float yn = lin_space(miny, maxy, (maxy - miny) / (float)(p.H - 1), py, p.H);
-  const float dc0 = (xn - p.pp[0]) / p.focal[0], dc1 = (yn - p.pp[1]) / p.focal[1], dc2 = 1.0f;
+  const float dc0 = (xn - cam.pp[0]) / cam.focal[0], dc1 = (yn - cam.pp[1]) / cam.focal[1], dc2 = 1.0f;
   float org[3], dir[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float r0 = p.Rm[j * 3 + 0], r1 = p.Rm[j * 3 + 1], r2 = p.Rm[j * 3 + 2];
-    const float p1 = (dc0 - p.T[0]) * r0 + (dc1 - p.T[1]) * r1 + (dc2 - p.T[2]) * r2;
-    const float p2 = (2.f * dc0 - p.T[0]) * r0 + (2.f * dc1 - p.T[1]) * r1 + (2.f * dc2 - p.T[2]) * r2;
+    const float r0 = cam.Rm[j * 3 + 0], r1 = cam.Rm[j * 3 + 1], r2 = cam.Rm[j * 3 + 2];
+    const float p1 = (dc0 - cam.T[0]) * r0 + (dc1 - cam.T[1]) * r1 + (dc2 - cam.T[2]) * r2;
+    const float p2 = (2.f * dc0 - cam.T[0]) * r0 + (2.f * dc1 - cam.T[1]) * r1 + (2.f * dc2 - cam.T[2]) * r2;
     dir[j] = p2 - p1;
     org[j] = p1 - dir[j];
   }
@@ -356,8 +364,8 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   //   cval [64][32 rays] float4  (sigma_raw, r, g, b) of the coarse samples
   //   fz   [nf][32 rays]         importance-sampled depths,  fval [nf][32] float4 their (sigma_raw, r, g, b)
   const int nc = p.n_coarse, nf = p.n_fine;
-  const float zstep = (p.zmax - p.zmin) / (float)(nc - 1);
-  const int64_t wslot = (int64_t)blockIdx.x * 4 + wave;
+  const float zstep = (cam.zmax - cam.zmin) / (float)(nc - 1);
+  const int64_t wslot = ((int64_t)cam_i * gridDim.x + blockIdx.x) * 4 + wave;
   float* cdf = p.cdf_ws + wslot * (MAXC * 64) + lane;  // element j at cdf[j*64]
   float4* cval = reinterpret_cast<float4*>(p.val_ws) + wslot * ((int64_t)(MAXC + p.n_fine) * 32) + li;
   float4* fval = cval + MAXC * 32;
@@ -368,9 +376,9 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   // ---- coarse pass (all rays of the wave in lock step): evaluate, composite, keep weights + values
   {
     float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
-    float zi = lin_space(p.zmin, p.zmax, zstep, 0, nc);
+    float zi = lin_space(cam.zmin, cam.zmax, zstep, 0, nc);
     for (int i = 0; i < nc; ++i) {
-      const float zn = (i + 1 < nc) ? lin_space(p.zmin, p.zmax, zstep, i + 1, nc) : 0.f;
+      const float zn = (i + 1 < nc) ? lin_space(cam.zmin, cam.zmax, zstep, i + 1, nc) : 0.f;
       float sg, cr, cg, cb;
       eval(zi, sg, cr, cg, cb);
       if (lh == 0) cval[i * 32] = make_float4(sg, cr, cg, cb);
@@ -388,12 +396,12 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
       Tr = 1.f - O;
       zi = zn;
     }
-    if (p.rgb_c && active && lh == 0) {
-      p.rgb_c[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
-      p.rgb_c[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
-      p.rgb_c[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
-      p.depth_c[ray] = ad;
-      p.mask_c[ray] = O;
+    if (o_rgb_c && active && lh == 0) {
+      o_rgb_c[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
+      o_rgb_c[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
+      o_rgb_c[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
+      o_depth_c[ray] = ad;
+      o_mask_c[ray] = O;
     }
   }
 
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   __builtin_amdgcn_wave_barrier();
 
   if (dbg && lane == 0) dbg[2] = HOLO_PROBE_CLOCK();
-  auto zcoarse = [&](int i) { return lin_space(p.zmin, p.zmax, zstep, i, nc); };
+  auto zcoarse = [&](int i) { return lin_space(cam.zmin, cam.zmax, zstep, i, nc); };
 
   // ---- importance-sample depths of all 32 rays, cooperatively: for one ray at a time lane j holds cdf[j] and lane
   //      kk computes the inverse CDF at u_kk = linspace(0,1,nf)[kk] with a binary search over the lanes' values
@@ -547,11 +555,11 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
       vhead = vnext;
     }
     if (active) {
-      p.rgb[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
-      p.rgb[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
-      p.rgb[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
-      p.depth[ray] = ad;
-      p.mask[ray] = O;
+      o_rgb[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
+      o_rgb[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
+      o_rgb[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
+      o_depth[ray] = ad;
+      o_mask[ray] = O;
     }
   }
   if (dbg && lane == 0) dbg[5] = HOLO_PROBE_CLOCK();
@@ -692,7 +700,11 @@ int render_launch(const RenderKernelParams& p, void* stream) {
     return -1;
   }
   const int npix = p.H * p.W;
-  dim3 grid((unsigned)cdiv(npix, 128));
+  if (p.n_cams < 1 || p.n_cams > RenderKernelParams::MAX_CAMS) {
+    set_error("render: %d cameras per launch (1..%d)", p.n_cams, RenderKernelParams::MAX_CAMS);
+    return -1;
+  }
+  dim3 grid((unsigned)cdiv(npix, 128), (unsigned)p.n_cams);
   switch (p.C) {
     case 16:
       HOLO_LAUNCH(render_kernel<8>, grid, dim3(256), stream, p);

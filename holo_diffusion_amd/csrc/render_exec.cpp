@@ -228,16 +228,20 @@ static size_t grid_cl_bytes(const HoloRenderer* r) {
   const size_t R = r->cfg.resol;
   return ((R * R * R * (size_t)r->cfg.feature_size * sizeof(float)) + 255) & ~(size_t)255;
 }
-static size_t n_render_waves(const HoloRenderer* r) {
+// frames rendered by one launch (RenderKernelParams::MAX_CAMS at most): the scratch is sized for that many
+static size_t cams_per_launch(int n_cameras) {
+  return (size_t)(n_cameras < 1 ? 1 : n_cameras > RenderKernelParams::MAX_CAMS ? RenderKernelParams::MAX_CAMS : n_cameras);
+}
+static size_t n_render_waves(const HoloRenderer* r, int n_cameras = 1) {
   const size_t npix = (size_t)r->cfg.image_height * r->cfg.image_width;
-  return ((npix + 127) / 128) * 4;
+  return ((npix + 127) / 128) * 4 * cams_per_launch(n_cameras);
 }
-static size_t cdf_ws_bytes(const HoloRenderer* r) { return n_render_waves(r) * 64 * 64 * sizeof(float); }
-static size_t val_ws_bytes(const HoloRenderer* r) {
-  return n_render_waves(r) * (size_t)(64 + r->cfg.n_pts_fine) * 32 * 4 * sizeof(float);
+static size_t cdf_ws_bytes(const HoloRenderer* r, int nc = 1) { return n_render_waves(r, nc) * 64 * 64 * sizeof(float); }
+static size_t val_ws_bytes(const HoloRenderer* r, int nc = 1) {
+  return n_render_waves(r, nc) * (size_t)(64 + r->cfg.n_pts_fine) * 32 * 4 * sizeof(float);
 }
-static size_t fz_ws_bytes(const HoloRenderer* r) {
-  return ((n_render_waves(r) * (size_t)r->cfg.n_pts_fine * 32 * sizeof(float)) + 255) & ~(size_t)255;
+static size_t fz_ws_bytes(const HoloRenderer* r, int nc = 1) {
+  return ((n_render_waves(r, nc) * (size_t)r->cfg.n_pts_fine * 32 * sizeof(float)) + 255) & ~(size_t)255;
 }
 
 int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
@@ -250,9 +254,8 @@ int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
 }
 
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
-  (void)n_cameras;  // frames are rendered one after the other on the stream and share the scratch
-  if (!r) return 0;
-  return grid_cl_bytes(r) + cdf_ws_bytes(r) + val_ws_bytes(r) + fz_ws_bytes(r) + 256;
+  if (!r) return 0;  // up to MAX_CAMS frames are in flight per launch, each with its own scratch
+  return grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras) + val_ws_bytes(r, n_cameras) + fz_ws_bytes(r, n_cameras) + 256;
 }
 
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
@@ -277,8 +280,9 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   if (rc) return HOLO_E_INVALID;
   const int H = c.image_height, Wd = c.image_width;
   const int64_t npix = (int64_t)H * Wd;
-  for (int ci = 0; ci < n_cameras; ++ci) {
-    const HoloCamera& cam = cameras[ci];
+  const int G = (int)cams_per_launch(n_cameras);  // frames per launch (the scratch was sized for G)
+  for (int c0 = 0; c0 < n_cameras; c0 += G) {
+    const int ng = n_cameras - c0 < G ? n_cameras - c0 : G;
     RenderKernelParams p;
     memset(&p, 0, sizeof p);
     p.grid_cl = grid_cl;
@@ -287,24 +291,29 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     const float voxel_size = c.volume_extent / (float)R;
     p.half_extent = 0.5f * (float)(R - 1) * voxel_size;
     fill_mlp(r, p.mlp);
-    for (int k = 0; k < 9; ++k) p.Rm[k] = cam.R[k];
-    for (int k = 0; k < 3; ++k) p.T[k] = cam.T[k];
-    for (int k = 0; k < 2; ++k) {
-      p.focal[k] = cam.focal[k];
-      p.pp[k] = cam.principal_point[k];
+    p.n_cams = ng;
+    for (int g = 0; g < ng; ++g) {
+      const HoloCamera& cam = cameras[c0 + g];
+      RenderKernelParams::Cam& pc = p.cams[g];
+      for (int k = 0; k < 9; ++k) pc.Rm[k] = cam.R[k];
+      for (int k = 0; k < 3; ++k) pc.T[k] = cam.T[k];
+      for (int k = 0; k < 2; ++k) {
+        pc.focal[k] = cam.focal[k];
+        pc.pp[k] = cam.principal_point[k];
+      }
+      // AdaptiveRaySampler: near/far from the camera centre C = -T R^T (fp32, as torch computes it)
+      float d2 = 0.f;
+      for (int j = 0; j < 3; ++j) {
+        float cj = -(cam.T[0] * cam.R[j * 3 + 0] + cam.T[1] * cam.R[j * 3 + 1] + cam.T[2] * cam.R[j * 3 + 2]);
+        const float d = cj - c.scene_center[j];
+        d2 += d * d;
+      }
+      if (d2 < 0.001f) d2 = 0.001f;
+      float dist = sqrtf(d2);
+      if (dist < c.scene_extent + 1e-3f) dist = c.scene_extent + 1e-3f;
+      pc.zmin = dist - c.scene_extent;
+      pc.zmax = dist + c.scene_extent;
     }
-    // AdaptiveRaySampler: near/far from the camera centre C = -T R^T (fp32, as torch computes it)
-    float d2 = 0.f;
-    for (int j = 0; j < 3; ++j) {
-      float cj = -(cam.T[0] * cam.R[j * 3 + 0] + cam.T[1] * cam.R[j * 3 + 1] + cam.T[2] * cam.R[j * 3 + 2]);
-      const float d = cj - c.scene_center[j];
-      d2 += d * d;
-    }
-    if (d2 < 0.001f) d2 = 0.001f;
-    float dist = sqrtf(d2);
-    if (dist < c.scene_extent + 1e-3f) dist = c.scene_extent + 1e-3f;
-    p.zmin = dist - c.scene_extent;
-    p.zmax = dist + c.scene_extent;
     p.H = H;
     p.W = Wd;
     if (Wd >= H) {
@@ -321,22 +330,22 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.pdf_eps = c.sample_pdf_eps;
     p.split3 = (r->split3 && c.feature_size == 32) ? 1 : 0;
     p.cdf_ws = (float*)((char*)workspace + grid_cl_bytes(r));
-    p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r));
-    p.fz_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r) + val_ws_bytes(r));
-    p.rgb = images + (size_t)ci * 3 * npix;
-    p.depth = depths + (size_t)ci * npix;
-    p.mask = masks + (size_t)ci * npix;
+    p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras));
+    p.fz_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras) + val_ws_bytes(r, n_cameras));
+    p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets (blockIdx.y)
+    p.depth = depths + (size_t)c0 * npix;
+    p.mask = masks + (size_t)c0 * npix;
     if (images_coarse && depths_coarse && masks_coarse) {
-      p.rgb_c = images_coarse + (size_t)ci * 3 * npix;
-      p.depth_c = depths_coarse + (size_t)ci * npix;
-      p.mask_c = masks_coarse + (size_t)ci * npix;
+      p.rgb_c = images_coarse + (size_t)c0 * 3 * npix;
+      p.depth_c = depths_coarse + (size_t)c0 * npix;
+      p.mask_c = masks_coarse + (size_t)c0 * npix;
     }
 #ifndef HOLO_EMU
     static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
 #else
     const bool timeline = false;
 #endif
-    const int nwaves = 4 * ((npix + 127) / 128);
+    const int nwaves = 4 * (int)((npix + 127) / 128) * ng;
 #ifndef HOLO_EMU
     if (timeline) {
       HIP_TRY(hipMalloc((void**)&p.dbg, (size_t)nwaves * 64));
@@ -358,8 +367,8 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
         if (d[w * 8] < t0) t0 = d[w * 8];
         if (d[w * 8 + 5] > t1) t1 = d[w * 8 + 5];
       }
-      fprintf(stderr, "[render timeline] waves %d span %.1f us | per wave: coarse %.1f  cdf %.1f  inverse-cdf %.1f  fine %.1f  "
-              "composite %.1f us\n", nwaves, (t1 - t0) * 0.01, ph[0] / nwaves * 0.01, ph[1] / nwaves * 0.01,
+      fprintf(stderr, "[render timeline] frames %d waves %d span %.1f us | per wave: coarse %.1f  cdf %.1f  inverse-cdf %.1f  "
+              "fine %.1f  composite %.1f us\n", ng, nwaves, (t1 - t0) * 0.01, ph[0] / nwaves * 0.01, ph[1] / nwaves * 0.01,
               ph[2] / nwaves * 0.01, ph[3] / nwaves * 0.01, ph[4] / nwaves * 0.01);
     }
 #endif

@@ -180,7 +180,8 @@ int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype);
 
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras);
 
-/* Render n_cameras full-grid frames of one voxel grid.
+/* Render n_cameras full-grid frames of one voxel grid (up to 8 frames per kernel launch: a single 400x400 frame
+ * cannot fill the chip; holo_render_workspace_bytes sizes the per-frame scratch accordingly).
  *   grid        : (1, C, R, R, R) fp32 NCDHW (what HoloDiffusionModel.forward binds as
  *                 voxel_grid_features, holo_diffusion_model.py:431-438)
  *   cameras     : host array of n_cameras HoloCamera (depth bounds are computed per camera)
