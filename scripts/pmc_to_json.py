@@ -38,7 +38,7 @@ for (k, grid), (n, f_kib) in fetch.items():
             continue
         label = f"conv_halo_kernel<{nwn}, {tz}, {sk}> at {od}^3 output"
     elif "render_kernel" in k:
-        label = "render_kernel<16> (one launch per frame)"
+        label = "render_kernel<16> (up to 8 frames per launch)"
     else:
         continue
     res[label] = {"fetch_bytes": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024), "dispatches": n,
