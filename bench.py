@@ -84,33 +84,52 @@ def max_over_ranks(x: float, world: int, device) -> float:
     return float(t.item())
 
 
-def cpu_baseline(w, usd, msd, budget_s=25.0):
-    """Bounded CPU sample of the same workload through the oracle (kind 'port')."""
+def cpu_baseline(w, usd, msd, budget_s=30.0):
+    """Bounded CPU sample of the same workload through the oracle (kind 'port'): DDPM steps at the
+    workload's grid size with torch on ALL host hardware threads, one 128x128 frame of the same grid."""
     from oracle import diffusion_oracle as do
     from oracle import render_oracle as ro
     from oracle import unet_oracle as uo
     from oracle.common import np_noise
-    # torch's CPU conv3d/GEMM stop scaling (and regress) far below the 256 hardware threads of the GPU box
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+    hw_threads = os.cpu_count() or 1
+    try:  # physical cores (threads / SMT siblings), reported next to the thread count actually used
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = len([x for part in sib.split(",") for x in (range(int(part.split("-")[0]), int(part.split("-")[-1]) + 1))])
+        phys = max(1, hw_threads // max(smt, 1))
+    except (OSError, ValueError):
+        phys = hw_threads
     cfg = uo.UNetCfg(image_size=w["resol"], in_channels=w["feature_size"], out_channels=w["feature_size"],
                      model_channels=w["model_channels"], num_res_blocks=2, channel_mult=w["channel_mult"],
                      attention_resolutions=w["attention_resolutions"], num_heads=2)
     orc = do.DiffusionOracle(1000)
     shape = (1, w["feature_size"]) + (w["resol"],) * 3
-    x = torch.from_numpy(np_noise(1, shape))
     eps = torch.from_numpy(np_noise(2, shape))
     model = lambda a, b: uo.unet_forward(usd, cfg, a, b)  # noqa: E731
-    t0 = time.time()
-    orc.p_sample(model, x, torch.tensor([999]), eps)  # warm-up
-    warm = time.time() - t0
-    n = max(1, min(5, int(budget_s * 0.6 / max(warm, 1e-3))))
-    t0 = time.time()
-    for i in range(n):
-        x = orc.p_sample(model, x, torch.tensor([998 - i]), eps)["sample"]
-    steps_per_s = n / (time.time() - t0)
-    # one small frame of the same grid size
-    Hs = Ws = 48
+
+    def steps(threads, budget):
+        torch.set_num_threads(threads)
+        x = torch.from_numpy(np_noise(1, shape))
+        t0 = time.time()
+        orc.p_sample(model, x, torch.tensor([999]), eps)  # warm-up
+        warm = time.time() - t0
+        n = max(1, min(5, int(budget / max(warm, 1e-3)) - 1))
+        t0 = time.time()
+        for i in range(n):
+            x = orc.p_sample(model, x, torch.tensor([998 - i]), eps)["sample"]
+        return n / (time.time() - t0), n
+
+    # all hardware threads (the 8d definition); torch's CPU conv3d/GEMM often stop scaling far below the thread count of
+    # the GPU box, so a second sample at <=32 threads is taken and the FASTER of the two is the reported baseline
+    by_threads = {}
+    sps, n = steps(hw_threads, budget_s * 0.35)
+    by_threads[hw_threads] = sps
+    if hw_threads > 32:
+        sps2, n2 = steps(32, budget_s * 0.25)
+        by_threads[32] = sps2
+    cores = max(by_threads, key=by_threads.get)
+    steps_per_s = by_threads[cores]
+    torch.set_num_threads(cores)
+    Hs = Ws = 128  # 8d: one 128x128 frame (16 384 rays, 64 + n_fine new samples per ray)
     rcfg = ro.RenderCfg(resol=w["resol"], feature_size=w["feature_size"], image_height=Hs, image_width=Ws)
     grid = torch.tanh(torch.from_numpy(np_noise(7, shape)))
     cams = ro.simple_360_cameras(4)
@@ -118,10 +137,54 @@ def cpu_baseline(w, usd, msd, budget_s=25.0):
     ro.render(grid, msd, {k: v[1:2] for k, v in cams.items()}, rcfg)
     rays_per_s = Hs * Ws / (time.time() - t0)
     return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "rays_per_sec": rays_per_s,
-            "sample": f"{n} oracle DDPM steps (UNet fwd + posterior) at {w['resol']}^3x{w['feature_size']} after 1 "
-                      f"warm-up; one {Hs}x{Ws} frame (64+128 samples/ray) of a {w['resol']}^3 grid; torch CPU, "
-                      f"{cores} threads"}
+            "rays_per_sec": rays_per_s, "host_hw_threads": hw_threads, "host_physical_cores": phys,
+            "steps_per_s_by_threads": {str(k): v for k, v in by_threads.items()},
+            "sample": f"oracle DDPM steps (UNet fwd + posterior) at {w['resol']}^3x{w['feature_size']} after 1 warm-up, "
+                      f"{n} timed at {hw_threads} threads" + (f" and {n2} at 32 threads" if hw_threads > 32 else "")
+                      + f" (reported: {cores} threads, the faster); one {Hs}x{Ws} frame (64 coarse + 128 fine samples"
+                      f"/ray) of a {w['resol']}^3 grid at {cores} threads; torch CPU"}
+
+
+def respawn_under_torchrun(n: int) -> None:
+    """``python bench.py --gpus N`` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args) -> None:
+    """Launch plumbing only (CPU-testable): rendezvous, barrier, max-over-ranks reduction, one JSON line from rank 0
+    with the LIVE world size.  No kernels run and nothing is measured."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if use_gpu else "gloo")
+    dev = "cuda" if use_gpu else "cpu"
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev)
+    pids = [os.getpid()]
+    live = 1
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        live = dist.get_world_size()
+        mine = torch.tensor([os.getpid()], dtype=torch.int64, device=dev)
+        parts = [torch.zeros_like(mine) for _ in range(live)]
+        dist.all_gather(parts, mine)
+        pids = [int(x.item()) for x in parts]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": live, "requested_gpus": args.gpus, "max_over_ranks": float(t.item()),
+                          "pids": pids, "backend": "nccl" if use_gpu else "gloo"}))
 
 
 def main():
@@ -140,12 +203,20 @@ def main():
                     help="f32 = the reported line (reference arithmetic); bf16 = opt-in bf16 products / fp32 accumulate in "
                          "the 3x3x3 convolutions (side measurement for the bf16 configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (rendezvous + reductions), no kernels")
     ap.add_argument("--conv-iters", type=int, default=3)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args.gpus)  # does not return
+    if args.dry_run:
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"# bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting the live world size",
+              file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -192,11 +263,15 @@ def main():
     cams = hda.get_simple_360_camera_trajectory(2 * math.pi, max(F, 2), -30.0 * (2 * math.pi / 360), 10,
                                                 (0.0, -1.0, 0.0), 3.2).to(device)
     vf = torch.clamp(img, -1, 1)
+    cams_f = cams[list(range(F))]
     with torch.no_grad():
-        model.render_views(vf, cams[[0]])  # warm-up (also caches tanh(net_3d(vf, 0)))
+        # warm-up with the SAME camera count as the timed call (workspace, output tensors and the cached
+        # tanh(net_3d(vf, 0)) all reach their steady state before the clock starts)
+        for _ in range(2):
+            model.render_views(vf, cams_f)
         barrier_sync(world)
         t0 = time.perf_counter()
-        out = model.render_views(vf, cams[list(range(F))])
+        out = model.render_views(vf, cams_f)
         barrier_sync(world)
         dtr = time.perf_counter() - t0
     dtr = max_over_ranks(dtr, world, device)
@@ -278,10 +353,10 @@ def main():
             if mode == "f32_bf16x3":  # the renderer has the same opt-in arithmetic
                 model.renderer.compute_dtype = mode
                 with torch.no_grad():
-                    model.render_views(vf, cams[[0]])
+                    model.render_views(vf, cams_f)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    model.render_views(vf, cams[list(range(F))])
+                    model.render_views(vf, cams_f)
                     torch.cuda.synchronize()
                     dtr2 = time.perf_counter() - t0
                 model.renderer.compute_dtype = "f32"

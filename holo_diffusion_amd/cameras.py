@@ -36,18 +36,37 @@ class PerspectiveCameras:
     def __len__(self):
         return self.R.shape[0]
 
+    # A host-side copy of the (tiny) camera parameters travels with the object, so that handing device-resident
+    # cameras to the renderer never costs a device->host synchronisation (the launch parameters are built on the host).
+    def host(self):
+        """(R, T, focal_xy, principal_point) as CPU float32 tensors.  Cached; call ``invalidate_host()`` after
+        modifying the tensors in place."""
+        h = self.__dict__.get("_host")
+        if h is None:
+            h = tuple(t.detach().to("cpu", torch.float32) for t in (self.R, self.T, self.focal_xy(), self.principal_point))
+            self.__dict__["_host"] = h
+        return h
+
+    def invalidate_host(self) -> None:
+        self.__dict__.pop("_host", None)
+
     def __getitem__(self, idx):
         if isinstance(idx, int):
             idx = [idx]
+        had = self.__dict__.get("_host")
         c = PerspectiveCameras.__new__(PerspectiveCameras)
         c.R, c.T = self.R[idx], self.T[idx]
         c.focal_length, c.principal_point = self.focal_length[idx], self.principal_point[idx]
+        if had is not None or not self.R.is_cuda:
+            c.__dict__["_host"] = tuple(t[idx] for t in self.host())
         return c
 
     def to(self, device):
+        host = self.host()  # taken BEFORE the move: free for CPU cameras, one sync for device cameras
         c = PerspectiveCameras.__new__(PerspectiveCameras)
         c.R, c.T = self.R.to(device), self.T.to(device)
         c.focal_length, c.principal_point = self.focal_length.to(device), self.principal_point.to(device)
+        c.__dict__["_host"] = host
         return c
 
     @property

@@ -142,9 +142,11 @@ def load_experiment(exp_dir: str, render_size: Optional[Tuple[int, int]] = None,
                     resume_epoch: int = -1, force_resume: bool = True):
     """Build :class:`HoloDiffusionModel` from ``<exp_dir>/expconfig.yaml`` and load its last checkpoint.
 
-    Returns ``(model, report)``.  ``force_resume`` (the value ``load_experiment`` of the reference sets,
-    checkpoint_utils.py:60) makes a missing checkpoint a ``FileNotFoundError``; with ``force_resume=False`` the model
-    keeps its initialisation like the factory's "starting from scratch" branch."""
+    Returns ``(model, report)``.  Same decision table as ``ImplicitronModelFactory.__call__``
+    (trainer/model_factory.py:96-133): a found checkpoint is loaded when ``force_resume`` (the value
+    ``load_experiment`` of the reference sets, checkpoint_utils.py:60) or the config's ``resume`` flag (default True)
+    is set, otherwise the model keeps its initialisation ("Not resuming -> starting from scratch"); a missing
+    checkpoint is a ``FileNotFoundError`` only under ``force_resume``."""
     from .model import HoloDiffusionModel
     cfg, fn = read_expconfig(exp_dir)
     kw, ignored = model_args_from_expconfig(cfg, render_size)
@@ -159,10 +161,14 @@ def load_experiment(exp_dir: str, render_size: Optional[Tuple[int, int]] = None,
             raise ValueError(f"Cannot find model from epoch {resume_epoch}.")
     else:
         path = find_last_checkpoint(exp_dir)
+    resume = bool(factory.get("resume", True))
     if path is not None:
-        state = torch.load(path, map_location="cpu", weights_only=True)
-        report.checkpoint_file = path
-        load_model_state(model, state, report)
+        if force_resume or resume:
+            state = torch.load(path, map_location="cpu", weights_only=True)
+            report.checkpoint_file = path
+            load_model_state(model, state, report)
+        else:
+            logger.info("Found %s but not resuming -> starting from scratch.", path)
     elif force_resume:
         raise FileNotFoundError(f"Cannot find a checkpoint in {exp_dir}!")
     if device is not None:

@@ -131,11 +131,32 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
                                             progress=loop_kwargs.pop("progress", False), **loop_kwargs)
 
     # ---- render (holo_diffusion_model.py:201-540, evaluation branch) ------------------------
+    def _weights_epoch(self):
+        net = self.net_3d
+        return (getattr(net, "_weights_epoch", 0), getattr(net, "compute_dtype", None), id(net))
+
+    def invalidate_refined_cache(self) -> None:
+        self._refined_cache = None
+
+    def _apply(self, fn, *a, **k):
+        self._refined_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._refined_cache = None
+        return super().load_state_dict(*a, **k)
+
     def _refine(self, voxel_features: torch.Tensor) -> torch.Tensor:
-        """tanh(net_3d(vf, t=0)) (:420-426)."""
-        key = (voxel_features.data_ptr(), voxel_features._version, tuple(voxel_features.shape))
-        if self.cache_refined_features and self._refined_cache is not None and self._refined_cache[0] == key:
-            return self._refined_cache[1]
+        """tanh(net_3d(vf, t=0)) (:420-426).
+
+        The cache HOLDS the input tensor: while it is cached its storage cannot be handed to another tensor by the
+        caching allocator, so identity (``is``) + ``_version`` + the denoiser's weight epoch / compute mode identify
+        the input.  (Grids written through raw pointers by the library are always fresh tensors: holo_ddpm_step and
+        holo_clip never write in place.)"""
+        c = self._refined_cache
+        if (self.cache_refined_features and c is not None and c[0] is voxel_features
+                and c[1] == voxel_features._version and c[2] == self._weights_epoch()):
+            return c[3]
         dev = voxel_features.device
         t0 = torch.zeros((1,), dtype=torch.long, device=dev)
         y = self.net_3d(voxel_features, t0)
@@ -144,7 +165,9 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         _lib.check(L, L.holo_tanh(runtime.ctx(dev), runtime.ptr(y), runtime.ptr(out), y.numel(),
                                   runtime.stream_ptr(dev)), "holo_tanh")
         if self.cache_refined_features:
-            self._refined_cache = (key, out)
+            self._refined_cache = (voxel_features, voxel_features._version, self._weights_epoch(), out)
+        else:
+            self._refined_cache = None
         return out
 
     def forward(self, *, image_rgb=None, camera: PerspectiveCameras, fg_probability=None, mask_crop=None,

@@ -218,6 +218,32 @@ class _NativeRenderMlp:
         self.close()
 
 
+def _camera_array(cams):
+    """HoloCamera[n] launch parameters from a camera batch, built on the host.  ``PerspectiveCameras`` of this package
+    carry a cached host copy (no device synchronisation); any other object with PyTorch3D's ``R, T, focal_length,
+    principal_point`` attributes is accepted and read back with one ``.cpu()`` each."""
+    if hasattr(cams, "host"):
+        Rc, Tc, fc, pc = cams.host()
+    else:
+        def cpu(x, last):
+            return torch.as_tensor(x).detach().to("cpu", torch.float32).reshape(-1, last)
+        Rc = cpu(cams.R, 9)
+        n = Rc.shape[0]
+        f = torch.as_tensor(cams.focal_length)
+        Tc, pc = cpu(cams.T, 3).expand(n, 3), cpu(cams.principal_point, 2).expand(n, 2)
+        fc = cpu(f, 2 if (f.dim() >= 1 and f.shape[-1] == 2) else 1).expand(n, -1)
+        fc = fc.expand(n, 2) if fc.shape[1] == 1 else fc
+    n_cam = Rc.shape[0]
+    arr = (_lib.HoloCamera * n_cam)()
+    Rl, Tl, fl, pl = Rc.reshape(n_cam, 9).tolist(), Tc.tolist(), fc.tolist(), pc.tolist()
+    for i in range(n_cam):
+        arr[i].R[:] = Rl[i]
+        arr[i].T[:] = Tl[i]
+        arr[i].focal[:] = fl[i]
+        arr[i].principal_point[:] = pl[i]
+    return arr
+
+
 class ImplicitFunctionBase(ReplaceableBase):
     @staticmethod
     def allows_multiple_passes() -> bool:
@@ -291,7 +317,7 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         dens = torch.empty(n, device=dev)
         col = torch.empty(n, 3, device=dev)
         nbytes = L.holo_render_workspace_bytes(h, 1) + 12 * dirsf.shape[0] + 256
-        ws = runtime.workspace(dev, f"implicit{id(self)}", nbytes)
+        ws = runtime.workspace(self, dev, nbytes)
         _lib.check(L, L.holo_implicit_eval(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf),
                                            runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens), runtime.ptr(col),
                                            runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_implicit_eval")
@@ -459,24 +485,14 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         cams = ray_bundle.camera
         n_cam = len(cams)
         H, W = ray_bundle.image_height, ray_bundle.image_width
-        arr = (_lib.HoloCamera * n_cam)()
-        Rc, Tc = cams.R.detach().cpu().float(), cams.T.detach().cpu().float()
-        fc, pc = cams.focal_xy().detach().cpu().float(), cams.principal_point.detach().cpu().float()
-        for i in range(n_cam):
-            for j, v in enumerate(Rc[i].reshape(-1).tolist()):
-                arr[i].R[j] = v
-            for j in range(3):
-                arr[i].T[j] = float(Tc[i, j])
-            for j in range(2):
-                arr[i].focal[j] = float(fc[i, j])
-                arr[i].principal_point[j] = float(pc[i, j])
+        arr = _camera_array(cams)
         grid = grid.contiguous().float()
         img = torch.empty(n_cam, 3, H, W, device=dev)
         dep = torch.empty(n_cam, 1, H, W, device=dev)
         msk = torch.empty(n_cam, 1, H, W, device=dev)
         imgc, depc, mskc = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(msk)
         nbytes = L.holo_render_workspace_bytes(h, n_cam)
-        ws = runtime.workspace(dev, f"render{id(self)}", nbytes)
+        ws = runtime.workspace(self, dev, nbytes)
         _lib.check(L, L.holo_render(h, runtime.ptr(grid), arr, n_cam, runtime.ptr(img), runtime.ptr(dep),
                                     runtime.ptr(msk), runtime.ptr(imgc), runtime.ptr(depc), runtime.ptr(mskc),
                                     runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_render")

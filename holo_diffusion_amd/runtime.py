@@ -12,7 +12,6 @@ import torch
 from . import _lib
 
 _CTX: Dict[int, C.c_void_p] = {}
-_WS: Dict[Tuple[int, str], torch.Tensor] = {}
 
 
 def lib() -> C.CDLL:
@@ -44,12 +43,20 @@ def ptr(t: torch.Tensor) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
-def workspace(device: torch.device, tag: str, nbytes: int) -> torch.Tensor:
-    """A cached byte buffer of at least ``nbytes`` for (device, tag)."""
+def workspace(owner, device: torch.device, nbytes: int) -> torch.Tensor:
+    """A byte buffer of at least ``nbytes`` on ``device``, owned by (and released with) ``owner``."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, tag)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _WS[key] = buf
-    return buf
+    held = owner.__dict__.get("_holo_ws")
+    if held is None or held[0] != idx or held[1].numel() < nbytes:
+        held = (idx, torch.empty(int(nbytes), dtype=torch.uint8, device=device))
+        owner.__dict__["_holo_ws"] = held  # bypasses nn.Module.__setattr__: not a buffer, not in the state_dict
+    return held[1]
+
+
+def sync_before_destroy(device) -> None:
+    """Kernels still in flight may read the native handle's private weight copies: drain the device first."""
+    try:
+        if device is not None and torch.cuda.is_available():
+            torch.cuda.synchronize(device)
+    except Exception:
+        pass

@@ -112,23 +112,34 @@ class SimpleUnet3D(Unet3DBase):
         return unet_param_shapes(self.image_size, self.in_channels, self.out_channels, self.model_channels,
                                  self.num_res_blocks, self.channel_mult, self.attention_resolutions)
 
-    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move the tensors: re-bind on next forward
+    def _mark_dirty(self) -> None:
         self._dirty = True
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1  # read by HoloDiffusionModel's refine cache
+
+    def _apply(self, fn, *a, **k):  # .to()/.cuda()/.float() move the tensors: re-bind on next forward
+        self._mark_dirty()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._dirty = True
+        self._mark_dirty()
         return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        # a PARENT module's load_state_dict (e.g. HoloDiffusionModel) recurses through _load_from_state_dict of every
+        # sub-module and never calls the child's load_state_dict: this is the hook that sees those loads
+        self._mark_dirty()
+        return super()._load_from_state_dict(*a, **k)
 
     def mark_parameters_changed(self) -> None:
         """Call after modifying parameter tensors in place so the library re-packs its private copies."""
-        self._dirty = True
+        self._mark_dirty()
 
     # ---- native handle --------------------------------------------------------------------
     def _ensure_handle(self, device: torch.device) -> C.c_void_p:
         L = runtime.lib()
         if self._handle is None or self._handle_device != device:
             if self._handle is not None:
+                runtime.sync_before_destroy(self._handle_device)
                 L.holo_unet_destroy(self._handle)
             h = C.c_void_p()
             cfg = self._cfg_struct()
@@ -170,6 +181,7 @@ class SimpleUnet3D(Unet3DBase):
     def __del__(self):
         try:
             if self._handle is not None:
+                runtime.sync_before_destroy(self._handle_device)
                 runtime.lib().holo_unet_destroy(self._handle)
         except Exception:
             pass
@@ -191,7 +203,7 @@ class SimpleUnet3D(Unet3DBase):
         if t.shape != (B,):
             raise _lib.HoloError("SimpleUnet3D.forward: timesteps must have shape (N,)")
         nbytes = L.holo_unet_workspace_bytes(h, B)
-        ws = runtime.workspace(dev, f"unet{id(self)}", nbytes)
+        ws = runtime.workspace(self, dev, nbytes)
         y = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=dev)
         _lib.check(L, L.holo_unet_forward(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
                                           ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
@@ -204,7 +216,7 @@ class SimpleUnet3D(Unet3DBase):
             raise _lib.HoloError("fetch_block: no forward has run yet")
         dev = self._handle_device
         L = runtime.lib()
-        ws = runtime.workspace(dev, f"unet{id(self)}", 0)
+        ws = runtime.workspace(self, dev, 0)
         dst = torch.empty(tuple(shape), device=dev)
         n = C.c_int64()
         _lib.check(L, L.holo_unet_fetch_block(self._handle, tag.encode(), runtime.ptr(dst), dst.numel(), C.byref(n),
@@ -220,7 +232,7 @@ class SimpleUnet3D(Unet3DBase):
         h = self._ensure_handle(device)
         L = runtime.lib()
         nbytes = L.holo_unet_workspace_bytes(h, batch)
-        ws = runtime.workspace(device, f"unet{id(self)}", nbytes)
+        ws = runtime.workspace(self, device, nbytes)
         ms, fl, nl = C.c_float(), C.c_double(), C.c_int()
         _lib.check(L, L.holo_unet_time_convs(h, batch, runtime.ptr(ws), ws.numel(), iters, runtime.stream_ptr(device),
                                              C.byref(ms), C.byref(fl), C.byref(nl)), "holo_unet_time_convs")
@@ -235,7 +247,7 @@ class SimpleUnet3D(Unet3DBase):
         h = self._ensure_handle(device)
         L = runtime.lib()
         nbytes = L.holo_unet_workspace_bytes(h, batch)
-        ws = runtime.workspace(device, f"unet{id(self)}", nbytes)
+        ws = runtime.workspace(self, device, nbytes)
         R = self.image_size
         x = torch.randn(batch, self.in_channels, R, R, R, device=device)
         y = torch.empty(batch, self.out_channels, R, R, R, device=device)

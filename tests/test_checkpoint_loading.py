@@ -144,3 +144,24 @@ def test_wrong_model_class_is_rejected(exp_dir):
     cfg["model_factory_ImplicitronModelFactory_args"]["model_class_type"] = "GenericModel"
     with pytest.raises(ValueError):
         ck.model_args_from_expconfig(cfg)
+
+
+def test_resume_flags_follow_the_model_factory(exp_dir):
+    """trainer/model_factory.py:96-133: a found checkpoint is loaded iff force_resume or the config's `resume`."""
+    model, _ = ck.load_experiment(exp_dir, force_resume=False)
+    sd = _reference_like_state(model, 11)
+    torch.save(sd, os.path.join(exp_dir, "model_epoch_00000002.pth"))
+    k0 = next(k for k in sd if k.startswith("net_3d."))
+    # resume: true in the config -> loaded even without force_resume
+    m1, r1 = ck.load_experiment(exp_dir, force_resume=False)
+    assert r1.checkpoint_file is not None and torch.equal(m1.state_dict()[k0], sd[k0])
+    # resume: false and no force_resume -> "Not resuming -> starting from scratch"
+    cfg = _expconfig()
+    cfg["model_factory_ImplicitronModelFactory_args"]["resume"] = False
+    with open(os.path.join(exp_dir, "expconfig.yaml"), "w") as f:
+        yaml.safe_dump(cfg, f)
+    m2, r2 = ck.load_experiment(exp_dir, force_resume=False)
+    assert r2.checkpoint_file is None and not torch.equal(m2.state_dict()[k0], sd[k0])
+    # force_resume (what the reference's load_experiment sets) overrides resume: false
+    m3, r3 = ck.load_experiment(exp_dir)
+    assert r3.checkpoint_file is not None and torch.equal(m3.state_dict()[k0], sd[k0])

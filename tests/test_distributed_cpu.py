@@ -43,3 +43,23 @@ def test_gather_frames_gloo_world2():
         for p in procs:
             p.join(timeout=60)
         assert res == [(0, True), (1, True)]
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` with no launcher must start 2 ranks itself and report the LIVE world size
+    (--dry-run: rendezvous + reductions only, gloo on CPU here, RCCL on the GPU node)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["requested_gpus"] == 2 and line["max_over_ranks"] == 2.0
+    assert len(set(line["pids"])) == 2
+    # a single-rank run reports 1
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dry-run"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert json.loads(res.stdout.strip().splitlines()[-1])["n_gpus"] == 1

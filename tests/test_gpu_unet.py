@@ -42,7 +42,7 @@ def test_tiny_unet_vs_reference_golden(gu, golden_dir):
         x = seeded_input(TINY_CFG, 7 + 500).to(gu.DEV)
         net(x, torch.tensor([500], device=gu.DEV))
         L = runtime.lib()
-        ws = runtime.workspace(gu.DEV, f"unet{id(net)}", 0)
+        ws = runtime.workspace(net, gu.DEV, 0)
         for k in g.files:
             if not k.startswith("t500.") or k in ("t500.y", "t500.emb"):
                 continue
