@@ -5,7 +5,8 @@ Plugin surface (same names as the reference's Implicitron plugins, SURVEY.md §8
 ``HoloMultiPassEmissionAbsorptionRenderer``, ``HoloDiffusionModel``; all arithmetic runs in
 ``libholo_mi355x.so`` (C ABI in ``include/holo_abi.h``).  There is no CPU fallback.
 """
-from .registry import registry, get_default_args, Configurable, ReplaceableBase  # noqa: F401
+from .registry import (registry, get_default_args, config_fields, Configurable, ReplaceableBase,  # noqa: F401
+                       HAVE_PYTORCH3D, pytorch3d_registered)
 from .unet import SimpleUnet3D, Unet3DBase  # noqa: F401
 from .diffusion import ImplicitronGaussianDiffusion, ModelMeanType, ModelVarType  # noqa: F401
 from .render import (  # noqa: F401

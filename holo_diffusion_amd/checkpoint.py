@@ -24,6 +24,8 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import yaml
 
+from .registry import config_fields
+
 logger = logging.getLogger(__name__)
 
 MODEL_FACTORY_KEY = "model_factory_ImplicitronModelFactory_args"
@@ -55,7 +57,7 @@ def read_expconfig(exp_dir_or_file: str) -> Tuple[Dict[str, Any], str]:
 
 
 def _filter_fields(cls, args: Optional[Dict[str, Any]], where: str, ignored: List[str]) -> Dict[str, Any]:
-    fields = cls.config_fields()
+    fields = config_fields(cls)
     out = {}
     for k, v in (args or {}).items():
         if k in fields:

@@ -59,14 +59,69 @@ def gather_frames(local: Dict[int, torch.Tensor], num_items: int, frame_shape: S
 
 
 @torch.no_grad()
-def render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
-                     camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
-                     hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
-                     device: torch.device = torch.device("cuda"), progressive_sampling_steps_per_render: int = -1,
-                     voxel_features: Optional[torch.Tensor] = None, batched: bool = True,
-                     sampler_kwargs: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+def render_flyaround(*args, **kwargs) -> Dict[str, torch.Tensor]:
     """Sample (unless ``voxel_features`` is given) and render one fly-around.  Returns stacked
-    ``images_render (n,3,H,W)``, ``depths_render``, ``masks_render (n,1,H,W)`` and ``voxel_features``."""
+    ``images_render (n,3,H,W)``, ``depths_render``, ``masks_render (n,1,H,W)`` and ``voxel_features``.
+
+    Two call forms are accepted:
+      * ``render_flyaround(model, n_flyaround_poses=..., ...)`` - the form the drivers of this package use;
+      * the reference's signature (flyaround.py:44-80)
+        ``render_flyaround(dataset, sequence_name, model, output_video_path, ..., sample_mode=True, ...)``:
+        ``dataset`` may be ``None`` in sample mode (flyaround.py:150-153), ``trajectory_type`` must be ``simple_360``
+        (the only one that needs no training cameras), displayable frames go to ``output_video_frames_dir`` (or next
+        to ``output_video_path``); video encoding / visdom are outside the path.  Reconstruction mode
+        (``sample_mode=False``) needs the encoder side and raises."""
+    first = args[0] if args else kwargs.get("model", kwargs.get("dataset"))
+    if isinstance(first, torch.nn.Module) and "sequence_name" not in kwargs:
+        return _render_flyaround(*args, **kwargs)
+    return _render_flyaround_reference_form(*args, **kwargs)
+
+
+def _render_flyaround_reference_form(dataset=None, sequence_name: str = "sample", model=None, output_video_path: str = "",
+                                     output_video_name: Optional[str] = None, n_flyaround_poses: int = 40, fps: int = 20,
+                                     trajectory_type: str = "circular_lsq_fit", max_angle: float = 2 * math.pi,
+                                     trajectory_scale: float = 1.1, scene_center=(0.0, 0.0, 0.0),
+                                     up=(0.0, -1.0, 0.0), camera_elevation: float = -30.0 * (2 * math.pi / 360),
+                                     camera_focal_length: float = 3.2, hemispherical_radius: float = 10,
+                                     traj_offset: float = 0.0, n_source_views: int = 9, visdom_show_preds: bool = False,
+                                     visdom_environment: str = "render_flyaround", visdom_server: str = "",
+                                     visdom_port: int = 8097, num_workers: int = 10, device="cuda", seed=None,
+                                     video_resize=None, output_video_frames_dir: Optional[str] = None,
+                                     sample_mode: bool = False, progressive_sampling_steps_per_render: int = -1,
+                                     visualize_preds_keys=("images_render", "masks_render", "depths_render"),
+                                     save_voxel_features: bool = False) -> Dict[str, torch.Tensor]:
+    if model is None:
+        raise TypeError("render_flyaround: `model` is required")
+    if not sample_mode:
+        raise NotImplementedError("render_flyaround(sample_mode=False): reconstruction of a dataset sequence needs the "
+                                  "encoder / view-pooling side (SURVEY.md 8f-3), which is outside this path")
+    if trajectory_type.lower() != "simple_360":
+        raise NotImplementedError(f"trajectory_type '{trajectory_type}' is fitted to training cameras; sample mode on "
+                                  "this path supports 'simple_360' (flyaround.py:176-184)")
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    out = _render_flyaround(model, n_flyaround_poses=n_flyaround_poses, up=tuple(up), camera_elevation=camera_elevation,
+                            camera_focal_length=camera_focal_length, hemispherical_radius=hemispherical_radius,
+                            max_angle=max_angle, device=dev,
+                            progressive_sampling_steps_per_render=progressive_sampling_steps_per_render)
+    name = output_video_name or sequence_name
+    frames_dir = output_video_frames_dir or (os.path.dirname(output_video_path) if output_video_path else None)
+    if frames_dir:
+        from .flyaround_output import export_flyaround_frames
+        os.makedirs(frames_dir, exist_ok=True)
+        export_flyaround_frames({k: v for k, v in out.items() if k in tuple(visualize_preds_keys)}, frames_dir, name)
+        if save_voxel_features and out.get("voxel_features") is not None:  # flyaround.py:288-294
+            torch.save(out["voxel_features"], os.path.join(frames_dir, f"{sequence_name}_voxel_features.pth"))
+    return out
+
+
+def _render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
+                      camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
+                      hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
+                      device: torch.device = torch.device("cuda"), progressive_sampling_steps_per_render: int = -1,
+                      voxel_features: Optional[torch.Tensor] = None, batched: bool = True,
+                      sampler_kwargs: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     cams = get_simple_360_camera_trajectory(max_angle, n_flyaround_poses, camera_elevation, hemispherical_radius, up,
                                             camera_focal_length).to(device)
     sampler_kwargs = dict(sampler_kwargs or {})
@@ -93,6 +148,35 @@ def render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float,
     out = {k: torch.cat(v, dim=0) for k, v in frames.items()}
     out["voxel_features"] = voxel_features
     return out
+
+
+@torch.no_grad()
+def render_progressive_turntable(model, n_views: int = 30, steps_per_render: int = 1,
+                                 up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
+                                 camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
+                                 hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
+                                 device: torch.device = torch.device("cuda"), sampler_kwargs: Optional[dict] = None):
+    """BASELINE configs[3] / SURVEY.md 8d config 4: the WHOLE ``n_views`` turntable after every ``steps_per_render``
+    denoising steps (progressive semantics of flyaround.py:236-245, with all cameras per step instead of one).  The
+    refinement ``tanh(net_3d(vf, 0))`` runs once per step and all cameras go into one batched render call.
+    Generator of dicts ``images_render (n_views,3,H,W)``, ``depths_render``, ``masks_render``, ``voxel_features``."""
+    cams = get_simple_360_camera_trajectory(max_angle, n_views, camera_elevation, hemispherical_radius, up,
+                                            camera_focal_length).to(device)
+    gen = model.sample_random_voxel_features_progressive(**dict(sampler_kwargs or {}))
+    done = False
+    while not done:
+        vf = None
+        for _ in range(max(1, steps_per_render)):
+            try:
+                vf = next(gen)
+            except StopIteration:
+                done = True
+                break
+        if vf is None:
+            break
+        out = model.render_views(vf, cams)
+        out["voxel_features"] = vf
+        yield out
 
 
 @torch.no_grad()

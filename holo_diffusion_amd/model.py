@@ -24,7 +24,7 @@ import torch
 from . import _lib, runtime
 from .cameras import PerspectiveCameras
 from .diffusion import ImplicitronGaussianDiffusion
-from .registry import ReplaceableBase, apply_config, get_default_args, registry
+from .registry import apply_config, get_default_args, pt3d_base, registry
 from .render import (AdaptiveRaySampler, BaseRenderer, EvaluationMode, HoloMultiPassEmissionAbsorptionRenderer,
                      HoloVoxelGridImplicitFunction, ImplicitFunctionBase, ImplicitFunctionWrapper, RenderSamplingMode)
 from .unet import SimpleUnet3D, Unet3DBase
@@ -32,8 +32,9 @@ from .unet import SimpleUnet3D, Unet3DBase
 logger = logging.getLogger(__name__)
 
 
-class ImplicitronModelBase(ReplaceableBase):
-    pass
+# pytorch3d.implicitron.models.base_model.ImplicitronModelBase when PyTorch3D is importable (so that Implicitron's
+# ModelFactory resolves `model_class_type: HoloDiffusionModel` to the class below), a stand-in otherwise
+ImplicitronModelBase = pt3d_base("implicitron.models.base_model", "ImplicitronModelBase")
 
 
 @registry.register

@@ -26,7 +26,7 @@ import torch
 
 from . import _lib, runtime
 from .cameras import PerspectiveCameras
-from .registry import Configurable, ReplaceableBase, apply_config, registry
+from .registry import Configurable, apply_config, pt3d_base, registry
 
 COLOUR_DIMS = 3
 
@@ -244,10 +244,8 @@ def _camera_array(cams):
     return arr
 
 
-class ImplicitFunctionBase(ReplaceableBase):
-    @staticmethod
-    def allows_multiple_passes() -> bool:
-        return False
+# PyTorch3D's own plugin bases when importable (registry keys of Implicitron's factories), stand-ins otherwise
+ImplicitFunctionBase = pt3d_base("implicitron.models.implicit_function.base", "ImplicitFunctionBase")
 
 
 @registry.register
@@ -374,8 +372,7 @@ class AdaptiveRaySampler(Configurable):
                                     scene_center=tuple(self.scene_center))
 
 
-class BaseRenderer(ReplaceableBase):
-    pass
+BaseRenderer = pt3d_base("implicitron.models.renderer.base", "BaseRenderer")
 
 
 @registry.register

@@ -272,28 +272,48 @@ def refine_lengths(lengths: torch.Tensor, weights: torch.Tensor, cfg: RenderCfg)
 
 
 @torch.no_grad()
-def render(grid: torch.Tensor, sd: Dict[str, torch.Tensor], cam: dict, cfg: RenderCfg, prefix: str = "",
-           chunk_rays: int = 4096, return_coarse: bool = False) -> Dict[str, torch.Tensor]:
-    """Full two-pass render of one camera.  Returns images (1,3,H,W), depths (1,1,H,W), masks (1,1,H,W)."""
-    origins, dirs, lengths = make_rays(cam, cfg)
-    outs = {k: [] for k in ("rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c", "fine_lengths")}
+def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.Tensor, dirs: torch.Tensor,
+                lengths: torch.Tensor, cfg: RenderCfg, prefix: str = "", chunk_rays: int = 4096,
+                with_normals: bool = False) -> Dict[str, torch.Tensor]:
+    """Two-pass render of an ARBITRARY set of rays (origins (n,3), directions (n,3), coarse lengths (n,P)): coarse pass
+    -> refiner -> fine pass (holo_multipass_ea.py:79-125).  Per-ray outputs: rgb (n,3), depth (n,1), mask (n,1), the
+    coarse-pass rgb_c / depth_c / mask_c and the sorted fine lengths; with ``with_normals`` also the rendered normals
+    of both passes, sum_i w_i n_i (holo_multipass_ea.py:105-109)."""
+    keys = ["rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c", "fine_lengths"] + (["normals", "normals_c"] if with_normals else [])
+    outs = {k: [] for k in keys}
     for s in range(0, origins.shape[0], chunk_rays):
         o, d, l = origins[s:s + chunk_rays], dirs[s:s + chunk_rays], lengths[s:s + chunk_rays]
         dens, col = implicit_function(grid, sd, o, d, l, cfg, prefix)
         rgb_c, dep_c, msk_c, w = ea_raymarch(dens, col, l, cfg)
         lf = refine_lengths(l, w, cfg)
         dens, col = implicit_function(grid, sd, o, d, lf, cfg, prefix)
-        rgb, dep, msk, _ = ea_raymarch(dens, col, lf, cfg)
-        for k, v in (("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c),
-                     ("mask_c", msk_c), ("fine_lengths", lf)):
+        rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg)
+        vals = [("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c), ("mask_c", msk_c),
+                ("fine_lengths", lf)]
+        if with_normals:
+            n_c = implicit_normals(grid, sd, o[:, None, :] + l[:, :, None] * d[:, None, :], cfg, prefix)
+            n_f = implicit_normals(grid, sd, o[:, None, :] + lf[:, :, None] * d[:, None, :], cfg, prefix)
+            vals += [("normals_c", (n_c * w[..., None]).sum(dim=-2)), ("normals", (n_f * wf[..., None]).sum(dim=-2))]
+        for k, v in vals:
             outs[k].append(v)
+    return {k: torch.cat(v) for k, v in outs.items()}
+
+
+@torch.no_grad()
+def render(grid: torch.Tensor, sd: Dict[str, torch.Tensor], cam: dict, cfg: RenderCfg, prefix: str = "",
+           chunk_rays: int = 4096, return_coarse: bool = False, with_normals: bool = False) -> Dict[str, torch.Tensor]:
+    """Full two-pass render of one camera.  Returns images (1,3,H,W), depths (1,1,H,W), masks (1,1,H,W)."""
+    origins, dirs, lengths = make_rays(cam, cfg)
+    cat = render_rays(grid, sd, origins, dirs, lengths, cfg, prefix, chunk_rays, with_normals)
     H, W = cfg.image_height, cfg.image_width
-    cat = {k: torch.cat(v) for k, v in outs.items()}
     res = {
         "images_render": cat["rgb"].reshape(1, H, W, 3).permute(0, 3, 1, 2).contiguous(),
         "depths_render": cat["depth"].reshape(1, H, W, 1).permute(0, 3, 1, 2).contiguous(),
         "masks_render": cat["mask"].reshape(1, H, W, 1).permute(0, 3, 1, 2).contiguous(),
     }
+    if with_normals:
+        res["normals_render"] = cat["normals"].reshape(1, H, W, 3).permute(0, 3, 1, 2).contiguous()
+        res["normals_coarse"] = cat["normals_c"].reshape(1, H, W, 3).permute(0, 3, 1, 2).contiguous()
     if return_coarse:
         res["images_coarse"] = cat["rgb_c"].reshape(1, H, W, 3).permute(0, 3, 1, 2).contiguous()
         res["depths_coarse"] = cat["depth_c"].reshape(1, H, W, 1).permute(0, 3, 1, 2).contiguous()

@@ -18,12 +18,47 @@ def golden_dir():
     return os.path.join(REPO, "tests", "golden")
 
 
+EMU = os.environ.get("HOLO_TEST_EMU") == "1"
+
+
+def _enable_emulation():
+    """TEST-ONLY (HOLO_TEST_EMU=1): run the `-m gpu` tests of tiny sizes in the GPU-less development container by
+    pointing the ctypes binding at tests/emu/libholo_emu.so (the same kernel sources compiled for host threads) and
+    letting the plugin classes work on CPU tensors.  Never active in the product or on the GPU box."""
+    import ctypes
+
+    import torch
+
+    from holo_diffusion_amd import _lib, runtime
+    emu = os.path.join(REPO, "tests", "emu", "libholo_emu.so")
+    if not os.path.isfile(emu):
+        raise RuntimeError("HOLO_TEST_EMU=1 needs `make -C holo_diffusion_amd/csrc emu`")
+    _lib._LIB = _lib.bind(ctypes.CDLL(emu))
+    runtime.require_device = lambda *a, **k: None
+    runtime.stream_ptr = lambda device=None: ctypes.c_void_p(None)
+    runtime.sync_before_destroy = lambda device=None: None
+    torch.cuda.current_device = lambda: 0
+
+    class _NoStream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+
+    torch.cuda.current_stream = lambda device=None: _NoStream()
+    torch.cuda.synchronize = lambda device=None: None
+
+
+if EMU:
+    _enable_emulation()
+
+
 def pytest_collection_modifyitems(config, items):
     """gpu-marked tests are SKIPPED (not failed) on a machine without an MI355X or without the built library, so a
     plain `pytest tests` works everywhere; `-m gpu` on the GPU box runs them."""
     import torch
     lib = os.path.join(REPO, "holo_diffusion_amd", "libholo_mi355x.so")
-    if torch.cuda.is_available() and os.path.isfile(lib):
+    if EMU or (torch.cuda.is_available() and os.path.isfile(lib)):
         return
     why = "no HIP device" if not torch.cuda.is_available() else "libholo_mi355x.so is not built"
     skip = pytest.mark.skip(reason=f"gpu test: {why}")

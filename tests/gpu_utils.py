@@ -6,7 +6,10 @@ from holo_diffusion_amd.weights import synth_state_dict
 from oracle import render_oracle as ro
 from oracle import unet_oracle as uo
 
-DEV = torch.device("cuda", 0)
+import os
+
+# HOLO_TEST_EMU=1 (tests/conftest.py): the same tests on the host emulation of the kernels, CPU tensors
+DEV = torch.device("cpu") if os.environ.get("HOLO_TEST_EMU") == "1" else torch.device("cuda", 0)
 
 
 def make_unet(cfg: uo.UNetCfg, seed: int = 1234, compute_dtype: str = "f32"):
