@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
 HOLO_DTYPE_F32_BF16X3 = 2
+ABI_VERSION = 2  # include/holo_abi.h HOLO_ABI_VERSION
 
 
 class HoloError(RuntimeError):
@@ -85,8 +86,8 @@ SIGNATURES = {
     "holo_renderer_set_param": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, C.c_int, _i64p, _vp]),
     "holo_renderer_commit": (C.c_int, [_vp, _vp]),
     "holo_renderer_set_compute_dtype": (C.c_int, [_vp, C.c_int]),
-    "holo_render_workspace_bytes": (C.c_size_t, [_vp, C.c_int]),
-    "holo_render": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "holo_render_workspace_bytes": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "holo_render": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, _vp]),
     "holo_implicit_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_implicit_normals": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, _vp]),

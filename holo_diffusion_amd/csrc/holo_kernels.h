@@ -4,6 +4,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// per-device context of the C ABI (holo_ctx_create)
+struct HoloCtx {
+  int device;
+  int num_cus;
+};
+
 namespace holo {
 
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +176,7 @@ struct RenderKernelParams {
     float Rm[9], T[3], focal[2], pp[2];
     float zmin, zmax;
   };
-  static constexpr int MAX_CAMS = 8;
+  static constexpr int MAX_CAMS = 32;
   Cam cams[MAX_CAMS];
   int n_cams;
   int H, W;
@@ -179,11 +185,14 @@ struct RenderKernelParams {
   float bg[3];
   float background_opacity;
   float pdf_eps;
-  // scratch, per wave (n_cams * 4 * ceil(H*W/128) waves): cdf_ws 64*64 floats (per-lane coarse weights / CDF columns),
-  // val_ws (64 + n_fine)*32 float4 (sigma, rgb of coarse and importance samples), fz_ws n_fine*32 floats
-  float* cdf_ws;
+  // persistent launch: n_tiles = n_cams * ceil(H*W/32) wave tiles, walked by gridDim.x * (waves per workgroup) resident
+  // waves; xcd > 1: XCD-aware tile order (workgroup b is taken to sit on XCD b % xcd)
+  int64_t n_tiles;
+  int xcd;
+  // scratch, one slot per RESIDENT wave: val_ws 64*32 float4 (sigma, rgb of the coarse samples); nrm_ws the same for
+  // their normals (null: normals are not rendered)
   float* val_ws;
-  float* fz_ws;
+  float* nrm_ws;
   // outputs (per camera): CHW planes
   float* rgb;
   float* depth;
@@ -191,7 +200,9 @@ struct RenderKernelParams {
   float* rgb_c;  // may be null
   float* depth_c;
   float* mask_c;
-  unsigned long long* dbg;  // optional per-wave phase timestamps [wave][8] (HOLO_RENDER_TIMELINE=1); null in production
+  float* nrm;    // rendered normals sum_i w_i n_i (n_cams,3,H,W), fine / coarse pass; may be null
+  float* nrm_c;
+  unsigned long long* dbg;  // optional per-slot phase clocks [slot][8] (HOLO_RENDER_TIMELINE=1); null in production
   int split3;  // 1: RenderMLP products on the bf16 matrix cores from an exact 3-term bf16 split (feature_size 32 only)
 };
 
@@ -212,6 +223,7 @@ struct ImplicitEvalParams {
 };
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
-int render_launch(const RenderKernelParams& p, void* stream);
+int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);
+int render_waves_per_wg(int C, int n_fine);
 
 }  // namespace holo

@@ -21,7 +21,7 @@
 // arbitrary points (holo_voxel_grid_implicit_function.py:182-269, incl. the pts_3d entry the reference's
 // tests use).
 //
-// Mapping: block = 4 waves, wave = 32 rays/points; lanes l and l+32 share item (l&31) and split the
+// Mapping: wave = 32 rays/points; lanes l and l+32 share item (l&31) and split the
 // feature channels in halves (lane half h owns channels [h*CH, h*CH+CH)), which is exactly the k index of
 // v_mfma_f32_32x32x2_f32.  Per step a wave evaluates 32 samples:
 //   D[hidden][sample] += W_eff[hidden][ch] * f[sample][ch]   (A = weights from LDS, B = the lane's own
@@ -74,14 +74,14 @@ __device__ __forceinline__ int lane_channel(int h, int k) {
 }
 
 template <int CH, bool SP>
-__device__ __forceinline__ void stage_mlp(MlpLds<CH, SP>& L, const MlpParams& m, int tid) {
+__device__ __forceinline__ void stage_mlp(MlpLds<CH, SP>& L, const MlpParams& m, int tid, int nthr = 256) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
   if (SP) {
     static_assert(!SP || CH == 16, "the split renderer is built for feature_size 32");
     uint32_t* wb = reinterpret_cast<uint32_t*>(L.w);
     constexpr int WPL = HD * (C / 2);
-    for (int i = tid; i < HD * (C / 2); i += 256) {  // one channel pair per step
+    for (int i = tid; i < HD * (C / 2); i += nthr) {  // one channel pair per step
       const int row = i / (C / 2), cp = i - row * (C / 2);
       const int c = 2 * cp;
       const float x0 = m.w_feat[row * C + c], x1 = m.w_feat[row * C + c + 1];
@@ -94,12 +94,12 @@ __device__ __forceinline__ void stage_mlp(MlpLds<CH, SP>& L, const MlpParams& m,
       wb[2 * WPL + word] = l;
     }
   } else {
-    for (int i = tid; i < HD * (C / 4); i += 256) {
+    for (int i = tid; i < HD * (C / 4); i += nthr) {
       const int row = i / (C / 4), c4 = i - row * (C / 4);
       *reinterpret_cast<float4*>(L.w + row * LDW + c4 * 4) = *reinterpret_cast<const float4*>(m.w_feat + row * C + c4 * 4);
     }
   }
-  for (int i = tid; i < NTILE * 2 * 16; i += 256) {
+  for (int i = tid; i < NTILE * 2 * 16; i += nthr) {
     const int r = i & 15, h = (i >> 4) & 1, t = i >> 5;
     const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
     L.bias[i] = m.b_feat[row];
@@ -107,7 +107,7 @@ __device__ __forceinline__ void stage_mlp(MlpLds<CH, SP>& L, const MlpParams& m,
     L.wr[1][i] = 0.4f * m.w_rad[1 * HD + row];
     L.wr[2][i] = 0.4f * m.w_rad[2 * HD + row];
   }
-  for (int i = tid; i < 2 * 4 * CH; i += 256) {
+  for (int i = tid; i < 2 * 4 * CH; i += nthr) {
     const int k = i % CH, j = (i / CH) & 3, h = i / (4 * CH);
     const int ch = lane_channel<CH, SP>(h, k);
     L.u[i] = (j == 0) ? m.w_dens[ch] : m.u_rad[(j - 1) * C + ch];
@@ -139,13 +139,18 @@ __device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy,
 
 // One sample of the implicit function for the lane's item: world point -> raw density, colour.
 // gbase already points at the lane half's first channel (grid + lane_channel(lh, 0)).
-template <int CH, bool SP = false>
+// NRM: also the normal of the density field at the point, normalize(d density / d point) (RenderMLP.get_normals,
+// holo_voxel_grid_implicit_function.py:131-145): the density pre-activation is affine in the interpolated features, so
+// its gradient follows from the eight per-corner scalars s_c = w_dens . F_c and the derivatives of the trilinear
+// weights (zero for corners outside the grid, like grid_sample's backward), times LeakyReLU'.
+template <int CH, bool SP = false, bool NRM = false>
 __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ gbase, int R, float Rm1,
                                            float half_extent, float b_dens, int li, int lh, float px, float py,
                                            float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
-                                           float& cb) {
+                                           float& cb, float* nrm = nullptr) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
+  float gx = 0.f, gy = 0.f, gz = 0.f;  // NRM: this lane half's part of d(pre-activation)/d(voxel index)
   // On gfx950 the fp32 MFMA runs on the same FMA lanes as ordinary vector instructions (tools/coexec_probe.cpp:
   // MFMA waves and VALU waves of one SIMD do not overlap), so every VALU instruction here costs MFMA time.  All
   // per-channel / per-row arithmetic is therefore written on register PAIRS (v_pk_fma_f32: two fmaf per instruction).
@@ -170,6 +175,16 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
     const int xa = max(x0, 0), xb = min(x0 + 1, R - 1);
     const int ya = max(y0, 0), yb = min(y0 + 1, R - 1);
     const int za = max(z0, 0), zb = min(z0 + 1, R - 1);
+    // NRM: derivative of the per-axis weights w.r.t. the voxel index (piecewise constant, zero outside the grid)
+    const float dxa = (NRM && fx0 >= 0.f && fx0 <= Rm1) ? -1.f : 0.f;
+    const float dxb = (NRM && fx0 >= -1.f && fx0 <= Rm1 - 1.f) ? 1.f : 0.f;
+    const float dya = (NRM && fy0 >= 0.f && fy0 <= Rm1) ? -1.f : 0.f;
+    const float dyb = (NRM && fy0 >= -1.f && fy0 <= Rm1 - 1.f) ? 1.f : 0.f;
+    const float dza = (NRM && fz0 >= 0.f && fz0 <= Rm1) ? -1.f : 0.f;
+    const float dzb = (NRM && fz0 >= -1.f && fz0 <= Rm1 - 1.f) ? 1.f : 0.f;
+    int lhn = lh;
+    if (NRM) HOLO_LAUNDER(lhn);
+    const float4* wdp = reinterpret_cast<const float4*>(L.u + lhn * 4 * CH);  // the lane half's slice of the density row
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
       const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
@@ -177,11 +192,23 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
       const int xx = dx ? xb : xa, yy = dy ? yb : ya, zz = dz ? zb : za;
       const float4* g = reinterpret_cast<const float4*>(gbase + ((int64_t)(zz * R + yy) * R + xx) * C);
       const f32x2 w2 = f32x2{w, w};
+      f32x2 sc2 = f32x2{0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < CH / 4; ++v) {
         const float4 t = g[SP ? 4 * (v >> 1) + (v & 1) : v];  // SP: 8 channels of every 16-channel k-step
         fv[2 * v + 0] = pk_fma(w2, f32x2{t.x, t.y}, fv[2 * v + 0]);
         fv[2 * v + 1] = pk_fma(w2, f32x2{t.z, t.w}, fv[2 * v + 1]);
+        if (NRM) {
+          const float4 wd = wdp[v];
+          sc2 = pk_fma(f32x2{wd.x, wd.y}, f32x2{t.x, t.y}, sc2);
+          sc2 = pk_fma(f32x2{wd.z, wd.w}, f32x2{t.z, t.w}, sc2);
+        }
+      }
+      if (NRM) {
+        const float sc = sc2.x + sc2.y;
+        gx = fmaf(((dx ? dxb : dxa) * (dy ? wyb : wya)) * (dz ? wzb : wza), sc, gx);
+        gy = fmaf(((dx ? wxb : wxa) * (dy ? dyb : dya)) * (dz ? wzb : wza), sc, gy);
+        gz = fmaf(((dx ? wxb : wxa) * (dy ? wyb : wya)) * (dz ? dzb : dza), sc, gz);
       }
     }
   }
@@ -299,15 +326,50 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
   cr = fast_sigmoid(leaky02(rp0 + rdir[0]));
   cg = fast_sigmoid(leaky02(rp1 + rdir[1]));
   cb = fast_sigmoid(leaky02(rp2 + rdir[2]));
+  if (NRM) {
+    gx += __shfl_xor(gx, 32);
+    gy += __shfl_xor(gy, 32);
+    gz += __shfl_xor(gz, 32);
+    // chain rule: LeakyReLU'(pre-activation) * d(voxel index)/d(world point); both factors positive, kept so that
+    // F.normalize's eps acts as in torch
+    const float k = ((dpart + b_dens) > 0.f ? 1.f : 0.2f) * (0.5f * Rm1 / half_extent);
+    gx *= k;
+    gy *= k;
+    gz *= k;
+    const float nn = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+    nrm[0] = gx / nn;
+    nrm[1] = gy / nn;
+    nrm[2] = gz / nn;
+  }
 }
 
-// The per-ray coarse weights / CDF (64 floats per ray) live in a global scratch, one private column per LANE
-// ([workgroup][wave][j][lane], L2-resident, coalesced when the lanes share j): keeping them in LDS (32 KB per
-// workgroup) capped the kernel at two workgroups per CU and left the matrix pipe idle whenever both resident
-// waves of a SIMD were in their gather / VALU phases.
-template <int CH, bool SP = false>
-__global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderKernelParams p) {
+// ---- the fused renderer -------------------------------------------------------------------------------------
+// PERSISTENT kernel: one workgroup of NW waves per CU shares one LDS image of the RenderMLP; every wave is an
+// independent worker that walks over "wave tiles" (32 consecutive rays of one frame), tile = slot, slot + nslots, ...
+// over ALL frames of the launch, so the tail of a launch is one tile and the scratch is sized for the RESIDENT waves
+// only, whatever the number of cameras.
+//
+// Per-wave state:
+//   LDS   cz[32 rays][ZCAP+1]   coarse weights -> CDF (in place) -> importance-sampled depths (in place); row stride
+//                               ZCAP+1 words: bank = (ray + j) mod 32, conflict-free for ray-parallel and j-parallel use
+//   HBM   cval[nc][32] float4   (sigma_raw, r, g, b) of the coarse samples (+ cnrm[nc][32] normals with NRM), one
+//                               32 KB slot per RESIDENT wave, re-used by every tile the wave processes
+// The fine pass never stores its values: the merged (sorted) list [coarse | new] is composited INCREMENTALLY inside the
+// fine loop - after fine sample k is evaluated, the coarse samples with depth <= z_k and then sample k itself are
+// composited; the coarse values stream back through a two-deep register prefetch.
+// Reference arithmetic kept: torch's CPU cumsum accumulates fp32 inputs in double (both the raymarcher's
+// cumsum(delta * sigma) and sample_pdf's cdf), so both running sums are doubles here.
+template <int CH, int ZCAP>
+constexpr int render_waves() {
+  return CH <= 16 ? (ZCAP <= 64 ? 12 : 6) : (ZCAP <= 64 ? 8 : 4);
+}
+
+template <int CH, bool SP, bool NRM, int ZCAP>
+__global__ __launch_bounds__((64 * render_waves<CH, ZCAP>())) void render_kernel(RenderKernelParams p) {
+  constexpr int NW = render_waves<CH, ZCAP>();
+  constexpr int ZS = ZCAP + 1;
   __shared__ __attribute__((aligned(16))) MlpLds<CH, SP> s_mlp;
+  __shared__ float s_cz[NW * 32 * ZS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -315,254 +377,279 @@ __global__ __launch_bounds__(256, (CH <= 16 ? 3 : 2)) void render_kernel(RenderK
   const int li = lane & 31;
   const int lh = lane >> 5;
 
-  stage_mlp<CH, SP>(s_mlp, p.mlp, tid);
-  __syncthreads();
+  stage_mlp<CH, SP>(s_mlp, p.mlp, tid, 64 * NW);
+  __syncthreads();  // the only workgroup-level synchronisation: from here on the waves are independent workers
 
-  // ---- ray setup (pytorch3d NDC grid: +x left, +y up; pixel centres)
+  float* const cz = s_cz + wave * (32 * ZS) + li * ZS;  // this ray's row
+  float* const czw = s_cz + wave * (32 * ZS);           // the wave's rows
   const int npix = p.H * p.W;
-  const int cam_i = blockIdx.y;  // frame of this workgroup
-  const RenderKernelParams::Cam& cam = p.cams[cam_i];
-  float* const o_rgb = p.rgb + (int64_t)cam_i * 3 * npix;
-  float* const o_depth = p.depth + (int64_t)cam_i * npix;
-  float* const o_mask = p.mask + (int64_t)cam_i * npix;
-  float* const o_rgb_c = p.rgb_c ? p.rgb_c + (int64_t)cam_i * 3 * npix : nullptr;
-  float* const o_depth_c = p.rgb_c ? p.depth_c + (int64_t)cam_i * npix : nullptr;
-  float* const o_mask_c = p.rgb_c ? p.mask_c + (int64_t)cam_i * npix : nullptr;
-  const int ray = blockIdx.x * 128 + wave * 32 + li;
-  const bool active = ray < npix;
-  const int rr = active ? ray : npix - 1;
-  const int py = rr / p.W, px = rr - py * p.W;
-  const float hx = p.range_x / (float)p.W, hy = p.range_y / (float)p.H;
-  const float minx = p.range_x - hx, maxx = -p.range_x + hx;
-  const float miny = p.range_y - hy, maxy = -p.range_y + hy;
-  const float xn = lin_space(minx, maxx, (maxx - minx) / (float)(p.W - 1), px, p.W);
-  const float yn = lin_space(miny, maxy, (maxy - miny) / (float)(p.H - 1), py, p.H);
-  const float dc0 = (xn - cam.pp[0]) / cam.focal[0], dc1 = (yn - cam.pp[1]) / cam.focal[1], dc2 = 1.0f;
-  float org[3], dir[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const float r0 = cam.Rm[j * 3 + 0], r1 = cam.Rm[j * 3 + 1], r2 = cam.Rm[j * 3 + 2];
-    const float p1 = (dc0 - cam.T[0]) * r0 + (dc1 - cam.T[1]) * r1 + (dc2 - cam.T[2]) * r2;
-    const float p2 = (2.f * dc0 - cam.T[0]) * r0 + (2.f * dc1 - cam.T[1]) * r1 + (2.f * dc2 - cam.T[2]) * r2;
-    dir[j] = p2 - p1;
-    org[j] = p1 - dir[j];
-  }
-  float rdir[3];
-  dir_term(p.mlp, dir[0], dir[1], dir[2], rdir);
-
   const int R = p.R;
   const float Rm1 = (float)(R - 1);
   const float* gbase = p.grid_cl + lane_channel<CH, SP>(lh, 0);
-
-  auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb) {
-    eval_point<CH, SP>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0], org[1] + z * dir[1],
-                   org[2] + z * dir[2], rdir, sigma, cr, cg, cb);
-  };
-
-  // Scratch columns of this wave (L2-resident, written and read back by the same lanes only):
-  //   cdf  [64][64 lanes]        coarse weights, then the CDF (every lane keeps its own copy)
-  //   cval [64][32 rays] float4  (sigma_raw, r, g, b) of the coarse samples
-  //   fz   [nf][32 rays]         importance-sampled depths,  fval [nf][32] float4 their (sigma_raw, r, g, b)
   const int nc = p.n_coarse, nf = p.n_fine;
-  const float zstep = (cam.zmax - cam.zmin) / (float)(nc - 1);
-  const int64_t wslot = ((int64_t)cam_i * gridDim.x + blockIdx.x) * 4 + wave;
-  float* cdf = p.cdf_ws + wslot * (MAXC * 64) + lane;  // element j at cdf[j*64]
-  float4* cval = reinterpret_cast<float4*>(p.val_ws) + wslot * ((int64_t)(MAXC + p.n_fine) * 32) + li;
-  float4* fval = cval + MAXC * 32;
-  float* fz = p.fz_ws + wslot * ((int64_t)p.n_fine * 32) + li;
-
-  unsigned long long* dbg = p.dbg ? p.dbg + wslot * 8 : nullptr;
-  if (dbg && lane == 0) dbg[0] = HOLO_PROBE_CLOCK();
-  // ---- coarse pass (all rays of the wave in lock step): evaluate, composite, keep weights + values
-  {
-    float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
-    float zi = lin_space(cam.zmin, cam.zmax, zstep, 0, nc);
-    for (int i = 0; i < nc; ++i) {
-      const float zn = (i + 1 < nc) ? lin_space(cam.zmin, cam.zmax, zstep, i + 1, nc) : 0.f;
-      float sg, cr, cg, cb;
-      eval(zi, sg, cr, cg, cb);
-      if (lh == 0) cval[i * 32] = make_float4(sg, cr, cg, cb);
-      const float delta = (i + 1 < nc) ? zn - zi : p.background_opacity;
-      const float x = delta * fmaxf(sg, 0.f);
-      const float cap = 1.f - __expf(-x);
-      cum += x;
-      O = 1.f - __expf(-cum);
-      const float w = cap * Tr;
-      ar = fmaf(w, cr, ar);
-      ag = fmaf(w, cg, ag);
-      ab = fmaf(w, cb, ab);
-      ad = fmaf(w, zi, ad);
-      if (lh == 0) cdf[i * 64] = w;  // weights for now; turned into the cdf below (private column of the ray)
-      Tr = 1.f - O;
-      zi = zn;
-    }
-    if (o_rgb_c && active && lh == 0) {
-      o_rgb_c[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
-      o_rgb_c[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
-      o_rgb_c[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
-      o_depth_c[ray] = ad;
-      o_mask_c[ray] = O;
-    }
-  }
-
-  // ---- weights[1:-1] -> pdf -> cdf (in place in the ray's private column; lane half 0 only)
-  // cdf has nb = nc-1 entries, cdf[0] = 0;  bins (interval mid points) also nb entries.  The finished CDF is also
-  // written ray-major into the unused half-1 columns of the wave's region (T[ray][j], two 128-byte runs per ray)
-  // for the cooperative inverse-CDF phase below.
-  if (dbg && lane == 0) dbg[1] = HOLO_PROBE_CLOCK();
   const int nb = nc - 1;
-  float* cdfT = p.cdf_ws + wslot * (MAXC * 64) + 32;  // T[r][j] at cdfT[(2*r + (j>>5))*64 + (j&31)]
-  if (lh == 0) {
-    // loads go out in batches of 8 (a plain loop makes every load a full L2 round trip); the additions keep
-    // their sequential order
-    float S = 0.f;
-    for (int m0 = 1; m0 < nc - 1; m0 += 8) {
-      float wv[8];
+
+  // worker slot and its scratch
+  const int slot = (int)blockIdx.x * NW + wave;
+  float4* const cval = reinterpret_cast<float4*>(p.val_ws) + (int64_t)slot * (MAXC * 32) + li;
+  float4* const cnrm = NRM ? reinterpret_cast<float4*>(p.nrm_ws) + (int64_t)slot * (MAXC * 32) + li : nullptr;
+  unsigned long long* dbg = p.dbg ? p.dbg + (int64_t)slot * 8 : nullptr;
+
+  // tile order: XCD-aware when the launch asks for it (p.xcd > 1): workgroups are dealt to the XCDs round-robin, so
+  // workgroup b sits on XCD b % xcd; each XCD works through its OWN contiguous range of tiles (neighbouring rays touch
+  // neighbouring voxels: one L2 then sees one region of the volume instead of all eight seeing all of it).  Purely an
+  // index permutation - correct whatever the real placement is.
+  const int64_t ntiles = p.n_tiles;
+  const int tiles_per_cam = (npix + 31) / 32;
+  const int xcd = p.xcd > 1 && ((int)gridDim.x % p.xcd) == 0 ? p.xcd : 1;
+  const int wg_in_x = (int)blockIdx.x / xcd, wgs_per_x = (int)gridDim.x / xcd, my_x = (int)blockIdx.x % xcd;
+  const int64_t x_lo = ntiles * my_x / xcd, x_hi = ntiles * (my_x + 1) / xcd;
+
+  for (int64_t t = x_lo + (int64_t)wg_in_x * NW + wave; t < x_hi; t += (int64_t)wgs_per_x * NW) {
+    if (dbg && lane == 0) dbg[6] = HOLO_PROBE_CLOCK();
+    // ---- ray setup (pytorch3d NDC grid: +x left, +y up; pixel centres)
+    const int cam_i = (int)(t / tiles_per_cam);
+    const RenderKernelParams::Cam& cam = p.cams[cam_i];
+    const int ray = (int)(t - (int64_t)cam_i * tiles_per_cam) * 32 + li;
+    const bool active = ray < npix;
+    const int rr = active ? ray : npix - 1;
+    const int py = rr / p.W, px = rr - py * p.W;
+    const float hx = p.range_x / (float)p.W, hy = p.range_y / (float)p.H;
+    const float minx = p.range_x - hx, maxx = -p.range_x + hx;
+    const float miny = p.range_y - hy, maxy = -p.range_y + hy;
+    const float xn = lin_space(minx, maxx, (maxx - minx) / (float)(p.W - 1), px, p.W);
+    const float yn = lin_space(miny, maxy, (maxy - miny) / (float)(p.H - 1), py, p.H);
+    const float dc0 = (xn - cam.pp[0]) / cam.focal[0], dc1 = (yn - cam.pp[1]) / cam.focal[1], dc2 = 1.0f;
+    float org[3], dir[3];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = cdf[min(m0 + q, nc - 2) * 64];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (m0 + q < nc - 1) S += wv[q] + p.pdf_eps;
+    for (int j = 0; j < 3; ++j) {
+      const float r0 = cam.Rm[j * 3 + 0], r1 = cam.Rm[j * 3 + 1], r2 = cam.Rm[j * 3 + 2];
+      const float p1 = (dc0 - cam.T[0]) * r0 + (dc1 - cam.T[1]) * r1 + (dc2 - cam.T[2]) * r2;
+      const float p2 = (2.f * dc0 - cam.T[0]) * r0 + (2.f * dc1 - cam.T[1]) * r1 + (2.f * dc2 - cam.T[2]) * r2;
+      dir[j] = p2 - p1;
+      org[j] = p1 - dir[j];
     }
-    float run = 0.f;
-    cdf[0] = 0.f;
-    cdfT[(2 * li) * 64] = 0.f;
-    for (int j0 = 1; j0 < nb; j0 += 8) {  // cdf[j] = cdf[j-1] + (w[j] + eps)/S ; slot j still holds w[j] here
-      float wv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = cdf[min(j0 + q, nb - 1) * 64];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = j0 + q;
-        if (j < nb) {
-          run += (wv[q] + p.pdf_eps) / S;
-          cdf[j * 64] = run;
-          cdfT[(2 * li + (j >> 5)) * 64 + (j & 31)] = run;
+    float rdir[3];
+    dir_term(p.mlp, dir[0], dir[1], dir[2], rdir);
+    const float zmin = cam.zmin, zmax = cam.zmax;
+    const float zstep = (zmax - zmin) / (float)(nc - 1);
+    auto zcoarse = [&](int i) { return lin_space(zmin, zmax, zstep, i, nc); };
+    auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb, float* nv) {
+      eval_point<CH, SP, NRM>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
+                              org[1] + z * dir[1], org[2] + z * dir[2], rdir, sigma, cr, cg, cb, nv);
+    };
+    const int64_t ob = (int64_t)cam_i * npix + ray;  // output pixel (1-channel planes); rgb planes at 3*cam*npix + c*npix
+
+    if (dbg && lane == 0) dbg[7] = HOLO_PROBE_CLOCK();
+    // ---- coarse pass (all rays of the wave in lock step): evaluate, composite, keep weights + values
+    {
+      double cum = 0.0;
+      float Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, anx = 0.f, any_ = 0.f, anz = 0.f;
+      float zi = zcoarse(0);
+      for (int i = 0; i < nc; ++i) {
+        const float zn = (i + 1 < nc) ? zcoarse(i + 1) : 0.f;
+        float sg, cr, cg, cb, nv[3];
+        eval(zi, sg, cr, cg, cb, nv);
+        if (lh == 0) {
+          cval[i * 32] = make_float4(sg, cr, cg, cb);
+          if (NRM) cnrm[i * 32] = make_float4(nv[0], nv[1], nv[2], 0.f);
+        }
+        const float delta = (i + 1 < nc) ? zn - zi : p.background_opacity;
+        const float x = delta * fmaxf(sg, 0.f);
+        const float cap = 1.f - __expf(-x);
+        cum += (double)x;
+        const float w = cap * Tr;
+        ar = fmaf(w, cr, ar);
+        ag = fmaf(w, cg, ag);
+        ab = fmaf(w, cb, ab);
+        ad = fmaf(w, zi, ad);
+        if (NRM) {
+          anx = fmaf(w, nv[0], anx);
+          any_ = fmaf(w, nv[1], any_);
+          anz = fmaf(w, nv[2], anz);
+        }
+        if (lh == 0) cz[i] = w;  // weights for now; turned into the cdf below
+        Tr = 1.f - (1.f - __expf(-(float)cum));  // T = 1 - O, O = 1 - exp(-cumsum) as the raymarcher forms them
+        zi = zn;
+      }
+      const float O = 1.f - __expf(-(float)cum);
+      if (p.rgb_c && active && lh == 0) {
+        float* o = p.rgb_c + (int64_t)cam_i * 3 * npix + ray;
+        o[0 * (int64_t)npix] = ar + (1.f - O) * p.bg[0];
+        o[1 * (int64_t)npix] = ag + (1.f - O) * p.bg[1];
+        o[2 * (int64_t)npix] = ab + (1.f - O) * p.bg[2];
+        p.depth_c[ob] = ad;
+        p.mask_c[ob] = O;
+        if (NRM && p.nrm_c) {
+          float* on = p.nrm_c + (int64_t)cam_i * 3 * npix + ray;
+          on[0 * (int64_t)npix] = anx;
+          on[1 * (int64_t)npix] = any_;
+          on[2 * (int64_t)npix] = anz;
         }
       }
     }
-  }
-  __threadfence();  // the T rows are read by OTHER lanes of this wave below
-  __builtin_amdgcn_wave_barrier();
 
-  if (dbg && lane == 0) dbg[2] = HOLO_PROBE_CLOCK();
-  auto zcoarse = [&](int i) { return lin_space(cam.zmin, cam.zmax, zstep, i, nc); };
+    // ---- weights[1:-1] + eps -> pdf -> cdf, in place in the ray's LDS row (RayPointRefiner / sample_pdf):
+    // cdf has nb = nc-1 entries, cdf[0] = 0, cdf[j] = sum_{m<=j} (w[m]+eps)/S; the running sums are doubles like torch's
+    if (dbg && lane == 0) dbg[1] += HOLO_PROBE_CLOCK() - dbg[7];
+    if (lh == 0) {
+      double S = 0.0;
+      for (int m = 1; m < nc - 1; ++m) S += (double)(cz[m] + p.pdf_eps);
+      const float Sf = (float)S;
+      double run = 0.0;
+      cz[0] = 0.f;
+      for (int j = 1; j < nb; ++j) {
+        run += (double)((cz[j] + p.pdf_eps) / Sf);
+        cz[j] = (float)run;
+      }
+    }
+    __threadfence();  // cval / cnrm of this tile are read back below (by both lane halves)
+    __builtin_amdgcn_wave_barrier();
 
-  // ---- importance-sample depths of all 32 rays, cooperatively: for one ray at a time lane j holds cdf[j] and lane
-  //      kk computes the inverse CDF at u_kk = linspace(0,1,nf)[kk] with a binary search over the lanes' values
-  //      (ds_bpermute): searchsorted(right=True), then the lerp of sample_pdf.  Replaces a per-ray serial walk whose
-  //      every step was three dependent L2 round trips in the middle of the evaluation loop.
-  {
-    const float ustep = 1.0f / (float)(nf - 1);
-    auto mid = [&](int i) {
-      const float a0 = zcoarse(i), a1 = zcoarse(i + 1);
-      return a0 - (a0 - a1) * 0.5f;  // torch.lerp(z[1:], z[:-1], 0.5)
-    };
-    float* fzw = p.fz_ws + wslot * ((int64_t)p.n_fine * 32);
-    for (int r0 = 0; r0 < 32; r0 += 8) {
-      float cv[8];  // the CDF rows of 8 rays are requested together
+    // ---- importance-sample depths of all 32 rays, cooperatively: for one ray at a time lane j holds cdf[j] and lane
+    //      kk computes the inverse CDF at u_kk = linspace(0,1,nf)[kk] with a binary search over the lanes' values:
+    //      searchsorted(right=True), then the lerp of sample_pdf.  The depths overwrite the ray's cdf row.
+    {
+      const float ustep = 1.0f / (float)(nf - 1);
+      auto mid = [&](int i) {
+        const float a0 = zcoarse(i), a1 = zcoarse(i + 1);
+        return a0 - (a0 - a1) * 0.5f;  // torch.lerp(z[1:], z[:-1], 0.5)
+      };
+      for (int r0 = 0; r0 < 32; r0 += 8) {
+        float cv[8];  // the CDF rows of 8 rays are read together
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        cv[q] = lane < nb ? cdfT[(2 * (r0 + q) + (lane >> 5)) * 64 + (lane & 31)] : 3.0e38f;
+        for (int q = 0; q < 8; ++q) cv[q] = lane < nb ? czw[(r0 + q) * ZS + lane] : 3.0e38f;
+        __builtin_amdgcn_wave_barrier();  // every lane holds its CDF entries before the rows are overwritten
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = r0 + q;
-        const float c = cv[q];
-        for (int kb = 0; kb < nf; kb += 64) {
-          const int kk = kb + lane;
-          const float u = lin_space(0.f, 1.f, ustep, kk < nf ? kk : nf - 1, nf);
-          int lo = 0, hi = nb;  // ind = #{j < nb : cdf[j] <= u}
+        for (int q = 0; q < 8; ++q) {
+          const int r = r0 + q;
+          const float c = cv[q];
+          for (int kb = 0; kb < nf; kb += 64) {
+            const int kk = kb + lane;
+            const float u = lin_space(0.f, 1.f, ustep, kk < nf ? kk : nf - 1, nf);
+            int lo = 0, hi = nb;  // ind = #{j < nb : cdf[j] <= u}
 #pragma unroll
-          for (int it = 0; it < 7; ++it) {  // nb <= 63 < 2^6 (+1 closing step); every lane runs all steps (shuffles)
-            const int md = (lo + hi) >> 1;
-            const float cm = __shfl(c, md < nb ? md : nb - 1);
-            const bool go = lo < hi && cm <= u;
-            const bool stay = lo < hi && !(cm <= u);
-            if (go) lo = md + 1;
-            if (stay) hi = md;
+            for (int it = 0; it < 7; ++it) {  // nb <= 63 < 2^6 (+1 closing step); every lane runs all steps (shuffles)
+              const int md = (lo + hi) >> 1;
+              const float cm = __shfl(c, md < nb ? md : nb - 1);
+              const bool go = lo < hi && cm <= u;
+              const bool stay = lo < hi && !(cm <= u);
+              if (go) lo = md + 1;
+              if (stay) hi = md;
+            }
+            const int ind = lo;
+            const int below = ind - 1 > 0 ? ind - 1 : 0;
+            const int above = ind < nb - 1 ? ind : nb - 1;
+            const float cb_ = __shfl(c, below), ca_ = __shfl(c, above);
+            float den = ca_ - cb_;
+            if (den < p.pdf_eps) den = 1.f;
+            const float tt = (u - cb_) / den;
+            const float bb = mid(below), ba = mid(above);
+            if (kk < nf) czw[r * ZS + kk] = bb + tt * (ba - bb);
           }
-          const int ind = lo;
-          const int below = ind - 1 > 0 ? ind - 1 : 0;
-          const int above = ind < nb - 1 ? ind : nb - 1;
-          const float cb_ = __shfl(c, below), ca_ = __shfl(c, above);
-          float den = ca_ - cb_;
-          if (den < p.pdf_eps) den = 1.f;
-          const float tt = (u - cb_) / den;
-          const float bb = mid(below), ba = mid(above);
-          if (kk < nf) fzw[kk * 32 + r] = bb + tt * (ba - bb);
         }
       }
     }
-  }
-  __threadfence();
-  __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();
 
-  if (dbg && lane == 0) dbg[3] = HOLO_PROBE_CLOCK();
-  // ---- fine pass, in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
-  //      those values are bit-identical to the coarse pass, so only the nf NEW points are evaluated here.
-  {
-    float zf = fz[0];
-    for (int kk = 0; kk < nf; ++kk) {
-      const float zf_next = fz[(kk + 1 < nf ? kk + 1 : kk) * 32];  // requested a whole evaluation ahead
-      float sg, cr, cg, cb;
-      eval(zf, sg, cr, cg, cb);
-      if (lh == 0) fval[kk * 32] = make_float4(sg, cr, cg, cb);
-      zf = zf_next;
-    }
-  }
-
-  if (dbg && lane == 0) dbg[4] = HOLO_PROBE_CLOCK();
-  // ---- fine composite: merge of the two sorted depth lists (== torch.sort of their concatenation), per ray,
-  //      no evaluation.  One lane per ray (half 0); no wave-collective operations below this point.
-  if (lh == 0) {
-    int ci = 0, k = 0;
-    float zc_head = zcoarse(0);
-    float zf_head = fz[0];
-    float4 vhead = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto pop = [&](float4& val) {
-      float v;
-      if (ci < nc && (k >= nf || zc_head <= zf_head)) {
-        v = zc_head;
-        val = cval[ci * 32];
-        ++ci;
-        if (ci < nc) zc_head = zcoarse(ci);
-      } else {
-        v = zf_head;
-        val = fval[k * 32];
-        ++k;
-        if (k < nf) zf_head = fz[k * 32];
+    if (dbg && lane == 0) dbg[2] += HOLO_PROBE_CLOCK() - dbg[7];
+    // ---- fine pass, in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
+    //      those values are bit-identical to the coarse pass, so only the nf NEW points are evaluated, and the merged
+    //      list (== torch.sort of the concatenated depths; a coarse sample goes first on a tie) is composited on the fly.
+    {
+      double cum = 0.0;
+      float Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, anx = 0.f, any_ = 0.f, anz = 0.f;
+      // Every depth of the merged list is known before its sample is evaluated (the new depths sit in the LDS row, the
+      // coarse ones are analytic), so a sample is composited the moment its values exist: its interval ends at
+      // min(next coarse depth, next new depth).  No "pending sample" state is carried across the evaluations.
+      auto emit = [&](float z, float delta, const float4& v, const float4& nv4) {
+        const float x = delta * fmaxf(v.x, 0.f);
+        const float cap = 1.f - __expf(-x);
+        cum += (double)x;
+        const float w = cap * Tr;
+        ar = fmaf(w, v.y, ar);
+        ag = fmaf(w, v.z, ag);
+        ab = fmaf(w, v.w, ab);
+        ad = fmaf(w, z, ad);
+        if (NRM) {
+          anx = fmaf(w, nv4.x, anx);
+          any_ = fmaf(w, nv4.y, any_);
+          anz = fmaf(w, nv4.z, anz);
+        }
+        Tr = 1.f - (1.f - __expf(-(float)cum));  // T = 1 - O, O = 1 - exp(-cumsum) as the raymarcher forms them
+      };
+      // coarse samples come back through a two-deep prefetch (q0 = entry ci, q1 = entry ci + 1)
+      int ci = 0;
+      float4 q0 = cval[0], q1 = cval[32];
+      float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+      if (NRM) {
+        m0 = cnrm[0];
+        m1 = cnrm[32];
       }
-      return v;
-    };
-    const int total = nc + nf;
-    float cum = 0.f, Tr = 1.f, ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, O = 0.f;
-    float zi = pop(vhead);
-    for (int s2 = 0; s2 < total; ++s2) {
-      float4 vnext = make_float4(0.f, 0.f, 0.f, 0.f);
-      const float zn = (s2 + 1 < total) ? pop(vnext) : 0.f;
-      const float delta = (s2 + 1 < total) ? zn - zi : p.background_opacity;
-      const float x = delta * fmaxf(vhead.x, 0.f);
-      const float cap = 1.f - __expf(-x);
-      cum += x;
-      O = 1.f - __expf(-cum);
-      const float w = cap * Tr;
-      ar = fmaf(w, vhead.y, ar);
-      ag = fmaf(w, vhead.z, ag);
-      ab = fmaf(w, vhead.w, ab);
-      ad = fmaf(w, zi, ad);
-      Tr = 1.f - O;
-      zi = zn;
-      vhead = vnext;
+      // composite coarse sample ci; `zlim` = depth of the next NEW sample (the coarse sample's interval ends at the
+      // nearer of it and the next coarse depth), `more_fine` = such a sample exists
+      auto pop_coarse = [&](float zlim, bool more_fine) {
+        const float zc = zcoarse(ci);
+        const bool more_coarse = ci + 1 < nc;
+        float znext = more_coarse ? zcoarse(ci + 1) : zlim;
+        if (more_fine) znext = fminf(znext, zlim);
+        const float delta = (more_coarse || more_fine) ? znext - zc : p.background_opacity;
+        emit(zc, delta, q0, m0);
+        q0 = q1;
+        const int nxt = ci + 2 < nc ? ci + 2 : nc - 1;
+        q1 = cval[nxt * 32];
+        if (NRM) {
+          m0 = m1;
+          m1 = cnrm[nxt * 32];
+        }
+        ++ci;
+      };
+      for (int kk = 0; kk < nf; ++kk) {
+        const float zf = cz[kk];
+        float sg, cr, cg, cb, nv[3];
+        eval(zf, sg, cr, cg, cb, nv);
+        for (;;) {  // wave-uniform loop, divergent body: every lane composites its coarse samples with depth <= zf
+          const bool need = ci < nc && zcoarse(ci < nc ? ci : nc - 1) <= zf;
+          if (!__any(need)) break;
+          if (need) pop_coarse(zf, true);
+        }
+        const bool more_fine = kk + 1 < nf, more_coarse = ci < nc;
+        float znext = more_fine ? cz[kk + 1 < nf ? kk + 1 : kk] : 0.f;
+        if (more_coarse) {
+          const float zc = zcoarse(ci < nc ? ci : nc - 1);
+          znext = more_fine ? fminf(znext, zc) : zc;
+        }
+        emit(zf, (more_fine || more_coarse) ? znext - zf : p.background_opacity, make_float4(sg, cr, cg, cb),
+             NRM ? make_float4(nv[0], nv[1], nv[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+      for (;;) {  // coarse samples behind the last new one
+        const bool need = ci < nc;
+        if (!__any(need)) break;
+        if (need) pop_coarse(0.f, false);
+      }
+      const float O = 1.f - __expf(-(float)cum);
+      if (active && lh == 0) {
+        float* o = p.rgb + (int64_t)cam_i * 3 * npix + ray;
+        o[0 * (int64_t)npix] = ar + (1.f - O) * p.bg[0];
+        o[1 * (int64_t)npix] = ag + (1.f - O) * p.bg[1];
+        o[2 * (int64_t)npix] = ab + (1.f - O) * p.bg[2];
+        p.depth[ob] = ad;
+        p.mask[ob] = O;
+        if (NRM && p.nrm) {
+          float* on = p.nrm + (int64_t)cam_i * 3 * npix + ray;
+          on[0 * (int64_t)npix] = anx;
+          on[1 * (int64_t)npix] = any_;
+          on[2 * (int64_t)npix] = anz;
+        }
+      }
     }
-    if (active) {
-      o_rgb[0 * npix + ray] = ar + (1.f - O) * p.bg[0];
-      o_rgb[1 * npix + ray] = ag + (1.f - O) * p.bg[1];
-      o_rgb[2 * npix + ray] = ab + (1.f - O) * p.bg[2];
-      o_depth[ray] = ad;
-      o_mask[ray] = O;
+    __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next tile's coarse pass
+    if (dbg && lane == 0) {
+      dbg[3] += HOLO_PROBE_CLOCK() - dbg[7];
+      dbg[0] += dbg[7] - dbg[6];
+      dbg[4] += 1;
     }
   }
-  if (dbg && lane == 0) dbg[5] = HOLO_PROBE_CLOCK();
 }
 
 // radiance direction term per ray direction (one thread per direction)
@@ -690,40 +777,58 @@ __global__ __launch_bounds__(256) void implicit_normals_kernel(ImplicitEvalParam
 
 }  // namespace
 
-int render_launch(const RenderKernelParams& p, void* stream) {
+template <int CH, bool SP>
+static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
+  const bool nrm = p.nrm_ws != nullptr;
+  if (p.n_fine <= 64) {
+    dim3 block(64 * render_waves<CH, 64>());
+    if (nrm) {
+      HOLO_LAUNCH((render_kernel<CH, SP, true, 64>), dim3((unsigned)n_wgs), block, stream, p);
+    } else {
+      HOLO_LAUNCH((render_kernel<CH, SP, false, 64>), dim3((unsigned)n_wgs), block, stream, p);
+    }
+  } else {
+    dim3 block(64 * render_waves<CH, 128>());
+    if (nrm) {
+      HOLO_LAUNCH((render_kernel<CH, SP, true, 128>), dim3((unsigned)n_wgs), block, stream, p);
+    } else {
+      HOLO_LAUNCH((render_kernel<CH, SP, false, 128>), dim3((unsigned)n_wgs), block, stream, p);
+    }
+  }
+  return 0;
+}
+
+// waves per workgroup of the persistent kernel for this configuration (the scratch has one slot per resident wave)
+int render_waves_per_wg(int C, int n_fine) {
+  const int zc = n_fine <= 64 ? 64 : 128;
+  if (C <= 32) return zc == 64 ? render_waves<16, 64>() : render_waves<16, 128>();
+  return zc == 64 ? render_waves<32, 64>() : render_waves<32, 128>();
+}
+
+int render_launch(const RenderKernelParams& p, void* stream, int n_wgs) {
   if (p.mlp.Hd != HD) {
     set_error("render: dnet_hidden_dim must be %d (got %d)", HD, p.mlp.Hd);
     return -1;
   }
-  if (p.n_coarse < 3 || p.n_coarse > MAXC || p.n_fine < 2) {
-    set_error("render: n_pts_coarse must be in [3,%d] and n_pts_fine >= 2", MAXC);
+  if (p.n_coarse < 3 || p.n_coarse > MAXC || p.n_fine < 2 || p.n_fine > 128) {
+    set_error("render: n_pts_coarse must be in [3,%d] and n_pts_fine in [2,128]", MAXC);
     return -1;
   }
-  const int npix = p.H * p.W;
-  if (p.n_cams < 1 || p.n_cams > RenderKernelParams::MAX_CAMS) {
+  if (p.n_cams < 1 || p.n_cams > RenderKernelParams::MAX_CAMS || n_wgs < 1) {
     set_error("render: %d cameras per launch (1..%d)", p.n_cams, RenderKernelParams::MAX_CAMS);
     return -1;
   }
-  dim3 grid((unsigned)cdiv(npix, 128), (unsigned)p.n_cams);
   switch (p.C) {
     case 16:
-      HOLO_LAUNCH(render_kernel<8>, grid, dim3(256), stream, p);
-      break;
+      return render_launch_t<8, false>(p, stream, n_wgs);
     case 32:
-      if (p.split3) {
-        HOLO_LAUNCH((render_kernel<16, true>), grid, dim3(256), stream, p);
-      } else {
-        HOLO_LAUNCH((render_kernel<16, false>), grid, dim3(256), stream, p);
-      }
-      break;
+      return p.split3 ? render_launch_t<16, true>(p, stream, n_wgs) : render_launch_t<16, false>(p, stream, n_wgs);
     case 64:
-      HOLO_LAUNCH(render_kernel<32>, grid, dim3(256), stream, p);
-      break;
+      return render_launch_t<32, false>(p, stream, n_wgs);
     default:
       set_error("render: feature_size must be 16, 32 or 64 (got %d)", p.C);
       return -1;
   }
-  return 0;
 }
 
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream) {

@@ -228,21 +228,20 @@ static size_t grid_cl_bytes(const HoloRenderer* r) {
   const size_t R = r->cfg.resol;
   return ((R * R * R * (size_t)r->cfg.feature_size * sizeof(float)) + 255) & ~(size_t)255;
 }
-// frames rendered by one launch (RenderKernelParams::MAX_CAMS at most): the scratch is sized for that many
-static size_t cams_per_launch(int n_cameras) {
-  return (size_t)(n_cameras < 1 ? 1 : n_cameras > RenderKernelParams::MAX_CAMS ? RenderKernelParams::MAX_CAMS : n_cameras);
+// The persistent render kernel runs ONE workgroup per CU; every wave of it is a worker with its own scratch slot
+// (64 coarse samples x 32 rays x float4 = 32 KB; the same again for the normals).  The scratch therefore depends on the
+// chip and the configuration only - not on the number of cameras or the image size.
+static int render_workgroups(const HoloRenderer* r) {
+#ifndef HOLO_EMU
+  static const char* e = getenv("HOLO_RENDER_WGS");  // development knob
+  if (e && atoi(e) > 0) return atoi(e);
+#endif
+  return r->ctx->num_cus > 0 ? r->ctx->num_cus : 256;
 }
-static size_t n_render_waves(const HoloRenderer* r, int n_cameras = 1) {
-  const size_t npix = (size_t)r->cfg.image_height * r->cfg.image_width;
-  return ((npix + 127) / 128) * 4 * cams_per_launch(n_cameras);
+static size_t render_slots(const HoloRenderer* r) {
+  return (size_t)render_workgroups(r) * (size_t)render_waves_per_wg(r->cfg.feature_size, r->cfg.n_pts_fine);
 }
-static size_t cdf_ws_bytes(const HoloRenderer* r, int nc = 1) { return n_render_waves(r, nc) * 64 * 64 * sizeof(float); }
-static size_t val_ws_bytes(const HoloRenderer* r, int nc = 1) {
-  return n_render_waves(r, nc) * (size_t)(64 + r->cfg.n_pts_fine) * 32 * 4 * sizeof(float);
-}
-static size_t fz_ws_bytes(const HoloRenderer* r, int nc = 1) {
-  return ((n_render_waves(r, nc) * (size_t)r->cfg.n_pts_fine * 32 * sizeof(float)) + 255) & ~(size_t)255;
-}
+static size_t val_ws_bytes(const HoloRenderer* r) { return render_slots(r) * 64 * 32 * 4 * sizeof(float); }
 
 int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
   if (!r || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_F32_BF16X3)) {
@@ -253,14 +252,15 @@ int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
   return 0;
 }
 
-size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras) {
-  if (!r) return 0;  // up to MAX_CAMS frames are in flight per launch, each with its own scratch
-  return grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras) + val_ws_bytes(r, n_cameras) + fz_ws_bytes(r, n_cameras) + 256;
+size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras, int with_normals) {
+  (void)n_cameras;  // the scratch is per resident wave: any number of cameras renders out of the same buffer
+  if (!r) return 0;
+  return grid_cl_bytes(r) + val_ws_bytes(r) * (with_normals ? 2 : 1) + 256;
 }
 
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
                 float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
-                void* workspace, size_t workspace_bytes, void* stream) {
+                float* normals, float* normals_coarse, void* workspace, size_t workspace_bytes, void* stream) {
   if (!r || !grid || !cameras || n_cameras < 1 || !images || !depths || !masks || !workspace) {
     set_error("holo_render: null/invalid argument");
     return HOLO_E_INVALID;
@@ -269,7 +269,8 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     set_error("holo_render: call holo_renderer_commit after setting the RenderMLP parameters");
     return HOLO_E_STATE;
   }
-  if (workspace_bytes < holo_render_workspace_bytes(r, n_cameras)) {
+  const bool want_nrm = normals != nullptr || normals_coarse != nullptr;
+  if (workspace_bytes < holo_render_workspace_bytes(r, n_cameras, want_nrm ? 1 : 0)) {
     set_error("holo_render: workspace too small");
     return HOLO_E_WORKSPACE;
   }
@@ -280,7 +281,17 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   if (rc) return HOLO_E_INVALID;
   const int H = c.image_height, Wd = c.image_width;
   const int64_t npix = (int64_t)H * Wd;
-  const int G = (int)cams_per_launch(n_cameras);  // frames per launch (the scratch was sized for G)
+  const int G = RenderKernelParams::MAX_CAMS;  // frames per launch (launch parameters hold that many cameras)
+  const int n_wgs_max = render_workgroups(r);
+  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine);
+#ifndef HOLO_EMU
+  static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
+  static const char* xcd_env = getenv("HOLO_RENDER_XCD");
+  const int xcd = xcd_env ? atoi(xcd_env) : 8;
+#else
+  const bool timeline = false;
+  const int xcd = 2;
+#endif
   for (int c0 = 0; c0 < n_cameras; c0 += G) {
     const int ng = n_cameras - c0 < G ? n_cameras - c0 : G;
     RenderKernelParams p;
@@ -329,10 +340,9 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.background_opacity = c.background_opacity;
     p.pdf_eps = c.sample_pdf_eps;
     p.split3 = (r->split3 && c.feature_size == 32) ? 1 : 0;
-    p.cdf_ws = (float*)((char*)workspace + grid_cl_bytes(r));
-    p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras));
-    p.fz_ws = (float*)((char*)workspace + grid_cl_bytes(r) + cdf_ws_bytes(r, n_cameras) + val_ws_bytes(r, n_cameras));
-    p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets (blockIdx.y)
+    p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r));
+    p.nrm_ws = want_nrm ? (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r)) : nullptr;
+    p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets
     p.depth = depths + (size_t)c0 * npix;
     p.mask = masks + (size_t)c0 * npix;
     if (images_coarse && depths_coarse && masks_coarse) {
@@ -340,36 +350,37 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
       p.depth_c = depths_coarse + (size_t)c0 * npix;
       p.mask_c = masks_coarse + (size_t)c0 * npix;
     }
-#ifndef HOLO_EMU
-    static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
-#else
-    const bool timeline = false;
-#endif
-    const int nwaves = 4 * (int)((npix + 127) / 128) * ng;
+    p.nrm = normals ? normals + (size_t)c0 * 3 * npix : nullptr;
+    p.nrm_c = (normals_coarse && p.rgb_c) ? normals_coarse + (size_t)c0 * 3 * npix : nullptr;
+    p.n_tiles = (int64_t)ng * ((npix + 31) / 32);
+    // no more workgroups than there is work for (a tiny launch must not stage the MLP on idle CUs)
+    int n_wgs = (int)((p.n_tiles + waves_per_wg - 1) / waves_per_wg);
+    if (n_wgs > n_wgs_max) n_wgs = n_wgs_max;
+    p.xcd = (xcd > 1 && n_wgs == n_wgs_max && n_wgs % xcd == 0) ? xcd : 1;
+    const int nslots = n_wgs * waves_per_wg;
 #ifndef HOLO_EMU
     if (timeline) {
-      HIP_TRY(hipMalloc((void**)&p.dbg, (size_t)nwaves * 64));
-      HIP_TRY(hipMemsetAsync(p.dbg, 0, (size_t)nwaves * 64, (hipStream_t)stream));
+      HIP_TRY(hipMalloc((void**)&p.dbg, (size_t)nslots * 64));
+      HIP_TRY(hipMemsetAsync(p.dbg, 0, (size_t)nslots * 64, (hipStream_t)stream));
     }
 #endif
-    rc = render_launch(p, stream);
+    rc = render_launch(p, stream, n_wgs);
     if (rc) return HOLO_E_INVALID;
 #ifndef HOLO_EMU
     if (timeline) {
-      std::vector<unsigned long long> d((size_t)nwaves * 8);
+      std::vector<unsigned long long> d((size_t)nslots * 8);
       HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
       HIP_TRY(hipMemcpy(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost));
       (void)hipFree(p.dbg);
-      double ph[5] = {0, 0, 0, 0, 0};
-      unsigned long long t0 = ~0ull, t1 = 0;
-      for (int w = 0; w < nwaves; ++w) {
-        for (int k = 0; k < 5; ++k) ph[k] += (double)(d[w * 8 + k + 1] - d[w * 8 + k]);
-        if (d[w * 8] < t0) t0 = d[w * 8];
-        if (d[w * 8 + 5] > t1) t1 = d[w * 8 + 5];
+      double ph[4] = {0, 0, 0, 0}, tiles = 0;
+      for (int w = 0; w < nslots; ++w) {
+        for (int k = 0; k < 4; ++k) ph[k] += (double)d[w * 8 + k];
+        tiles += (double)d[w * 8 + 4];
       }
-      fprintf(stderr, "[render timeline] frames %d waves %d span %.1f us | per wave: coarse %.1f  cdf %.1f  inverse-cdf %.1f  "
-              "fine %.1f  composite %.1f us\n", ng, nwaves, (t1 - t0) * 0.01, ph[0] / nwaves * 0.01, ph[1] / nwaves * 0.01,
-              ph[2] / nwaves * 0.01, ph[3] / nwaves * 0.01, ph[4] / nwaves * 0.01);
+      if (tiles < 1) tiles = 1;
+      fprintf(stderr, "[render timeline] frames %d slots %d tiles %.0f | per tile: setup %.1f  coarse %.1f  cdf+inverse-cdf %.1f  "
+              "fine+composite %.1f us\n", ng, nslots, tiles, ph[0] / tiles * 0.01, ph[1] / tiles * 0.01,
+              (ph[2] - ph[1]) / tiles * 0.01, (ph[3] - ph[2]) / tiles * 0.01);
     }
 #endif
   }

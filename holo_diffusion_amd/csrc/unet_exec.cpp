@@ -43,10 +43,7 @@ const char* get_error() { return g_err; }
 
 using namespace holo;
 
-struct HoloCtx {
-  int device;
-  int num_cus;
-};
+// struct HoloCtx { device, num_cus }: holo_kernels.h (shared with render_exec.cpp)
 
 // ---------------------------------------------------------------------------------------------
 // structure description

@@ -200,6 +200,11 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         preds["images_render"] = rendered.features.permute(0, 3, 1, 2)
         preds["depths_render"] = rendered.depths.permute(0, 3, 1, 2)
         preds["masks_render"] = rendered.masks.permute(0, 3, 1, 2)
+        if rendered.normals is not None:
+            # build-side addition: the reference renders the normals when the implicit function has render_normals=True
+            # (released YAMLs) but never exports them; `normals_render` is the key its own fly-around output stage looks
+            # for (flyaround.py:440-445, _make_shaded_from_normals)
+            preds["normals_render"] = rendered.normals.permute(0, 3, 1, 2)
         return preds
 
     def render_views(self, voxel_features: torch.Tensor, cameras: PerspectiveCameras) -> Dict[str, torch.Tensor]:
@@ -214,6 +219,9 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
                                  evaluation_mode=EvaluationMode.EVALUATION)
         for func in self._implicit_functions:
             func.unbind_args()
-        return {"images_render": rendered.features.permute(0, 3, 1, 2),
-                "depths_render": rendered.depths.permute(0, 3, 1, 2),
-                "masks_render": rendered.masks.permute(0, 3, 1, 2)}
+        out = {"images_render": rendered.features.permute(0, 3, 1, 2),
+               "depths_render": rendered.depths.permute(0, 3, 1, 2),
+               "masks_render": rendered.masks.permute(0, 3, 1, 2)}
+        if rendered.normals is not None:
+            out["normals_render"] = rendered.normals.permute(0, 3, 1, 2)
+        return out

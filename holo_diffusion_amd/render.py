@@ -314,7 +314,7 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         L = runtime.lib()
         dens = torch.empty(n, device=dev)
         col = torch.empty(n, 3, device=dev)
-        nbytes = L.holo_render_workspace_bytes(h, 1) + 12 * dirsf.shape[0] + 256
+        nbytes = L.holo_render_workspace_bytes(h, 1, 0) + 12 * dirsf.shape[0] + 256
         ws = runtime.workspace(self, dev, nbytes)
         _lib.check(L, L.holo_implicit_eval(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf),
                                            runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens), runtime.ptr(col),
@@ -488,14 +488,23 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         dep = torch.empty(n_cam, 1, H, W, device=dev)
         msk = torch.empty(n_cam, 1, H, W, device=dev)
         imgc, depc, mskc = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(msk)
-        nbytes = L.holo_render_workspace_bytes(h, n_cam)
+        # render_normals (released YAMLs set it on the implicit function, configs/apple.yaml:203): the normals of both
+        # passes are composited inside the same kernel (holo_multipass_ea.py:105-109)
+        want_normals = bool(getattr(fn, "render_normals", False))
+        nrm = torch.empty_like(img) if want_normals else None
+        nrmc = torch.empty_like(img) if want_normals else None
+        nbytes = L.holo_render_workspace_bytes(h, n_cam, 1 if want_normals else 0)
         ws = runtime.workspace(self, dev, nbytes)
+        nul = C.c_void_p(None)
         _lib.check(L, L.holo_render(h, runtime.ptr(grid), arr, n_cam, runtime.ptr(img), runtime.ptr(dep),
                                     runtime.ptr(msk), runtime.ptr(imgc), runtime.ptr(depc), runtime.ptr(mskc),
+                                    runtime.ptr(nrm) if want_normals else nul, runtime.ptr(nrmc) if want_normals else nul,
                                     runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_render")
         coarse = RendererOutput(features=imgc.permute(0, 2, 3, 1), depths=depc.permute(0, 2, 3, 1),
-                                masks=mskc.permute(0, 2, 3, 1))
+                                masks=mskc.permute(0, 2, 3, 1),
+                                normals=nrmc.permute(0, 2, 3, 1) if want_normals else None)
         if len(implicit_functions) == 1:
             return coarse
         return RendererOutput(features=img.permute(0, 2, 3, 1), depths=dep.permute(0, 2, 3, 1),
-                              masks=msk.permute(0, 2, 3, 1), prev_stage=coarse)
+                              masks=msk.permute(0, 2, 3, 1), prev_stage=coarse,
+                              normals=nrm.permute(0, 2, 3, 1) if want_normals else None)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 1
+#define HOLO_ABI_VERSION 2
 
 enum {
   HOLO_OK = 0,
@@ -178,18 +178,25 @@ int holo_renderer_commit(HoloRenderer* r, void* stream);
  * product, fp32 accumulation; feature_size 32 only, other sizes keep the exact path).  Opt-in. */
 int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype);
 
-size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras);
+/* Scratch of holo_render.  The renderer is a PERSISTENT kernel (one workgroup per CU, every wave a worker with a
+ * private 32 KB slot for the coarse-pass values of its 32 rays - twice that when normals are rendered), so the size
+ * depends on the device and the configuration only: `n_cameras` is accepted for interface stability and ignored. */
+size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras, int with_normals);
 
-/* Render n_cameras full-grid frames of one voxel grid (up to 8 frames per kernel launch: a single 400x400 frame
- * cannot fill the chip; holo_render_workspace_bytes sizes the per-frame scratch accordingly).
+/* Render n_cameras full-grid frames of one voxel grid (up to 32 cameras per kernel launch; all wave tiles of all
+ * frames of a launch are walked by the resident waves, so a launch has one tail whatever the frame count).
  *   grid        : (1, C, R, R, R) fp32 NCDHW (what HoloDiffusionModel.forward binds as
  *                 voxel_grid_features, holo_diffusion_model.py:431-438)
  *   cameras     : host array of n_cameras HoloCamera (depth bounds are computed per camera)
  *   images      : (n_cameras, 3, H, W); depths, masks : (n_cameras, 1, H, W)   [fine pass]
- *   *_coarse    : optional (may be NULL) outputs of the coarse pass (RendererOutput.prev_stage) */
+ *   *_coarse    : optional (may be NULL) outputs of the coarse pass (RendererOutput.prev_stage)
+ *   normals, normals_coarse : optional (may be NULL) rendered normals sum_i w_i n_i, (n_cameras, 3, H, W)
+ *                 (holo_multipass_ea.py:105-109 with render_normals=True; n_i = RenderMLP.get_normals,
+ *                 holo_voxel_grid_implicit_function.py:131-145, evaluated analytically); normals_coarse needs the
+ *                 other *_coarse outputs */
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
                 float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
-                void* workspace, size_t workspace_bytes, void* stream);
+                float* normals, float* normals_coarse, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Stand-alone implicit function.  Replaces HoloVoxelGridImplicitFunction.forward
  * (holo_voxel_grid_implicit_function.py:182-269): trilinear fetch of `grid` at the world points, RenderMLP.

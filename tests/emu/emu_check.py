@@ -199,11 +199,11 @@ def check_render(C_feat=32, R=8, H=8, W=16, n_fine=64, split=False):
         hc.principal_point[i] = float(cam["pp"].reshape(-1)[i])
     img, dep, msk = torch.empty(1, 3, H, W), torch.empty(1, 1, H, W), torch.empty(1, 1, H, W)
     imgc, depc, mskc = torch.empty(1, 3, H, W), torch.empty(1, 1, H, W), torch.empty(1, 1, H, W)
-    wsb = lib.holo_render_workspace_bytes(r, 1)
+    wsb = lib.holo_render_workspace_bytes(r, 1, 0)
     ws = torch.zeros(wsb // 4 + 64)
     t0 = time.time()
     _lib.check(lib, lib.holo_render(r, ptr(grid), C.byref(hc), 1, ptr(img), ptr(dep), ptr(msk), ptr(imgc), ptr(depc),
-                                    ptr(mskc), ptr(ws), wsb, None), "render")
+                                    ptr(mskc), None, None, ptr(ws), wsb, None), "render")
     print(f"  render took {time.time() - t0:.1f}s (emulated)")
     ok = True
     ok &= report("coarse rgb", imgc, ref["images_coarse"], 2e-4)

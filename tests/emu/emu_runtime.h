@@ -239,6 +239,19 @@ static inline float __shfl(float v, int src) {
   return r;
 }
 
+// wave vote: true if the predicate holds on any lane (every lane of the wave must call it)
+static inline int __any(int pred) {
+  emu::WaveCtx& w = emu_wave();
+  const int lane = emu::t_tid & 63;
+  w.a[lane] = pred ? 1.f : 0.f;
+  w.bar.wait();
+  int r = 0;
+  const int n = w.bar.expected.load();
+  for (int l = 0; l < n && l < 64; ++l) r |= (w.a[l] != 0.f);
+  w.bar.wait();
+  return r;
+}
+
 static inline double atomicAdd(double* p, double v) {
   std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
   double o = *p;

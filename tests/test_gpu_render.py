@@ -200,3 +200,30 @@ def test_standalone_normals_vs_autograd_oracle(gu, C):
     assert 0.2 < inside.float().mean() < 0.98
     assert (got[inside] - ref[inside]).abs().max() < 2e-4
     assert got[~inside].abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("C,resol,H,W,n_fine", [(32, 8, 12, 20, 64), (16, 8, 9, 11, 16), (64, 8, 8, 8, 64)])
+def test_rendered_normals_vs_oracle(gu, C, resol, H, W, n_fine):
+    """render_normals=True (released YAMLs): the normals of both passes composited inside the fused renderer,
+    sum_i w_i n_i (holo_multipass_ea.py:105-109), against the oracle (autograd normals, RenderMLP.get_normals,
+    composited with the oracle's own weights); the other outputs must not change when normals are switched on."""
+    model, _, _, rcfg, msd = gu.make_model(resol, C, H, W, TINY_UNET, n_fine=n_fine, density_bias=0.05)
+    model.net_3d_enabled = False
+    grid = torch.tanh(torch.from_numpy(np_noise(37, (1, C, resol, resol, resol))))
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2)
+    plain = model(camera=cams[1].to(gu.DEV), voxel_features=grid.to(gu.DEV))
+    assert "normals_render" not in plain and plain["rendered"].normals is None
+    model._implicit_functions[0]._fn.render_normals = True
+    preds = model(camera=cams[1].to(gu.DEV), voxel_features=grid.to(gu.DEV))
+    for k in ("images_render", "depths_render", "masks_render"):
+        assert torch.equal(preds[k], plain[k]), k
+    ref = ro.render(grid, msd, gu.cam_dict(cams, 1), rcfg, return_coarse=True, with_normals=True)
+    assert preds["normals_render"].shape == (1, 3, H, W)
+    # |sum w n| <= 1; the composite inherits the 2e-4 of the weights plus the normals' own error
+    assert (preds["normals_render"].cpu() - ref["normals_render"]).abs().max().item() < 5e-4
+    prev = preds["rendered"].prev_stage
+    assert (prev.normals.permute(0, 3, 1, 2).cpu() - ref["normals_coarse"]).abs().max().item() < 5e-4
+    assert ref["normals_render"].abs().max() > 0.05  # the case has non-trivial normals
+    # batched call carries them too
+    allv = model.render_views(grid.to(gu.DEV), cams.to(gu.DEV))
+    assert torch.equal(allv["normals_render"][1], preds["normals_render"][0])

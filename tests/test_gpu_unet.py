@@ -25,7 +25,7 @@ def gu():
 
 def test_native_library_loaded():
     lib = runtime.lib()
-    assert lib.holo_abi_version() == 1
+    assert lib.holo_abi_version() == 2
     assert os.path.basename(_lib.LIB_PATH) == "libholo_mi355x.so"
 
 
