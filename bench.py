@@ -401,7 +401,9 @@ def main():
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
             "roofline": roof,
-            "roofline_render": {"bound": "mfma+gather", "kernel": "render_kernel<16> (up to 8 frames per launch)",
+            "roofline_render": {"bound": "mfma+gather",
+                                "kernel": "render_kernel<16, false, false, 64> (persistent: one 12-wave workgroup per CU walks "
+                                          "the 32-ray wave tiles of all frames of the call)",
                                 "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,
                                 "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,
                                 "peak_hbm_GBps": PEAK_HBM_GBPS,

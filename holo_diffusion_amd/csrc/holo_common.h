@@ -20,6 +20,8 @@ static inline uint32_t pack_bf16x2(float lo, float hi) { return emu_bf16_bits(lo
 static inline f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
 static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return emu_mfma_f32_32x32x16_bf16(a, b, c); }
 #define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
+static inline float holo_rcp(float x) { return 1.0f / x; }
+static inline float holo_rcp_exact(float x) { return 1.0f / x; }
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
 #define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
@@ -48,6 +50,9 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(holo_bf16x8, a), __builtin_bit_cast(holo_bf16x8, b), c,
                                                  0, 0, 0);
 }
+// v_rcp_f32 (1 ulp) / the correctly rounded reciprocal
+__device__ __forceinline__ float holo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)
 // Passes a per-lane value through an empty asm: the optimiser can no longer prove it loop-invariant, so index

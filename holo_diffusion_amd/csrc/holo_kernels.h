@@ -224,6 +224,6 @@ struct ImplicitEvalParams {
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
 int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);
-int render_waves_per_wg(int C, int n_fine);
+int render_waves_per_wg(int C, int n_fine, int with_normals);
 
 }  // namespace holo

@@ -50,7 +50,13 @@ __device__ __forceinline__ float lin_space(float start, float end, float step, i
   return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
 }
 __device__ __forceinline__ float leaky02(float v) { return fmaxf(v, 0.2f * v); }
-__device__ __forceinline__ float fast_sigmoid(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_sigmoid(float v) { return holo_rcp(1.f + __expf(-v)); }
+// x / h for a wave-uniform h with rh = 1/h precomputed: one Newton step on the product (Markstein): correctly rounded
+// except in rare double-rounding cases (1 ulp), three VALU operations instead of the eleven of an IEEE division
+__device__ __forceinline__ float div_uniform(float x, float h, float rh) {
+  const float q = x * rh;
+  return fmaf(fmaf(-q, h, x), rh, q);
+}
 
 // LDS image of the packed MLP shared by the block
 // SP (fp32-accurate bf16x3 split, opt-in): W_eff is held as three bf16 planes (hi, mid, lo; 64-byte rows of 4
@@ -138,14 +144,14 @@ __device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy,
 }
 
 // One sample of the implicit function for the lane's item: world point -> raw density, colour.
-// gbase already points at the lane half's first channel (grid + lane_channel(lh, 0)).
+// grid is the wave-uniform channels-last grid, lane_off the lane half's first channel (lane_channel(lh, 0)).
 // NRM: also the normal of the density field at the point, normalize(d density / d point) (RenderMLP.get_normals,
 // holo_voxel_grid_implicit_function.py:131-145): the density pre-activation is affine in the interpolated features, so
 // its gradient follows from the eight per-corner scalars s_c = w_dens . F_c and the derivatives of the trilinear
 // weights (zero for corners outside the grid, like grid_sample's backward), times LeakyReLU'.
 template <int CH, bool SP = false, bool NRM = false>
-__device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ gbase, int R, float Rm1,
-                                           float half_extent, float b_dens, int li, int lh, float px, float py,
+__device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ grid, uint32_t lane_off,
+                                           int R, float Rm1, float half_extent, float b_dens, int li, int lh, float px, float py,
                                            float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
                                            float& cb, float* nrm = nullptr) {
   constexpr int C = 2 * CH;
@@ -158,7 +164,9 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
 #pragma unroll
   for (int k = 0; k < CH / 2; ++k) fv[k] = f32x2{0.f, 0.f};
   {
-    const float lx = px / half_extent, ly = py / half_extent, lz = pz / half_extent;
+    const float rh = holo_rcp_exact(half_extent);  // wave-uniform
+    const float lx = div_uniform(px, half_extent, rh), ly = div_uniform(py, half_extent, rh),
+                lz = div_uniform(pz, half_extent, rh);
     const float ix = ((lx + 1.f) * 0.5f) * Rm1, iy = ((ly + 1.f) * 0.5f) * Rm1, iz = ((lz + 1.f) * 0.5f) * Rm1;
     const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
     // zeros padding as per-axis weights: a corner outside [0, R-1] gets weight 0.  All 8 corner fetches are
@@ -190,7 +198,8 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
       const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
       const float w = ((dx ? wxb : wxa) * (dy ? wyb : wya)) * (dz ? wzb : wza);
       const int xx = dx ? xb : xa, yy = dy ? yb : ya, zz = dz ? zb : za;
-      const float4* g = reinterpret_cast<const float4*>(gbase + ((int64_t)(zz * R + yy) * R + xx) * C);
+      // 32-bit element offset from the wave-uniform grid pointer (a 128^3 x 64 grid is 2^27 elements)
+      const float4* g = reinterpret_cast<const float4*>(grid + ((uint32_t)((zz * R + yy) * R + xx) * (uint32_t)C + lane_off));
       const f32x2 w2 = f32x2{w, w};
       f32x2 sc2 = f32x2{0.f, 0.f};
 #pragma unroll
@@ -359,17 +368,27 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
 // composited; the coarse values stream back through a two-deep register prefetch.
 // Reference arithmetic kept: torch's CPU cumsum accumulates fp32 inputs in double (both the raymarcher's
 // cumsum(delta * sigma) and sample_pdf's cdf), so both running sums are doubles here.
-template <int CH, int ZCAP>
+// waves per workgroup (= per CU): 12 (3 per SIMD, 168 VGPRs) for the released configurations; the normals variant and
+// 64-feature grids need more registers per wave (2 per SIMD, 256 VGPRs); 128 new samples per ray need twice the LDS rows
+template <int CH, int ZCAP, bool NRM>
 constexpr int render_waves() {
-  return CH <= 16 ? (ZCAP <= 64 ? 12 : 6) : (ZCAP <= 64 ? 8 : 4);
+  return (CH <= 16 && !NRM) ? (ZCAP <= 64 ? 12 : 6) : (ZCAP <= 64 ? 8 : 4);
 }
 
 template <int CH, bool SP, bool NRM, int ZCAP>
-__global__ __launch_bounds__((64 * render_waves<CH, ZCAP>())) void render_kernel(RenderKernelParams p) {
-  constexpr int NW = render_waves<CH, ZCAP>();
+__global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_kernel(RenderKernelParams p) {
+  constexpr int NW = render_waves<CH, ZCAP, NRM>();
   constexpr int ZS = ZCAP + 1;
-  __shared__ __attribute__((aligned(16))) MlpLds<CH, SP> s_mlp;
-  __shared__ float s_cz[NW * 32 * ZS];
+  // ONE LDS object with the RenderMLP image FIRST: the workgroup uses more than 64 KB of LDS and a ds_read carries a
+  // 16-bit offset, so everything the evaluation loop reads (20 reads per 32-row tile) has to sit below 64 KB to be
+  // addressed as base + immediate; the per-ray rows behind it are touched twice per evaluation
+  struct Smem {
+    MlpLds<CH, SP> mlp;
+    float cz[NW * 32 * ZS];
+  };
+  __shared__ __attribute__((aligned(16))) Smem s_mem;
+  MlpLds<CH, SP>& s_mlp = s_mem.mlp;
+  float* const s_cz = s_mem.cz;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -385,7 +404,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP>())) void render_kernel
   const int npix = p.H * p.W;
   const int R = p.R;
   const float Rm1 = (float)(R - 1);
-  const float* gbase = p.grid_cl + lane_channel<CH, SP>(lh, 0);
+  const uint32_t lane_off = (uint32_t)lane_channel<CH, SP>(lh, 0);
   const int nc = p.n_coarse, nf = p.n_fine;
   const int nb = nc - 1;
 
@@ -435,7 +454,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP>())) void render_kernel
     const float zstep = (zmax - zmin) / (float)(nc - 1);
     auto zcoarse = [&](int i) { return lin_space(zmin, zmax, zstep, i, nc); };
     auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb, float* nv) {
-      eval_point<CH, SP, NRM>(s_mlp, gbase, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
+      eval_point<CH, SP, NRM>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
                               org[1] + z * dir[1], org[2] + z * dir[2], rdir, sigma, cr, cg, cb, nv);
     };
     const int64_t ob = (int64_t)cam_i * npix + ray;  // output pixel (1-channel planes); rgb planes at 3*cam*npix + c*npix
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParam
   stage_mlp<CH, false>(s_mlp, p.mlp, tid);
   __syncthreads();
   const float Rm1 = (float)(p.R - 1);
-  const float* gbase = p.grid_cl + lh * CH;
+  const uint32_t lane_off = (uint32_t)(lh * CH);
   const int64_t ngroups = (p.n_points + 127) / 128;
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
     const int64_t i = g * 128 + wave * 32 + li;
@@ -686,7 +705,8 @@ __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParam
     const int64_t di = ii / p.pts_per_dir;
     const float rdir[3] = {p.rdir[di * 3 + 0], p.rdir[di * 3 + 1], p.rdir[di * 3 + 2]};
     float sg, cr, cg, cb;
-    eval_point<CH, false>(s_mlp, gbase, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg, cr, cg, cb);
+    eval_point<CH, false>(s_mlp, p.grid_cl, lane_off, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg,
+                          cr, cg, cb);
     if (active && lh == 0) {
       p.densities[i] = sg;
       p.colours[i * 3 + 0] = cr;
@@ -781,28 +801,29 @@ template <int CH, bool SP>
 static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
   const bool nrm = p.nrm_ws != nullptr;
   if (p.n_fine <= 64) {
-    dim3 block(64 * render_waves<CH, 64>());
     if (nrm) {
-      HOLO_LAUNCH((render_kernel<CH, SP, true, 64>), dim3((unsigned)n_wgs), block, stream, p);
+      HOLO_LAUNCH((render_kernel<CH, SP, true, 64>), dim3((unsigned)n_wgs), dim3(64 * render_waves<CH, 64, true>()), stream, p);
     } else {
-      HOLO_LAUNCH((render_kernel<CH, SP, false, 64>), dim3((unsigned)n_wgs), block, stream, p);
+      HOLO_LAUNCH((render_kernel<CH, SP, false, 64>), dim3((unsigned)n_wgs), dim3(64 * render_waves<CH, 64, false>()), stream, p);
     }
   } else {
-    dim3 block(64 * render_waves<CH, 128>());
     if (nrm) {
-      HOLO_LAUNCH((render_kernel<CH, SP, true, 128>), dim3((unsigned)n_wgs), block, stream, p);
+      HOLO_LAUNCH((render_kernel<CH, SP, true, 128>), dim3((unsigned)n_wgs), dim3(64 * render_waves<CH, 128, true>()), stream, p);
     } else {
-      HOLO_LAUNCH((render_kernel<CH, SP, false, 128>), dim3((unsigned)n_wgs), block, stream, p);
+      HOLO_LAUNCH((render_kernel<CH, SP, false, 128>), dim3((unsigned)n_wgs), dim3(64 * render_waves<CH, 128, false>()), stream, p);
     }
   }
   return 0;
 }
 
 // waves per workgroup of the persistent kernel for this configuration (the scratch has one slot per resident wave)
-int render_waves_per_wg(int C, int n_fine) {
-  const int zc = n_fine <= 64 ? 64 : 128;
-  if (C <= 32) return zc == 64 ? render_waves<16, 64>() : render_waves<16, 128>();
-  return zc == 64 ? render_waves<32, 64>() : render_waves<32, 128>();
+int render_waves_per_wg(int C, int n_fine, int with_normals) {
+  const bool z64 = n_fine <= 64;
+  if (C <= 32) {
+    if (with_normals) return z64 ? render_waves<16, 64, true>() : render_waves<16, 128, true>();
+    return z64 ? render_waves<16, 64, false>() : render_waves<16, 128, false>();
+  }
+  return z64 ? render_waves<32, 64, false>() : render_waves<32, 128, false>();
 }
 
 int render_launch(const RenderKernelParams& p, void* stream, int n_wgs) {

@@ -238,10 +238,12 @@ static int render_workgroups(const HoloRenderer* r) {
 #endif
   return r->ctx->num_cus > 0 ? r->ctx->num_cus : 256;
 }
-static size_t render_slots(const HoloRenderer* r) {
-  return (size_t)render_workgroups(r) * (size_t)render_waves_per_wg(r->cfg.feature_size, r->cfg.n_pts_fine);
+static size_t render_slots(const HoloRenderer* r, int with_normals) {
+  return (size_t)render_workgroups(r) * (size_t)render_waves_per_wg(r->cfg.feature_size, r->cfg.n_pts_fine, with_normals);
 }
-static size_t val_ws_bytes(const HoloRenderer* r) { return render_slots(r) * 64 * 32 * 4 * sizeof(float); }
+static size_t val_ws_bytes(const HoloRenderer* r, int with_normals) {
+  return render_slots(r, with_normals) * 64 * 32 * 4 * sizeof(float);
+}
 
 int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
   if (!r || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_F32_BF16X3)) {
@@ -255,7 +257,7 @@ int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras, int with_normals) {
   (void)n_cameras;  // the scratch is per resident wave: any number of cameras renders out of the same buffer
   if (!r) return 0;
-  return grid_cl_bytes(r) + val_ws_bytes(r) * (with_normals ? 2 : 1) + 256;
+  return grid_cl_bytes(r) + val_ws_bytes(r, with_normals) * (with_normals ? 2 : 1) + 256;
 }
 
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
@@ -283,7 +285,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   const int64_t npix = (int64_t)H * Wd;
   const int G = RenderKernelParams::MAX_CAMS;  // frames per launch (launch parameters hold that many cameras)
   const int n_wgs_max = render_workgroups(r);
-  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine);
+  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, want_nrm ? 1 : 0);
 #ifndef HOLO_EMU
   static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
   static const char* xcd_env = getenv("HOLO_RENDER_XCD");
@@ -341,7 +343,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.pdf_eps = c.sample_pdf_eps;
     p.split3 = (r->split3 && c.feature_size == 32) ? 1 : 0;
     p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r));
-    p.nrm_ws = want_nrm ? (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r)) : nullptr;
+    p.nrm_ws = want_nrm ? (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r, 1)) : nullptr;
     p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets
     p.depth = depths + (size_t)c0 * npix;
     p.mask = masks + (size_t)c0 * npix;

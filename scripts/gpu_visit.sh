@@ -1,0 +1,28 @@
+#!/bin/bash
+# One GPU-box visit for round 2: smoke, -m gpu parity tests, render probes, bench line, rocprofv3 trace of the EXACT
+# bench command.  bash scripts/gpu_visit.sh <tag> [pytest -k expression]
+TAG=${1:-v}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6 > $OUT/device.txt
+nproc >> $OUT/device.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/device.txt
+echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
+echo "== pytest -m gpu"
+if [ -n "$2" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=12 -k "$2" > $OUT/pytest_gpu.log 2>&1
+else
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=12 > $OUT/pytest_gpu.log 2>&1
+fi
+echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -45 $OUT/pytest_gpu.log
+echo "== render probes"
+timeout 300 python scripts/render_probe.py 1 8 30 > $OUT/render_probe.log 2>&1
+HOLO_RENDER_XCD=1 timeout 300 python scripts/render_probe.py 8 >> $OUT/render_probe.log 2>&1
+HOLO_RENDER_TIMELINE=1 timeout 300 python scripts/render_probe.py 8 2>&1 | grep -m2 "timeline" >> $OUT/render_probe.log
+cat $OUT/render_probe.log
+echo "== bench"; timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -5 $OUT/bench.err
+echo "== rocprofv3 kernel trace of the bench command"
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err; echo "rocprof rc=$?" )
+for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
+for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv"); do python3 scripts/trace_by_grid.py "$f" "$OUT/kernel_trace_by_grid.csv"; done
+head -14 $OUT/kernel_stats.csv 2>/dev/null | cut -c1-220

@@ -60,13 +60,26 @@ def _border_and_random_rays(H, W, n_random, seed):
 
 
 def _check_rays(preds, ref, idx, H, W, tol=2e-4, coarse=None):
+    """rgb and mask: EVERY ray within `tol`.  Depth: 99 % of the rays within tol x far, every ray within 5e-3 x far.
+    Why depth gets a quantile: sample_pdf switches `den = cdf_a - cdf_b` to 1 when it is below eps = 1e-5, and for an
+    opaque ray an empty bin has den = 1e-5 / (1 + 6e-4) - 0.6 % under the threshold, while the fp32 cdf values it is the
+    difference of are quantised to 6e-8 (0.6 % of it).  Which side an empty bin falls on is therefore decided by the
+    LAST BIT of the cumulative sums; any two correct evaluations (the reference on CPU vs on CUDA, the oracle vs the
+    oracle on a grid perturbed by 1e-6: 0.7 % of the rays move a new depth by > 1e-3) disagree on it for a few per cent
+    of the rays, where one importance sample then sits elsewhere inside an (almost) empty interval.  The colour and the
+    mask barely notice; sum w z does, at the 1e-3 level, on those rays."""
     flat = lambda t: t.reshape(t.shape[1], H * W).t().cpu()[idx]  # noqa: E731  (1,c,H,W) -> (n,c)
-    for k, rk, tl in (("images_render", "rgb", tol), ("masks_render", "mask", tol), ("depths_render", "depth", tol * FAR)):
+    for k, rk in (("images_render", "rgb"), ("masks_render", "mask")):
         err = (flat(preds[k]) - ref[rk]).abs().max().item()
-        assert err < tl, (k, err)
-    if coarse is not None:
-        e = (coarse.features.permute(0, 3, 1, 2).reshape(3, H * W).t().cpu()[idx] - ref["rgb_c"]).abs().max().item()
-        assert e < tol, ("coarse rgb", e)
+        assert err < tol, (k, err)
+    e = (flat(preds["depths_render"]) - ref["depth"]).abs().flatten()
+    q99 = e.kthvalue(max(1, int(0.99 * e.numel())))[0].item()
+    assert q99 < tol * FAR and e.max().item() < 5e-3 * FAR, ("depths_render", q99, e.max().item(), e.median().item())
+    if coarse is not None:  # the coarse pass has no resampling: every ray, every output
+        cf = lambda t: t.permute(0, 3, 1, 2).reshape(t.shape[3], H * W).t().cpu()[idx]  # noqa: E731
+        assert (cf(coarse.features) - ref["rgb_c"]).abs().max().item() < tol
+        assert (cf(coarse.masks) - ref["mask_c"]).abs().max().item() < tol
+        assert (cf(coarse.depths) - ref["depth_c"]).abs().max().item() < tol * FAR
 
 
 def test_north_star_ray_subset_vs_oracle(gu):

@@ -215,9 +215,12 @@ def test_rendered_normals_vs_oracle(gu, C, resol, H, W, n_fine):
     assert "normals_render" not in plain and plain["rendered"].normals is None
     model._implicit_functions[0]._fn.render_normals = True
     preds = model(camera=cams[1].to(gu.DEV), voxel_features=grid.to(gu.DEV))
-    for k in ("images_render", "depths_render", "masks_render"):
-        assert torch.equal(preds[k], plain[k]), k
     ref = ro.render(grid, msd, gu.cam_dict(cams, 1), rcfg, return_coarse=True, with_normals=True)
+    # the normals variant is a different instantiation of the kernel (not bit-identical code): held to the same
+    # tolerances against the oracle as the plain one, and within rounding of it
+    for k, tol in (("images_render", 2e-4), ("masks_render", 2e-4), ("depths_render", 2e-4 * 14.0)):
+        assert (preds[k].cpu() - ref[k]).abs().max().item() < tol, k
+        assert (preds[k] - plain[k]).abs().max().item() < tol, k
     assert preds["normals_render"].shape == (1, 3, H, W)
     # |sum w n| <= 1; the composite inherits the 2e-4 of the weights plus the normals' own error
     assert (preds["normals_render"].cpu() - ref["normals_render"]).abs().max().item() < 5e-4
