@@ -53,7 +53,7 @@ class HoloOpTiming(C.Structure):
     _fields_ = [("op", C.c_int32), ("kernel", C.c_int32), ("tile_depth", C.c_int32), ("fused_skip", C.c_int32),
                 ("nsplit", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("out_dim", C.c_int32),
                 ("stride", C.c_int32), ("upsample", C.c_int32), ("ksz", C.c_int32), ("ms", C.c_float),
-                ("flops", C.c_double)]
+                ("flops", C.c_double), ("flops_executed", C.c_double)]
 
 
 _vp = C.c_void_p

@@ -62,14 +62,21 @@ struct ConvParams {
   int stagger_ticks;      // halo kernel: phase offset (100 MHz ticks) of the workgroup in the odd slot of a CU
   unsigned long long* dbg;  // optional timeline probe (scripts/conv_timeline.cpp): [tile][8] {t_start, t_first_halo,
                             // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
-  int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel
+  int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel
+  // Winograd-in-depth form of the 128-voxel halo kernel (conv_wino_kernel): weights pre-transformed along kz,
+  // U_xi = sum_kz G[xi][kz] w[kz], packed like w with 36 pseudo-taps xi*9 + ky*3 + kx; the fused skip as 2 pseudo-taps
+  // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
+  const float* w_wino;
+  const float* skip_w_wino;
+  int wino;               // set by conv_plan
 };
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
 size_t conv_plan(ConvParams& p, int num_cus);
 int conv_launch(const ConvParams& p, void* stream);
 int conv_stats_slabs(const ConvParams& p);
-double conv_flops(const ConvParams& p);
+double conv_flops(const ConvParams& p);       // algorithmic (the reference's multiply-adds x 2)
+double conv_exec_flops(const ConvParams& p);  // issued to the matrix pipe (differs for the Winograd-in-depth kernel)
 
 // ---------------------------------------------------------------------------------------------
 // batched GEMM on fp32 MFMA (kernels_gemm.hip):  C[b] = alpha * A[b] * B[b]^T
@@ -144,6 +151,10 @@ int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* s
 int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int Cin, int taps, int CoutP, int CinP,
                                    void* stream);
 // OIDHW [Cout][Cin][taps] -> zero padded MFMA-fragment-packed layout (see ConvParams::w)
+// OIDHW 3x3x3 (src_taps = 27) -> 36 Winograd-in-depth pseudo-taps, or a 1x1x1 skip weight (src_taps = 1) -> its 2
+// pseudo-taps; same packed layout as repack_conv_weight_launch
+int repack_conv_weight_wino_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
+                                   void* stream);
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
                               void* stream);
 

@@ -665,6 +665,338 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
+// Winograd-in-depth form of the halo kernel for the 128-voxel tiles (the 64^3 level: 80 % of the FLOPs).
+//
+// The exact-fp32 MFMA runs at the vector rate, so the only way below the 27-tap multiply count in fp32 is to multiply
+// less.  The 2 x 8 x 8 output tile needs exactly the 4 input planes of ONE Winograd F(2,3) tile along z:
+//   V_xi = (B^T d)_xi        d = the 4 activated halo planes of a (y,x) column    B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+//   M_xi = sum_{ky,kx,ci} U_xi[ky][kx][ci][co] * V_xi(y+ky, x+kx, ci)              U_xi = sum_kz G[xi][kz] w[kz]  (prepared once)
+//   out(z0) = M_0 + M_1 + M_2,   out(z1) = M_1 - M_2 - M_3
+// i.e. 4 x 9 = 36 pseudo-taps produce TWO output planes where the direct form spends 2 x 27 = 54: 2/3 of the MFMAs,
+// same data movement.  The transform of the inputs happens ONCE per workgroup while the halo is committed to LDS (the
+// thread that stages a (y,x) column holds its four planes): the four LDS planes simply hold V_0..V_3 instead of the raw
+// planes, and the tap loop below is the direct kernel's with "plane" read as "xi".  The output transform is lane-local
+// (a lane's accumulators of the four xi belong to the same voxels).  Arithmetic: fp32 throughout; F(2,3) adds one
+// rounding of an add before and after the products (measured against float64: same error as the direct form).
+// The fused 1x1x1 skip connection (centre tap) becomes the two pseudo-taps xi = 1, 2 with weights +w/2, -w/2.
+// ---------------------------------------------------------------------------------------------
+template <bool SKIP>
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
+  constexpr int RS = LDK;
+  constexpr int MT = 4;                // 16-voxel tiles of the 8 x 8 plane (each accumulates four xi)
+  constexpr int PLANE = HY * HX;       // 100 (y,x) columns of the halo
+  constexpr int HALO_VOX = 4 * PLANE;  // four xi planes
+  constexpr int COLS_IT = (PLANE * 8 + 255) / 256;  // (column, channel quad) items per thread: 4
+  __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * RS];
+  __shared__ int s_hcol[COLS_IT * 256];  // clamped source (y,x) offset of every item, per tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = tid >> 6;  // the wave owns output channels [16 wn, 16 wn + 16) of the block's 64
+  const int lj = lane & 15;
+  const int kq = lane >> 4;
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + BK - 1) / BK;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD >> 1;
+  int tile = blockIdx.x;
+  const int tx0 = (tile % ntx) << 3;
+  tile /= ntx;
+  const int ty0 = (tile % nty) << 3;
+  tile /= nty;
+  const int tz0 = (tile % ntz) * 2;
+  const int n = tile / ntz;
+  const int n0 = blockIdx.y * 64;
+  const int SCin = p.skip_C0 + p.skip_C1;
+  const int nsk = SKIP ? (SCin + BK - 1) / BK : 0;
+  const int cc_begin = blockIdx.z * p.chunks_per_split;
+  int cc_end = cc_begin + p.chunks_per_split;
+  if (cc_end > ncc) cc_end = ncc;
+  const int sk_begin = ncc + blockIdx.z * p.skip_chunks_per_split;
+  int sk_end = sk_begin + p.skip_chunks_per_split;
+  if (sk_end > ncc + nsk) sk_end = ncc + nsk;
+  const int SD = p.ups ? (p.ID >> 1) : p.ID;
+  const int SH = p.ups ? (p.IH >> 1) : p.IH;
+  const int SW = p.ups ? (p.IW >> 1) : p.IW;
+
+  // ---- staging: item = ((y,x) column, channel quad); the thread loads the column's four planes, activates them,
+  //      applies the input transform along z and writes the four xi values
+  const int q = tid & 7;
+  float4 hreg[COLS_IT][4];
+  unsigned cvalid = 0;  // bit i: column of item i is inside the volume (y,x)
+  unsigned zvalid = 0;  // bit pl: plane pl is inside the volume (z), uniform
+  int zsrc[4];
+#pragma unroll
+  for (int pl = 0; pl < 4; ++pl) {
+    int z = tz0 + pl - 1;
+    zvalid |= (z >= 0 && z < p.ID ? 1u : 0u) << pl;
+    z = min(max(z, 0), p.ID - 1);
+    if (p.ups) z >>= 1;
+    zsrc[pl] = z * SH * SW;
+  }
+#pragma unroll
+  for (int i = 0; i < COLS_IT; ++i) {
+    const int col = min((tid >> 3) + 32 * i, PLANE - 1);
+    const int hy = col / HX, hx = col - hy * HX;
+    int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+    y = min(max(y, 0), p.IH - 1);
+    x = min(max(x, 0), p.IW - 1);
+    if (p.ups) {
+      y >>= 1;
+      x >>= 1;
+    }
+    s_hcol[i * 256 + tid] = y * SW + x;
+    cvalid |= (ok ? 1u : 0u) << i;
+  }
+  int hcoef_c = 0;
+  bool h_is_skip = false;
+  bool h_cvalid = false;
+  auto halo_issue = [&](int cc) {
+    h_is_skip = SKIP && cc >= ncc;
+    int c = (h_is_skip ? cc - ncc : cc) * BK + q * 4;
+    hcoef_c = c;
+    h_cvalid = c < (h_is_skip ? SCin : Cin);
+    if (!h_cvalid) c = 0;  // clamped, masked below
+    const float* src = h_is_skip ? p.skip_src0 : p.src0;
+    const int C0s = h_is_skip ? p.skip_C0 : p.C0;
+    int Cs = C0s, cs = c;
+    if (c >= C0s) {
+      src = h_is_skip ? p.skip_src1 : p.src1;
+      Cs = h_is_skip ? p.skip_C1 : p.C1;
+      cs = c - C0s;
+    }
+    // unconditional loads from clamped addresses, masked afterwards; uniform base + 32-bit byte offsets
+    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)n * SD * SH * SW * Cs);
+    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
+    int tl = tid;
+    HOLO_LAUNDER(tl);
+#pragma unroll
+    for (int i = 0; i < COLS_IT; ++i) {
+      const unsigned yx = (unsigned)s_hcol[i * 256 + tl];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl)
+        hreg[i][pl] = *reinterpret_cast<const float4*>(sbase + (((unsigned)zsrc[pl] + yx) * cbytes + cofs));
+    }
+  };
+  auto halo_commit = [&]() {
+    f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
+    const bool xform = p.coef && !h_is_skip;  // the skip path reads the raw block input
+    if (xform) {
+      const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
+      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
+      const float4 c01 = cf[0], c23 = cf[1];  // (a,b) interleaved per channel
+      a01 = f32x2{c01.x, c01.z};
+      b01 = f32x2{c01.y, c01.w};
+      a23 = f32x2{c23.x, c23.z};
+      b23 = f32x2{c23.y, c23.w};
+    }
+#pragma unroll
+    for (int i = 0; i < COLS_IT; ++i) {
+      const int col = (tid >> 3) + 32 * i;
+      f32x2 v01[4], v23[4];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) {
+        v01[pl] = f32x2{hreg[i][pl].x, hreg[i][pl].y};
+        v23[pl] = f32x2{hreg[i][pl].z, hreg[i][pl].w};
+        if (xform) {
+          v01[pl] = pk_fma(v01[pl], a01, b01);
+          v23[pl] = pk_fma(v23[pl], a23, b23);
+          if (p.act) {
+            v01[pl] = f32x2{silu_f(v01[pl].x), silu_f(v01[pl].y)};
+            v23[pl] = f32x2{silu_f(v23[pl].x), silu_f(v23[pl].y)};
+          }
+        }
+        // zero padding is applied AFTER the activation
+        const float keep = (h_cvalid && ((cvalid >> i) & 1u) && ((zvalid >> pl) & 1u)) ? 1.f : 0.f;
+        const f32x2 k2 = f32x2{keep, keep};
+        v01[pl] = pk_mul(v01[pl], k2);
+        v23[pl] = pk_mul(v23[pl], k2);
+      }
+      if (col < PLANE) {
+        // B^T d: xi0 = d0 - d2, xi1 = d1 + d2, xi2 = d2 - d1, xi3 = d1 - d3
+        const f32x2 m1 = f32x2{-1.f, -1.f}, o1 = f32x2{1.f, 1.f};
+        const f32x2 x0a = pk_fma(v01[2], m1, v01[0]), x0b = pk_fma(v23[2], m1, v23[0]);
+        const f32x2 x1a = pk_fma(v01[2], o1, v01[1]), x1b = pk_fma(v23[2], o1, v23[1]);
+        const f32x2 x2a = pk_fma(v01[1], m1, v01[2]), x2b = pk_fma(v23[1], m1, v23[2]);
+        const f32x2 x3a = pk_fma(v01[3], m1, v01[1]), x3b = pk_fma(v23[3], m1, v23[1]);
+        float* dst = s_halo + col * RS + q * 4;
+        *reinterpret_cast<float4*>(dst + 0 * PLANE * RS) = make_float4(x0a.x, x0a.y, x0b.x, x0b.y);
+        *reinterpret_cast<float4*>(dst + 1 * PLANE * RS) = make_float4(x1a.x, x1a.y, x1b.x, x1b.y);
+        *reinterpret_cast<float4*>(dst + 2 * PLANE * RS) = make_float4(x2a.x, x2a.y, x2b.x, x2b.y);
+        *reinterpret_cast<float4*>(dst + 3 * PLANE * RS) = make_float4(x3a.x, x3a.y, x3b.x, x3b.y);
+      }
+    }
+  };
+
+  f32x4 acc[4][MT];  // [xi][16-voxel tile of the plane]
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[xi][t][r] = 0.f;
+
+  // A addressing (as in the direct kernel): the 16 voxels of tile t are x = 0..7 of rows y = t and t + 4
+  int a_off[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = ((t + 4 * (lj >> 3)) * HX + (lj & 7)) * RS + kq * 8;
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
+  constexpr int WBLK = 512;
+  const float* w_lane = p.w_wino + (int64_t)((n0 >> 4) + wn) * WBLK + lane * 4;
+
+  auto load_a = [&](float4 (&a)[MT], int pt, int half) {  // pseudo-tap pt = xi * 9 + ky * 3 + kx
+    const int xi = pt / 9, kh = (pt - xi * 9) / 3, kw = pt - xi * 9 - kh * 3;
+    const int toff = ((xi * HY + kh) * HX + kw) * RS + half * 4;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) a[t] = *reinterpret_cast<const float4*>(s_halo + a_off[t] + toff);
+  };
+  auto load_b = [&](float4 (&b)[2], int cc, int pt) {
+    const float* wp = w_lane + (int64_t)(pt * wncc + cc) * wnsl * WBLK;
+    b[0] = *reinterpret_cast<const float4*>(wp);
+    b[1] = *reinterpret_cast<const float4*>(wp + 256);
+  };
+  auto mfma_half = [&](f32x4 (&ac)[MT], const float4 (&a)[MT], const float4& b) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, b.x, ac[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, b.y, ac[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, b.z, ac[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) ac[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, b.w, ac[t], 0, 0, 0);
+  };
+
+  float4 aA[MT] = {}, aB[MT] = {}, aC[MT] = {};  // first half of this pseudo-tap, second half, first half of the next
+  float4 b0[2] = {}, b1[2] = {};
+  auto tap_body = [&](f32x4 (&ac)[MT], float4 (&cur)[MT], float4 (&nxt)[MT], float4 (&bc)[2], float4 (&bn)[2], int cc,
+                      int pt, bool prefetch) {
+    load_a(aB, pt, 1);
+    if (prefetch) load_b(bn, cc, pt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the requests above AHEAD of the MFMAs that hide their latency
+    mfma_half(ac, cur, bc[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prefetch) load_a(nxt, pt + 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(ac, aB, bc[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  HOLO_PHASE_DELAY(p.stagger_ticks);
+  for (int cc = cc_begin; cc < cc_end; ++cc) {
+    halo_issue(cc);
+    halo_commit();
+    load_b(b0, cc, 0);
+    __syncthreads();  // transformed halo of chunk cc visible
+    load_a(aA, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 36; pt += 2) {  // fully unrolled: the accumulator set acc[pt / 9] is a compile-time choice
+      tap_body(acc[pt / 9], aA, aC, b0, b1, cc, pt, true);
+      tap_body(acc[(pt + 1) / 9], aC, aA, b1, b0, cc, pt + 1, pt + 1 < 35);
+    }
+    __syncthreads();  // everyone done reading this halo before it is overwritten
+  }
+  if (SKIP) {
+    // fused 1x1x1 skip connection: centre (ky,kx) of the block-input halo, pseudo-taps xi = 1, 2 (weights +w/2, -w/2)
+    for (int cc = sk_begin; cc < sk_end; ++cc) {
+      halo_issue(cc);
+      halo_commit();
+      const float* wp = p.skip_w_wino + ((int64_t)(cc - ncc) * wnsl + (n0 >> 4) + wn) * WBLK + lane * 4;
+      const int64_t tap_stride = (int64_t)(p.skip_CinP / BK) * wnsl * WBLK;
+      b0[0] = *reinterpret_cast<const float4*>(wp);
+      b0[1] = *reinterpret_cast<const float4*>(wp + 256);
+      b1[0] = *reinterpret_cast<const float4*>(wp + tap_stride);
+      b1[1] = *reinterpret_cast<const float4*>(wp + tap_stride + 256);
+      __syncthreads();
+      load_a(aA, 1 * 9 + 4, 0);
+      load_a(aB, 1 * 9 + 4, 1);
+      mfma_half(acc[1], aA, b0[0]);
+      mfma_half(acc[1], aB, b0[1]);
+      load_a(aA, 2 * 9 + 4, 0);
+      load_a(aB, 2 * 9 + 4, 1);
+      mfma_half(acc[2], aA, b1[0]);
+      mfma_half(acc[2], aB, b1[1]);
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform (lane-local) + epilogue.  16x16x4 D layout: col = lane&15 (Cout), row = 4*(lane>>4) + r
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int co = n0 + wn * 16 + lj;
+  const int coc = co < p.Cout ? co : p.Cout - 1;
+  float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  if (p.nsplit == 1 && p.skip_bias) bv += p.skip_bias[coc];
+  float ssum = 0.f, ssq = 0.f;
+  const int64_t tbase = ((((int64_t)n * p.OD + tz0) * p.OH + ty0) * p.OW + tx0) * p.Cout;
+  const int zstride = p.OH * p.OW * p.Cout;
+  int off[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) off[t] = ((t + 4 * (kq >> 1)) * p.OW + 4 * (kq & 1)) * p.Cout;
+  // out(z0) = M0 + M1 + M2, out(z1) = M1 - M2 - M3, written over acc[0] / acc[3]
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m0 = acc[0][t][r], m1 = acc[1][t][r], m2 = acc[2][t][r], m3 = acc[3][t][r];
+      acc[0][t][r] = (m0 + m1) + m2;
+      acc[3][t][r] = (m1 - m2) - m3;
+    }
+  if (p.nsplit == 1) {
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      f32x4 (&o)[MT] = z ? acc[3] : acc[0];
+      if (p.residual) {
+        const float* rp = p.residual + tbase + z * (int64_t)zstride + coc;
+        float res[MT][4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[t][r] += res[t][r];
+      }
+      float* op = p.out + tbase + z * (int64_t)zstride + coc;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = o[t][r] + bv;
+          if (co < p.Cout) op[off[t] + r * p.Cout] = v;
+          ssum += v;
+          ssq += v * v;
+        }
+      }
+    }
+  } else if (co < p.Cout) {
+    float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + co;
+#pragma unroll
+    for (int z = 0; z < 2; ++z) {
+      f32x4 (&o)[MT] = z ? acc[3] : acc[0];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[z * (int64_t)zstride + off[t] + r * p.Cout] = o[t][r];
+    }
+  }
+  // GroupNorm statistics of the tensor just produced: one slab per workgroup, as the direct 128-voxel kernel
+  if (p.stats && p.nsplit == 1) {
+    ssum += __shfl_xor(ssum, 16);
+    ssq += __shfl_xor(ssq, 16);
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (kq == 0 && co < p.Cout) {
+      const int tiles_per_sample = ntx * nty * ntz;
+      const int slab = (int)blockIdx.x % tiles_per_sample;
+      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
+      d[0] = (double)ssum;
+      d[1] = (double)ssq;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // fp32-accurate convolution on the bf16 matrix cores ("bf16x3 split", opt-in: ConvParams::bf16 == 2).
 //
 // On gfx950 the exact-fp32 MFMA runs on the vector FMA lanes (157 TF, shared with every VALU instruction); the bf16
@@ -1345,7 +1677,9 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
     p.tz = 2;
     int64_t htiles = tiles;
-    if (tiles < target) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
+    const char* f2 = getenv("HOLO_CONV_FORCE_TZ2");  // test knob: 128-voxel tiles (hence the Winograd-in-depth kernel) on small grids
+    const bool force_tz2 = f2 && f2[0] == '1';
+    if (tiles < target && !force_tz2) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
@@ -1363,6 +1697,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     // next tile's halo prefetched under the last tap; measured on MI355X that is no faster than letting the
     // dispatcher refill the slots, which also balances the load dynamically: tools/conv_timeline.cpp.)
     p.grid_x = (int)(M / (64 * p.tz));
+    // exact-fp32 128-voxel tiles: the Winograd-in-depth form (2/3 of the MFMAs) when its weights were prepared
+    p.wino = (p.tz == 2 && p.w_wino && p.bf16 == 0 && p.Cout >= 64 && (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino)) ? 1 : 0;
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (tiles < target) {
@@ -1398,6 +1734,14 @@ double conv_flops(const ConvParams& p) {
   return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * p.ksz * p.ksz * p.ksz + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
 }
 
+// multiply-adds actually issued to the matrix pipe (x2): the Winograd-in-depth kernel spends 36 pseudo-taps where the
+// direct form spends 54 (two output planes), and 2 instead of 2 x 1 for the fused skip
+double conv_exec_flops(const ConvParams& p) {
+  if (!p.wino) return conv_flops(p);
+  const double M = (double)p.N * p.OD * p.OH * p.OW;
+  return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 18.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
+}
+
 int conv_launch(const ConvParams& p, void* stream) {
   const int Cin = p.C0 + p.C1;
   if ((Cin & 3) || (p.C0 & 3) || (p.Cout & 3) || (p.src1 && (p.C0 % BK))) {
@@ -1416,7 +1760,13 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (p.bf16 == 2 && p.w_bf && wide && !sk) {
+    if (p.wino) {
+      if (sk) {
+        HOLO_LAUNCH(conv_wino_kernel<true>, hgrid, block, stream, p);
+      } else {
+        HOLO_LAUNCH(conv_wino_kernel<false>, hgrid, block, stream, p);
+      }
+    } else if (p.bf16 == 2 && p.w_bf && wide && !sk) {
       if (p.tz == 2) {
         HOLO_LAUNCH(conv_halo_split_kernel<2>, hgrid, dim3(512), stream, p);
       } else {

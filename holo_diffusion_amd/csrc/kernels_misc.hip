@@ -332,6 +332,42 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
   }
 }
 
+// Winograd-in-depth weights (conv_wino_kernel): pseudo-tap pt = xi*9 + ky*3 + kx of a 3x3x3 kernel is
+// U_xi[ky][kx] = sum_kz G[xi][kz] w[kz][ky][kx] with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] (formed in double, rounded
+// once); a 1x1x1 skip weight (centre tap) has the two non-zero pseudo-taps xi = 1, 2: +w/2, -w/2.  Packed layout as above.
+__global__ __launch_bounds__(256) void repack_conv_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                      int Cout, int Cin, int src_taps, int CoutP, int CinP) {
+  const int taps = src_taps == 27 ? 36 : 2;
+  const int64_t total = (int64_t)CoutP * CinP * taps;
+  const int ncc = CinP >> 5, nsl = CoutP >> 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 3);
+    const int lj = (int)((i >> 2) & 15);
+    const int kq = (int)((i >> 6) & 3);
+    const int half = (int)((i >> 8) & 1);
+    int64_t blk = i >> 9;
+    const int slice = (int)(blk % nsl);
+    blk /= nsl;
+    const int cc = (int)(blk % ncc);
+    const int pt = (int)(blk / ncc);
+    const int co = slice * 16 + lj;
+    const int ci = cc * 32 + kq * 8 + half * 4 + e;
+    float v = 0.f;
+    if (ci < Cin && co < Cout) {
+      const float* src = w + ((int64_t)co * Cin + ci) * src_taps;
+      if (src_taps == 27) {
+        const int xi = pt / 9, kyx = pt - xi * 9;
+        const double g0 = src[kyx], g1 = src[9 + kyx], g2 = src[18 + kyx];
+        const double u = xi == 0 ? g0 : xi == 1 ? 0.5 * (g0 + g1 + g2) : xi == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+        v = (float)u;
+      } else {
+        v = pt == 0 ? 0.5f * src[0] : -0.5f * src[0];
+      }
+    }
+    out[i] = v;
+  }
+}
+
 // OIDHW [Cout][Cin][taps] -> THREE bf16 planes (hi, mid, lo with w = hi + mid + lo exactly: hi = rne(w),
 // mid = rne(w - hi), lo = rne(w - hi - mid)), each packed [tap][CinP/32][CoutP/16][lane = 16*kq + lj][8]: lane's 8
 // values are channels 8*kq .. 8*kq+7 of the chunk for output channel 16*slice + lj (B operand of
@@ -463,6 +499,19 @@ int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int 
   if (blocks > 8192) blocks = 8192;
   HOLO_LAUNCH(repack_conv_weight_bf16_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, taps, CoutP,
               CinP);
+  return 0;
+}
+int repack_conv_weight_wino_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
+                                   void* stream) {
+  if (src_taps != 27 && src_taps != 1) {
+    set_error("repack_conv_weight_wino: 27 or 1 source taps");
+    return -1;
+  }
+  int64_t total = (int64_t)CoutP * CinP * (src_taps == 27 ? 36 : 2);
+  int64_t blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  HOLO_LAUNCH(repack_conv_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, src_taps,
+              CoutP, CinP);
   return 0;
 }
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,

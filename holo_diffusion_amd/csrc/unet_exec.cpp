@@ -70,6 +70,7 @@ struct ParamSlot {
   ParamKind kind;
   float* priv;  // private (repacked) device copy
   uint16_t* priv_bf = nullptr;  // conv weights: bf16 (RNE) copy packed for v_mfma_f32_16x16x32_bf16
+  float* priv_wino = nullptr;   // conv weights of the wide top levels: Winograd-in-depth pseudo-taps (conv_wino_kernel)
   bool set;
 };
 
@@ -163,6 +164,8 @@ struct HoloUnet {
   float* pstore = nullptr;  // one allocation for all private parameter copies
   uint16_t* pstore_bf = nullptr;                       // bf16 copies of the conv weights
   std::map<const float*, const uint16_t*> bf_of;       // fp32 private copy -> bf16 copy
+  float* pstore_wino = nullptr;                        // Winograd-in-depth copies (36 / 2 pseudo-taps)
+  std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
   int compute_mode = 0;  // holo_unet_set_compute_dtype: 0 exact fp32 MFMA, 1 bf16 products, 2 bf16x3 split (fp32-accurate)
   // concatenated emb_layers
   int emb_rows = 0;
@@ -450,6 +453,10 @@ struct Planner {
       p.w_bf = it == u->bf_of.end() ? nullptr : it->second;
       p.bf16 = u->compute_mode;
     }
+    if (u->compute_mode == 0) {  // exact fp32: the Winograd-in-depth kernel where conv_plan finds 128-voxel tiles
+      auto it = u->wino_of.find(w);
+      p.w_wino = it == u->wino_of.end() ? nullptr : it->second;
+    }
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
     p.bias = bias;
@@ -464,6 +471,10 @@ struct Planner {
       if (u->compute_mode) {
         auto it = u->bf_of.find(skip_w);
         p.skip_w_bf = it == u->bf_of.end() ? nullptr : it->second;
+      }
+      if (u->compute_mode == 0) {
+        auto it = u->wino_of.find(skip_w);
+        p.skip_w_wino = it == u->wino_of.end() ? nullptr : it->second;
       }
       p.skip_CinP = pad_cin(p.skip_C0 + p.skip_C1);
       p.skip_bias = skip_bias;
@@ -894,6 +905,37 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
         cb += 3 * ((priv_numel(s) + 63) & ~(int64_t)63);
       }
   }
+  {  // Winograd-in-depth copies for the convolutions that can land on 128-voxel tiles: the wide top levels
+     // (a 3x3x3 conv of <= 256 channels: 36 pseudo-taps; a ResBlock's 1x1x1 skip connection: 2 pseudo-taps)
+    const char* we = getenv("HOLO_CONV_WINO");
+    const bool enable = !(we && we[0] == '0');
+    auto wino_numel = [](const ParamSlot& s) -> int64_t {
+      const bool c3 = s.kind == P_CONV3;
+      const bool sk = s.kind == P_CONV1 && s.name.find("skip_connection") != std::string::npos;
+      if (!(c3 || sk) || s.shape[0] > 256 || s.shape[1] > 256 || s.shape[0] % 64) return 0;
+      return (int64_t)(c3 ? 36 : 2) * pad_cout((int)s.shape[0]) * pad_cin((int)s.shape[1]);
+    };
+    int64_t tw = 0;
+    if (enable)
+      for (auto& s : u->params) tw += (wino_numel(s) + 63) & ~(int64_t)63;
+    if (tw > 0) {
+      if (hipMalloc((void**)&u->pstore_wino, (size_t)tw * sizeof(float)) != hipSuccess) {
+        set_error("holo_unet_create: hipMalloc of %lld Winograd weights failed", (long long)tw);
+        (void)hipFree(u->pstore);
+        (void)hipFree(u->pstore_bf);
+        delete u;
+        return HOLO_E_HIP;
+      }
+      float* cw = u->pstore_wino;
+      for (auto& s : u->params) {
+        const int64_t nw = wino_numel(s);
+        if (nw == 0) continue;
+        s.priv_wino = cw;
+        u->wino_of[s.priv] = cw;
+        cw += (nw + 63) & ~(int64_t)63;
+      }
+    }
+  }
   u->emb_w = cur;
   cur += ((int64_t)u->emb_rows * u->ted + 63) & ~(int64_t)63;
   u->emb_b = cur;
@@ -912,6 +954,7 @@ int holo_unet_destroy(HoloUnet* net) {
   if (!net) return 0;
   if (net->pstore) (void)hipFree(net->pstore);
   if (net->pstore_bf) (void)hipFree(net->pstore_bf);
+  if (net->pstore_wino) (void)hipFree(net->pstore_wino);
   delete net;
   return 0;
 }
@@ -965,6 +1008,12 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
                                         s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]),
                                         stream);
     if (rc) return rc;
+    if (s.priv_wino) {
+      rc = repack_conv_weight_wino_launch((const float*)dev_ptr, s.priv_wino, (int)s.shape[0], (int)s.shape[1],
+                                          s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]),
+                                          pad_cin((int)s.shape[1]), stream);
+      if (rc) return rc;
+    }
   } else {
     HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
@@ -1124,7 +1173,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.mode;
+        t.kernel = c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;
@@ -1135,6 +1184,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
         t.upsample = c.ups;
         t.ksz = c.ksz;
         t.flops = conv_flops(c);
+        t.flops_executed = conv_exec_flops(c);
       } else if (op.kind == OP_FLASH) {
         t.cin = t.cout = op.attn.C;
         t.out_dim = op.attn.T;

@@ -240,7 +240,7 @@ class SimpleUnet3D(Unet3DBase):
 
     OP_NAMES = ("memset", "layout_in", "time_embed", "emb_linears", "gn_stats", "gn_finalize", "conv", "gemm",
                 "softmax", "flash_attn", "layout_out")
-    CONV_KERNELS = ("conv_igemm_kernel", "conv_halo_kernel", "conv_small_kernel")
+    CONV_KERNELS = ("conv_igemm_kernel", "conv_halo_kernel", "conv_small_kernel", "conv_wino_kernel")
 
     def time_ops(self, batch: int, iters: int, device: torch.device):
         """Per-op timing of one forward in execution order (hipEvents on the launch stream): list of dicts."""
@@ -261,7 +261,8 @@ class SimpleUnet3D(Unet3DBase):
         ops = []
         for i in range(min(n.value, cap)):
             a = arr[i]
-            d = dict(op=self.OP_NAMES[a.op], ms=a.ms, flops=a.flops, cin=a.cin, cout=a.cout, out_dim=a.out_dim)
+            d = dict(op=self.OP_NAMES[a.op], ms=a.ms, flops=a.flops, flops_executed=a.flops_executed or a.flops, cin=a.cin,
+                     cout=a.cout, out_dim=a.out_dim)
             if a.op == 6:
                 d.update(kernel=self.CONV_KERNELS[a.kernel], tile_depth=a.tile_depth, fused_skip=bool(a.fused_skip),
                          nsplit=a.nsplit, stride=a.stride, upsample=bool(a.upsample), ksz=a.ksz)

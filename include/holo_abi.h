@@ -243,7 +243,8 @@ typedef struct {
   int32_t op, kernel, tile_depth, fused_skip, nsplit;
   int32_t cin, cout, out_dim, stride, upsample, ksz;
   float ms;
-  double flops;
+  double flops;          /* algorithmic: the reference's multiply-adds x 2 */
+  double flops_executed; /* issued to the matrix pipe (kernel 3, the Winograd-in-depth conv, spends 2/3 of `flops`) */
 } HoloOpTiming;
 int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
                        size_t workspace_bytes, int iters, void* stream, HoloOpTiming* out, int cap, int* n_ops);

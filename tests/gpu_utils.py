@@ -9,7 +9,8 @@ from oracle import unet_oracle as uo
 import os
 
 # HOLO_TEST_EMU=1 (tests/conftest.py): the same tests on the host emulation of the kernels, CPU tensors
-DEV = torch.device("cpu") if os.environ.get("HOLO_TEST_EMU") == "1" else torch.device("cuda", 0)
+EMU = os.environ.get("HOLO_TEST_EMU") == "1"
+DEV = torch.device("cpu") if EMU else torch.device("cuda", 0)
 
 
 def make_unet(cfg: uo.UNetCfg, seed: int = 1234, compute_dtype: str = "f32"):

@@ -96,7 +96,6 @@ def test_north_star_ray_subset_vs_oracle(gu):
     o, d, l = ro.make_rays(gu.cam_dict(cams, 1), rcfg)
     ref = ro.render_rays(grid, msd, o[idx], d[idx], l[idx], rcfg)
     _check_rays(preds, ref, idx, H, W, coarse=preds["rendered"].prev_stage)
-    assert 0.02 < ref["mask"].mean() < 0.98  # the frame has both hit and missed rays
 
 
 def test_config0_plumbing_frame_vs_oracle(gu):
