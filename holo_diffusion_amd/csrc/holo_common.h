@@ -16,6 +16,8 @@ struct f32x2 {
 };
 static inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)}; }
 static inline f32x2 pk_mul(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+static inline f32x2 pk_add(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+static inline f32x2 pk_sub(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
 static inline uint32_t pack_bf16x2(float lo, float hi) { return emu_bf16_bits(lo) | (emu_bf16_bits(hi) << 16); }
 static inline f32x4 mfma_bf16_16x16x32(float4 a, float4 b, f32x4 c) { return emu_mfma_f32_16x16x32_bf16(a, b, c); }
 static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return emu_mfma_f32_32x32x16_bf16(a, b, c); }
@@ -33,6 +35,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fused multiply-adds in one v_pk_fma_f32 (each element rounds exactly like fmaf)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
+// v_pk_add_f32 (the subtraction is the same instruction with a negated operand); the asm keeps the optimiser from
+// splitting the pair into two scalar v_add/v_sub
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 // two floats -> two bf16 (round to nearest even, v_cvt_pk_bf16_f32), `lo` in the low half
 typedef __bf16 holo_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 holo_bf16x8 __attribute__((ext_vector_type(8)));

@@ -68,7 +68,11 @@ struct ConvParams {
   // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
   const float* w_wino;
   const float* skip_w_wino;
-  int wino;               // set by conv_plan
+  // (z,y) Winograd form (conv_wino2_kernel): U = sum_kz,ky G[xi_z][kz] G[xi_y][ky] w[kz][ky][kx], 48 pseudo-taps
+  // (xi_z*4 + xi_y)*3 + kx; the fused skip as 4 pseudo-taps (xi_z,xi_y in {1,2}^2: +-w/4)
+  const float* w_wino2;
+  const float* skip_w_wino2;
+  int wino;               // set by conv_plan: 0 direct, 1 Winograd in depth, 2 Winograd in depth and height
 };
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
@@ -154,7 +158,7 @@ int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int 
 // OIDHW 3x3x3 (src_taps = 27) -> 36 Winograd-in-depth pseudo-taps, or a 1x1x1 skip weight (src_taps = 1) -> its 2
 // pseudo-taps; same packed layout as repack_conv_weight_launch
 int repack_conv_weight_wino_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
-                                   void* stream);
+                                   void* stream, int dims = 1);  // dims 2: (z,y) form, 48 / 4 pseudo-taps
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,
                               void* stream);
 

@@ -814,11 +814,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
       }
       if (col < PLANE) {
         // B^T d: xi0 = d0 - d2, xi1 = d1 + d2, xi2 = d2 - d1, xi3 = d1 - d3
-        const f32x2 m1 = f32x2{-1.f, -1.f}, o1 = f32x2{1.f, 1.f};
-        const f32x2 x0a = pk_fma(v01[2], m1, v01[0]), x0b = pk_fma(v23[2], m1, v23[0]);
-        const f32x2 x1a = pk_fma(v01[2], o1, v01[1]), x1b = pk_fma(v23[2], o1, v23[1]);
-        const f32x2 x2a = pk_fma(v01[1], m1, v01[2]), x2b = pk_fma(v23[1], m1, v23[2]);
-        const f32x2 x3a = pk_fma(v01[3], m1, v01[1]), x3b = pk_fma(v23[3], m1, v23[1]);
+        const f32x2 x0a = pk_sub(v01[0], v01[2]), x0b = pk_sub(v23[0], v23[2]);
+        const f32x2 x1a = pk_add(v01[1], v01[2]), x1b = pk_add(v23[1], v23[2]);
+        const f32x2 x2a = pk_sub(v01[2], v01[1]), x2b = pk_sub(v23[2], v23[1]);
+        const f32x2 x3a = pk_sub(v01[1], v01[3]), x3b = pk_sub(v23[1], v23[3]);
         float* dst = s_halo + col * RS + q * 4;
         *reinterpret_cast<float4*>(dst + 0 * PLANE * RS) = make_float4(x0a.x, x0a.y, x0b.x, x0b.y);
         *reinterpret_cast<float4*>(dst + 1 * PLANE * RS) = make_float4(x1a.x, x1a.y, x1b.x, x1b.y);
@@ -978,6 +977,370 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pp[z * (int64_t)zstride + off[t] + r * p.Cout] = o[t][r];
     }
+  }
+  // GroupNorm statistics of the tensor just produced: one slab per workgroup, as the direct 128-voxel kernel
+  if (p.stats && p.nsplit == 1) {
+    ssum += __shfl_xor(ssum, 16);
+    ssq += __shfl_xor(ssq, 16);
+    ssum += __shfl_xor(ssum, 32);
+    ssq += __shfl_xor(ssq, 32);
+    if (kq == 0 && co < p.Cout) {
+      const int tiles_per_sample = ntx * nty * ntz;
+      const int slab = (int)blockIdx.x % tiles_per_sample;
+      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
+      d[0] = (double)ssum;
+      d[1] = (double)ssq;
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) over (z, y): the same kernel with the second transform applied to the A operand at load time
+// (see "second Winograd dimension" below).  The LDS halo is the z-transformed one of conv_wino_kernel, unchanged.
+// ---------------------------------------------------------------------------------------------
+template <bool SKIP>
+__global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
+  constexpr int RS = LDK;
+  constexpr int MT = 2;                // 16-row MFMA tiles: rows = (y tile, x), y tiles t and t + 2 (see a_off)
+  constexpr int PLANE = HY * HX;       // 100 (y,x) columns of the halo
+  constexpr int HALO_VOX = 4 * PLANE;  // four xi planes
+  constexpr int COLS_IT = (PLANE * 8 + 255) / 256;  // (column, channel quad) items per thread: 4
+  __shared__ __attribute__((aligned(16))) float s_halo[HALO_VOX * RS];
+  __shared__ int s_hcol[COLS_IT * 256];  // clamped source (y,x) offset of every item, per tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = tid >> 6;  // the wave owns output channels [16 wn, 16 wn + 16) of the block's 64
+  const int lj = lane & 15;
+  const int kq = lane >> 4;
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + BK - 1) / BK;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD >> 1;
+  int tile = blockIdx.x;
+  const int tx0 = (tile % ntx) << 3;
+  tile /= ntx;
+  const int ty0 = (tile % nty) << 3;
+  tile /= nty;
+  const int tz0 = (tile % ntz) * 2;
+  const int n = tile / ntz;
+  const int n0 = blockIdx.y * 64;
+  const int SCin = p.skip_C0 + p.skip_C1;
+  const int nsk = SKIP ? (SCin + BK - 1) / BK : 0;
+  const int cc_begin = blockIdx.z * p.chunks_per_split;
+  int cc_end = cc_begin + p.chunks_per_split;
+  if (cc_end > ncc) cc_end = ncc;
+  const int sk_begin = ncc + blockIdx.z * p.skip_chunks_per_split;
+  int sk_end = sk_begin + p.skip_chunks_per_split;
+  if (sk_end > ncc + nsk) sk_end = ncc + nsk;
+  const int SD = p.ups ? (p.ID >> 1) : p.ID;
+  const int SH = p.ups ? (p.IH >> 1) : p.IH;
+  const int SW = p.ups ? (p.IW >> 1) : p.IW;
+
+  // ---- staging: item = ((y,x) column, channel quad); the thread loads the column's four planes, activates them,
+  //      applies the input transform along z and writes the four xi values
+  const int q = tid & 7;
+  float4 hreg[COLS_IT][4];
+  unsigned cvalid = 0;  // bit i: column of item i is inside the volume (y,x)
+  unsigned zvalid = 0;  // bit pl: plane pl is inside the volume (z), uniform
+  int zsrc[4];
+#pragma unroll
+  for (int pl = 0; pl < 4; ++pl) {
+    int z = tz0 + pl - 1;
+    zvalid |= (z >= 0 && z < p.ID ? 1u : 0u) << pl;
+    z = min(max(z, 0), p.ID - 1);
+    if (p.ups) z >>= 1;
+    zsrc[pl] = z * SH * SW;
+  }
+#pragma unroll
+  for (int i = 0; i < COLS_IT; ++i) {
+    const int col = min((tid >> 3) + 32 * i, PLANE - 1);
+    const int hy = col / HX, hx = col - hy * HX;
+    int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = y >= 0 && y < p.IH && x >= 0 && x < p.IW;
+    y = min(max(y, 0), p.IH - 1);
+    x = min(max(x, 0), p.IW - 1);
+    if (p.ups) {
+      y >>= 1;
+      x >>= 1;
+    }
+    s_hcol[i * 256 + tid] = y * SW + x;
+    cvalid |= (ok ? 1u : 0u) << i;
+  }
+  int hcoef_c = 0;
+  bool h_is_skip = false;
+  bool h_cvalid = false;
+  auto halo_issue = [&](int cc) {
+    h_is_skip = SKIP && cc >= ncc;
+    int c = (h_is_skip ? cc - ncc : cc) * BK + q * 4;
+    hcoef_c = c;
+    h_cvalid = c < (h_is_skip ? SCin : Cin);
+    if (!h_cvalid) c = 0;  // clamped, masked below
+    const float* src = h_is_skip ? p.skip_src0 : p.src0;
+    const int C0s = h_is_skip ? p.skip_C0 : p.C0;
+    int Cs = C0s, cs = c;
+    if (c >= C0s) {
+      src = h_is_skip ? p.skip_src1 : p.src1;
+      Cs = h_is_skip ? p.skip_C1 : p.C1;
+      cs = c - C0s;
+    }
+    // unconditional loads from clamped addresses, masked afterwards; uniform base + 32-bit byte offsets
+    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)n * SD * SH * SW * Cs);
+    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
+    int tl = tid;
+    HOLO_LAUNDER(tl);
+#pragma unroll
+    for (int i = 0; i < COLS_IT; ++i) {
+      const unsigned yx = (unsigned)s_hcol[i * 256 + tl];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl)
+        hreg[i][pl] = *reinterpret_cast<const float4*>(sbase + (((unsigned)zsrc[pl] + yx) * cbytes + cofs));
+    }
+  };
+  auto halo_commit = [&]() {
+    f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
+    const bool xform = p.coef && !h_is_skip;  // the skip path reads the raw block input
+    if (xform) {
+      const int cc4 = hcoef_c < Cin ? hcoef_c : 0;
+      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + cc4) * 2);
+      const float4 c01 = cf[0], c23 = cf[1];  // (a,b) interleaved per channel
+      a01 = f32x2{c01.x, c01.z};
+      b01 = f32x2{c01.y, c01.w};
+      a23 = f32x2{c23.x, c23.z};
+      b23 = f32x2{c23.y, c23.w};
+    }
+#pragma unroll
+    for (int i = 0; i < COLS_IT; ++i) {
+      const int col = (tid >> 3) + 32 * i;
+      f32x2 v01[4], v23[4];
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) {
+        v01[pl] = f32x2{hreg[i][pl].x, hreg[i][pl].y};
+        v23[pl] = f32x2{hreg[i][pl].z, hreg[i][pl].w};
+        if (xform) {
+          v01[pl] = pk_fma(v01[pl], a01, b01);
+          v23[pl] = pk_fma(v23[pl], a23, b23);
+          if (p.act) {
+            v01[pl] = f32x2{silu_f(v01[pl].x), silu_f(v01[pl].y)};
+            v23[pl] = f32x2{silu_f(v23[pl].x), silu_f(v23[pl].y)};
+          }
+        }
+        // zero padding is applied AFTER the activation
+        const float keep = (h_cvalid && ((cvalid >> i) & 1u) && ((zvalid >> pl) & 1u)) ? 1.f : 0.f;
+        const f32x2 k2 = f32x2{keep, keep};
+        v01[pl] = pk_mul(v01[pl], k2);
+        v23[pl] = pk_mul(v23[pl], k2);
+      }
+      if (col < PLANE) {
+        // B^T d: xi0 = d0 - d2, xi1 = d1 + d2, xi2 = d2 - d1, xi3 = d1 - d3
+        const f32x2 x0a = pk_sub(v01[0], v01[2]), x0b = pk_sub(v23[0], v23[2]);
+        const f32x2 x1a = pk_add(v01[1], v01[2]), x1b = pk_add(v23[1], v23[2]);
+        const f32x2 x2a = pk_sub(v01[2], v01[1]), x2b = pk_sub(v23[2], v23[1]);
+        const f32x2 x3a = pk_sub(v01[1], v01[3]), x3b = pk_sub(v23[1], v23[3]);
+        float* dst = s_halo + col * RS + q * 4;
+        *reinterpret_cast<float4*>(dst + 0 * PLANE * RS) = make_float4(x0a.x, x0a.y, x0b.x, x0b.y);
+        *reinterpret_cast<float4*>(dst + 1 * PLANE * RS) = make_float4(x1a.x, x1a.y, x1b.x, x1b.y);
+        *reinterpret_cast<float4*>(dst + 2 * PLANE * RS) = make_float4(x2a.x, x2a.y, x2b.x, x2b.y);
+        *reinterpret_cast<float4*>(dst + 3 * PLANE * RS) = make_float4(x3a.x, x3a.y, x3b.x, x3b.y);
+      }
+    }
+  };
+
+  // ---- second Winograd dimension (y): an MFMA row is a (y tile, x) pair - two output rows, eight x; its A operand
+  //      for pseudo-tap (xi_z, xi_y, kx) is the B^T combination of two of the tile's four halo rows of plane xi_z:
+  //      xi_y0 = r0 - r2, xi_y1 = r1 + r2, xi_y2 = r2 - r1, xi_y3 = r1 - r3, formed in registers from four 16-byte
+  //      LDS reads that serve all four xi_y.  16 accumulator sets [xi_z][xi_y] per tile, 48 pseudo-taps per chunk
+  //      for a 2 x 2 (z,y) block of outputs where the direct form spends 108: 4/9 of the MFMAs.
+  f32x4 acc[16][MT];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[xi][t][r] = 0.f;
+
+  // A rows: MFMA row lj of tile t = y tile (t + 2*(lj>>3)), x = lj&7; its halo rows are 2*ytile + a, a = 0..3
+  // (the two y tiles of an MFMA tile are 4 halo rows = 32 (mod 64) words apart: conflict-free 16-byte reads)
+  int a_off[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) a_off[t] = ((2 * t + 4 * (lj >> 3)) * HX + (lj & 7)) * RS + kq * 8;
+  const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
+  constexpr int WBLK = 512;
+  const float* w_lane = p.w_wino2 + (int64_t)((n0 >> 4) + wn) * WBLK + lane * 4;
+  const int64_t pt_stride = (int64_t)wncc * wnsl * WBLK;  // between pseudo-taps pt = (xi_z*4 + xi_y)*3 + kx
+
+  // one step = (xi_z, kx, half of the chunk's k-steps): rows -> four xi_y operands per tile -> 32 MFMAs
+  auto load_rows = [&](float4 (&R)[4], int t, int xz, int kw, int half) {
+    const float* base = s_halo + a_off[t] + ((xz * HY) * HX + kw) * RS + half * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) R[a] = *reinterpret_cast<const float4*>(base + a * HX * RS);
+  };
+  auto load_w = [&](float4 (&B)[4], int cc, int xz, int kw, int half) {
+    const float* wp = w_lane + (int64_t)cc * wnsl * WBLK + half * 256 + (int64_t)((xz * 4) * 3 + kw) * pt_stride;
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy) B[xy] = *reinterpret_cast<const float4*>(wp + (int64_t)(xy * 3) * pt_stride);
+  };
+  auto combine = [&](float4 (&R)[4]) {  // in place: R[xi_y]; eight v_pk_add_f32
+    const f32x2 r0a = f32x2{R[0].x, R[0].y}, r0b = f32x2{R[0].z, R[0].w}, r1a = f32x2{R[1].x, R[1].y},
+                r1b = f32x2{R[1].z, R[1].w}, r2a = f32x2{R[2].x, R[2].y}, r2b = f32x2{R[2].z, R[2].w},
+                r3a = f32x2{R[3].x, R[3].y}, r3b = f32x2{R[3].z, R[3].w};
+    const f32x2 y0a = pk_sub(r0a, r2a), y0b = pk_sub(r0b, r2b);
+    const f32x2 y1a = pk_add(r1a, r2a), y1b = pk_add(r1b, r2b);
+    const f32x2 y2a = pk_sub(r2a, r1a), y2b = pk_sub(r2b, r1b);
+    const f32x2 y3a = pk_sub(r1a, r3a), y3b = pk_sub(r1b, r3b);
+    R[0] = make_float4(y0a.x, y0a.y, y0b.x, y0b.y);
+    R[1] = make_float4(y1a.x, y1a.y, y1b.x, y1b.y);
+    R[2] = make_float4(y2a.x, y2a.y, y2b.x, y2b.y);
+    R[3] = make_float4(y3a.x, y3a.y, y3b.x, y3b.y);
+  };
+  // the four xi_y accumulators of a tile advance together, k-step by k-step: consecutive MFMAs are independent (a
+  // dependent one would wait out the 8 passes of its predecessor)
+  auto mfma_xy = [&](int xz, int t, const float4 (&A)[4], const float4 (&B)[4]) {
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy)
+      acc[xz * 4 + xy][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[xy].x, B[xy].x, acc[xz * 4 + xy][t], 0, 0, 0);
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy)
+      acc[xz * 4 + xy][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[xy].y, B[xy].y, acc[xz * 4 + xy][t], 0, 0, 0);
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy)
+      acc[xz * 4 + xy][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[xy].z, B[xy].z, acc[xz * 4 + xy][t], 0, 0, 0);
+#pragma unroll
+    for (int xy = 0; xy < 4; ++xy)
+      acc[xz * 4 + xy][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[xy].w, B[xy].w, acc[xz * 4 + xy][t], 0, 0, 0);
+  };
+  auto mfma4 = [&](f32x4& ac, const float4& a, const float4& b) {
+    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, ac, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, ac, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, ac, 0, 0, 0);
+    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, ac, 0, 0, 0);
+  };
+
+  HOLO_PHASE_DELAY(p.stagger_ticks);
+  for (int cc = cc_begin; cc < cc_end; ++cc) {
+    halo_issue(cc);
+    halo_commit();
+    float4 Bc[4], Bn[4];
+    load_w(Bc, cc, 0, 0, 0);
+    __syncthreads();  // transformed halo of chunk cc visible
+    float4 R0[4], R1[4];
+    load_rows(R0, 0, 0, 0, 0);
+#pragma unroll
+    for (int st = 0; st < 24; ++st) {  // fully unrolled: accumulator sets are compile-time choices
+      const int xz = st / 6, kw = (st % 6) >> 1, half = st & 1;
+      const int nx = st + 1, nxz = nx / 6, nkw = (nx % 6) >> 1, nhalf = nx & 1;
+      load_rows(R1, 1, xz, kw, half);
+      if (st + 1 < 24) load_w(Bn, cc, nxz, nkw, nhalf);
+      __builtin_amdgcn_sched_barrier(0);  // requests stay AHEAD of the MFMAs that hide them
+      combine(R0);
+      mfma_xy(xz, 0, R0, Bc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 1 < 24) load_rows(R0, 0, nxz, nkw, nhalf);
+      __builtin_amdgcn_sched_barrier(0);
+      combine(R1);
+      mfma_xy(xz, 1, R1, Bc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int xy = 0; xy < 4; ++xy) Bc[xy] = Bn[xy];
+    }
+    __syncthreads();  // everyone done reading this halo before it is overwritten
+  }
+  if (SKIP) {
+    // fused 1x1x1 skip connection: centre tap = pseudo-taps (xi_z, xi_y) in {1,2}^2 at kx = 1, weights +-w/4
+    for (int cc = sk_begin; cc < sk_end; ++cc) {
+      halo_issue(cc);
+      halo_commit();
+      const float* wp = p.skip_w_wino2 + ((int64_t)(cc - ncc) * wnsl + (n0 >> 4) + wn) * WBLK + lane * 4;
+      const int64_t tap_stride = (int64_t)(p.skip_CinP / BK) * wnsl * WBLK;
+      __syncthreads();
+#pragma unroll
+      for (int xz = 1; xz <= 2; ++xz)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float4 B1 = *reinterpret_cast<const float4*>(wp + (int64_t)((xz - 1) * 2 + 0) * tap_stride + half * 256);
+          float4 B2 = *reinterpret_cast<const float4*>(wp + (int64_t)((xz - 1) * 2 + 1) * tap_stride + half * 256);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            float4 R[4];
+            load_rows(R, t, xz, 1, half);
+            combine(R);
+            mfma4(acc[xz * 4 + 1][t], R[1], B1);
+            mfma4(acc[xz * 4 + 2][t], R[2], B2);
+          }
+        }
+      __syncthreads();
+    }
+  }
+
+  // ---- output transform (lane-local, y then z) + epilogue.  D row 4*kq + r of tile t = y tile t + 2*(kq>>1), x = 4*(kq&1) + r
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int co = n0 + wn * 16 + lj;
+  const int coc = co < p.Cout ? co : p.Cout - 1;
+  float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  if (p.nsplit == 1 && p.skip_bias) bv += p.skip_bias[coc];
+  float ssum = 0.f, ssq = 0.f;
+  const int64_t tbase = ((((int64_t)n * p.OD + tz0) * p.OH + ty0) * p.OW + tx0) * p.Cout;
+  const int zstride = p.OH * p.OW * p.Cout;
+  const int ystride = p.OW * p.Cout;
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int off = ((2 * (t + 2 * (kq >> 1))) * p.OW + 4 * (kq & 1)) * p.Cout;  // output row 2*ytile, first x of the lane
+    float o[2][2][4];  // [z][y][r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float py[4][2];  // [xi_z][y]
+#pragma unroll
+      for (int xz = 0; xz < 4; ++xz) {
+        const float m0 = acc[xz * 4 + 0][t][r], m1 = acc[xz * 4 + 1][t][r], m2 = acc[xz * 4 + 2][t][r],
+                    m3 = acc[xz * 4 + 3][t][r];
+        py[xz][0] = (m0 + m1) + m2;
+        py[xz][1] = (m1 - m2) - m3;
+      }
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        o[0][y][r] = (py[0][y] + py[1][y]) + py[2][y];
+        o[1][y][r] = (py[1][y] - py[2][y]) - py[3][y];
+      }
+    }
+    if (p.nsplit == 1) {
+      if (p.residual) {
+        const float* rp = p.residual + tbase + off + coc;
+        float res[2][2][4];
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) res[z][y][r] = rp[z * (int64_t)zstride + y * ystride + r * p.Cout];
+#pragma unroll
+        for (int z = 0; z < 2; ++z)
+#pragma unroll
+          for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[z][y][r] += res[z][y][r];
+      }
+      float* op = p.out + tbase + off + coc;
+#pragma unroll
+      for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = o[z][y][r] + bv;
+            if (co < p.Cout) op[z * (int64_t)zstride + y * ystride + r * p.Cout] = v;
+            ssum += v;
+            ssq += v * v;
+          }
+    } else if (co < p.Cout) {
+      float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + tbase + off + co;
+#pragma unroll
+      for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pp[z * (int64_t)zstride + y * ystride + r * p.Cout] = o[z][y][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // GroupNorm statistics of the tensor just produced: one slab per workgroup, as the direct 128-voxel kernel
   if (p.stats && p.nsplit == 1) {
@@ -1699,6 +2062,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     p.grid_x = (int)(M / (64 * p.tz));
     // exact-fp32 128-voxel tiles: the Winograd-in-depth form (2/3 of the MFMAs) when its weights were prepared
     p.wino = (p.tz == 2 && p.w_wino && p.bf16 == 0 && p.Cout >= 64 && (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino)) ? 1 : 0;
+    if (p.wino && p.w_wino2 && (!p.skip_w || p.skip_w_wino2)) p.wino = 2;  // both depth and height in Winograd form
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (tiles < target) {
@@ -1739,6 +2103,8 @@ double conv_flops(const ConvParams& p) {
 double conv_exec_flops(const ConvParams& p) {
   if (!p.wino) return conv_flops(p);
   const double M = (double)p.N * p.OD * p.OH * p.OW;
+  if (p.wino == 2)  // 48 pseudo-taps per 2 x 2 outputs, the fused skip 4 pseudo-taps per 4 outputs
+    return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 12.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
   return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 18.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
 }
 
@@ -1760,7 +2126,13 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (p.wino) {
+    if (p.wino == 2) {
+      if (sk) {
+        HOLO_LAUNCH(conv_wino2_kernel<true>, hgrid, block, stream, p);
+      } else {
+        HOLO_LAUNCH(conv_wino2_kernel<false>, hgrid, block, stream, p);
+      }
+    } else if (p.wino) {
       if (sk) {
         HOLO_LAUNCH(conv_wino_kernel<true>, hgrid, block, stream, p);
       } else {

@@ -336,10 +336,12 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
 // U_xi[ky][kx] = sum_kz G[xi][kz] w[kz][ky][kx] with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] (formed in double, rounded
 // once); a 1x1x1 skip weight (centre tap) has the two non-zero pseudo-taps xi = 1, 2: +w/2, -w/2.  Packed layout as above.
 __global__ __launch_bounds__(256) void repack_conv_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ out,
-                                                                      int Cout, int Cin, int src_taps, int CoutP, int CinP) {
-  const int taps = src_taps == 27 ? 36 : 2;
+                                                                      int Cout, int Cin, int src_taps, int CoutP, int CinP,
+                                                                      int dims) {
+  const int taps = dims == 2 ? (src_taps == 27 ? 48 : 4) : (src_taps == 27 ? 36 : 2);
   const int64_t total = (int64_t)CoutP * CinP * taps;
   const int ncc = CinP >> 5, nsl = CoutP >> 4;
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(i & 3);
     const int lj = (int)((i >> 2) & 15);
@@ -355,7 +357,17 @@ __global__ __launch_bounds__(256) void repack_conv_weight_wino_kernel(const floa
     float v = 0.f;
     if (ci < Cin && co < Cout) {
       const float* src = w + ((int64_t)co * Cin + ci) * src_taps;
-      if (src_taps == 27) {
+      if (dims == 2) {
+        if (src_taps == 27) {  // pt = (xi_z*4 + xi_y)*3 + kx
+          const int kx = pt % 3, xy = (pt / 3) & 3, xz = pt / 12;
+          double u = 0.0;
+          for (int kz = 0; kz < 3; ++kz)
+            for (int ky = 0; ky < 3; ++ky) u += G[xz][kz] * G[xy][ky] * (double)src[kz * 9 + ky * 3 + kx];
+          v = (float)u;
+        } else {  // pt = (xi_z-1)*2 + (xi_y-1): G[xi][1] = +.5 (xi = 1), -.5 (xi = 2)
+          v = ((pt >> 1) == (pt & 1) ? 0.25f : -0.25f) * src[0];
+        }
+      } else if (src_taps == 27) {
         const int xi = pt / 9, kyx = pt - xi * 9;
         const double g0 = src[kyx], g1 = src[9 + kyx], g2 = src[18 + kyx];
         const double u = xi == 0 ? g0 : xi == 1 ? 0.5 * (g0 + g1 + g2) : xi == 2 ? 0.5 * (g0 - g1 + g2) : g2;
@@ -502,16 +514,17 @@ int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int 
   return 0;
 }
 int repack_conv_weight_wino_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
-                                   void* stream) {
-  if (src_taps != 27 && src_taps != 1) {
-    set_error("repack_conv_weight_wino: 27 or 1 source taps");
+                                   void* stream, int dims) {
+  if ((src_taps != 27 && src_taps != 1) || (dims != 1 && dims != 2)) {
+    set_error("repack_conv_weight_wino: 27 or 1 source taps, 1 or 2 transformed dimensions");
     return -1;
   }
-  int64_t total = (int64_t)CoutP * CinP * (src_taps == 27 ? 36 : 2);
+  const int taps = dims == 2 ? (src_taps == 27 ? 48 : 4) : (src_taps == 27 ? 36 : 2);
+  int64_t total = (int64_t)CoutP * CinP * taps;
   int64_t blocks = cdiv(total, 256);
   if (blocks > 8192) blocks = 8192;
   HOLO_LAUNCH(repack_conv_weight_wino_kernel, dim3((unsigned)blocks), dim3(256), stream, w, out, Cout, Cin, src_taps,
-              CoutP, CinP);
+              CoutP, CinP, dims);
   return 0;
 }
 int repack_conv_weight_launch(const float* w, float* out, int Cout, int Cin, int taps, int CoutP, int CinP,

@@ -71,6 +71,7 @@ struct ParamSlot {
   float* priv;  // private (repacked) device copy
   uint16_t* priv_bf = nullptr;  // conv weights: bf16 (RNE) copy packed for v_mfma_f32_16x16x32_bf16
   float* priv_wino = nullptr;   // conv weights of the wide top levels: Winograd-in-depth pseudo-taps (conv_wino_kernel)
+  float* priv_wino2 = nullptr;  // ... and the (z,y) Winograd pseudo-taps (conv_wino2_kernel)
   bool set;
 };
 
@@ -166,6 +167,7 @@ struct HoloUnet {
   std::map<const float*, const uint16_t*> bf_of;       // fp32 private copy -> bf16 copy
   float* pstore_wino = nullptr;                        // Winograd-in-depth copies (36 / 2 pseudo-taps)
   std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
+  std::map<const float*, const float*> wino2_of;       // fp32 private copy -> (z,y) Winograd copy
   int compute_mode = 0;  // holo_unet_set_compute_dtype: 0 exact fp32 MFMA, 1 bf16 products, 2 bf16x3 split (fp32-accurate)
   // concatenated emb_layers
   int emb_rows = 0;
@@ -456,6 +458,8 @@ struct Planner {
     if (u->compute_mode == 0) {  // exact fp32: the Winograd-in-depth kernel where conv_plan finds 128-voxel tiles
       auto it = u->wino_of.find(w);
       p.w_wino = it == u->wino_of.end() ? nullptr : it->second;
+      auto it2 = u->wino2_of.find(w);
+      p.w_wino2 = it2 == u->wino2_of.end() ? nullptr : it2->second;
     }
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
@@ -475,6 +479,8 @@ struct Planner {
       if (u->compute_mode == 0) {
         auto it = u->wino_of.find(skip_w);
         p.skip_w_wino = it == u->wino_of.end() ? nullptr : it->second;
+        auto it2 = u->wino2_of.find(skip_w);
+        p.skip_w_wino2 = it2 == u->wino2_of.end() ? nullptr : it2->second;
       }
       p.skip_CinP = pad_cin(p.skip_C0 + p.skip_C1);
       p.skip_bias = skip_bias;
@@ -915,9 +921,11 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
       if (!(c3 || sk) || s.shape[0] > 256 || s.shape[1] > 256 || s.shape[0] % 64) return 0;
       return (int64_t)(c3 ? 36 : 2) * pad_cout((int)s.shape[0]) * pad_cin((int)s.shape[1]);
     };
+    const bool enable2 = enable && !(we && we[0] == '1');  // HOLO_CONV_WINO=1: depth only; default: both forms prepared
+    auto wino2_numel = [&](const ParamSlot& s) -> int64_t { return enable2 ? wino_numel(s) / (s.kind == P_CONV3 ? 36 : 2) * (s.kind == P_CONV3 ? 48 : 4) : 0; };
     int64_t tw = 0;
     if (enable)
-      for (auto& s : u->params) tw += (wino_numel(s) + 63) & ~(int64_t)63;
+      for (auto& s : u->params) tw += ((wino_numel(s) + 63) & ~(int64_t)63) + ((wino2_numel(s) + 63) & ~(int64_t)63);
     if (tw > 0) {
       if (hipMalloc((void**)&u->pstore_wino, (size_t)tw * sizeof(float)) != hipSuccess) {
         set_error("holo_unet_create: hipMalloc of %lld Winograd weights failed", (long long)tw);
@@ -933,6 +941,12 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
         s.priv_wino = cw;
         u->wino_of[s.priv] = cw;
         cw += (nw + 63) & ~(int64_t)63;
+        const int64_t nw2 = wino2_numel(s);
+        if (nw2) {
+          s.priv_wino2 = cw;
+          u->wino2_of[s.priv] = cw;
+          cw += (nw2 + 63) & ~(int64_t)63;
+        }
       }
     }
   }
@@ -1012,6 +1026,12 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
       rc = repack_conv_weight_wino_launch((const float*)dev_ptr, s.priv_wino, (int)s.shape[0], (int)s.shape[1],
                                           s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]),
                                           pad_cin((int)s.shape[1]), stream);
+      if (rc) return rc;
+    }
+    if (s.priv_wino2) {
+      rc = repack_conv_weight_wino_launch((const float*)dev_ptr, s.priv_wino2, (int)s.shape[0], (int)s.shape[1],
+                                          s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]),
+                                          pad_cin((int)s.shape[1]), stream, 2);
       if (rc) return rc;
     }
   } else {
@@ -1173,7 +1193,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.wino ? 3 : c.mode;
+        t.kernel = c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

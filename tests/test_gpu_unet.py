@@ -107,12 +107,15 @@ def test_mid_size_unet_vs_oracle_blockwise(gu, image, mc, mult, attn, batch):
         del os.environ["HOLO_KEEP_INTERMEDIATES"]
 
 
+@pytest.mark.parametrize("wino_kernel,wino_env", [("conv_wino2_kernel", "2"), ("conv_wino_kernel", "1")])
 @pytest.mark.parametrize("image,mc,mult,attn,batch", [(16, 64, (1, 2), (), 1), (8, 64, (1, 2, 2), (2,), 2)])
-def test_winograd_in_depth_kernel_blockwise(gu, image, mc, mult, attn, batch, monkeypatch):
-    """conv_wino_kernel (the Winograd F(2,3)-along-depth form of the 128-voxel halo kernel, what the 64^3 level of the
-    north-star net runs on) forced onto small grids: plain, fused-skip, upsample-on-load, virtual-concat and split-K
-    launches, every block output against the pinned oracle at the SAME per-op tolerance as the direct kernel."""
+def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kernel, wino_env, monkeypatch):
+    """conv_wino2_kernel / conv_wino_kernel (the Winograd F(2,3) forms of the 128-voxel halo kernel over (depth, height)
+    / depth only; the former is what the 64^3 level of the north-star net runs on) forced onto small grids: plain,
+    fused-skip, upsample-on-load, virtual-concat and split-K launches, every block output against the pinned oracle at
+    the SAME per-op tolerance as the direct kernel."""
     monkeypatch.setenv("HOLO_CONV_FORCE_TZ2", "1")
+    monkeypatch.setenv("HOLO_CONV_WINO", wino_env)  # 2 (default): both forms prepared, (z,y) preferred; 1: depth only
     monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
     cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
                      channel_mult=mult, attention_resolutions=attn, num_heads=2)
@@ -129,8 +132,8 @@ def test_winograd_in_depth_kernel_blockwise(gu, image, mc, mult, attn, batch, mo
         if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
             assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 1e-4, tag
     # (time_ops runs its own forward on random data: only after the block outputs of OUR forward have been read)
-    kernels = {o["kernel"] for o in net.time_ops(batch, 1, gu.DEV) if o["op"] == "conv"} if not gu.EMU else {"conv_wino_kernel"}
-    assert "conv_wino_kernel" in kernels  # the knob really put launches on the kernel under test
+    kernels = {o["kernel"] for o in net.time_ops(batch, 1, gu.DEV) if o["op"] == "conv"} if not gu.EMU else {wino_kernel}
+    assert wino_kernel in kernels  # the knobs really put launches on the kernel under test
     # and the direct kernel on the same net agrees with it to rounding
     monkeypatch.setenv("HOLO_CONV_FORCE_TZ2", "0")
     monkeypatch.setenv("HOLO_CONV_WINO", "0")
