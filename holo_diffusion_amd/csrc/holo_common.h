@@ -35,18 +35,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fused multiply-adds in one v_pk_fma_f32 (each element rounds exactly like fmaf)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) { return a * b; }
-// v_pk_add_f32 (the subtraction is the same instruction with a negated operand); the asm keeps the optimiser from
-// splitting the pair into two scalar v_add/v_sub
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// v_pk_add_f32 (a subtraction is the same instruction with a negated operand).  Plain vector arithmetic, NOT inline
+// asm: the hazard recogniser does not see inside an asm statement, and a hand-placed VALU write next to in-flight
+// MFMAs produced wrong results on gfx950.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
 // two floats -> two bf16 (round to nearest even, v_cvt_pk_bf16_f32), `lo` in the low half
 typedef __bf16 holo_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 holo_bf16x8 __attribute__((ext_vector_type(8)));

@@ -1220,28 +1220,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   for (int cc = cc_begin; cc < cc_end; ++cc) {
     halo_issue(cc);
     halo_commit();
-    float4 Bc[4], Bn[4];
-    load_w(Bc, cc, 0, 0, 0);
+    // weights: global -> registers, requested TWO steps (2 x 32 MFMAs, ~0.85 us of matrix time) ahead of their use -
+    // one step does not cover an L2 round trip; the A rows use ONE buffer: a tile's rows are re-requested as soon as
+    // the MFMAs that read the previous ones have been issued, their ~100 cycles hide behind those queued MFMAs
+    float4 Bw[3][4];
+    load_w(Bw[0], cc, 0, 0, 0);
+    load_w(Bw[1], cc, 0, 0, 1);
     __syncthreads();  // transformed halo of chunk cc visible
-    float4 R0[4], R1[4];
+    float4 R0[4];
     load_rows(R0, 0, 0, 0, 0);
 #pragma unroll
-    for (int st = 0; st < 24; ++st) {  // fully unrolled: accumulator sets are compile-time choices
+    for (int st = 0; st < 24; ++st) {  // fully unrolled: accumulator sets and ring slots are compile-time choices
       const int xz = st / 6, kw = (st % 6) >> 1, half = st & 1;
       const int nx = st + 1, nxz = nx / 6, nkw = (nx % 6) >> 1, nhalf = nx & 1;
-      load_rows(R1, 1, xz, kw, half);
-      if (st + 1 < 24) load_w(Bn, cc, nxz, nkw, nhalf);
+      const int n2 = st + 2, n2xz = n2 / 6, n2kw = (n2 % 6) >> 1, n2half = n2 & 1;
+      if (st + 2 < 24) load_w(Bw[(st + 2) % 3], cc, n2xz, n2kw, n2half);
       __builtin_amdgcn_sched_barrier(0);  // requests stay AHEAD of the MFMAs that hide them
       combine(R0);
-      mfma_xy(xz, 0, R0, Bc);
+      mfma_xy(xz, 0, R0, Bw[st % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(R0, 1, xz, kw, half);
+      __builtin_amdgcn_sched_barrier(0);
+      combine(R0);
+      mfma_xy(xz, 1, R0, Bw[st % 3]);
       __builtin_amdgcn_sched_barrier(0);
       if (st + 1 < 24) load_rows(R0, 0, nxz, nkw, nhalf);
       __builtin_amdgcn_sched_barrier(0);
-      combine(R1);
-      mfma_xy(xz, 1, R1, Bc);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int xy = 0; xy < 4; ++xy) Bc[xy] = Bn[xy];
     }
     __syncthreads();  // everyone done reading this halo before it is overwritten
   }
@@ -2042,7 +2046,13 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     int64_t htiles = tiles;
     const char* f2 = getenv("HOLO_CONV_FORCE_TZ2");  // test knob: 128-voxel tiles (hence the Winograd-in-depth kernel) on small grids
     const bool force_tz2 = f2 && f2[0] == '1';
-    if (tiles < target && !force_tz2) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
+    // exact-fp32 launches whose Winograd weights exist keep the 128-voxel tile on under-filled levels too: the Winograd
+    // kernels do 4/9 (2/3) of the MFMAs per voxel, which buys more than the doubled workgroup count of 64-voxel tiles;
+    // the chip is filled by split-K over the channel chunks instead
+    const char* ws = getenv("HOLO_CONV_WINO_SMALL");
+    const bool wino_small = !(ws && ws[0] == '0') && p.w_wino && p.bf16 == 0 && p.Cout >= 64 && (p.Cout % 64) == 0 &&
+                            (!p.skip_w || p.skip_w_wino) && ncc >= 2;
+    if (tiles < target && !force_tz2 && !wino_small) {  // under-filled chip: 64-voxel tiles double the workgroups before resorting to split-K
       p.tz = 1;
       htiles = (M / 64) * cdiv(p.Cout, bn);
     }
