@@ -277,13 +277,26 @@ def main():
     dtr = max_over_ranks(dtr, world, device)
     assert torch.isfinite(out["images_render"]).all()
     rays_per_s = world * F * H * W / dtr
+    # the same leg at the length of a reference fly-around (render_flyaround's default n_flyaround_poses = 40,
+    # flyaround.py:50): a secondary figure, the reported rays_per_sec stays the --frames call above
+    F40 = 40
+    cams40 = hda.get_simple_360_camera_trajectory(2 * math.pi, F40, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0),
+                                                  3.2).to(device)
+    with torch.no_grad():
+        model.render_views(vf, cams40)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        model.render_views(vf, cams40)
+        barrier_sync(world)
+        dtr40 = max_over_ranks(time.perf_counter() - t0, world, device)
+    rays_per_s_40 = world * F40 * H * W / dtr40
 
     # ---------------- roofline of the dominant kernel, hipEvents on the launch stream (holo_unet_time_ops)
     roof = None
     if rank == 0:
         all_ops = net.time_ops(1, args.conv_iters, device)
         ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
-        HALO = ("conv_halo_kernel", "conv_wino_kernel")
+        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel")
         variants = {}
         for o in ops:
             key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"], 4 if o["cout"] >= 64 else 2) \
@@ -308,6 +321,10 @@ def main():
             label = f"{kname}<{'true' if sk else 'false'}> at {od}^3 output"
             what = ("3x3x3 conv3d, LDS voxel-halo implicit GEMM in Winograd F(2,3) form along depth: 36 pseudo-taps per two "
                     "output planes instead of 54")
+        elif kname == "conv_wino2_kernel":
+            label = f"{kname}<{'true' if sk else 'false'}> at {od}^3 output"
+            what = ("3x3x3 conv3d, LDS voxel-halo implicit GEMM in Winograd F(2x2,3x3) form over (depth, height): 48 "
+                    "pseudo-taps per 2x2 outputs instead of 108")
         else:
             label, what = kname, "conv3d"
         traffic = None
@@ -345,6 +362,15 @@ def main():
         if os.environ.get("HOLO_BENCH_OPS"):
             for o in all_ops:
                 print("# op", json.dumps({**o, "tflops": o["flops"] / (o["ms"] * 1e-3) / 1e12}), file=sys.stderr)
+            by_op = {}
+            for o in all_ops:
+                k = o["op"] if o["op"] != "conv" else f"conv:{o.get('kernel')}"
+                by_op.setdefault(k, [0, 0.0])
+                by_op[k][0] += 1
+                by_op[k][1] += o["ms"]
+            print("# per-op totals (launches, ms/forward):", json.dumps({k: (v[0], round(v[1], 4)) for k, v in
+                                                                        sorted(by_op.items(), key=lambda kv: -kv[1][1])}),
+                  "sum", round(sum(v[1] for v in by_op.values()), 3), file=sys.stderr)
     # ---------------- side measurements (N=1 only, never the reported value): the opt-in matrix-core modes
     alt = None
     if world == 1 and args.compute_dtype == "f32" and args.workload == "north":
@@ -403,6 +429,18 @@ def main():
         samples_ref, samples = 64 + 128, 128
         gather_bytes_per_ray = samples * 8 * C * 4
         mlp_flops_per_ray = samples * (2 * 257 * C + 2 * 3 * 256 + 2 * 3 * 27)
+        render_traffic = None
+        try:  # fabric-side bytes per FRAME of the render kernel from the committed PMC pass
+            ent = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("render_kernel<16, false, false, 64>")
+            if ent and args.workload == "north":
+                fpl = ent.get("frames_per_launch", 1)
+                render_traffic = {"bytes_per_frame": (ent["fetch_bytes"] + ent["write_bytes"]) / fpl,
+                                  "fetch_bytes_per_frame": ent["fetch_bytes"] / fpl,
+                                  "write_bytes_per_frame": ent["write_bytes"] / fpl,
+                                  "compulsory_bytes_per_frame": 4.0 * (w["feature_size"] * w["resol"] ** 3 + 10 * H * W),
+                                  "source": ent.get("source")}
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "denoise-steps/sec + rendered-rays/sec, 64^3x32 grid @400^2 render",
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -418,9 +456,10 @@ def main():
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
+            "rays_per_sec_40_frame_flyaround": rays_per_s_40, "ms_per_frame_40_frame_flyaround": 1e3 * dtr40 / F40,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
             "roofline": roof,
-            "roofline_render": {"bound": "mfma+gather",
+            "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,
                                 "kernel": "render_kernel<16, false, false, 64> (persistent: one 12-wave workgroup per CU walks "
                                           "the 32-ray wave tiles of all frames of the call)",
                                 "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,

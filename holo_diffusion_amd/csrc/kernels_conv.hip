@@ -1217,7 +1217,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   };
 
   HOLO_PHASE_DELAY(p.stagger_ticks);
+  unsigned long long* dbg = p.dbg ? p.dbg + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
+  unsigned long long t_stage = 0;
+  if (dbg && tid == 0) dbg[0] = HOLO_PROBE_CLOCK();
   for (int cc = cc_begin; cc < cc_end; ++cc) {
+    const unsigned long long ts0 = dbg ? HOLO_PROBE_CLOCK() : 0ull;
     halo_issue(cc);
     halo_commit();
     // weights: global -> registers, requested TWO steps (2 x 32 MFMAs, ~0.85 us of matrix time) ahead of their use -
@@ -1227,6 +1231,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
     load_w(Bw[0], cc, 0, 0, 0);
     load_w(Bw[1], cc, 0, 0, 1);
     __syncthreads();  // transformed halo of chunk cc visible
+    if (dbg) {
+      const unsigned long long ts1 = HOLO_PROBE_CLOCK();
+      t_stage += ts1 - ts0;
+      if (tid == 0 && cc == cc_begin) dbg[1] = ts1;
+    }
     float4 R0[4];
     load_rows(R0, 0, 0, 0, 0);
 #pragma unroll
@@ -1276,6 +1285,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
     }
   }
 
+  if (dbg && tid == 0) {
+    dbg[2] = HOLO_PROBE_CLOCK();
+    dbg[6] = t_stage;
+  }
   // ---- output transform (lane-local, y then z) + epilogue.  D row 4*kq + r of tile t = y tile t + 2*(kq>>1), x = 4*(kq&1) + r
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int co = n0 + wn * 16 + lj;
@@ -1359,6 +1372,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
       d[0] = (double)ssum;
       d[1] = (double)ssq;
     }
+  }
+  if (dbg && tid == 0) {
+    dbg[3] = HOLO_PROBE_CLOCK();
+    unsigned hw, xcc;
+    HOLO_PROBE_HWID(hw, xcc);
+    dbg[4] = hw;
+    dbg[5] = xcc;
   }
 }
 

@@ -283,7 +283,10 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   if (rc) return HOLO_E_INVALID;
   const int H = c.image_height, Wd = c.image_width;
   const int64_t npix = (int64_t)H * Wd;
-  const int G = RenderKernelParams::MAX_CAMS;  // frames per launch (launch parameters hold that many cameras)
+  // frames per launch: the launch parameters hold MAX_CAMS cameras; more cameras are split EVENLY over the launches
+  // (40 frames = 20 + 20, not 32 + 8: every launch then ends on an almost full round of wave tiles)
+  const int n_launches = (n_cameras + RenderKernelParams::MAX_CAMS - 1) / RenderKernelParams::MAX_CAMS;
+  const int G = (n_cameras + n_launches - 1) / n_launches;
   const int n_wgs_max = render_workgroups(r);
   const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, want_nrm ? 1 : 0);
 #ifndef HOLO_EMU

@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "$2" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -25 $OUT/pytest.log
-timeout 600 python bench.py --no-cpu-baseline $3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
+HOLO_BENCH_OPS=1 timeout 600 python bench.py --no-cpu-baseline $3 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -3 $OUT/bench.err
 python3 - <<PY
 import json
 d=json.load(open("$OUT/bench.json")); r=d["roofline"]

@@ -27,7 +27,9 @@ write = load(f"gpurun_out/{tag}/pmc_write.csv")
 res = {}
 for (k, grid), (n, f_kib) in fetch.items():
     w_kib = write.get((k, grid), (0, 0.0))[1]
+    frames = None
     m = re.search(r"conv_halo_kernel<(\d), (\d), (true|false)(?:, (true|false))?>", k)
+    mw = re.search(r"conv_wino(2?)_kernel<(true|false)>", k)
     if m and m.group(4) == "true":
         continue  # bf16-product instantiation (opt-in mode): not the reported kernel
     if m:
@@ -37,14 +39,24 @@ for (k, grid), (n, f_kib) in fetch.items():
         if od ** 3 != tiles * 64 * tz or od not in (32, 64):
             continue
         label = f"conv_halo_kernel<{nwn}, {tz}, {sk}> at {od}^3 output"
+    elif mw:
+        tiles = grid // 256  # 128-voxel tiles; only the un-split single-Cout-block launches of the 64^3 level are unambiguous
+        od = round((tiles * 128) ** (1 / 3))
+        if od ** 3 != tiles * 128 or od != 64:
+            continue
+        label = f"conv_wino{mw.group(1)}_kernel<{mw.group(2)}> at {od}^3 output"
     elif "render_kernel" in k:
-        label = "render_kernel<16> (up to 8 frames per launch)"
+        mr = re.search(r"render_kernel<([^>]*)>", k)
+        label = f"render_kernel<{mr.group(1)}>"
+        frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # frames per launch of the profiled command
     else:
         continue
     res[label] = {"fetch_bytes": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024), "dispatches": n,
                   "fetch_size_raw_kib": f_kib, "write_size_raw_kib": w_kib,
-                  "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 2 --frames 1, "
-                            f"profiles/{tag}_fetch.csv + _write.csv; FETCH_SIZE doubled per the gfx950 note of "
+                  "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the command of scripts/gpu_pmc.sh, "
+                            f"profiles/{tag}_pmc_fetch.csv + _pmc_write.csv; FETCH_SIZE doubled per the gfx950 note of "
                             "MI355X_MICROARCH.md; fabric-side L2 misses (Infinity-Cache hits included)"}
+    if frames:
+        res[label]["frames_per_launch"] = frames
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-print(json.dumps(res, indent=1)[:1500])
+print(json.dumps(res, indent=1)[:2500])

@@ -1,7 +1,7 @@
 // conv_timeline — per-workgroup timeline of one LDS-halo conv3d launch (development probe, not part of the library).
 // Build: hipcc -O2 --offload-arch=gfx950 tools/conv_timeline.cpp holo_diffusion_amd/csrc/kernels_conv.o \
 //              holo_diffusion_amd/csrc/kernels_misc.o holo_diffusion_amd/csrc/err.o -o tools/conv_timeline
-// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [unused] [tile_depth=0 (planner)] [stagger_us=0]
+// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [wino: 0 direct, 2 = (z,y) Winograd] [tile_depth=0 (planner)] [stagger_us=0]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +26,13 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   ConvParams p{}; p.src0 = src; p.C0 = Cin; p.N = 1; p.ID = p.IH = p.IW = p.OD = p.OH = p.OW = R; p.stride = 1; p.pad = 1; p.ksz = 3;
   p.Cout = Cout; p.w = w; p.CoutP = CoutP; p.CinP = CinP; p.out = out;
+  float* w2 = nullptr;
+  if (gx == 2) {  // (z,y) Winograd form: 48 pseudo-taps (random values: timing only)
+    CK(hipMalloc(&w2, (size_t)48 * CinP * CoutP * 4));
+    std::vector<float> hw2((size_t)48 * CinP * CoutP); for (auto& x : hw2) x = (rand() % 2001 - 1000) * 1e-4f;
+    CK(hipMemcpy(w2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice));
+    p.w_wino = w2; p.w_wino2 = w2;
+  }
   conv_plan(p, 256);
   if (tzo > 0) { p.tz = tzo; p.grid_x = (int)(V / (64 * p.tz)); }
   (void)gx;  // (the persistent multi-tile form was removed from the kernel after these measurements; one tile per workgroup)
@@ -54,6 +61,7 @@ int main(int argc, char** argv) {
   const double n = ntile * ny, tick = 0.01;  // us per 100 MHz tick
   printf("event ms %.4f  span(first start..last end) %.2f us\n", ms, (t1 - t0) * tick);
   printf("per tile: prologue %.2f us  loops %.2f us  epilogue %.2f us  total %.2f us\n", pro / n * tick, loop / n * tick, epi / n * tick, (pro + loop + epi) / n * tick);
+  { double stg = 0; for (int i = 0; i < ntile * ny; ++i) stg += d[(size_t)i * 8 + 6]; printf("per tile: staging (issue -> barrier, all chunks) %.2f us [wino %d]\n", stg / n * tick, p.wino); }
   // occupancy of CU slots over time
   double busy = 0, gaps = 0; int ncu = 0; double firsts = 0, lasts = 0;
   for (auto& kv : per_cu) {
