@@ -4,6 +4,10 @@ Follows ``holo_diffusion/utils/render_utils/flyaround.py``:
 
 * ``_images_from_preds`` (:422-488): per key, masks / depths become 3-channel images; depth maps are normalised with
   PyTorch3D's ``make_depth_image`` and composited over a white background with the (nearest-resized) render mask;
+* ``_make_shaded_from_normals`` (:400-420) behind the ``_shaded_depth_render`` key (:440-445): a head-light shading
+  of the rendered normals (``normals_render``, produced by the fused renderer when the implicit function has
+  ``render_normals=True``); the reference's alternative for that key - ``shaded_depth_render.depth_to_shaded``, a
+  PyTorch3D mesh/point-cloud rasterisation of the depth map - is outside this path;
 * ``_generate_prediction_videos`` (:553-610): one clip per key, frames clipped to [0, 1].
 
 ``make_depth_image`` lives in PyTorch3D 0.7.4 (``implicitron/tools/vis_utils.py``), which is not available here: its
@@ -42,12 +46,31 @@ def make_depth_image(depths: torch.Tensor, masks: torch.Tensor, max_quantile: fl
     return ((out * (max_out_depth - min_out_depth) + min_out_depth) * masks.float()).clamp(0.0, 1.0)
 
 
+def make_shaded_from_normals(n: torch.Tensor, mask: torch.Tensor, diffuse_strength: float = 0.3,
+                             specular_strength: float = 0.1, ambient_strength: float = 0.3,
+                             specular_hardness: float = 10.0) -> torch.Tensor:
+    """``_make_shaded_from_normals`` (flyaround.py:400-420): a point light at the camera centre; the LAST normal
+    component is the shading term.  n (N,3,H,W), mask (N or 1,1,H,W) -> (N,1,H,W) in [0,1], white background."""
+    shading = n[:, -1:].clamp(0.0)
+    shading_ambient = (shading * diffuse_strength + specular_strength * shading ** specular_hardness
+                       + ambient_strength) / (diffuse_strength + specular_strength + ambient_strength)
+    return (shading_ambient * mask + (1 - mask)).clamp(0.0, 1.0)
+
+
 def images_from_preds(preds: Dict[str, torch.Tensor],
                       extract_keys: Sequence[str] = ("images_render", "masks_render", "depths_render")
                       ) -> Dict[str, torch.Tensor]:
-    """``_images_from_preds`` for the keys the HIP path produces: every entry becomes an (N,3,H,W) CPU tensor."""
+    """``_images_from_preds`` for the keys the HIP path produces: every entry becomes an (N,3,H,W) CPU tensor.
+    ``_shaded_depth_render`` needs ``normals_render`` (flyaround.py:440-445)."""
     imout = {}
     for k in extract_keys:
+        if k == "_shaded_depth_render":
+            if preds.get("normals_render") is None:
+                continue  # (the depth-map rasterisation fallback of the reference needs PyTorch3D's renderer)
+            v = make_shaded_from_normals(preds["normals_render"].detach().float().cpu().clone(),
+                                         preds["masks_render"].detach().float().cpu().clone())
+            imout[k] = v.repeat(1, 3, 1, 1)
+            continue
         if k not in preds or preds[k] is None:
             continue
         v = preds[k].detach().float().cpu().clone()
@@ -74,7 +97,9 @@ def export_flyaround_frames(frames: Dict[str, torch.Tensor], out_dir: str, seque
                             keys: Optional[Sequence[str]] = None) -> Dict[str, str]:
     """Frames of one fly-around ((F,C,H,W) per key, as ``render_flyaround`` returns them) -> one directory of PPM
     frames per key, named like the reference's per-key clips (``<sequence_name>_<key>``).  Returns key -> directory."""
-    ims = images_from_preds(frames, tuple(keys) if keys else ("images_render", "masks_render", "depths_render"))
+    default_keys = ("images_render", "masks_render", "depths_render") + (
+        ("_shaded_depth_render",) if frames.get("normals_render") is not None else ())
+    ims = images_from_preds(frames, tuple(keys) if keys else default_keys)
     dirs = {}
     for k, v in ims.items():
         d = os.path.join(out_dir, f"{sequence_name}_{k}")

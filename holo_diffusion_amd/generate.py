@@ -134,7 +134,7 @@ def _render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float
         out = model.render_views(voxel_features, cams)
         out["voxel_features"] = voxel_features
         return out
-    frames = {"images_render": [], "depths_render": [], "masks_render": []}
+    frames = {"images_render": [], "depths_render": [], "masks_render": [], "normals_render": []}
     for n in range(n_flyaround_poses):
         if gen is not None:
             for _ in range(progressive_sampling_steps_per_render):
@@ -144,8 +144,9 @@ def _render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float
                     break
         preds = model(camera=cams[n], evaluation_mode=EvaluationMode.EVALUATION, voxel_features=voxel_features)
         for k in frames:
-            frames[k].append(preds[k])
-    out = {k: torch.cat(v, dim=0) for k, v in frames.items()}
+            if k in preds:
+                frames[k].append(preds[k])
+    out = {k: torch.cat(v, dim=0) for k, v in frames.items() if v}
     out["voxel_features"] = voxel_features
     return out
 

@@ -230,3 +230,31 @@ def test_rendered_normals_vs_oracle(gu, C, resol, H, W, n_fine):
     # batched call carries them too
     allv = model.render_views(grid.to(gu.DEV), cams.to(gu.DEV))
     assert torch.equal(allv["normals_render"][1], preds["normals_render"][0])
+
+
+@pytest.mark.parametrize("C", [16, 32])
+def test_standalone_implicit_function_vs_reference_render_mlp(gu, golden_dir, C):
+    """The HIP implicit function against outputs of the REFERENCE's own RenderMLP class body (tests/golden/
+    ref_render_mlp.npz, oracle/make_golden_render.py): the fixture's feature vectors are placed in the voxels of an 8^3
+    grid and queried at the voxel centres (where the trilinear fetch returns the voxel itself), pts_3d entry (the
+    reference's dummy (1,1,1) directions)."""
+    import os
+    g = np.load(os.path.join(golden_dir, "ref_render_mlp.npz"))
+    feats = torch.from_numpy(g[f"C{C}.features"]).reshape(-1, C)  # (231, C)
+    R = 8
+    fn = hda.HoloVoxelGridImplicitFunction(resol=R, n_hidden=C, feature_dim=0)
+    sd = gu.synth_state_dict(ro.render_mlp_param_shapes(ro.RenderCfg(resol=R, feature_size=C)), int(g[f"C{C}.seed"]))
+    sd["_density_net.mlp.3.0.bias"][-1] += 0.05
+    fn.render_mlp.load_state_dict(sd)
+    fn.to(gu.DEV)
+    grid = torch.zeros(R ** 3, C)
+    grid[:feats.shape[0]] = feats
+    grid = grid.reshape(R, R, R, C).permute(3, 0, 1, 2)[None].contiguous()  # (1,C,D,H,W): voxel v = (z*R + y)*R + x
+    v = torch.arange(feats.shape[0])
+    idx = torch.stack([v % R, (v // R) % R, v // (R * R)], dim=-1).float()  # (x,y,z)
+    pts = (idx - (R - 1) / 2.0) * (8.0 / R)                                 # world coordinates of the voxel centres
+    dens, col, _ = fn(pts_3d=pts[None, :, None, :].to(gu.DEV), voxel_grid_features=grid.to(gu.DEV))
+    ref_d = torch.from_numpy(g[f"C{C}.densities_ones_dir"]).reshape(-1)
+    ref_c = torch.from_numpy(g[f"C{C}.colours_ones_dir"]).reshape(-1, 3)
+    assert (dens.reshape(-1).cpu() - ref_d).abs().max().item() < 1e-4
+    assert (col.reshape(-1, 3).cpu() - ref_c).abs().max().item() < 1e-4
