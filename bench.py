@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8,
                     help="timed 400x400 frames in the render leg (one holo_render call; a fly-around is 40-75 frames, "
                          "the library renders them 8 per kernel launch)")
+    ap.add_argument("--flyaround-frames", type=int, default=40,
+                    help="length of the secondary fly-around render leg (0 = skip; the profiling scripts skip it so that "
+                         "every render dispatch of a profile has --frames frames)")
     ap.add_argument("--image-size", type=int, default=400)
     ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
                     help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "
@@ -203,6 +206,7 @@ def main():
                     help="f32 = the reported line (reference arithmetic); bf16 = opt-in bf16 products / fp32 accumulate in "
                          "the 3x3x3 convolutions (side measurement for the bf16 configurations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-opt-in", action="store_true", help="skip the side measurements of the opt-in arithmetic modes")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (rendezvous + reductions), no kernels")
     ap.add_argument("--conv-iters", type=int, default=3)
     args = ap.parse_args()
@@ -279,17 +283,19 @@ def main():
     rays_per_s = world * F * H * W / dtr
     # the same leg at the length of a reference fly-around (render_flyaround's default n_flyaround_poses = 40,
     # flyaround.py:50): a secondary figure, the reported rays_per_sec stays the --frames call above
-    F40 = 40
-    cams40 = hda.get_simple_360_camera_trajectory(2 * math.pi, F40, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0),
-                                                  3.2).to(device)
-    with torch.no_grad():
-        model.render_views(vf, cams40)
-        barrier_sync(world)
-        t0 = time.perf_counter()
-        model.render_views(vf, cams40)
-        barrier_sync(world)
-        dtr40 = max_over_ranks(time.perf_counter() - t0, world, device)
-    rays_per_s_40 = world * F40 * H * W / dtr40
+    F40 = args.flyaround_frames
+    rays_per_s_40, dtr40 = None, None
+    if F40 > 0:
+        cams40 = hda.get_simple_360_camera_trajectory(2 * math.pi, max(F40, 2), -30.0 * (2 * math.pi / 360), 10,
+                                                      (0.0, -1.0, 0.0), 3.2).to(device)[list(range(F40))]
+        with torch.no_grad():
+            model.render_views(vf, cams40)
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            model.render_views(vf, cams40)
+            barrier_sync(world)
+            dtr40 = max_over_ranks(time.perf_counter() - t0, world, device)
+        rays_per_s_40 = world * F40 * H * W / dtr40
 
     # ---------------- roofline of the dominant kernel, hipEvents on the launch stream (holo_unet_time_ops)
     roof = None
@@ -373,7 +379,7 @@ def main():
                   "sum", round(sum(v[1] for v in by_op.values()), 3), file=sys.stderr)
     # ---------------- side measurements (N=1 only, never the reported value): the opt-in matrix-core modes
     alt = None
-    if world == 1 and args.compute_dtype == "f32" and args.workload == "north":
+    if world == 1 and args.compute_dtype == "f32" and args.workload == "north" and not args.no_opt_in:
         alt = {}
         for mode in ("f32_bf16x3", "bf16"):
             net.compute_dtype = mode
@@ -456,7 +462,8 @@ def main():
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
-            "rays_per_sec_40_frame_flyaround": rays_per_s_40, "ms_per_frame_40_frame_flyaround": 1e3 * dtr40 / F40,
+            "rays_per_sec_flyaround": rays_per_s_40, "flyaround_frames": F40,
+            "ms_per_frame_flyaround": (1e3 * dtr40 / F40) if F40 > 0 else None,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,
