@@ -14,7 +14,8 @@ from .render import (  # noqa: F401
     RenderMLP, RendererOutput, ImplicitronRayBundle, AdaptiveRaySampler)
 from .model import HoloDiffusionModel  # noqa: F401
 from .cameras import PerspectiveCameras, look_at_view_transform, get_simple_360_camera_trajectory  # noqa: F401
-from . import checkpoint, flyaround_output, generate, model, render  # noqa: F401,E402
+from .viewpool import ViewPooler, AngleWeightedReductionFeatureAggregator  # noqa: F401,E402
+from . import checkpoint, flyaround_output, generate, model, render, viewpool  # noqa: F401,E402
 from .checkpoint import load_experiment  # noqa: F401,E402
 
 __all__ = ["registry", "SimpleUnet3D", "Unet3DBase", "ImplicitronGaussianDiffusion", "HoloVoxelGridImplicitFunction",

@@ -49,6 +49,16 @@ class HoloCamera(C.Structure):
                 ("principal_point", C.c_float * 2)]
 
 
+class HoloViewFeature(C.Structure):
+    _fields_ = [("feats", C.c_void_p), ("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32)]
+
+
+class HoloViewPoolCfg(C.Structure):
+    _fields_ = [("resol", C.c_int32), ("volume_extent", C.c_float), ("feature_size", C.c_int32),
+                ("weight_by_ray_angle_gamma", C.c_float), ("min_ray_angle_weight", C.c_float),
+                ("projection_eps", C.c_float)]
+
+
 class HoloOpTiming(C.Structure):
     _fields_ = [("op", C.c_int32), ("kernel", C.c_int32), ("tile_depth", C.c_int32), ("fused_skip", C.c_int32),
                 ("nsplit", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("out_dim", C.c_int32),
@@ -91,6 +101,9 @@ SIGNATURES = {
                               C.c_size_t, _vp]),
     "holo_implicit_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_implicit_normals": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
+    "holo_view_pool_workspace_bytes": (C.c_size_t, [C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
+    "holo_view_pool": (C.c_int, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int,
+                                 C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_event_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "holo_event_timer_start": (C.c_int, [_vp, _vp]),
     "holo_event_timer_stop": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),

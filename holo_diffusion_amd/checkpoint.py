@@ -103,6 +103,28 @@ def model_args_from_expconfig(cfg: Dict[str, Any], render_size: Optional[Tuple[i
         ifa["render_mlp_args"] = _filter_fields(
             RenderMLP, ifa["render_mlp_args"],
             f"{MODEL_ARGS_KEY}.implicit_function_HoloVoxelGridImplicitFunction_args.render_mlp_args", ignored)
+    # encoder side (view pooling): kept when the configured pooler is one the fused kernel implements (the released
+    # YAMLs: AngleWeightedReductionFeatureAggregator [AVG, STD], bilinear, unmasked), dropped - and reported - otherwise,
+    # so that sampling from ANY HoloDiffusion checkpoint keeps working
+    if kw.get("view_pooler_enabled"):
+        from .viewpool import AngleWeightedReductionFeatureAggregator, ViewPooler, ViewSampler
+        vpa = _filter_fields(ViewPooler, kw.get("view_pooler_args") or {}, f"{MODEL_ARGS_KEY}.view_pooler_args", ignored)
+        try:
+            if vpa.get("view_sampler_args") is not None:
+                vpa["view_sampler_args"] = _filter_fields(ViewSampler, vpa["view_sampler_args"],
+                                                          f"{MODEL_ARGS_KEY}.view_pooler_args.view_sampler_args", ignored)
+            akey = "feature_aggregator_AngleWeightedReductionFeatureAggregator_args"
+            if vpa.get(akey) is not None:
+                vpa[akey] = _filter_fields(AngleWeightedReductionFeatureAggregator, vpa[akey],
+                                           f"{MODEL_ARGS_KEY}.view_pooler_args.{akey}", ignored)
+            ViewPooler(**vpa)  # validates the configuration
+            kw["view_pooler_args"] = vpa
+        except (NotImplementedError, ValueError, TypeError, KeyError) as e:
+            ignored.append(f"{MODEL_ARGS_KEY}.view_pooler_enabled (view pooling disabled: {e})")
+            kw["view_pooler_enabled"] = False
+            kw.pop("view_pooler_args", None)
+    else:
+        kw.pop("view_pooler_args", None)
     if render_size is not None:
         kw["render_image_width"], kw["render_image_height"] = int(render_size[0]), int(render_size[1])
     return kw, ignored

@@ -236,6 +236,32 @@ struct ImplicitEvalParams {
   float* densities;
   float* colours;
 };
+// view pooling (kernels_viewpool.hip): source-view feature maps -> voxel feature grid
+struct ViewPoolParams {
+  static constexpr int MAX_VIEWS = 16, MAX_FEATS = 8, MAX_AGG = 512;
+  struct Cam {
+    float Rm[9], T[3], focal[2], pp[2], centre[3];
+  };
+  struct Feat {
+    const float* data;  // (n_views, H, W, Cp) channels-last, Cp = C rounded up to 4
+    int C, Cp, H, W;
+    int quad0;          // first channel quad of this map in the concatenated quad list
+    int out0;           // first aggregated feature of this key: [AVG (C) | STD (C)]
+  };
+  Cam cams[MAX_VIEWS];
+  Feat feat[MAX_FEATS];
+  int n_views, n_feats, n_quads;
+  int R;
+  float half_extent;
+  float gamma, min_weight, proj_eps;
+  int A, F;           // aggregated features (2 sum C), output features
+  const float* wt;    // (A, F) transposed mapper weight
+  const float* bias;  // (F) or null
+  float* out;         // (1, F, R, R, R)
+};
+int view_pool_launch(const ViewPoolParams& p, void* stream);
+int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
+int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
 int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);

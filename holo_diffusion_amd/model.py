@@ -65,6 +65,10 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
     renderer_HoloMultiPassEmissionAbsorptionRenderer_args: Optional[dict] = None
     implicit_function_class_type: str = "HoloVoxelGridImplicitFunction"
     implicit_function_HoloVoxelGridImplicitFunction_args: Optional[dict] = None
+    # ---- encoder side (holo_diffusion_model.py:113-116,327-374).  Off by default HERE (the released
+    # YAMLs enable it): the sampling drivers never pool views; with it on the model owns `pooled_feature_mapper`.
+    view_pooler_enabled: bool = False
+    view_pooler_args: Optional[dict] = None
     # host-side switch: the reference re-runs tanh(net_3d(vf, 0)) for EVERY rendered frame even when vf is
     # unchanged (holo_diffusion_model.py:420-426); cache it on the identity of the voxel_features tensor.
     cache_refined_features: bool = True
@@ -88,6 +92,16 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         self.renderer = registry.get(BaseRenderer, self.renderer_class_type)(**r_args)
         self._implicit_functions = self._construct_implicit_functions()
         self._refined_cache = None
+        self.view_pooler = None
+        self.image_feature_extractor = None  # any callable (image_rgb, fg_probability) -> {key: (n, C, H, W)}; the
+        # reference's ResNetFeatureExtractor is outside this path
+        if self.view_pooler_enabled:
+            from .viewpool import ViewPooler
+            self.view_pooler = ViewPooler(**dict(self.view_pooler_args or {}))
+            # (holo_diffusion_model.py:114-116: "Setting target view exclusion to False by hard!")
+            self.view_pooler.feature_aggregator.exclude_target_view = False
+            self.view_pooler.feature_aggregator.exclude_target_view_mask_features = False
+            self.pooled_feature_mapper = torch.nn.LazyLinear(self.feature_size)  # LazyLinearWithXavierInit (:113)
 
     def create_net_3d(self):
         self.net_3d = None
@@ -175,13 +189,26 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
                 depth_map=None, sequence_name=None, frame_timestamp=None,
                 evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION,
                 voxel_features: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, Any]:
-        if evaluation_mode != EvaluationMode.EVALUATION or image_rgb is not None:
-            raise NotImplementedError("only the evaluation/sampling branch (image_rgb=None) is on the hot path")
+        if evaluation_mode != EvaluationMode.EVALUATION:
+            raise NotImplementedError("training-mode forward (mask-sampled rays, density noise, losses) is outside this path")
+        image_features = kwargs.pop("image_features", None)
         n_targets = 1  # EVALUATION renders one target camera per call (:263-269)
         target_cameras = camera[list(range(n_targets))]
         sampling_mode = RenderSamplingMode(self.sampling_mode_evaluation)
         if sampling_mode != RenderSamplingMode.FULL_GRID:
             raise NotImplementedError("evaluation uses full_grid sampling")
+        if image_rgb is not None or image_features is not None:
+            # ---- view pooling: views -> voxel grid (:327-374), one fused kernel behind the image feature extractor
+            assert self.view_pooler_enabled, "view_pooler must be enabled to use image_rgb"
+            assert voxel_features is None, "Cannot provide both image_rgb and voxel_features"
+            batch_size = len(camera)
+            if image_features is None:
+                assert self.image_feature_extractor is not None, "Need an image_feature_extractor"
+                src = slice(n_targets, None) if batch_size > 1 else slice(None)
+                image_features = self.image_feature_extractor(
+                    image_rgb[src], fg_probability[src] if fg_probability is not None else None)
+            source_cameras = camera[list(range(n_targets, batch_size))] if batch_size > 1 else camera
+            voxel_features = self.pool_views_to_voxel_features(image_features, source_cameras)
         if voxel_features is None:
             voxel_features = self.sample_random_voxel_features()
         if self.check_ranges:
@@ -206,6 +233,24 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             # for (flyaround.py:440-445, _make_shaded_from_normals)
             preds["normals_render"] = rendered.normals.permute(0, 3, 1, 2)
         return preds
+
+    @torch.no_grad()
+    def pool_views_to_voxel_features(self, image_features: Dict[str, torch.Tensor], source_cameras) -> torch.Tensor:
+        """tanh(pooled_feature_mapper(view_pooler(grid points, source views))) (:349-373) -> (1, F, R, R, R).
+        ``image_features``: the image feature extractor's dict for the SOURCE views, key -> (n_src, C, H, W)."""
+        assert self.view_pooler_enabled and self.view_pooler is not None, "view_pooler must be enabled"
+        pm = self.pooled_feature_mapper
+        A = self.view_pooler.get_aggregated_feature_dim(image_features)
+        if isinstance(pm.weight, torch.nn.parameter.UninitializedParameter):  # first use of the LazyLinear (Xavier, :37-41)
+            dev = next(iter(image_features.values())).device
+            pm.in_features = A
+            pm.weight.materialize((self.feature_size, A), device=dev)
+            pm.bias.materialize((self.feature_size,), device=dev)
+            torch.nn.init.xavier_uniform_(pm.weight.data)
+            pm.bias.data.zero_()
+            pm.__class__ = torch.nn.Linear
+        return self.view_pooler.pool_to_voxel_features(image_features, source_cameras, pm.weight, pm.bias, self.resol,
+                                                       self.volume_extent)
 
     def render_views(self, voxel_features: torch.Tensor, cameras: PerspectiveCameras) -> Dict[str, torch.Tensor]:
         """Batched turntable render: all cameras of a fly-around in ONE holo_render call (BASELINE config 4).

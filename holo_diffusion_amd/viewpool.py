@@ -1,0 +1,135 @@
+"""Encoder-side plugins: source-view feature maps -> voxel feature grid on the HIP path.
+
+Reference interfaces mirrored (paths relative to /root/reference/holo_diffusion):
+  * the ``view_pooler`` member of the model (PyTorch3D ``ViewPooler`` = ``ViewSampler`` + feature aggregator), called
+    with ``pts = VolumeLocator.get_coord_grid()`` at holo_diffusion_model.py:349-367; released configuration
+    configs/apple.yaml:183-196 (``masked_sampling: false``, ``sampling_mode: bilinear``,
+    ``AngleWeightedReductionFeatureAggregator`` with ``[AVG, STD]``, gamma 1.0, min weight 0.1); the model forces
+    ``exclude_target_view = exclude_target_view_mask_features = False`` (:114-116)
+  * ``pooled_feature_mapper`` (``LazyLinearWithXavierInit(feature_size)``, :113) and ``tanh`` (:368-373)
+
+All arithmetic - projection, bilinear gather, angle-weighted AVG/STD reduction, the mapper's Linear and the tanh - runs
+in ONE kernel (``holo_view_pool``, csrc/kernels_viewpool.hip); the classes here carry the configuration.  The image
+feature extractor (PyTorch3D's ResNetFeatureExtractor) is outside this path: its output dict is the input here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, runtime
+from .registry import Configurable, apply_config, pt3d_base, registry
+
+
+class ReductionFunction(enum.Enum):
+    AVG = "avg"
+    MAX = "max"
+    STD = "std"
+    STD_AVG = "std_avg"
+
+
+class ViewSampler(Configurable):
+    masked_sampling: bool = False
+    sampling_mode: str = "bilinear"
+
+    def __init__(self, **kwargs):
+        apply_config(self, kwargs)
+        if self.masked_sampling or self.sampling_mode != "bilinear":
+            raise NotImplementedError("ViewSampler: the fused kernel supports the released configuration "
+                                      "(masked_sampling false, bilinear; configs/apple.yaml:185-187)")
+
+
+FeatureAggregatorBase = pt3d_base("implicitron.models.view_pooler.feature_aggregator", "FeatureAggregatorBase")
+
+
+@registry.register
+class AngleWeightedReductionFeatureAggregator(FeatureAggregatorBase):
+    exclude_target_view: bool = True
+    exclude_target_view_mask_features: bool = True
+    concatenate_output: bool = True
+    reduction_functions: Tuple[ReductionFunction, ...] = (ReductionFunction.AVG, ReductionFunction.STD)
+    weight_by_ray_angle_gamma: float = 1.0
+    min_ray_angle_weight: float = 0.1
+
+    def __init__(self, **kwargs):
+        apply_config(self, kwargs)
+        self.reduction_functions = tuple(ReductionFunction[r] if isinstance(r, str) else r
+                                         for r in self.reduction_functions)
+        if self.reduction_functions != (ReductionFunction.AVG, ReductionFunction.STD) or not self.concatenate_output:
+            raise NotImplementedError("AngleWeightedReductionFeatureAggregator: the fused kernel implements the released "
+                                      "reduction [AVG, STD] with concatenated output (configs/apple.yaml:188-196)")
+
+    def get_aggregated_feature_dim(self, feats_or_feats_dim) -> int:
+        d = feats_or_feats_dim if isinstance(feats_or_feats_dim, int) else sum(
+            int(t.shape[1]) for t in feats_or_feats_dim.values())
+        return len(self.reduction_functions) * d
+
+
+class ViewPooler(Configurable, torch.nn.Module):
+    view_sampler_args: Optional[dict] = None
+    feature_aggregator_class_type: str = "AngleWeightedReductionFeatureAggregator"
+    feature_aggregator_AngleWeightedReductionFeatureAggregator_args: Optional[dict] = None
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        apply_config(self, kwargs)
+        self.view_sampler = ViewSampler(**dict(self.view_sampler_args or {}))
+        agg_type = registry.get(FeatureAggregatorBase, self.feature_aggregator_class_type)
+        self.feature_aggregator = agg_type(**dict(
+            getattr(self, f"feature_aggregator_{self.feature_aggregator_class_type}_args", None) or {}))
+
+    def get_aggregated_feature_dim(self, feats) -> int:
+        return self.feature_aggregator.get_aggregated_feature_dim(feats)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("ViewPooler: pooling at arbitrary points is not on this path; the model pools onto its "
+                                  "voxel grid through pool_to_voxel_features() (one fused kernel incl. the mapper)")
+
+    @torch.no_grad()
+    def pool_to_voxel_features(self, feats: Dict[str, torch.Tensor], camera, mapper_weight: torch.Tensor,
+                               mapper_bias: Optional[torch.Tensor], resol: int, volume_extent: float) -> torch.Tensor:
+        """feats: key -> (n_src, C_k, H_k, W_k) float32 on the device (the image feature extractor's dict, in its
+        order); camera: the n_src source cameras.  Returns tanh(mapper(aggregated)) as (1, F, R, R, R)."""
+        agg = self.feature_aggregator
+        if agg.exclude_target_view or agg.exclude_target_view_mask_features:
+            raise _lib.HoloError("view pooling: exclude_target_view(_mask_features) must be False "
+                                 "(HoloDiffusionModel sets both, holo_diffusion_model.py:114-116)")
+        from .render import _camera_array
+        keys = list(feats)
+        if not keys:
+            raise ValueError("view pooling needs at least one feature map")
+        t0 = feats[keys[0]]
+        runtime.require_device(t0, "ViewPooler.pool_to_voxel_features")
+        dev, n_src = t0.device, int(t0.shape[0])
+        arr = (_lib.HoloViewFeature * len(keys))()
+        held = []
+        for i, k in enumerate(keys):
+            t = feats[k]
+            if t.dim() != 4 or t.shape[0] != n_src or t.device != dev:
+                raise _lib.HoloError(f"feature map '{k}' must be (n_src={n_src}, C, H, W) on {dev}, got {tuple(t.shape)}")
+            t = t.contiguous().float()
+            held.append(t)
+            arr[i].feats = t.data_ptr()
+            arr[i].channels, arr[i].height, arr[i].width = int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+        cams = _camera_array(camera)
+        if len(cams) != n_src:
+            raise _lib.HoloError(f"{len(cams)} cameras for {n_src} source views")
+        F = int(mapper_weight.shape[0])
+        A = self.get_aggregated_feature_dim({k: feats[k] for k in keys})
+        if tuple(mapper_weight.shape) != (F, A):
+            raise _lib.HoloError(f"pooled_feature_mapper.weight must be ({F}, {A}), got {tuple(mapper_weight.shape)}")
+        cfg = _lib.HoloViewPoolCfg(int(resol), float(volume_extent), F, float(agg.weight_by_ray_angle_gamma),
+                                   float(agg.min_ray_angle_weight), 1e-2)
+        L = runtime.lib()
+        nbytes = L.holo_view_pool_workspace_bytes(C.byref(cfg), arr, len(keys), n_src)
+        ws = runtime.workspace(self, dev, nbytes)
+        out = torch.empty(1, F, resol, resol, resol, device=dev)
+        w = mapper_weight.detach().contiguous().float()
+        b = mapper_bias.detach().contiguous().float() if mapper_bias is not None else None
+        _lib.check(L, L.holo_view_pool(runtime.ctx(dev), C.byref(cfg), arr, len(keys), cams, n_src, runtime.ptr(w),
+                                       runtime.ptr(b) if b is not None else C.c_void_p(None), runtime.ptr(out),
+                                       runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_view_pool")
+        return out

@@ -216,6 +216,37 @@ int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, 
                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * View pooling: source-view feature maps -> voxel feature grid.  Replaces, fused in one kernel, the image_rgb branch
+ * of HoloDiffusionModel.forward behind the image feature extractor (holo_diffusion_model.py:340-373):
+ *   VolumeLocator.get_coord_grid, ViewPooler (PyTorch3D ViewSampler: NDC projection + bilinear ndc_grid_sample, masks = 1
+ *   with masked_sampling false; AngleWeightedReductionFeatureAggregator with [AVG, STD], configs/apple.yaml:183-196;
+ *   _get_point_to_source_camera_ray_dirs, custom_modules.py:279-334), pooled_feature_mapper (:113,368), tanh (:373).
+ * The image feature extractor itself (ResNet34) is outside this library: its output maps are the input here.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* feats; /* device, (n_views, channels, height, width) fp32 NCHW: one entry of the extractor's dict */
+  int32_t channels, height, width;
+} HoloViewFeature;
+
+typedef struct {
+  int32_t resol;                   /* HoloDiffusionModel.resol */
+  float volume_extent;             /* 8.0 */
+  int32_t feature_size;            /* output channels of pooled_feature_mapper = HoloDiffusionModel.feature_size */
+  float weight_by_ray_angle_gamma; /* 1.0 */
+  float min_ray_angle_weight;      /* 0.1 */
+  float projection_eps;            /* |z| clamp of transform_points, 1e-2 */
+} HoloViewPoolCfg;
+
+size_t holo_view_pool_workspace_bytes(const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats, int n_views);
+
+/* cameras: the n_views SOURCE cameras (host array; view 0 is the reference direction of the angular weights);
+ * mapper_weight (feature_size, 2 * sum channels) / mapper_bias (feature_size, may be NULL): pooled_feature_mapper, its
+ * input ordered per feature key [AVG | STD] in the order of `feats`;  voxel_features: (1, feature_size, R, R, R). */
+int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
+                   const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
+                   float* voxel_features, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
  * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).
  * ------------------------------------------------------------------------------------------ */

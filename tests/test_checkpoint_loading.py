@@ -63,13 +63,18 @@ def _expconfig(resol=8, feat=16, mc=32):
 
 def _reference_like_state(model, seed):
     """A checkpoint as the reference trainer would have written it: hot-path tensors + encoder-side tensors."""
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    # (pooled_feature_mapper is a LazyLinear: no shape until a checkpoint or the first pooled batch gives it one)
+    lazy = torch.nn.parameter.UninitializedParameter
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not isinstance(v, lazy)}
+    if getattr(model, "view_pooler_enabled", False):  # 2 x (64 ResNet + 1 mask + 3 image) aggregated features
+        shapes["pooled_feature_mapper.weight"] = (model.feature_size, 136)
+        shapes["pooled_feature_mapper.bias"] = (model.feature_size,)
     sd = synth_state_dict(shapes, seed)
     for k in list(sd):  # the passes share ONE implicit function (holo_diffusion_model.py:165-169): identical tensors
         if k.startswith("_implicit_functions.") and not k.startswith("_implicit_functions.0."):
             sd[k] = sd["_implicit_functions.0." + k.split(".", 2)[2]].clone()
     sd["image_feature_extractor.stem.0.weight"] = torch.zeros(4, 3, 3, 3)
-    sd["pooled_feature_mapper.0.weight"] = torch.zeros(8, 8)
+    sd["view_pooler.feature_aggregator._dummy"] = torch.zeros(1)
     return sd
 
 
@@ -88,7 +93,10 @@ def test_model_args_from_expconfig_filters_out_of_scope_fields(exp_dir):
     kw, ignored = ck.model_args_from_expconfig(cfg, render_size=(96, 64))
     assert kw["render_image_width"] == 96 and kw["render_image_height"] == 64  # load_experiment(render_size=...)
     assert kw["resol"] == 8 and kw["feature_size"] == 16
-    assert "log_vars" not in kw and "view_pooler_args" not in kw
+    assert "log_vars" not in kw and "image_feature_extractor_class_type" not in kw
+    # the encoder side is kept: the configured pooler is the one the fused view-pooling kernel implements
+    assert kw["view_pooler_enabled"] is True
+    assert kw["view_pooler_args"]["feature_aggregator_class_type"] == "AngleWeightedReductionFeatureAggregator"
     assert any(s.endswith(".log_vars") for s in ignored)
     assert any(s.endswith("raysampler_AdaptiveRaySampler_args.cast_ray_bundle_as_cone") for s in ignored)
     assert kw["implicit_function_HoloVoxelGridImplicitFunction_args"]["render_mlp_args"]["activation_fn"] == "LEAKYRELU"
@@ -105,8 +113,11 @@ def test_load_experiment_picks_last_checkpoint_and_binds_every_path_parameter(ex
     assert ck.find_last_checkpoint(exp_dir).endswith("model_epoch_00000012.pth")
     model, rep = ck.load_experiment(exp_dir, render_size=(32, 24))
     assert rep.checkpoint_file.endswith("model_epoch_00000012.pth") and not rep.strict
-    assert sorted(rep.unexpected_keys) == ["image_feature_extractor.stem.0.weight", "pooled_feature_mapper.0.weight"]
+    assert sorted(rep.unexpected_keys) == ["image_feature_extractor.stem.0.weight", "view_pooler.feature_aggregator._dummy"]
     assert rep.missing_keys == []
+    # the encoder-side mapper of the checkpoint lands in the (lazy) pooled_feature_mapper
+    assert tuple(model.pooled_feature_mapper.weight.shape) == (model.feature_size, 136)
+    assert torch.equal(model.pooled_feature_mapper.weight.detach().cpu(), new["pooled_feature_mapper.weight"])
     got = model.state_dict()
     for k, v in new.items():
         if k.startswith(ck.PATH_PREFIXES):

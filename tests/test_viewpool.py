@@ -1,0 +1,128 @@
+"""View pooling: known-answer tests of the CPU restatement (PARITY UNPINNED: the arithmetic is
+PyTorch3D's, see oracle/viewpool_oracle.py) and, with `-m gpu`, the fused HIP kernel against it."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import holo_diffusion_amd as hda
+from holo_diffusion_amd.weights import synth_state_dict
+from oracle import render_oracle as ro
+from oracle import viewpool_oracle as vo
+from oracle.common import np_noise
+
+
+def _cams(n, radius=10.0):
+    return ro.simple_360_cameras(n, radius=radius)
+
+
+def test_coord_grid_is_the_renderers_voxel_centres():
+    """Trilinear fetch (the renderer's locator) at the pooled points returns the voxels themselves."""
+    R, C = 6, 5
+    grid = torch.from_numpy(np_noise(1, (1, C, R, R, R)))
+    pts = vo.coord_grid(R, 8.0)
+    f = ro.trilinear(grid, pts, ro.RenderCfg(resol=R, feature_size=C))
+    ref = grid[0].reshape(C, -1).t()
+    assert (f - ref).abs().max() < 1e-5
+    assert torch.allclose(pts[0], torch.full((3,), -0.5 * (R - 1) * (8.0 / R)))
+
+
+def test_points_on_a_pixel_ray_project_to_that_pixel_and_sample_it():
+    """project_ndc inverts the ray sampler's un-projection; ndc_grid_sample at a pixel-centre NDC returns the pixel."""
+    H, W = 6, 10  # non-square: the longer side spans +-(W/H) in NDC
+    rcfg = ro.RenderCfg(image_height=H, image_width=W)
+    cams = _cams(4)
+    cam = {k: v[1:2] for k, v in cams.items()}
+    o, d, l = ro.make_rays(cam, rcfg)
+    xy = ro.ndc_pixel_grid(H, W).reshape(-1, 2)
+    for depth in (7.0, 10.0, 12.5):
+        ndc = vo.project_ndc(o + depth * d, cams["R"][1], cams["T"][1], cams["focal"][1], cams["pp"][1])
+        assert (ndc - xy).abs().max() < 2e-5
+    img = torch.from_numpy(np_noise(3, (4, H, W)))
+    s = vo.ndc_grid_sample(img, xy)
+    assert (s - img.reshape(4, -1).t()).abs().max() < 1e-5
+
+
+def test_aggregator_closed_forms():
+    R = 4
+    cams = _cams(3)
+    const = {"a": torch.full((3, 2, 5, 5), 0.7)}
+    agg = vo.pool_views(const, cams, R, 0.5)  # a tiny volume at the centre: every voxel projects inside every view
+    assert agg.shape == (R ** 3, 4)
+    assert (agg[:, :2] - 0.7).abs().max() < 1e-6           # AVG of identical views
+    assert (agg[:, 2:] - 1e-2).abs().max() < 1e-6          # STD = sqrt(clamp(0, 1e-4))
+    # two opposite cameras: the second view's direction is the negated first -> angular weight clamps at min
+    R0, T0 = ro.look_at_view_transform(10.0, 0.0, 0.0)
+    R1, T1 = ro.look_at_view_transform(10.0, 0.0, 180.0)
+    two = {"R": torch.cat([R0, R1]), "T": torch.cat([T0, T1]), "focal": torch.full((2, 2), 3.2), "pp": torch.zeros(2, 2)}
+    f = {"a": torch.stack([torch.zeros(1, 4, 4), torch.ones(1, 4, 4)])}
+    agg = vo.pool_views(f, two, 2, 0.05, min_weight=0.1)
+    # weights ~ (1, 0.1): AVG = 0.1 / 1.1
+    assert (agg[:, 0] - 0.1 / 1.1).abs().max() < 2e-3
+
+
+# --------------------------------------------------------------------------------------------------------------
+def _synthetic_views(n_src, seed):
+    feats = {"res": torch.tanh(torch.from_numpy(np_noise(seed, (n_src, 16, 20, 24)))),
+             "mask": torch.sigmoid(torch.from_numpy(np_noise(seed + 1, (n_src, 1, 30, 30)))),
+             "rgb": torch.sigmoid(torch.from_numpy(np_noise(seed + 2, (n_src, 3, 17, 13))))}
+    A = 2 * (16 + 1 + 3)
+    return feats, A
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,n_src,radius,gamma", [(8, 3, 10.0, 1.0), (16, 5, 6.0, 2.0), (8, 9, 3.0, 1.0)])
+def test_view_pool_kernel_vs_oracle(R, n_src, radius, gamma):
+    """holo_view_pool (projection + bilinear gather + angle-weighted AVG/STD + mapper + tanh, one kernel) against the
+    oracle: non-square maps of three sizes, channel counts 16 / 1 / 3, cameras far, near and INSIDE the volume's
+    bounding sphere (radius 3: many voxels project outside the images or behind a camera -> zeros padding, |z| clamp)."""
+    import tests.gpu_utils as gu
+    F = 16
+    feats, A = _synthetic_views(n_src, 50 + R)
+    cams_d = _cams(n_src, radius=radius)
+    w = synth_state_dict({"w": (F, A), "b": (F,)}, 9)
+    w["b"] = 0.1 * torch.from_numpy(np_noise(4, (F,)))
+    ref = vo.voxel_features_from_views(feats, cams_d, w["w"], w["b"], R, 8.0, gamma=gamma)
+    model = hda.HoloDiffusionModel(resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False,
+                                   diffusion_enabled=False, render_image_width=8, render_image_height=8,
+                                   view_pooler_args=dict(feature_aggregator_AngleWeightedReductionFeatureAggregator_args=dict(
+                                       weight_by_ray_angle_gamma=gamma)))
+    model.load_state_dict({"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}, strict=False)
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    got = model.pool_views_to_voxel_features({k: v.to(gu.DEV) for k, v in feats.items()}, cams.to(gu.DEV))
+    assert got.shape == (1, F, R, R, R)
+    assert (got.cpu() - ref).abs().max().item() < 1e-4
+    assert ref.abs().max() <= 1.0 and ref.std() > 0.05
+
+
+@pytest.mark.gpu
+def test_model_forward_from_source_views():
+    """HoloDiffusionModel.forward with source-view features (the reconstruction entry, holo_diffusion_model.py:327-374):
+    camera batch = [target, sources...]; the pooled grid goes through tanh(net_3d(., 0)) and the renderer like a
+    sampled one.  The frame equals rendering the pooled grid directly."""
+    import tests.gpu_utils as gu
+    n_src, R, F = 4, 8, 16
+    feats, A = _synthetic_views(n_src, 77)
+    model, *_ = gu.make_model(R, F, 10, 12, dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2)))
+    assert model.view_pooler is None
+    m2 = hda.HoloDiffusionModel(resol=R, feature_size=F, render_image_width=12, render_image_height=10,
+                                view_pooler_enabled=True,
+                                net_3d_SimpleUnet3D_args=dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2)))
+    sd = {k: v for k, v in model.state_dict().items()}
+    w = synth_state_dict({"pooled_feature_mapper.weight": (F, A), "pooled_feature_mapper.bias": (F,)}, 5)
+    m2.load_state_dict({**{k: v.cpu() for k, v in sd.items()}, **w})
+    m2.to(gu.DEV)
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_src + 1, -0.5, 10, (0.0, -1.0, 0.0), 3.2).to(gu.DEV)
+    dfeats = {k: v.to(gu.DEV) for k, v in feats.items()}
+    preds = m2(camera=cams, image_features=dfeats)
+    assert preds["images_render"].shape == (1, 3, 10, 12) and torch.isfinite(preds["images_render"]).all()
+    vf = m2.pool_views_to_voxel_features(dfeats, cams[list(range(1, n_src + 1))])
+    direct = m2(camera=cams[0], voxel_features=vf)
+    assert torch.equal(direct["images_render"], preds["images_render"])
+    # an extractor callable is used when raw images come in
+    m2.image_feature_extractor = lambda rgb, fg: dfeats
+    p3 = m2(camera=cams, image_rgb=torch.zeros(n_src + 1, 3, 8, 8, device=gu.DEV))
+    assert torch.equal(p3["images_render"], preds["images_render"])
