@@ -999,10 +999,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvParams p) {
 // Winograd F(2x2, 3x3) over (z, y): the same kernel with the second transform applied to the A operand at load time
 // (see "second Winograd dimension" below).  The LDS halo is the z-transformed one of conv_wino_kernel, unchanged.
 // ---------------------------------------------------------------------------------------------
-template <bool SKIP>
+// NWN: waves along Cout.  4: the workgroup covers 64 output channels, every wave both MFMA tiles of the plane pair;
+// 2 (32-channel convolutions, e.g. the output conv): waves 0,1 take tile 0 and waves 2,3 tile 1 of the same 32 channels.
+template <bool SKIP, int NWN = 4>
 __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   constexpr int RS = LDK;
-  constexpr int MT = 2;                // 16-row MFMA tiles: rows = (y tile, x), y tiles t and t + 2 (see a_off)
+  constexpr int MT = NWN == 4 ? 2 : 1;  // 16-row MFMA tiles per wave: rows = (y tile, x), y tiles T and T + 2 (see a_off)
   constexpr int PLANE = HY * HX;       // 100 (y,x) columns of the halo
   constexpr int HALO_VOX = 4 * PLANE;  // four xi planes
   constexpr int COLS_IT = (PLANE * 8 + 255) / 256;  // (column, channel quad) items per thread: 4
@@ -1011,7 +1013,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wn = tid >> 6;  // the wave owns output channels [16 wn, 16 wn + 16) of the block's 64
+  const int wn = (tid >> 6) % NWN;             // the wave owns output channels [16 wn, 16 wn + 16) of the block's 16*NWN
+  const int wm = NWN == 4 ? 0 : (tid >> 6) / NWN;  // ... and MFMA tiles wm*MT .. wm*MT + MT - 1
   const int lj = lane & 15;
   const int kq = lane >> 4;
   const int Cin = p.C0 + p.C1;
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   tile /= nty;
   const int tz0 = (tile % ntz) * 2;
   const int n = tile / ntz;
-  const int n0 = blockIdx.y * 64;
+  const int n0 = blockIdx.y * (16 * NWN);
   const int SCin = p.skip_C0 + p.skip_C1;
   const int nsk = SKIP ? (SCin + BK - 1) / BK : 0;
   const int cc_begin = blockIdx.z * p.chunks_per_split;
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   // (the two y tiles of an MFMA tile are 4 halo rows = 32 (mod 64) words apart: conflict-free 16-byte reads)
   int a_off[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) a_off[t] = ((2 * t + 4 * (lj >> 3)) * HX + (lj & 7)) * RS + kq * 8;
+  for (int t = 0; t < MT; ++t) a_off[t] = ((2 * (wm * MT + t) + 4 * (lj >> 3)) * HX + (lj & 7)) * RS + kq * 8;
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
   constexpr int WBLK = 512;
   const float* w_lane = p.w_wino2 + (int64_t)((n0 >> 4) + wn) * WBLK + lane * 4;
@@ -1248,11 +1251,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
       combine(R0);
       mfma_xy(xz, 0, R0, Bw[st % 3]);
       __builtin_amdgcn_sched_barrier(0);
-      load_rows(R0, 1, xz, kw, half);
-      __builtin_amdgcn_sched_barrier(0);
-      combine(R0);
-      mfma_xy(xz, 1, R0, Bw[st % 3]);
-      __builtin_amdgcn_sched_barrier(0);
+      if (MT == 2) {
+        load_rows(R0, 1, xz, kw, half);
+        __builtin_amdgcn_sched_barrier(0);
+        combine(R0);
+        mfma_xy(xz, MT - 1, R0, Bw[st % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (st + 1 < 24) load_rows(R0, 0, nxz, nkw, nhalf);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1301,7 +1306,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
   const int ystride = p.OW * p.Cout;
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
-    const int off = ((2 * (t + 2 * (kq >> 1))) * p.OW + 4 * (kq & 1)) * p.Cout;  // output row 2*ytile, first x of the lane
+    const int off = ((2 * (wm * MT + t + 2 * (kq >> 1))) * p.OW + 4 * (kq & 1)) * p.Cout;  // output row 2*ytile, first x of the lane
     float o[2][2][4];  // [z][y][r]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1367,8 +1372,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_kernel(ConvParams p) {
     ssq += __shfl_xor(ssq, 32);
     if (kq == 0 && co < p.Cout) {
       const int tiles_per_sample = ntx * nty * ntz;
-      const int slab = (int)blockIdx.x % tiles_per_sample;
-      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co) * 2;
+      const int slab = ((int)blockIdx.x % tiles_per_sample) * (4 / NWN) + wm;  // one slab per (workgroup, wave row)
+      const int nslab = tiles_per_sample * (4 / NWN);
+      double* d = p.stats + (((int64_t)n * nslab + slab) * p.Cout + co) * 2;
       d[0] = (double)ssum;
       d[1] = (double)ssq;
     }
@@ -2093,6 +2099,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     // exact-fp32 128-voxel tiles: the Winograd-in-depth form (2/3 of the MFMAs) when its weights were prepared
     p.wino = (p.tz == 2 && p.w_wino && p.bf16 == 0 && p.Cout >= 64 && (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino)) ? 1 : 0;
     if (p.wino && p.w_wino2 && (!p.skip_w || p.skip_w_wino2)) p.wino = 2;  // both depth and height in Winograd form
+    if (p.tz == 2 && p.w_wino2 && p.bf16 == 0 && p.Cout == 32 && !p.skip_w) p.wino = 2;  // 32-channel (z,y) form, two wave rows
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (tiles < target) {
@@ -2157,10 +2164,12 @@ int conv_launch(const ConvParams& p, void* stream) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
     if (p.wino == 2) {
-      if (sk) {
-        HOLO_LAUNCH(conv_wino2_kernel<true>, hgrid, block, stream, p);
+      if (!wide) {
+        HOLO_LAUNCH((conv_wino2_kernel<false, 2>), hgrid, block, stream, p);
+      } else if (sk) {
+        HOLO_LAUNCH((conv_wino2_kernel<true, 4>), hgrid, block, stream, p);
       } else {
-        HOLO_LAUNCH(conv_wino2_kernel<false>, hgrid, block, stream, p);
+        HOLO_LAUNCH((conv_wino2_kernel<false, 4>), hgrid, block, stream, p);
       }
     } else if (p.wino) {
       if (sk) {

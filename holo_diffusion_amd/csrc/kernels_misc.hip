@@ -149,26 +149,42 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int Cin = C0 + C1;
   const int cpg = Cin / groups;
+  // Every (slab, channel-of-the-group) pair is one 16-byte (sum, sumsq) record; consecutive channels of a slab are
+  // contiguous, so the threads walk the pairs with the channel index fastest (coalesced runs of cpg records) and keep
+  // eight independent loads in flight.  The summation order depends on nothing but the launch geometry: deterministic.
   double s = 0.0, sq = 0.0;
-  for (int k = 0; k < cpg; ++k) {
-    const int cc = g * cpg + k;
-    const double* p;
-    int Cs, cs, B;
-    if (cc < C0) {
-      p = part0;
-      Cs = C0;
-      cs = cc;
-      B = B0;
-    } else {
-      p = part1;
-      Cs = C1;
-      cs = cc - C0;
-      B = B1;
-    }
-    for (int b = tid; b < B; b += 256) {
-      const double* e = p + (((int64_t)n * B + b) * Cs + cs) * 2;
-      s += e[0];
-      sq += e[1];
+  {
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    // the group may straddle the seam of the virtual concat: channels [c_lo, c_mid) come from part0, [c_mid, c_hi) from part1
+    const int c_mid = c_lo < C0 ? (c_hi < C0 ? c_hi : C0) : c_lo;
+    for (int half = 0; half < 2; ++half) {
+      const int ca = half == 0 ? c_lo : c_mid, cb = half == 0 ? c_mid : c_hi;
+      const int nch = cb - ca;
+      if (nch <= 0) continue;
+      const double* p = half == 0 && ca < C0 ? part0 : part1;
+      const int Cs = p == part0 ? C0 : C1, B = p == part0 ? B0 : B1;
+      const int cs0 = p == part0 ? ca : ca - C0;
+      const int64_t total = (int64_t)B * nch;
+      const double* base = p + ((int64_t)n * B * Cs + cs0) * 2;
+      int64_t i = tid;
+      for (; i + 7 * 256 < total; i += 8 * 256) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t j = i + u * 256;
+          v[u] = *reinterpret_cast<const double2*>(base + ((j / nch) * Cs + (j % nch)) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s += v[u].x;
+          sq += v[u].y;
+        }
+      }
+      for (; i < total; i += 256) {
+        const double2 v = *reinterpret_cast<const double2*>(base + ((i / nch) * Cs + (i % nch)) * 2);
+        s += v.x;
+        sq += v.y;
+      }
     }
   }
   rs[tid] = s;

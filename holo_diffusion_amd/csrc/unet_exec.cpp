@@ -919,7 +919,7 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
       const bool c3 = s.kind == P_CONV3;
       const bool sk = s.kind == P_CONV1 && s.name.find("skip_connection") != std::string::npos;
       // (the levels with 8-divisible planes: up to 256 output channels, up to 768 input channels with the skip concat)
-      if (!(c3 || sk) || s.shape[0] > 256 || s.shape[1] > 768 || s.shape[0] % 64) return 0;
+      if (!(c3 || sk) || s.shape[0] > 256 || s.shape[1] > 768 || (s.shape[0] % 64 && !(c3 && s.shape[0] == 32))) return 0;
       return (int64_t)(c3 ? 36 : 2) * pad_cout((int)s.shape[0]) * pad_cin((int)s.shape[1]);
     };
     const bool enable2 = enable && !(we && we[0] == '1');  // HOLO_CONV_WINO=1: depth only; default: both forms prepared

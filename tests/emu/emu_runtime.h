@@ -32,6 +32,9 @@ static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct float2 {
   float x, y;
 };
+struct double2 {
+  double x, y;
+};
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef float f32x16 __attribute__((vector_size(64)));
