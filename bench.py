@@ -192,12 +192,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8,
-                    help="timed 400x400 frames in the render leg (one holo_render call; a fly-around is 40-75 frames, "
-                         "the library renders them 8 per kernel launch)")
-    ap.add_argument("--flyaround-frames", type=int, default=40,
-                    help="length of the secondary fly-around render leg (0 = skip; the profiling scripts skip it so that "
-                         "every render dispatch of a profile has --frames frames)")
+    ap.add_argument("--frames", type=int, default=40,
+                    help="timed 400x400 frames in the render leg: one render call of a whole fly-around (render_flyaround's "
+                         "default n_flyaround_poses = 40, flyaround.py:50; generate_samples.py uses 75)")
+    ap.add_argument("--flyaround-frames", type=int, default=8,
+                    help="frame count of the SECONDARY render leg (0 = skip; the profiling scripts skip it so that every "
+                         "render dispatch of a profile has --frames frames).  8 = the call size round 1 reported: 40 000 "
+                         "wave tiles on 3 072 resident waves are 13.02 rounds, i.e. 7 % lost to the last round")
     ap.add_argument("--image-size", type=int, default=400)
     ap.add_argument("--workload", choices=["north", "small", "donut128"], default="north",
                     help="north = BASELINE configs[1] (the reported line); small / donut128 = configs[0] / [4] grid "
@@ -281,8 +282,7 @@ def main():
     dtr = max_over_ranks(dtr, world, device)
     assert torch.isfinite(out["images_render"]).all()
     rays_per_s = world * F * H * W / dtr
-    # the same leg at the length of a reference fly-around (render_flyaround's default n_flyaround_poses = 40,
-    # flyaround.py:50): a secondary figure, the reported rays_per_sec stays the --frames call above
+    # the same leg at a second call size (default: the 8-frame call round 1 reported): a secondary figure
     F40 = args.flyaround_frames
     rays_per_s_40, dtr40 = None, None
     if F40 > 0:
@@ -462,8 +462,8 @@ def main():
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
-            "rays_per_sec_flyaround": rays_per_s_40, "flyaround_frames": F40,
-            "ms_per_frame_flyaround": (1e3 * dtr40 / F40) if F40 > 0 else None,
+            "rays_per_sec_second_call_size": rays_per_s_40, "second_call_frames": F40,
+            "ms_per_frame_second_call_size": (1e3 * dtr40 / F40) if F40 > 0 else None,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,

@@ -4,8 +4,8 @@ TAG=${1:-pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-# every render dispatch of this command is an 8-frame launch (frames_per_launch of scripts/pmc_to_json.py); no opt-in modes
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames 8 --flyaround-frames 0 --no-opt-in --no-cpu-baseline --conv-iters 1"
+# every render dispatch of this command is a 20-frame launch (what a 40-frame call splits into) (frames_per_launch of scripts/pmc_to_json.py); no opt-in modes
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frames 20 --flyaround-frames 0 --no-opt-in --no-cpu-baseline --conv-iters 1"
 run_pass () {
   name=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_${TAG}_$name -o p -- $CMD > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$name.err ; echo "pass $name rc=$?" )
