@@ -29,7 +29,7 @@ for (k, grid), (n, f_kib) in fetch.items():
     w_kib = write.get((k, grid), (0, 0.0))[1]
     frames = None
     m = re.search(r"conv_halo_kernel<(\d), (\d), (true|false)(?:, (true|false))?>", k)
-    mw = re.search(r"conv_wino(2?)_kernel<(true|false)>", k)
+    mw = re.search(r"conv_wino(2?)_kernel<(true|false)(?:, (\d))?>", k)
     if m and m.group(4) == "true":
         continue  # bf16-product instantiation (opt-in mode): not the reported kernel
     if m:
@@ -44,6 +44,8 @@ for (k, grid), (n, f_kib) in fetch.items():
         od = round((tiles * 128) ** (1 / 3))
         if od ** 3 != tiles * 128 or od != 64:
             continue
+        if mw.group(3) == "2":
+            continue  # the 32-channel two-wave-row variant: its grid is not distinguishable from the 64-channel one here
         label = f"conv_wino{mw.group(1)}_kernel<{mw.group(2)}> at {od}^3 output"
     elif "render_kernel" in k:
         mr = re.search(r"render_kernel<([^>]*)>", k)
@@ -54,7 +56,7 @@ for (k, grid), (n, f_kib) in fetch.items():
     res[label] = {"fetch_bytes": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024), "dispatches": n,
                   "fetch_size_raw_kib": f_kib, "write_size_raw_kib": w_kib,
                   "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the command of scripts/gpu_pmc.sh, "
-                            f"profiles/{tag}_pmc_fetch.csv + _pmc_write.csv; FETCH_SIZE doubled per the gfx950 note of "
+                            f"profiles/{tag}_fetch.csv + _write.csv; FETCH_SIZE doubled per the gfx950 note of "
                             "MI355X_MICROARCH.md; fabric-side L2 misses (Infinity-Cache hits included)"}
     if frames:
         res[label]["frames_per_launch"] = frames
