@@ -73,6 +73,17 @@ struct ConvParams {
   const float* w_wino2;
   const float* skip_w_wino2;
   int wino;               // set by conv_plan: 0 direct, 1 Winograd in depth, 2 Winograd in depth and height
+  // bf16 wide-tile kernel (conv_bf16t_kernel, 8x8x8 output tiles, v_mfma_f32_32x32x16_bf16): plane 3 of the bf16
+  // weight buffer, packed [ksz^3][CinP/16][CoutP/32][lane 64][8 bf16] = one 1 KB block of B operands per
+  // (tap, 16-channel chunk, 32-Cout slice); lane's 8 values are channels 8*(lane>>5) .. +7 of output channel lane&31
+  const uint16_t* w_bft;
+  const uint16_t* skip_w_bft;
+  int bf16t;              // set by conv_plan: the launch runs on conv_bf16t_kernel
+  // bf16 STORAGE (compute mode bf16): the buffers behind these float* are bf16 (uint16_t) channels-last tensors;
+  // coefficients, bias, statistics and split-K scratch stay fp32 / double
+  int in_bf16;            // src0 / src1 / skip_src0 / skip_src1
+  int res_bf16;           // residual
+  int out_bf16;           // out
 };
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
@@ -123,13 +134,14 @@ int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);
 // ---------------------------------------------------------------------------------------------
 // misc (kernels_misc.hip)
 // ---------------------------------------------------------------------------------------------
-int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream);
-int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream);
+int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream,
+                          int out_bf16 = 0);  // out_bf16 / in_bf16 / x_bf16: the channels-last tensor is bf16
+int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream, int in_bf16 = 0);
 
 // GroupNorm statistics, stage 1: partial[n][b][c] = (sum, sumsq) in double over voxel slab b (deterministic,
 // no atomics).  gn_stats_geometry gives the slab count B(C, V) the buffers must be sized for.
 void gn_stats_geometry(int C, int64_t V, int* n_blocks, int* vox_per_block);
-int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream);
+int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream, int x_bf16 = 0);
 
 // stage 2: GroupNorm(32 groups, eps) folded to per-channel (a,b), optionally composed with FiLM
 // (unet.py:248-250): y = GN(x)*(1+scale)+shift.  Channels [0,C0) use part0 (B0 slabs), [C0,C0+C1) part1.

@@ -22,6 +22,7 @@
 // (and 16 per B tile) for the 16 MFMA k-steps of the chunk with four ds_read_b128.
 // Double buffered: global loads of chunk k+1 are issued before the MFMAs of chunk k and written to the
 // other LDS buffer afterwards; one barrier per chunk.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "holo_common.h"
@@ -36,6 +37,35 @@ constexpr int BK = 32;
 constexpr int LDK = 36;
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// bf16 paths: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (the result is rounded to bf16 anyway)
+__device__ __forceinline__ float silu_fast(float v) { return v * holo_rcp(1.0f + __expf(-v)); }
+
+// activation element access for the bf16 storage mode: `bf` = the buffer behind the float* holds bf16
+__device__ __forceinline__ float bf16_load(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+__device__ __forceinline__ uint16_t bf16_round(float v) { return (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float4 ld_act4(const float* base, int64_t idx, int bf) {
+  if (bf) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  }
+  return *reinterpret_cast<const float4*>(base + idx);
+}
+__device__ __forceinline__ void st_act4(float* base, int64_t idx, const float4& v, int bf) {
+  if (bf)
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(base) + idx) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  else
+    *reinterpret_cast<float4*>(base + idx) = v;
+}
+__device__ __forceinline__ float ld_act1(const float* base, int64_t idx, int bf) {
+  return bf ? bf16_load(reinterpret_cast<const uint16_t*>(base) + idx) : base[idx];
+}
+__device__ __forceinline__ void st_act1(float* base, int64_t idx, float v, int bf) {
+  if (bf)
+    reinterpret_cast<uint16_t*>(base)[idx] = bf16_round(v);
+  else
+    base[idx] = v;
+}
 
 // Packed conv weights (repack_conv_weight_kernel): [tap][chunk = cin/32][slice = cout/16][half][kq][lj][4], i.e. one
 // 2 KB block per (tap, 32-channel chunk, 16-Cout slice) holding exactly the B fragments of a v_mfma_f32_16x16x4_f32
@@ -129,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         x >>= 1;
       }
       const int64_t idx = ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs;
-      ra[j] = *reinterpret_cast<const float4*>(src + idx);
+      ra[j] = ld_act4(src, idx, p.in_bf16);
       amask |= (ok ? 1u : 0u) << j;
       if (p.coef) {
         const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
@@ -245,13 +275,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
       if (p.residual) {  // one batch of loads (clamped addresses), no per-element branch
         float res[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) res[r] = p.residual[mo[r] + coc];
+        for (int r = 0; r < 16; ++r) res[r] = ld_act1(p.residual, mo[r] + coc, p.res_bf16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] += res[r];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (mv[r]) p.out[mo[r] + co] = acc[t][r] + bv;
+        if (mv[r]) st_act1(p.out, mo[r] + co, acc[t][r] + bv, p.out_bf16);
     } else {
       float* pp = p.partial + (int64_t)blockIdx.z * M * p.Cout + coc;
 #pragma unroll
@@ -401,13 +431,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     // Every load is issued unconditionally from a clamped (always valid) address and masked afterwards:
     // a "load or zero" branch would make the compiler wait for each load before the next one is issued.
     // uniform 64-bit base + one 32-bit byte offset per load (conv_plan keeps a source volume below 4 GB on this path)
-    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)n * SD * SH * SW * Cs);
-    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
+    constexpr unsigned ES = BF ? 2u : 4u;  // bf16 mode = bf16 storage: 8 bytes per (voxel, 4 channels)
+    const char* sbase = reinterpret_cast<const char*>(src) + (int64_t)n * SD * SH * SW * Cs * ES;
+    const unsigned cbytes = (unsigned)Cs * ES, cofs = (unsigned)cs * ES;
     int tl = tid;
     HOLO_LAUNDER(tl);  // (otherwise the compiler forwards the values stored by halo_prepare and keeps them in VGPRs)
 #pragma unroll
-    for (int i = 0; i < HALO_IT; ++i)
-      hreg[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs));
+    for (int i = 0; i < HALO_IT; ++i) {
+      const char* a = sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs);
+      if (BF) {  // raw bits; unpacked in halo_commit (no wait on the load here)
+        const uint2 u = *reinterpret_cast<const uint2*>(a);
+        hreg[i].x = __uint_as_float(u.x);
+        hreg[i].y = __uint_as_float(u.y);
+      } else {
+        hreg[i] = *reinterpret_cast<const float4*>(a);
+      }
+    }
   };
   auto halo_commit = [&]() {
     f32x2 a01 = f32x2{1.f, 1.f}, b01 = f32x2{0.f, 0.f}, a23 = a01, b23 = b01;
@@ -425,6 +464,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
     for (int i = 0; i < HALO_IT; ++i) {
       const int hv = r0 + 32 * i;
       f32x2 v01 = f32x2{hreg[i].x, hreg[i].y}, v23 = f32x2{hreg[i].z, hreg[i].w};
+      if (BF) {
+        const uint32_t w0 = __float_as_uint(hreg[i].x), w1 = __float_as_uint(hreg[i].y);
+        v01 = f32x2{__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u)};
+        v23 = f32x2{__uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u)};
+      }
       if (xform) {
         v01 = pk_fma(v01, a01, b01);
         v23 = pk_fma(v23, a23, b23);
@@ -599,24 +643,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   }
   if (p.nsplit == 1) {
     if (p.residual) {
-      const float* rp = p.residual + tbase + coc;
       float res[MT][4];
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[t][r] = rp[off[t] + r * p.Cout];
+        for (int r = 0; r < 4; ++r) res[t][r] = ld_act1(p.residual, tbase + coc + off[t] + r * p.Cout, BF);
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[t][r] += res[t][r];
     }
-    float* op = p.out + tbase + coc;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float v = acc[t][r] + bv;
-        if (co < p.Cout) op[off[t] + r * p.Cout] = v;
+        if (co < p.Cout) st_act1(p.out, tbase + coc + off[t] + r * p.Cout, v, BF && p.out_bf16);
         ssum += v;
         ssq += v * v;
       }
@@ -662,6 +704,413 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
   }  // tile loop
 }
 
+
+
+// ---------------------------------------------------------------------------------------------
+// bf16 wide-tile kernel for the stride-1 3x3x3 convolutions of the filled levels (bf16 compute mode).
+//
+// v_mfma_f32_32x32x16_bf16 moves 16x the flops of the fp32 instruction per operand byte, so the operand traffic that
+// the 128-voxel halo kernel affords (every wave re-reads the whole tile's A operand for its 16 output channels: 9
+// fragment loads per 8 MFMAs) is 2x the LDS bandwidth at the bf16 rate.  This kernel register-blocks 4 x NT:
+//   workgroup = 4 waves, output tile = 8 x 8 x 8 voxels x 32*NT output channels;
+//   wave = 2 z-planes = 128 voxels = 4 MFMA row tiles x NT column tiles (128 accumulator registers at NT = 2);
+//   per tap and 16-channel chunk a wave reads 4 A fragments from the LDS halo (ds_read_b128) and NT B fragments
+//   straight from global/L1 (all four waves read the same 1 KB blocks) for 4*NT MFMAs: LDS at 50 %, L1 at 50 % of their
+//   bandwidth when the matrix pipe is saturated.
+// The 10^3 halo of ONE 16-channel chunk is staged per pass (48-byte LDS rows: 32 B of bf16 + 16 B padding, conflict
+// free for the A reads: a 32-row MFMA tile is the y rows {a, a+4, b, b+4} of a plane, 480 words = 32 banks apart);
+// GroupNorm*FiLM + SiLU, zero padding, nearest-x2 upsampling and the channel concat are applied while staging, as in
+// the halo kernel.  The next chunk's raw halo is requested under tap 16 and committed after the last tap (two barriers
+// per chunk); the activation arithmetic of one workgroup overlaps the tap loop of the other resident workgroup (the bf16
+// matrix pipe does not use the vector lanes).  A fused 1x1x1 skip connection is one more tap whose A operands come
+// straight from global memory (a wave's voxels are its own).  The epilogue transposes the accumulators through LDS
+// so that residual, statistics and stores are 16-byte operations.  Split-K over 16-channel chunks.
+// IOBF: activations / residual / output are bf16 in HBM (bf16 storage mode).
+// ---------------------------------------------------------------------------------------------
+constexpr int T_H = 10;                 // halo edge of an 8^3 tile
+constexpr int T_HV = T_H * T_H * T_H;   // halo voxels
+constexpr int T_CK = 16;                // channels per chunk = K of one v_mfma_f32_32x32x16_bf16
+constexpr int T_RS = 12;                // LDS words per halo voxel
+constexpr int T_IT = 8;                 // staging items (voxel, 8-channel half) per thread: 2000 / 256
+
+__device__ __forceinline__ void unpack_bf16x8(const float4& v, float (&f)[8]) {
+  const uint32_t w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+  f[0] = __uint_as_float(w0 << 16);
+  f[1] = __uint_as_float(w0 & 0xffff0000u);
+  f[2] = __uint_as_float(w1 << 16);
+  f[3] = __uint_as_float(w1 & 0xffff0000u);
+  f[4] = __uint_as_float(w2 << 16);
+  f[5] = __uint_as_float(w2 & 0xffff0000u);
+  f[6] = __uint_as_float(w3 << 16);
+  f[7] = __uint_as_float(w3 & 0xffff0000u);
+}
+__device__ __forceinline__ float4 pack_bf16x8(const float (&f)[8]) {
+  return make_float4(__uint_as_float(pack_bf16x2(f[0], f[1])), __uint_as_float(pack_bf16x2(f[2], f[3])),
+                     __uint_as_float(pack_bf16x2(f[4], f[5])), __uint_as_float(pack_bf16x2(f[6], f[7])));
+}
+
+template <int NT, bool SKIP, bool IOBF>
+__global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
+  constexpr int ES = IOBF ? 2 : 4;  // bytes per activation element in HBM
+  constexpr int NV = IOBF ? 1 : 2;  // 16-byte loads per staging item
+  constexpr int BN = 32 * NT;
+  __shared__ __attribute__((aligned(16))) float s_halo[T_HV * T_RS];
+  __shared__ int s_hvox[T_IT * 256];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;  // MFMA row (A) / column (B, D)
+  const int kg = lane >> 5;  // MFMA k-group: channels 8*kg .. 8*kg+7 of the chunk
+  const int hh = tid & 1;    // staging: which 8-channel half of the chunk
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + T_CK - 1) / T_CK;
+  const int SCin = p.skip_C0 + p.skip_C1;
+  const int nsk = SKIP ? (SCin + T_CK - 1) / T_CK : 0;
+  const int cc_begin = blockIdx.z * p.chunks_per_split;
+  int cc_end = cc_begin + p.chunks_per_split;
+  if (cc_end > ncc) cc_end = ncc;
+  const int sk_begin = ncc + blockIdx.z * p.skip_chunks_per_split;
+  int sk_end = sk_begin + p.skip_chunks_per_split;
+  if (sk_end > ncc + nsk) sk_end = ncc + nsk;
+  const int SD = p.ups ? (p.ID >> 1) : p.ID;
+  const int SH = p.ups ? (p.IH >> 1) : p.IH;
+  const int SW = p.ups ? (p.IW >> 1) : p.IW;
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD >> 3;
+  int bt = blockIdx.x;
+  const int tx0 = (bt % ntx) << 3;
+  bt /= ntx;
+  const int ty0 = (bt % nty) << 3;
+  bt /= nty;
+  const int tz0 = (bt % ntz) << 3;
+  const int n = bt / ntz;
+  const int n0 = blockIdx.y * BN;
+  unsigned long long* dbg = p.dbg ? p.dbg + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 : nullptr;
+  if (dbg && tid == 0) dbg[0] = HOLO_PROBE_CLOCK();
+
+  // ---- halo staging
+  float4 hreg[T_IT][NV];
+  unsigned hvalid = 0, hmask = 0;
+  int hcoef_c = 0;
+#pragma unroll
+  for (int i = 0; i < T_IT; ++i) {
+    const int id = tid + 256 * i;
+    const int hv = min(id >> 1, T_HV - 1);
+    const int hz = hv / (T_H * T_H);
+    const int rem = hv - hz * (T_H * T_H);
+    const int hy = rem / T_H;
+    const int hx = rem - hy * T_H;
+    int z = tz0 + hz - 1, y = ty0 + hy - 1, x = tx0 + hx - 1;
+    const bool ok = z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW && id < 2 * T_HV;
+    z = min(max(z, 0), p.ID - 1);
+    y = min(max(y, 0), p.IH - 1);
+    x = min(max(x, 0), p.IW - 1);
+    if (p.ups) {
+      z >>= 1;
+      y >>= 1;
+      x >>= 1;
+    }
+    s_hvox[i * 256 + tid] = (z * SH + y) * SW + x;
+    hvalid |= (ok ? 1u : 0u) << i;
+  }
+  auto halo_issue = [&](int cc) {
+    int c = cc * T_CK + hh * 8;
+    const bool cvalid = c < Cin;
+    if (!cvalid) c = 0;  // clamped, masked in halo_commit
+    hcoef_c = c;
+    const float* src = p.src0;
+    int Cs = p.C0, cs = c;
+    if (c >= p.C0) {
+      src = p.src1;
+      Cs = p.C1;
+      cs = c - p.C0;
+    }
+    hmask = cvalid ? hvalid : 0u;
+    // uniform 64-bit base + one 32-bit byte offset per load (conv_plan keeps a source sample below 4 GB on this path)
+    const char* sbase = reinterpret_cast<const char*>(src) + (int64_t)n * SD * SH * SW * Cs * ES;
+    const unsigned cbytes = (unsigned)Cs * ES, cofs = (unsigned)cs * ES;
+    int tl = tid;
+    HOLO_LAUNDER(tl);
+#pragma unroll
+    for (int i = 0; i < T_IT; ++i) {
+      const char* a = sbase + ((unsigned)s_hvox[i * 256 + tl] * cbytes + cofs);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) hreg[i][v] = *reinterpret_cast<const float4*>(a + 16 * v);
+    }
+  };
+  auto halo_commit = [&]() {
+    const bool xform = p.coef != nullptr;
+    float ca[8], cb[8];
+    if (xform) {
+      const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + hcoef_c) * 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 c = cf[j];  // (a, b) interleaved per channel
+        ca[2 * j] = c.x;
+        cb[2 * j] = c.y;
+        ca[2 * j + 1] = c.z;
+        cb[2 * j + 1] = c.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < T_IT; ++i) {
+      float f[8];
+      if (IOBF) {
+        unpack_bf16x8(hreg[i][0], f);
+      } else {
+        f[0] = hreg[i][0].x, f[1] = hreg[i][0].y, f[2] = hreg[i][0].z, f[3] = hreg[i][0].w;
+        f[4] = hreg[i][NV - 1].x, f[5] = hreg[i][NV - 1].y, f[6] = hreg[i][NV - 1].z, f[7] = hreg[i][NV - 1].w;
+      }
+      if (xform) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          f[j] = fmaf(f[j], ca[j], cb[j]);
+          if (p.act) f[j] = silu_fast(f[j]);
+        }
+      }
+      const bool keep = (hmask >> i) & 1u;  // zero padding is applied AFTER the activation
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = keep ? f[j] : 0.f;
+      const int id = tid + 256 * i;
+      if (id < 2 * T_HV) *reinterpret_cast<float4*>(s_halo + (id >> 1) * T_RS + hh * 4) = pack_bf16x8(f);
+    }
+  };
+
+  f32x16 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // A addressing.  MFMA row li of row tile mt (0..3) of this wave: plane z = 2*wave + (mt>>1); with ys = li>>3 the
+  // y row is 2*(mt&1) + (ys>>1) + 4*(ys&1) (so the two 16-lane groups of a ds_read_b128 each cover rows a, a+4), x = li&7.
+  const int ys = li >> 3;
+  const int a_base = (((2 * wave) * T_H + (ys >> 1) + 4 * (ys & 1)) * T_H + (li & 7)) * T_RS + kg * 4;
+  auto load_a = [&](float4 (&a)[4], int tap) {
+    const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+    const int toff = ((kd * T_H + kh) * T_H + kw) * T_RS;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      a[mt] = *reinterpret_cast<const float4*>(s_halo + a_base + ((mt >> 1) * T_H * T_H + 2 * (mt & 1) * T_H) * T_RS + toff);
+  };
+  // B addressing: 1 KB blocks [tap][chunk][32-Cout slice], 16 bytes per lane
+  const int nsl = p.CoutP >> 5;
+  const int wncc = p.CinP / T_CK;
+  const float* w_lane = reinterpret_cast<const float*>(p.w_bft) + (int64_t)(n0 >> 5) * 256 + lane * 4;
+  const float* skw_lane = reinterpret_cast<const float*>(p.skip_w_bft) + (int64_t)(n0 >> 5) * 256 + lane * 4;
+  auto load_b = [&](float4 (&b)[NT], int cc, int tap) {
+    const float* wp = w_lane + (int64_t)(tap * wncc + cc) * nsl * 256;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp + nt * 256);
+  };
+  auto load_b_skip = [&](float4 (&b)[NT], int cc) {
+    const float* wp = skw_lane + (int64_t)(cc - ncc) * nsl * 256;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp + nt * 256);
+  };
+  auto mfma_tap = [&](const float4 (&a)[4], const float4 (&b)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16_32x32x16(a[mt], b[nt], acc[mt][nt]);
+  };
+
+  float4 A[2][4];
+  float4 B[3][NT];
+
+  HOLO_PHASE_DELAY(p.stagger_ticks);
+  halo_issue(cc_begin);
+  load_b(B[0], cc_begin, 0);
+  load_b(B[1], cc_begin, 1);
+  halo_commit();
+  __syncthreads();
+  if (dbg && tid == 0) dbg[1] = HOLO_PROBE_CLOCK();
+  for (int cc = cc_begin; cc < cc_end; ++cc) {
+    const bool has_next = cc + 1 < cc_end;
+    load_a(A[0], 0);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + 1 < 27) load_a(A[(tap + 1) & 1], tap + 1);
+      if (tap + 2 < 27) load_b(B[(tap + 2) % 3], cc, tap + 2);
+      if (tap == 16 && has_next) halo_issue(cc + 1);  // the next chunk's raw halo flies under taps 16..26
+      __builtin_amdgcn_sched_barrier(0);  // keep the requests above AHEAD of the MFMAs that hide their latency
+      mfma_tap(A[tap & 1], B[tap % 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has_next) {
+      load_b(B[0], cc + 1, 0);
+      load_b(B[1], cc + 1, 1);
+    }
+    const unsigned long long ta = dbg ? HOLO_PROBE_CLOCK() : 0ull;
+    __syncthreads();  // everyone done reading this halo before it is overwritten (by the next chunk or the epilogue)
+    if (has_next) {
+      halo_commit();
+      __syncthreads();
+    }
+    if (dbg && tid == 0) dbg[6] += HOLO_PROBE_CLOCK() - ta;  // barrier + commit + barrier: time outside the tap loop
+  }
+  if (SKIP) {
+    // Fused 1x1x1 skip connection (unet.py:222,256: skip_connection(x) + h): one tap, no halo, no activation - and a
+    // wave's 128 voxels are its own, so its A operands come straight from global memory (16 bytes per lane and row
+    // tile: channels 8*kg .. +7 of voxel li), four 16-channel k-steps per round trip; no LDS, no barrier.
+    const uint16_t* ssrc0 = reinterpret_cast<const uint16_t*>(p.skip_src0);
+    const uint16_t* ssrc1 = reinterpret_cast<const uint16_t*>(p.skip_src1);
+    const int64_t vbase = (((int64_t)n * p.OD + tz0 + 2 * wave) * p.OH + ty0 + (ys >> 1) + 4 * (ys & 1)) * p.OW + tx0 + (li & 7);
+    int vo[4];  // row tile mt: uniform offsets from the lane's voxel of row tile 0
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) vo[mt] = ((mt >> 1) * p.OH + 2 * (mt & 1)) * p.OW;
+    constexpr int SKG = 4;
+    for (int g = sk_begin; g < sk_end; g += SKG) {
+      float4 SA[SKG][4], SB[SKG][NT];
+#pragma unroll
+      for (int j = 0; j < SKG; ++j) {
+        const int cc = min(g + j, sk_end - 1);
+        int c = (cc - ncc) * T_CK + kg * 8;
+        if (c >= SCin) c = 0;  // (the packed weights of padding channels are zero)
+        const bool second = c >= p.skip_C0;
+        const int Cs = second ? p.skip_C1 : p.skip_C0;
+        const int cs = second ? c - p.skip_C0 : c;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          if (IOBF) {
+            SA[j][mt] = *reinterpret_cast<const float4*>((second ? ssrc1 : ssrc0) + (vbase + vo[mt]) * Cs + cs);
+          } else {
+            const float* fp = (second ? p.skip_src1 : p.skip_src0) + (vbase + vo[mt]) * Cs + cs;
+            const float4 f0 = *reinterpret_cast<const float4*>(fp), f1 = *reinterpret_cast<const float4*>(fp + 4);
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            SA[j][mt] = pack_bf16x8(f);
+          }
+        }
+        load_b_skip(SB[j], cc);
+      }
+#pragma unroll
+      for (int j = 0; j < SKG; ++j)
+        if (g + j < sk_end) mfma_tap(SA[j], SB[j]);  // (uniform)
+    }
+  }
+  if (dbg && tid == 0) dbg[2] = HOLO_PROBE_CLOCK();
+
+  // ---- epilogue.  D layout of 32x32: column = li (Cout), row i = (r&3) + 8*(r>>2) + 4*kg of the row tile (x = i&7,
+  // ys = i>>3).  Written straight from that layout a lane would issue 128 two-byte stores (measured: 17 of a tile's
+  // 68 us); instead each wave passes one 32-voxel row tile at a time through its own slice of the (now dead) halo
+  // LDS as fp32 [voxel][channel] and leaves with 8 channels of one voxel per lane: bias, residual, GroupNorm
+  // statistics and the store are 16-byte operations on that form.
+  constexpr int EW = 68;           // words per voxel row of the transposition tile (16-byte reads conflict free)
+  constexpr int LPV = BN / 8;      // lanes per voxel
+  constexpr int VPP = 64 / LPV;    // voxels per pass
+  constexpr int NPASS = 32 / VPP;
+  float* s_ep = s_halo + wave * (32 * EW);
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int ch8 = (lane % LPV) * 8;
+  const bool cvalid = n0 + ch8 < p.Cout;
+  const int co8 = cvalid ? n0 + ch8 : 0;
+  float bv[8], es[8], eq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = es[e] = eq[e] = 0.f;
+  if (p.nsplit == 1 && p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co8), b1 = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
+    bv[0] = b0.x, bv[1] = b0.y, bv[2] = b0.z, bv[3] = b0.w, bv[4] = b1.x, bv[5] = b1.y, bv[6] = b1.z, bv[7] = b1.w;
+  }
+  if (p.nsplit == 1 && p.skip_bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.skip_bias + co8), b1 = *reinterpret_cast<const float4*>(p.skip_bias + co8 + 4);
+    bv[0] += b0.x, bv[1] += b0.y, bv[2] += b0.z, bv[3] += b0.w, bv[4] += b1.x, bv[5] += b1.y, bv[6] += b1.z, bv[7] += b1.w;
+  }
+  float* pp = p.nsplit > 1 ? p.partial + (int64_t)blockIdx.z * M * p.Cout : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ep[((r & 3) + 8 * (r >> 2) + 4 * kg) * EW + nt * 32 + li] = acc[mt][nt][r];
+    __syncthreads();
+    const int z = tz0 + 2 * wave + (mt >> 1);
+    int64_t o[NPASS];
+    float4 res[NPASS][2];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int i = ps * VPP + lane / LPV;
+      const int ys = i >> 3;
+      const int y = ty0 + 2 * (mt & 1) + (ys >> 1) + 4 * (ys & 1);
+      o[ps] = ((((int64_t)n * p.OD + z) * p.OH + y) * p.OW + tx0 + (i & 7)) * p.Cout + co8;
+      if (p.nsplit == 1 && p.residual) {  // (uniform)
+        if (IOBF) {
+          res[ps][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const uint16_t*>(p.residual) + o[ps]);
+        } else {
+          res[ps][0] = *reinterpret_cast<const float4*>(p.residual + o[ps]);
+          res[ps][1] = *reinterpret_cast<const float4*>(p.residual + o[ps] + 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int i = ps * VPP + lane / LPV;
+      const float4 v0 = *reinterpret_cast<const float4*>(s_ep + i * EW + ch8);
+      const float4 v1 = *reinterpret_cast<const float4*>(s_ep + i * EW + ch8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (p.nsplit == 1) {
+        if (p.residual) {
+          float rf[8];
+          if (IOBF) {
+            unpack_bf16x8(res[ps][0], rf);
+          } else {
+            rf[0] = res[ps][0].x, rf[1] = res[ps][0].y, rf[2] = res[ps][0].z, rf[3] = res[ps][0].w;
+            rf[4] = res[ps][1].x, rf[5] = res[ps][1].y, rf[6] = res[ps][1].z, rf[7] = res[ps][1].w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] += bv[e];
+          es[e] += v[e];
+          eq[e] += v[e] * v[e];
+        }
+        if (cvalid) {
+          if (IOBF && p.out_bf16) {
+            *reinterpret_cast<float4*>(reinterpret_cast<uint16_t*>(p.out) + o[ps]) = pack_bf16x8(v);
+          } else {
+            *reinterpret_cast<float4*>(p.out + o[ps]) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.out + o[ps] + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
+      } else if (cvalid) {
+        *reinterpret_cast<float4*>(pp + o[ps]) = v0;
+        *reinterpret_cast<float4*>(pp + o[ps] + 4) = v1;
+      }
+    }
+    __syncthreads();  // the tile is overwritten by the next row tile
+  }
+  // GroupNorm statistics of the tensor just produced: one slab per wave (128 voxels) -> stats[n][slab][Cout][2]
+  if (p.stats && p.nsplit == 1) {
+    const int tiles_per_sample = ntx * nty * ntz;
+    const int slab = (blockIdx.x % tiles_per_sample) * 4 + wave;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = LPV; m < 64; m <<= 1) {
+        es[e] += __shfl_xor(es[e], m);
+        eq[e] += __shfl_xor(eq[e], m);
+      }
+    }
+    if (lane < LPV && cvalid) {
+      double* d = p.stats + (((int64_t)n * tiles_per_sample * 4 + slab) * p.Cout + co8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        d[2 * e] = (double)es[e];
+        d[2 * e + 1] = (double)eq[e];
+      }
+    }
+  }
+  if (dbg && tid == 0) {
+    dbg[3] = HOLO_PROBE_CLOCK();
+    unsigned hw, xcc;
+    HOLO_PROBE_HWID(hw, xcc);
+    dbg[4] = hw;
+    dbg[5] = xcc;
+  }
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1766,7 +2215,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
         x >>= 1;
       }
       // unconditional load from a clamped address, masked afterwards (see the halo kernel)
-      ra[i][j] = *reinterpret_cast<const float4*>(src + ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs);
+      ra[i][j] = ld_act4(src, ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs, p.in_bf16);
       amask[i] |= (ok ? 1u : 0u) << j;
       if (p.coef) {
         const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
@@ -1886,7 +2335,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) res[t][r] = p.residual[mo[t][r] + coc];
+        for (int r = 0; r < 4; ++r) res[t][r] = ld_act1(p.residual, mo[t][r] + coc, p.res_bf16);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1898,7 +2347,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       for (int r = 0; r < 4; ++r) {
         const float v = acc[t][r] + bv;
         if (mv[t][r]) {
-          p.out[mo[t][r] + co] = v;
+          st_act1(p.out, mo[t][r] + co, v, p.out_bf16);
           ssum += v;
           ssq += v * v;
         }
@@ -1938,7 +2387,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ bias2,
                                                             const float* __restrict__ residual,
-                                                            float* __restrict__ out, double* __restrict__ stats) {
+                                                            float* __restrict__ out, double* __restrict__ stats,
+                                                            int res_bf16, int out_bf16) {
   __shared__ double red[256 * 8];
   const int n = blockIdx.y;
   const int c_base = blockIdx.z * 1024;  // column blocks of <= 1024 channels (qkv convs are up to 1536 wide)
@@ -1996,13 +2446,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         s.w += t.w;
       }
       if (residual) {
-        const float4 r = *reinterpret_cast<const float4*>(residual + i);
+        const float4 r = ld_act4(residual, i, res_bf16);
         s.x += r.x;
         s.y += r.y;
         s.z += r.z;
         s.w += r.w;
       }
-      *reinterpret_cast<float4*>(out + i) = s;
+      st_act4(out, i, s, out_bf16);
       fs[0] += s.x;
       fs[1] += s.y;
       fs[2] += s.z;
@@ -2067,6 +2517,35 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     p.chunks_per_split = cps;
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
+  p.bf16t = 0;
+  if (p.mode == 1 && p.bf16 == 1 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.Cout % 32) == 0 &&
+      (p.C0 % 8) == 0 && (p.skip_C0 % 8) == 0 && ((p.skip_C0 + p.skip_C1) % 8) == 0 && (p.Cout >= 64 || !p.skip_w)) {
+    // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup) where it fills the chip without
+    // split-K; HOLO_CONV_BF16T=0 disables it, =1 forces it (tests)
+    const char* e = getenv("HOLO_CONV_BF16T");
+    const int64_t t8 = (M / 512) * cdiv(p.Cout, bn);
+    if (!(e && e[0] == '0') && (t8 >= target || (e && e[0] == '1'))) {
+      const int ncc16 = (Cin + 15) / 16;
+      const int nsk16 = p.skip_w ? (p.skip_C0 + p.skip_C1 + 15) / 16 : 0;
+      if (t8 < target) {
+        nsplit = (int)cdiv(target, t8);
+        if (nsplit > ncc16) nsplit = ncc16;
+      }
+      const int cps = (int)cdiv(ncc16, nsplit);
+      nsplit = (int)cdiv(ncc16, cps);
+      p.bf16t = 1;
+      p.tz = 8;
+      p.wino = 0;
+      p.nsplit = nsplit;
+      p.chunks_per_split = cps;
+      p.skip_chunks_per_split = (int)cdiv(nsk16, nsplit);
+      p.grid_x = (int)(M / 512);
+      if (getenv("HOLO_DEBUG_PLAN"))
+        fprintf(stderr, "[plan] conv %d->%d @%d^3: bf16 wide-tile kernel, %d tiles x %d slices, split-K %d%s\n", Cin, p.Cout,
+                p.OD, p.grid_x, (int)cdiv(p.Cout, bn), nsplit, p.skip_w ? ", fused skip" : "");
+      return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
+    }
+  }
   if (p.mode == 1) {  // halo kernel: split over 32-channel chunks (each split walks all 27 taps)
     p.tz = 2;
     int64_t htiles = tiles;
@@ -2124,6 +2603,7 @@ int conv_stats_slabs(const ConvParams& p) {
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     return B;
   }
+  if (p.mode == 1 && p.bf16t) return (int)(V / 128);  // wide-tile bf16 kernel: one slab per wave
   if (p.mode == 1 && p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w) return (int)(V / 32);  // bf16x3 kernel: per half 8x8 slab
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
@@ -2163,7 +2643,24 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (p.wino == 2) {
+    if (p.bf16t) {
+#define HOLO_BF16T(NT_, SK_)                                                                \
+  do {                                                                                      \
+    if (p.in_bf16) {                                                                        \
+      HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, true>), hgrid, block, stream, p);            \
+    } else {                                                                                \
+      HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, false>), hgrid, block, stream, p);           \
+    }                                                                                       \
+  } while (0)
+      if (!wide) {
+        HOLO_BF16T(1, false);
+      } else if (sk) {
+        HOLO_BF16T(2, true);
+      } else {
+        HOLO_BF16T(2, false);
+      }
+#undef HOLO_BF16T
+    } else if (p.wino == 2) {
       if (!wide) {
         HOLO_LAUNCH((conv_wino2_kernel<false, 2>), hgrid, block, stream, p);
       } else if (sk) {
@@ -2185,6 +2682,10 @@ int conv_launch(const ConvParams& p, void* stream) {
       }
     } else {
     const bool bf = p.bf16 == 1 && p.w_bf && (!sk || p.skip_w_bf);
+    if ((p.in_bf16 != 0) != bf || (p.residual && (p.res_bf16 != 0) != bf)) {
+      set_error("conv_launch: the bf16 halo kernel and bf16 activation storage go together");
+      return -1;
+    }
     if (!wide && sk) {
       set_error("conv_launch: fused skip needs Cout >= 64");
       return -1;
@@ -2227,7 +2728,7 @@ int conv_launch(const ConvParams& p, void* stream) {
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N, (unsigned)cdiv(p.Cout, 1024)), dim3(256), stream,
                 (const float*)p.partial,
-                p.nsplit, MC, p.Cout, V, vpb, p.bias, p.skip_bias, p.residual, p.out, p.stats);
+                p.nsplit, MC, p.Cout, V, vpb, p.bias, p.skip_bias, p.residual, p.out, p.stats, p.res_bf16, p.out_bf16);
   }
   return 0;
 }

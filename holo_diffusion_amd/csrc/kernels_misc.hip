@@ -16,15 +16,16 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // [N][C][V] -> [N][V][C] through a 32x33 LDS tile.  grid = (V/32, C/32, N), block = (32, 8)
 // ---------------------------------------------------------------------------------------------
+// out_bf16 / in_bf16: the channels-last side is a bf16 tensor (bf16 storage mode of the denoiser)
 __global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                             int C, int64_t V, int tanh_flag) {
+                                                             int C, int64_t V, int tanh_flag, int out_bf16) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int64_t v0 = (int64_t)blockIdx.x * 32;
   const int c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   in += (int64_t)n * C * V;
-  out += (int64_t)n * C * V;
+  const int64_t obase = (int64_t)n * C * V;
   for (int j = ty; j < 32; j += 8) {
     const int c = c0 + j;
     const int64_t v = v0 + tx;
@@ -37,24 +38,31 @@ __global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __rest
   for (int j = ty; j < 32; j += 8) {
     const int64_t v = v0 + j;
     const int c = c0 + tx;
-    if (c < C && v < V) out[v * C + c] = tile[tx][j];
+    if (c < C && v < V) {
+      if (out_bf16)
+        reinterpret_cast<uint16_t*>(out)[obase + v * C + c] = (uint16_t)(pack_bf16x2(tile[tx][j], 0.f) & 0xffffu);
+      else
+        out[obase + v * C + c] = tile[tx][j];
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                             int C, int64_t V) {
+                                                             int C, int64_t V, int in_bf16) {
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const int64_t v0 = (int64_t)blockIdx.x * 32;
   const int c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  in += (int64_t)n * C * V;
+  const int64_t ibase = (int64_t)n * C * V;
   out += (int64_t)n * C * V;
   for (int j = ty; j < 32; j += 8) {
     const int64_t v = v0 + j;
     const int c = c0 + tx;
     float x = 0.f;
-    if (c < C && v < V) x = in[v * C + c];
+    if (c < C && v < V)
+      x = in_bf16 ? __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(in)[ibase + v * C + c] << 16)
+                  : in[ibase + v * C + c];
     tile[j][tx] = x;
   }
   __syncthreads();
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __rest
 //                          slabs, then folds GroupNorm(eps) + affine (+ FiLM) into per-channel (a, b).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ partial,
-                                                       int C, int64_t V, int vox_per_block) {
+                                                       int C, int64_t V, int vox_per_block, int x_bf16) {
   __shared__ double red[256 * 8];
   const int n = blockIdx.y;
   const int cq = C >> 2;
@@ -85,14 +93,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   const int64_t vbeg = (int64_t)blockIdx.x * vox_per_block;
   int64_t vend = vbeg + vox_per_block;
   if (vend > V) vend = V;
-  const float* xp = x + (int64_t)n * V * C;
+  const int64_t xbase = (int64_t)n * V * C;
   double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
   if (vr < rows) {
     float fs[4] = {0, 0, 0, 0}, fq[4] = {0, 0, 0, 0};
     int cnt = 0;
 #pragma unroll 4
     for (int64_t v = vbeg + vr; v < vend; v += rows) {
-      const float4 t = *reinterpret_cast<const float4*>(xp + v * C + c4 * 4);
+      float4 t;
+      if (x_bf16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + xbase + v * C + c4 * 4);
+        t = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                        __uint_as_float(u.y & 0xffff0000u));
+      } else {
+        t = *reinterpret_cast<const float4*>(x + xbase + v * C + c4 * 4);
+      }
       fs[0] += t.x;
       fs[1] += t.y;
       fs[2] += t.z;
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(256) void repack_conv_weight_wino_kernel(const floa
   }
 }
 
-// OIDHW [Cout][Cin][taps] -> THREE bf16 planes (hi, mid, lo with w = hi + mid + lo exactly: hi = rne(w),
+// OIDHW [Cout][Cin][taps] -> FOUR bf16 planes: (hi, mid, lo with w = hi + mid + lo exactly: hi = rne(w),
 // mid = rne(w - hi), lo = rne(w - hi - mid)), each packed [tap][CinP/32][CoutP/16][lane = 16*kq + lj][8]: lane's 8
 // values are channels 8*kq .. 8*kq+7 of the chunk for output channel 16*slice + lj (B operand of
 // v_mfma_f32_16x16x32_bf16).  Plane 0 alone is the plain bf16 rounding used by the bf16 mode.
@@ -425,19 +440,34 @@ __global__ __launch_bounds__(256) void repack_conv_weight_bf16_kernel(const floa
     o32[i] = h;
     o32[total + i] = m;
     o32[2 * total + i] = l;
+    // plane 3: the bf16 rounding again, packed for v_mfma_f32_32x32x16_bf16 (conv_bf16t_kernel):
+    // [tap][CinP/16][CoutP/32][lane][8], lane's 8 values = channels 8*(lane>>5) .. +7 of the chunk, output channel lane&31
+    {
+      const int nc16 = CinP >> 4, ns32 = CoutP >> 5;
+      int64_t b2 = i >> 8;
+      const int sl2 = (int)(b2 % ns32);
+      b2 /= ns32;
+      const int cc2 = (int)(b2 % nc16);
+      const int tap2 = (int)(b2 / nc16);
+      const int co2 = sl2 * 32 + (lane & 31);
+      const int ci2 = cc2 * 16 + (lane >> 5) * 8 + e2 * 2;
+      const float u0 = (ci2 < Cin && co2 < Cout) ? w[((int64_t)co2 * Cin + ci2) * taps + tap2] : 0.f;
+      const float u1 = (ci2 + 1 < Cin && co2 < Cout) ? w[((int64_t)co2 * Cin + ci2 + 1) * taps + tap2] : 0.f;
+      o32[3 * total + i] = pack_bf16x2(u0, u1);
+    }
   }
 }
 
 }  // namespace
 
-int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream) {
+int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream, int out_bf16) {
   dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(C, 32), (unsigned)N);
-  HOLO_LAUNCH(ncdhw_to_ndhwc_kernel, grid, dim3(256), stream, in, out, C, V, tanh_flag);
+  HOLO_LAUNCH(ncdhw_to_ndhwc_kernel, grid, dim3(256), stream, in, out, C, V, tanh_flag, out_bf16);
   return 0;
 }
-int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream) {
+int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream, int in_bf16) {
   dim3 grid((unsigned)cdiv(V, 32), (unsigned)cdiv(C, 32), (unsigned)N);
-  HOLO_LAUNCH(ndhwc_to_ncdhw_kernel, grid, dim3(256), stream, in, out, C, V);
+  HOLO_LAUNCH(ndhwc_to_ncdhw_kernel, grid, dim3(256), stream, in, out, C, V, in_bf16);
   return 0;
 }
 
@@ -452,7 +482,7 @@ void gn_stats_geometry(int C, int64_t V, int* n_blocks, int* vox_per_block) {
   *vox_per_block = (int)vpb;
 }
 
-int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream) {
+int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, void* stream, int x_bf16) {
   if ((C & 3) || (C >> 2) > 256) {
     set_error("gn_stats: unsupported C=%d", C);
     return -1;
@@ -460,7 +490,7 @@ int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, vo
   int B, vpb;
   gn_stats_geometry(C, V, &B, &vpb);
   dim3 grid((unsigned)B, (unsigned)N);
-  HOLO_LAUNCH(gn_stats_kernel, grid, dim3(256), stream, x, partial, C, V, vpb);
+  HOLO_LAUNCH(gn_stats_kernel, grid, dim3(256), stream, x, partial, C, V, vpb, x_bf16);
   return 0;
 }
 

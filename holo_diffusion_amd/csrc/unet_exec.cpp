@@ -165,10 +165,14 @@ struct HoloUnet {
   float* pstore = nullptr;  // one allocation for all private parameter copies
   uint16_t* pstore_bf = nullptr;                       // bf16 copies of the conv weights
   std::map<const float*, const uint16_t*> bf_of;       // fp32 private copy -> bf16 copy
+  std::map<const float*, const uint16_t*> bft_of;      // fp32 private copy -> bf16 copy packed for the wide-tile kernel
   float* pstore_wino = nullptr;                        // Winograd-in-depth copies (36 / 2 pseudo-taps)
   std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
   std::map<const float*, const float*> wino2_of;       // fp32 private copy -> (z,y) Winograd copy
-  int compute_mode = 0;  // holo_unet_set_compute_dtype: 0 exact fp32 MFMA, 1 bf16 products, 2 bf16x3 split (fp32-accurate)
+  // holo_unet_set_compute_dtype: 0 exact fp32 MFMA; 1 bf16: activations stored as bf16 in HBM, bf16 products with fp32
+  // accumulation in the 3x3x3 convolutions and the long-sequence attention, fp32 GroupNorm statistics; 2 bf16x3 split
+  // (fp32 storage, fp32-accurate)
+  int compute_mode = 0;
   // concatenated emb_layers
   int emb_rows = 0;
   std::map<std::string, int> emb_row_off;  // resblock prefix -> first row
@@ -365,12 +369,13 @@ struct Planner {
     return reinterpret_cast<T*>(base + off);
   }
   int64_t vox(int R) const { return (int64_t)R * R * R; }
+  bool bfs() const { return u->compute_mode == 1; }  // bf16 storage of the activations
 
-  Act new_act(int C, int R) {
+  Act new_act(int C, int R, bool f32 = false) {
     Act a;
     a.C = C;
     a.R = R;
-    a.bytes = (size_t)N * vox(R) * C * sizeof(float);
+    a.bytes = (size_t)N * vox(R) * C * ((bfs() && !f32) ? 2 : sizeof(float));
     a.off = arena_base + arena.alloc(a.bytes);
     return a;
   }
@@ -401,6 +406,7 @@ struct Planner {
     op.f0 = ptr<float>(a.off);
     op.dout = ptr<double>(a.stats_off);
     op.i0 = a.C;
+    op.i1 = bfs() ? 1 : 0;
     op.l0 = vox(a.R);
     ops.push_back(op);
   }
@@ -430,11 +436,15 @@ struct Planner {
   void emit_conv(const Act& x0, const Act* x1, int in_R_logical, int ups, int out_R, int stride, int ksz,
                  const float* w, const float* bias, size_t coef_off, bool has_coef, int act, const float* residual,
                  float* out, int Cout, Act* stats_of = nullptr, const Act* skip0 = nullptr,
-                 const Act* skip1 = nullptr, const float* skip_w = nullptr, const float* skip_bias = nullptr) {
+                 const Act* skip1 = nullptr, const float* skip_w = nullptr, const float* skip_bias = nullptr,
+                 bool in_f32 = false, bool out_f32 = false) {
     Op op;
     op.kind = OP_CONV;
     ConvParams& p = op.conv;
     memset(&p, 0, sizeof p);
+    p.in_bf16 = bfs() && !in_f32;
+    p.res_bf16 = bfs();
+    p.out_bf16 = bfs() && !out_f32;
     p.src0 = ptr<float>(x0.off);
     p.src1 = x1 ? ptr<float>(x1->off) : nullptr;
     p.C0 = x0.C;
@@ -453,6 +463,8 @@ struct Planner {
     if (u->compute_mode) {  // halo-path launches multiply on the bf16 matrix cores (conv_launch checks the pointers)
       auto it = u->bf_of.find(w);
       p.w_bf = it == u->bf_of.end() ? nullptr : it->second;
+      auto itt = u->bft_of.find(w);
+      p.w_bft = itt == u->bft_of.end() ? nullptr : itt->second;
       p.bf16 = u->compute_mode;
     }
     if (u->compute_mode == 0) {  // exact fp32: the Winograd-in-depth kernel where conv_plan finds 128-voxel tiles
@@ -475,6 +487,8 @@ struct Planner {
       if (u->compute_mode) {
         auto it = u->bf_of.find(skip_w);
         p.skip_w_bf = it == u->bf_of.end() ? nullptr : it->second;
+        auto itt = u->bft_of.find(skip_w);
+        p.skip_w_bft = itt == u->bft_of.end() ? nullptr : itt->second;
       }
       if (u->compute_mode == 0) {
         auto it = u->wino_of.find(skip_w);
@@ -550,8 +564,9 @@ struct Planner {
     const size_t s_bytes = (size_t)N * H * T * T * sizeof(float);
     const size_t a_bytes = (size_t)N * T * C * sizeof(float);
     size_t qkv = scratch_alloc(qkv_bytes);
+    // (the attention internals - qkv and the attention output - stay fp32 in every mode)
     emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
-              ptr<float>(qkv), 3 * C);
+              ptr<float>(qkv), 3 * C, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true);
     size_t a = scratch_alloc(a_bytes);
     const bool flash = flash_attn_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_ATTN");
     if (flash) {
@@ -645,7 +660,7 @@ struct Planner {
     av.C = C;
     av.R = R;
     emit_conv(av, nullptr, R, 0, R, 1, 1, P(u, p + ".proj_out.weight"), P(u, p + ".proj_out.bias"), 0, false, 0,
-              ptr<float>(x.off), ptr<float>(out.off), C, &out);
+              ptr<float>(x.off), ptr<float>(out.off), C, &out, nullptr, nullptr, nullptr, nullptr, /*in_f32=*/true);
     scratch_free(qkv, qkv_bytes);
     scratch_free(a, a_bytes);
     return out;
@@ -725,6 +740,7 @@ struct Planner {
       op.kind = OP_IN;
       op.o0 = ptr<float>(x.off);
       op.i0 = c.in_channels;
+      op.i1 = bfs() ? 1 : 0;
       op.l0 = vox(R);
       ops.push_back(op);
     }
@@ -749,9 +765,9 @@ struct Planner {
       u->block_outputs[tag] = h;
     }
     size_t coef = emit_finalize(h, nullptr, P(u, "out.0.weight"), P(u, "out.0.bias"), nullptr, 0);
-    Act y = new_act(c.out_channels, R);
+    Act y = new_act(c.out_channels, R, /*f32=*/true);  // the network output stays fp32
     emit_conv(h, nullptr, R, 0, R, 1, 3, P(u, "out.2.weight"), P(u, "out.2.bias"), coef, true, 1, nullptr,
-              ptr<float>(y.off), c.out_channels);
+              ptr<float>(y.off), c.out_channels, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true);
     release(h);
     {
       Op op;
@@ -792,13 +808,13 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
       HIP_TRY(hipMemsetAsync(op.o0, 0, op.bytes, (hipStream_t)stream));
       return 0;
     case OP_IN:
-      return ncdhw_to_ndhwc_launch(x, op.o0, N, op.i0, op.l0, 0, stream);
+      return ncdhw_to_ndhwc_launch(x, op.o0, N, op.i0, op.l0, 0, stream, op.i1);
     case OP_TEMB:
       return time_embed_launch(t, N, u->cfg.model_channels, u->ted, op.f0, op.f1, op.f2, op.f3, op.o0, op.o1, stream);
     case OP_EMBLIN:
       return rows_linear_launch(op.f0, op.f1, op.f2, op.o0, N, u->emb_rows, u->ted, stream);
     case OP_STATS:
-      return gn_stats_launch(op.f0, op.dout, N, op.i0, op.l0, stream);
+      return gn_stats_launch(op.f0, op.dout, N, op.i0, op.l0, stream, op.i1);
     case OP_FINAL:
       return gn_finalize_launch(op.d0, op.i0, op.i4, op.d1, op.i1, op.i5, N, op.l0, 32, 1e-5f, op.f0, op.f1, op.f2,
                                 op.i2, op.i3, op.o0, stream);
@@ -896,7 +912,7 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
   {  // bf16 copies of the conv weights (same padded element counts, 2 bytes each)
     int64_t tb = 0;
     for (auto& s : u->params)
-      if (s.kind == P_CONV3 || s.kind == P_CONV1) tb += 3 * ((priv_numel(s) + 63) & ~(int64_t)63);  // hi, mid, lo planes
+      if (s.kind == P_CONV3 || s.kind == P_CONV1) tb += 4 * ((priv_numel(s) + 63) & ~(int64_t)63);  // hi, mid, lo planes + the 32x32x16 packing of hi
     if (hipMalloc((void**)&u->pstore_bf, (size_t)tb * sizeof(uint16_t)) != hipSuccess) {
       set_error("holo_unet_create: hipMalloc of %lld bf16 weights failed", (long long)tb);
       (void)hipFree(u->pstore);
@@ -908,7 +924,8 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
       if (s.kind == P_CONV3 || s.kind == P_CONV1) {
         s.priv_bf = cb;
         u->bf_of[s.priv] = cb;
-        cb += 3 * ((priv_numel(s) + 63) & ~(int64_t)63);
+        u->bft_of[s.priv] = cb + 3 * priv_numel(s);  // plane 3 (the repack kernel lays the planes out back to back)
+        cb += 4 * ((priv_numel(s) + 63) & ~(int64_t)63);
       }
   }
   {  // Winograd-in-depth copies for the convolutions that can land on 128-voxel tiles: the wide top levels
@@ -1118,7 +1135,8 @@ int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t ds
     set_error("holo_unet_fetch_block: destination too small");
     return HOLO_E_INVALID;
   }
-  return ndhwc_to_ncdhw_launch((const float*)((char*)workspace + a.off), dst, net->plan_batch, a.C, V, stream);
+  return ndhwc_to_ncdhw_launch((const float*)((char*)workspace + a.off), dst, net->plan_batch, a.C, V, stream,
+                               net->compute_mode == 1 ? 1 : 0);
 }
 
 int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t workspace_bytes, int iters, void* stream,
@@ -1194,7 +1212,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
+        t.kernel = c.bf16t ? 5 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

@@ -149,6 +149,11 @@ static inline f32x4 emu_mfma_f32_16x16x4f32(float a, float b, f32x4 c) {
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32(a, b, c)
 
+static inline uint32_t __float_as_uint(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
 static inline float __uint_as_float(uint32_t u) {
   float f;
   std::memcpy(&f, &u, 4);

@@ -1,7 +1,8 @@
 // conv_timeline — per-workgroup timeline of one LDS-halo conv3d launch (development probe, not part of the library).
 // Build: hipcc -O2 --offload-arch=gfx950 tools/conv_timeline.cpp holo_diffusion_amd/csrc/kernels_conv.o \
 //              holo_diffusion_amd/csrc/kernels_misc.o holo_diffusion_amd/csrc/err.o -o tools/conv_timeline
-// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [wino: 0 direct, 2 = (z,y) Winograd] [tile_depth=0 (planner)] [stagger_us=0]
+// Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [kernel: 0 direct, 2 = (z,y) Winograd, 3 = bf16 wide-tile (bf16 storage)]
+//                      [tile_depth=0 (planner)] [stagger_us=0] [act=0: 1 = GroupNorm affine + SiLU while staging]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,6 +33,21 @@ int main(int argc, char** argv) {
     std::vector<float> hw2((size_t)48 * CinP * CoutP); for (auto& x : hw2) x = (rand() % 2001 - 1000) * 1e-4f;
     CK(hipMemcpy(w2, hw2.data(), hw2.size() * 4, hipMemcpyHostToDevice));
     p.w_wino = w2; p.w_wino2 = w2;
+  }
+  const int act = argc > 7 ? atoi(argv[7]) : 0;
+  if (act) {
+    float* coef; CK(hipMalloc(&coef, (size_t)Cin * 2 * 4));
+    std::vector<float> hc((size_t)Cin * 2); for (int c = 0; c < Cin; ++c) { hc[2 * c] = 1.0f + 0.01f * (c % 7); hc[2 * c + 1] = 0.01f * (c % 5); }
+    CK(hipMemcpy(coef, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    p.coef = coef; p.act = 1;
+  }
+  if (gx == 3) {  // bf16 storage + wide-tile kernel: bf16 activations and packed bf16 weights (random values: timing only)
+    std::vector<uint16_t> hb((size_t)V * Cin); for (auto& x : hb) x = (uint16_t)(0x3c00 + rand() % 0x300) | (rand() & 1 ? 0x8000 : 0);
+    CK(hipMemcpy(src, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    uint16_t* wb; CK(hipMalloc(&wb, (size_t)27 * CinP * CoutP * 2));
+    std::vector<uint16_t> hwb((size_t)27 * CinP * CoutP); for (auto& x : hwb) x = (uint16_t)(0x3800 + rand() % 0x300) | (rand() & 1 ? 0x8000 : 0);
+    CK(hipMemcpy(wb, hwb.data(), hwb.size() * 2, hipMemcpyHostToDevice));
+    p.bf16 = 1; p.w_bf = wb; p.w_bft = wb; p.in_bf16 = p.res_bf16 = p.out_bf16 = 1;
   }
   conv_plan(p, 256);
   if (tzo > 0) { p.tz = tzo; p.grid_x = (int)(V / (64 * p.tz)); }
