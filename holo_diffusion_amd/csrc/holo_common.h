@@ -24,6 +24,7 @@ static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return e
 #define HOLO_LAUNDER(x) asm volatile("" : "+r"(x))
 static inline float holo_rcp(float x) { return 1.0f / x; }
 static inline float holo_rcp_exact(float x) { return 1.0f / x; }
+static inline float holo_exp2(float x) { return std::exp2(x); }
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
 #define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
@@ -59,6 +60,8 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 
 }
 // v_rcp_f32 (1 ulp) / the correctly rounded reciprocal
 __device__ __forceinline__ float holo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_exp_f32 (2^x, no denormal fix-up: the callers' results are rounded to bf16 or summed in fp32)
+__device__ __forceinline__ float holo_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)

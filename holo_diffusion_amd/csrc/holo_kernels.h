@@ -127,6 +127,14 @@ int flash_attn_launch(const AttnParams& p, void* stream);
 // bf16-product variant (shared K/V tiles in LDS, v_mfma_f32_16x16x32_bf16), for the opt-in bf16 mode
 bool flash_attn_bf16_supported(int T, int head_channels);
 int flash_attn_bf16_launch(const AttnParams& p, void* stream);
+// Second form of the bf16 attention (bf16 storage mode, long sequences): a pre-pass rewrites qkv once per call as
+// bf16 Q (pre-scaled) / K per head and V TRANSPOSED per head, so that the main kernel stages plain 16-byte rows;
+// 64-key blocks, 64 queries per wave, v_mfma_f32_32x32x16_bf16, exp2-domain softmax; the key range is split across
+// workgroups (and recombined) when one workgroup per 256 queries would leave half of the chip's wave slots empty.
+// `work` (flash_attn_bf16v2_workspace_bytes) holds the packed operands and the split partials; out_bf16: `out` is bf16.
+bool flash_attn_bf16v2_supported(int T, int head_channels);
+size_t flash_attn_bf16v2_workspace_bytes(const AttnParams& p, int num_cus);
+int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream);
 
 // in-place row softmax over `rows` rows of length `cols` (unet.py:453, fp32)
 int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);

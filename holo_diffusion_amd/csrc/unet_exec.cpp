@@ -568,6 +568,8 @@ struct Planner {
     emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
               ptr<float>(qkv), 3 * C, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true);
     size_t a = scratch_alloc(a_bytes);
+    size_t v2_work = 0, v2_bytes = 0;
+    bool a_is_bf16 = false;
     const bool flash = flash_attn_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_ATTN");
     if (flash) {
       Op op;
@@ -585,9 +587,18 @@ struct Planner {
       const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
       const int64_t min_t = mt ? atoll(mt) : 8192;
       op.i0 = (u->compute_mode == 1 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
+      if (op.i0 && flash_attn_bf16v2_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_V2")) {
+        // second form: packed bf16 operands (V transposed) in scratch, bf16 attention output
+        op.i0 = 2;
+        v2_bytes = flash_attn_bf16v2_workspace_bytes(op.attn, u->ctx->num_cus);
+        v2_work = scratch_alloc(v2_bytes);
+        op.o1 = ptr<float>(v2_work);
+        op.i1 = 1;
+        a_is_bf16 = true;
+      }
       if (getenv("HOLO_DEBUG_PLAN"))
         fprintf(stderr, "[plan] attention %s: T=%lld C=%d heads=%d -> %s flash kernel\n", p.c_str(), (long long)T, C, H,
-                op.i0 ? "bf16" : "fp32");
+                op.i0 == 2 ? "bf16 (second form)" : op.i0 ? "bf16" : "fp32");
       ops.push_back(op);
     } else {
       size_t S = scratch_alloc(s_bytes);
@@ -660,7 +671,8 @@ struct Planner {
     av.C = C;
     av.R = R;
     emit_conv(av, nullptr, R, 0, R, 1, 1, P(u, p + ".proj_out.weight"), P(u, p + ".proj_out.bias"), 0, false, 0,
-              ptr<float>(x.off), ptr<float>(out.off), C, &out, nullptr, nullptr, nullptr, nullptr, /*in_f32=*/true);
+              ptr<float>(x.off), ptr<float>(out.off), C, &out, nullptr, nullptr, nullptr, nullptr, /*in_f32=*/!a_is_bf16);
+    if (v2_bytes) scratch_free(v2_work, v2_bytes);
     scratch_free(qkv, qkv_bytes);
     scratch_free(a, a_bytes);
     return out;
@@ -825,6 +837,7 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
     case OP_SOFTMAX:
       return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
     case OP_FLASH:
+      if (op.i0 == 2) return flash_attn_bf16v2_launch(op.attn, op.o1, op.i1, u->ctx->num_cus, stream);
       return op.i0 ? flash_attn_bf16_launch(op.attn, stream) : flash_attn_launch(op.attn, stream);
     case OP_OUT:
       return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
