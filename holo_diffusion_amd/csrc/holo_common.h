@@ -25,6 +25,7 @@ static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return e
 static inline float holo_rcp(float x) { return 1.0f / x; }
 static inline float holo_rcp_exact(float x) { return 1.0f / x; }
 static inline float holo_exp2(float x) { return std::exp2(x); }
+#define HOLO_WAVE_SYNC() emu_wave().bar.wait()
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
 #define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
@@ -68,6 +69,14 @@ __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
 // Passes a per-lane value through an empty asm: the optimiser can no longer prove it loop-invariant, so index
 // arithmetic derived from it is recomputed where it is used instead of being hoisted and kept live in VGPRs.
 #define HOLO_LAUNDER(x) asm volatile("" : "+v"(x))
+// Orders the LDS traffic of ONE wave (its lanes exchange data through a region no other wave touches): the LDS unit
+// serves a wave's requests in issue order, so only the compiler has to be kept from moving accesses across this point.
+#define HOLO_WAVE_SYNC()                                   \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 #define HOLO_PROBE_CLOCK() wall_clock64()
 // Delays the waves that landed in an odd wave slot of their SIMD (= the second resident workgroup of the CU).
 #define HOLO_PHASE_DELAY(ticks)                                                      \

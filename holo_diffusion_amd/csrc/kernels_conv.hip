@@ -725,6 +725,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 // matrix pipe does not use the vector lanes).  A fused 1x1x1 skip connection is one more tap whose A operands come
 // straight from global memory (a wave's voxels are its own).  The epilogue transposes the accumulators through LDS
 // so that residual, statistics and stores are 16-byte operations.  Split-K over 16-channel chunks.
+// (A persistent form - each workgroup walking several tiles, the next tile's first halo requested before the
+// epilogue - was measured: the prologue drops from 7 to 4 us per tile but the epilogue's own loads and stores then
+// queue behind the halo loads (in-order vmcnt) and it doubles to 18 us; one tile per workgroup is faster.)
 // IOBF: activations / residual / output are bf16 in HBM (bf16 storage mode).
 // ---------------------------------------------------------------------------------------------
 constexpr int T_H = 10;                 // halo edge of an 8^3 tile
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_ep[((r & 3) + 8 * (r >> 2) + 4 * kg) * EW + nt * 32 + li] = acc[mt][nt][r];
-    __syncthreads();
+    HOLO_WAVE_SYNC();  // (the transposition tile is private to the wave)
     const int z = tz0 + 2 * wave + (mt >> 1);
     int64_t o[NPASS];
     float4 res[NPASS][2];
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
         *reinterpret_cast<float4*>(pp + o[ps] + 4) = v1;
       }
     }
-    __syncthreads();  // the tile is overwritten by the next row tile
+    HOLO_WAVE_SYNC();  // the tile is overwritten by the next row tile
   }
   // GroupNorm statistics of the tensor just produced: one slab per wave (128 voxels) -> stats[n][slab][Cout][2]
   if (p.stats && p.nsplit == 1) {

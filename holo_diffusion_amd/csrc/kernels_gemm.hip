@@ -602,7 +602,8 @@ struct AttnV2 {
   int N, T, C, H, ksplit, out_bf16;
 };
 
-template <int CH>
+// QT: 32-query tiles per wave (2; 1 for head channels 128, whose 64-query wave tile would need 320 registers)
+template <int CH, int QT>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   constexpr int KB = 64;
   constexpr int KW = CH / 2 + 4;  // words per K row
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   const int wave = tid >> 6;
   const int li = lane & 31;
   const int kg = lane >> 5;
-  const int qtiles = p.T / 256;
+  const int qtiles = p.T / (128 * QT);
   int b = blockIdx.x;
   const int qt256 = b % qtiles;
   b /= qtiles;
@@ -627,26 +628,28 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   const int head = b % p.H;
   const int n = b / p.H;
   const int64_t hb = (int64_t)n * p.H + head;
-  const int q0 = qt256 * 256 + wave * 64;
+  const int q0 = qt256 * (128 * QT) + wave * (32 * QT);
   const int klen = p.T / p.ksplit;
   const int kbeg = ks * klen;
   const int nblk = klen / KB;
 
-  float4 qf[2][NKS];
+  float4 qf[QT][NKS];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
       qf[qt][s] = *reinterpret_cast<const float4*>(p.qb + (hb * p.T + q0 + qt * 32 + li) * CH + s * 16 + kg * 8);
 
-  f32x16 oacc[NCT][2];
+  f32x16 oacc[NCT][QT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[ct][qt][r] = 0.f;
-  float m_run[2] = {-3.0e38f, -3.0e38f}, l_run[2] = {0.f, 0.f};
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) m_run[qt] = -3.0e38f, l_run[qt] = 0.f;
 
   float4 kreg[PER], vreg[PER];
   auto stage_load = [&](int blk) {
@@ -680,11 +683,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     const int buf = blk & 1;
     if (blk + 1 < nblk) stage_load(blk + 1);
     // ---- S^T tiles [key tile kt][query tile qt]
-    f32x16 sacc[2][2];
+    f32x16 sacc[2][QT];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[kt][qt][r] = 0.f;
 #pragma unroll
@@ -693,12 +696,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
       for (int kt = 0; kt < 2; ++kt) {
         const float4 ka = *reinterpret_cast<const float4*>(&s_k[buf][(kt * 32 + li) * KW + s * 8 + kg * 4]);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) sacc[kt][qt] = mfma_bf16_32x32x16(ka, qf[qt][s], sacc[kt][qt]);
+        for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = mfma_bf16_32x32x16(ka, qf[qt][s], sacc[kt][qt]);
       }
     // ---- online softmax per query column (exp2 domain), P^T operands straight from the registers
-    float4 pf[2][2][2];  // [qt][kt][h]
+    float4 pf[QT][2][2];  // [qt][kt][h]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       float mx = sacc[0][qt][0];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
           const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
           const float4 va = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) oacc[ct][qt] = mfma_bf16_32x32x16(va, pf[qt][kt][h], oacc[ct][qt]);
+          for (int qt = 0; qt < QT; ++qt) oacc[ct][qt] = mfma_bf16_32x32x16(va, pf[qt][kt][h], oacc[ct][qt]);
         }
     if (blk + 1 < nblk) stage_store(buf ^ 1);
     __syncthreads();
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
 
   // ---- D rows = channels ct*32 + (r&3) + 8(r>>2) + 4kg, column = query li
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 32 + li;
     if (p.ksplit == 1) {
       const float inv = 1.f / l_run[qt];
@@ -881,10 +884,9 @@ int flash_attn_bf16_launch(const AttnParams& p, void* stream) {
   return 0;
 }
 
-// (head channels 128 would need 320 registers for the 64-query wave tile: those shapes stay on the first form)
-bool flash_attn_bf16v2_supported(int T, int ch) { return (T % 256) == 0 && (ch == 32 || ch == 64); }
+bool flash_attn_bf16v2_supported(int T, int ch) { return (T % 256) == 0 && (ch == 32 || ch == 64 || ch == 128); }
 static int attn_v2_ksplit(const AttnParams& p, int num_cus) {
-  const int64_t wgs = (int64_t)p.N * p.H * (p.T / 256);
+  const int64_t wgs = (int64_t)p.N * p.H * (p.T / (p.C / p.H == 128 ? 128 : 256));
   int ks = 1;
   while (wgs * ks < 2 * (int64_t)num_cus && ks < 8 && (p.T / (ks * 2)) % 64 == 0) ks *= 2;
   return ks;
@@ -916,15 +918,19 @@ int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int 
   a.out_bf16 = out_bf16;
   const float qscale = p.scale2 * 1.4426950408889634f;  // softmax in the exp2 domain
   dim3 pgrid((unsigned)((int64_t)p.N * p.H * (p.T / 64)));
-  dim3 grid((unsigned)((int64_t)p.N * p.H * a.ksplit * (p.T / 256)));
+  dim3 grid((unsigned)((int64_t)p.N * p.H * a.ksplit * (p.T / (ch == 128 ? 128 : 256))));
   switch (ch) {
     case 32:
       HOLO_LAUNCH(attn_pack_kernel<32>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH(flash_attn_bf16v2_kernel<32>, grid, dim3(256), stream, a);
+      HOLO_LAUNCH((flash_attn_bf16v2_kernel<32, 2>), grid, dim3(256), stream, a);
+      break;
+    case 64:
+      HOLO_LAUNCH(attn_pack_kernel<64>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
+      HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
       break;
     default:
-      HOLO_LAUNCH(attn_pack_kernel<64>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH(flash_attn_bf16v2_kernel<64>, grid, dim3(256), stream, a);
+      HOLO_LAUNCH(attn_pack_kernel<128>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
+      HOLO_LAUNCH((flash_attn_bf16v2_kernel<128, 1>), grid, dim3(256), stream, a);
       break;
   }
   if (a.ksplit > 1) {

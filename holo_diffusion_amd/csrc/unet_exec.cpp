@@ -587,8 +587,10 @@ struct Planner {
       const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
       const int64_t min_t = mt ? atoll(mt) : 8192;
       op.i0 = (u->compute_mode == 1 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
-      if (op.i0 && flash_attn_bf16v2_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_V2")) {
-        // second form: packed bf16 operands (V transposed) in scratch, bf16 attention output
+      // the second form splits the key range to fill the chip, so it also serves the shorter sequences
+      if (u->compute_mode == 1 && T >= (min_t < 1024 ? min_t : 1024) && flash_attn_bf16v2_supported((int)T, ch) &&
+          !getenv("HOLO_NO_FLASH_V2")) {
+        // packed bf16 operands (V transposed) in scratch, bf16 attention output
         op.i0 = 2;
         v2_bytes = flash_attn_bf16v2_workspace_bytes(op.attn, u->ctx->num_cus);
         v2_work = scratch_alloc(v2_bytes);
