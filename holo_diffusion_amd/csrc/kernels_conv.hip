@@ -1085,10 +1085,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
     }
     HOLO_WAVE_SYNC();  // the tile is overwritten by the next row tile
   }
-  // GroupNorm statistics of the tensor just produced: one slab per wave (128 voxels) -> stats[n][slab][Cout][2]
+  // GroupNorm statistics of the tensor just produced: one slab per tile (512 voxels) -> stats[n][tile][Cout][2]; the
+  // four waves' sums meet in LDS in a fixed order (deterministic)
   if (p.stats && p.nsplit == 1) {
     const int tiles_per_sample = ntx * nty * ntz;
-    const int slab = (blockIdx.x % tiles_per_sample) * 4 + wave;
+    const int slab = blockIdx.x % tiles_per_sample;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -1097,12 +1098,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
         eq[e] += __shfl_xor(eq[e], m);
       }
     }
-    if (lane < LPV && cvalid) {
-      double* d = p.stats + (((int64_t)n * tiles_per_sample * 4 + slab) * p.Cout + co8) * 2;
+    __syncthreads();  // every wave is done with its transposition tile
+    if (lane < LPV) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        d[2 * e] = (double)es[e];
-        d[2 * e + 1] = (double)eq[e];
+        s_halo[(wave * LPV + lane) * 16 + e] = es[e];
+        s_halo[(wave * LPV + lane) * 16 + 8 + e] = eq[e];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < LPV && cvalid) {
+      double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += s_halo[(w * LPV + lane) * 16 + e];
+          s2 += s_halo[(w * LPV + lane) * 16 + 8 + e];
+        }
+        d[2 * e] = (double)s1;
+        d[2 * e + 1] = (double)s2;
       }
     }
   }
@@ -2142,8 +2158,13 @@ constexpr int SM_ROWS = 64;
 constexpr int SG = 8;
 constexpr int SGH = 4;  // activation chunks requested per staging batch (register budget)
 
+// BF (bf16 compute mode): the activation rows are rounded to bf16 when they are committed to LDS (80-byte rows), the
+// weights are the bf16 plane packed for v_mfma_f32_16x16x32_bf16 (one 1 KB block per wave, tap and chunk), and one
+// MFMA per 16-voxel tile covers a chunk's 32 channels (eight fp32 ones otherwise).
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
-  __shared__ __attribute__((aligned(16))) float s_a[SG * SM_ROWS * LDK];
+  constexpr int RW = BF ? 20 : LDK;  // LDS words per activation row
+  __shared__ __attribute__((aligned(16))) float s_a[SG * SM_ROWS * RW];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -2248,7 +2269,11 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       v.y *= keep;
       v.z *= keep;
       v.w *= keep;
-      *reinterpret_cast<float4*>(s_a + slot * (SM_ROWS * LDK) + (r0 + 32 * j) * LDK + q * 4) = v;
+      if (BF)
+        *reinterpret_cast<uint2*>(s_a + slot * (SM_ROWS * RW) + (r0 + 32 * j) * RW + q * 2) =
+            make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      else
+        *reinterpret_cast<float4*>(s_a + slot * (SM_ROWS * RW) + (r0 + 32 * j) * RW + q * 4) = v;
     }
   };
 
@@ -2259,7 +2284,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
     for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
 
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
-  const float* w_lane = p.w + (int64_t)((n0 >> 4) + wave) * 512 + lane * 4;  // 1 KB contiguous per wave instruction
+  constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, 16-Cout slice) block
+  const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;  // 1 KB contiguous per wave instruction
 
   for (int g = kc_begin; g < kc_end; g += SG) {
     if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
@@ -2282,20 +2308,25 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       const int kc = min(g + i, kc_end - 1);
       const int tap = kc / ncc;
       const int cc = kc - tap * ncc;
-      const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * 512;
+      const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
       bw[i][0] = *reinterpret_cast<const float4*>(wp);
-      bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
+      if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
       if (g + i < kc_end) {  // uniform
-        const float* ab = s_a + i * (SM_ROWS * LDK) + lj * LDK + kq * 8;
+        const float* ab = s_a + i * (SM_ROWS * RW) + lj * RW + kq * (BF ? 4 : 8);
         float4 a0[4], a1[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          a0[t] = *reinterpret_cast<const float4*>(ab + t * 16 * LDK);
-          a1[t] = *reinterpret_cast<const float4*>(ab + t * 16 * LDK + 4);
+          a0[t] = *reinterpret_cast<const float4*>(ab + t * 16 * RW);
+          if (!BF) a1[t] = *reinterpret_cast<const float4*>(ab + t * 16 * RW + 4);
+        }
+        if (BF) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16_16x16x32(a0[t], bw[i][0], acc[t]);
+          continue;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t].x, bw[i][0].x, acc[t], 0, 0, 0);
@@ -2606,7 +2637,7 @@ int conv_stats_slabs(const ConvParams& p) {
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     return B;
   }
-  if (p.mode == 1 && p.bf16t) return (int)(V / 128);  // wide-tile bf16 kernel: one slab per wave
+  if (p.mode == 1 && p.bf16t) return (int)(V / 512);  // wide-tile bf16 kernel: one slab per tile
   if (p.mode == 1 && p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w) return (int)(V / 32);  // bf16x3 kernel: per half 8x8 slab
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
@@ -2718,7 +2749,11 @@ int conv_launch(const ConvParams& p, void* stream) {
     }
   } else if (p.mode == 2) {
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
-    HOLO_LAUNCH(conv_small_kernel, sgrid, block, stream, p);
+    if (p.bf16 == 1 && p.w_bf) {  // bf16 compute mode
+      HOLO_LAUNCH(conv_small_kernel<true>, sgrid, block, stream, p);
+    } else {
+      HOLO_LAUNCH(conv_small_kernel<false>, sgrid, block, stream, p);
+    }
   } else if (wide) {
     HOLO_LAUNCH(conv_igemm_kernel<2>, grid, block, stream, p);
   } else {
