@@ -288,6 +288,7 @@ static inline float __frcp_rn(float x) { return 1.0f / x; }
 
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 static inline void emu_wave_barrier() { emu_wave().bar.wait(); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
