@@ -302,7 +302,7 @@ def main():
     if rank == 0:
         all_ops = net.time_ops(1, args.conv_iters, device)
         ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
-        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel")
+        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_bf16t_kernel")
         variants = {}
         for o in ops:
             key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"], 4 if o["cout"] >= 64 else 2) \
@@ -331,6 +331,10 @@ def main():
             label = f"{kname}<{'true' if sk else 'false'}> at {od}^3 output"
             what = ("3x3x3 conv3d, LDS voxel-halo implicit GEMM in Winograd F(2x2,3x3) form over (depth, height): 48 "
                     "pseudo-taps per 2x2 outputs instead of 108")
+        elif kname == "conv_bf16t_kernel":
+            label = f"{kname}<{2 if nwn == 4 else 1}, {'true' if sk else 'false'}, true> at {od}^3 output"
+            what = ("3x3x3 conv3d on bf16 activations, 8x8x8 output tiles, LDS voxel-halo implicit GEMM, "
+                    "v_mfma_f32_32x32x16_bf16 with 4x2 register blocking")
         else:
             label, what = kname, "conv3d"
         traffic = None
@@ -359,8 +363,8 @@ def main():
                                       "algorithmic_gflop_per_forward": all_fl / 1e9,
                                       "executed_gflop_per_forward": all_fx / 1e9,
                                       "achieved": all_fl / (all_ms * 1e-3) / 1e12,
-                                      "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                      "frac_executed": all_fx / (all_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                                      "frac": all_fl / (all_ms * 1e-3) / 1e12 / peak,
+                                      "frac_executed": all_fx / (all_ms * 1e-3) / 1e12 / peak},
                 "by_variant": [{"kernel": k[0], "wave_cols": k[4], "tile_depth": k[1], "fused_skip": k[2], "out_dim": k[3],
                                 "launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                 "tflops_executed": v["fexec"] / (v["ms"] * 1e-3) / 1e12}
@@ -452,19 +456,21 @@ def main():
             "value": steps_per_s, "unit": "denoise-steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32",
-                      "bf16": "bf16 products / f32 accumulate in the 3x3x3 convs, f32 elsewhere",
+                      "bf16": "bf16 activations in HBM, bf16 products / f32 accumulate (convolutions, long-sequence "
+                              "attention), f32 GroupNorm statistics, f32 network input/output",
                       "f32_bf16x3": "f32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product, f32 accumulate "
                                     "(3x3x3 convs); f32 elsewhere"}[args.compute_dtype],
             "data": "synthetic",
             "config": {"workload": ({"north": "apple.yaml single-sample DDPM, 64^3x32 grid, 1 MI355X per chain; ",
                                      "small": "32^3x16 plumbing grid; ",
-                                     "donut128": "128^3x32 grid (donut.yaml size) on the fp32 path; "}[args.workload])
+                                     "donut128": f"128^3x32 grid (donut.yaml size), compute_dtype={args.compute_dtype}; "}[args.workload])
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
             "rays_per_sec_second_call_size": rays_per_s_40, "second_call_frames": F40,
             "ms_per_frame_second_call_size": (1e3 * dtr40 / F40) if F40 > 0 else None,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
+            "unet_workspace_bytes": net.workspace_bytes(1, device),
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,
                                 "kernel": "render_kernel<16, false, false, 64> (persistent: one 12-wave workgroup per CU walks "

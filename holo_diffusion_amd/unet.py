@@ -78,7 +78,8 @@ class SimpleUnet3D(Unet3DBase):
     # 3d down/upsamples have the same size in all 3 dims
     homogeneous_resample: bool = True
     # build-side extension (not a reference field): arithmetic of the stride-1 3x3x3 convolutions, "f32" (exact fp32
-    # MFMA, the reference's arithmetic) or "bf16" (bf16 products on the matrix cores, fp32 accumulation; opt-in for
+    # MFMA, the reference's arithmetic) or "bf16" (activations stored as bf16 in HBM, bf16 products on the matrix
+    # cores with fp32 accumulation, fp32 GroupNorm statistics, fp32 network input / output; opt-in for
     # the bf16 configurations, tolerance rtol 2e-2) or "f32_bf16x3" (fp32 operands split exactly into three bf16
     # terms, six bf16 MFMAs per product: fp32-accurate on the bf16 matrix cores) - holo_unet_set_compute_dtype
     compute_dtype: str = "f32"
@@ -208,6 +209,11 @@ class SimpleUnet3D(Unet3DBase):
         _lib.check(L, L.holo_unet_forward(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
                                           ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
         return y
+
+    def workspace_bytes(self, batch: int, device: torch.device) -> int:
+        """Caller-owned HBM workspace of one forward at this batch size in the current compute mode (activations, GroupNorm
+        partial sums, split-K / attention scratch)."""
+        return int(runtime.lib().holo_unet_workspace_bytes(self._ensure_handle(device), batch))
 
     def fetch_block(self, tag: str, shape) -> torch.Tensor:
         """Debug/parity hook: output of block ``tag`` ("input_blocks.<i>", "middle_block", "output_blocks.<i>") of

@@ -85,11 +85,13 @@ int holo_unet_param_info(const HoloUnet* net, int index, char* name, int name_ca
 int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, int dtype, int ndim,
                         const int64_t* shape, void* stream);
 
-/* Arithmetic of the stride-1 3x3x3 convolutions (95% of the FLOPs):
+/* Arithmetic and storage mode of the denoiser:
  *   HOLO_DTYPE_F32  (default) exact-fp32 MFMA, the reference's arithmetic (unet.py:639)
- *   HOLO_DTYPE_BF16 operands rounded to bf16 (RNE) at the LDS halo / weight pack, products on the bf16 matrix
- *                   cores, fp32 accumulation; activations in HBM, GroupNorm, attention, 1x1x1 and strided convs
- *                   stay fp32.  Opt-in for the bf16 configurations (BASELINE configs[4]); tolerance rtol 2e-2.
+ *   HOLO_DTYPE_BF16 bf16 mode: every activation inside the library is STORED as bf16 in the workspace (half the HBM
+ *                   footprint and traffic), convolutions and the attention of long sequences multiply on the bf16
+ *                   matrix cores with fp32 accumulation, GroupNorm statistics are fp32/double sums of the fp32
+ *                   values before rounding, x / y at the boundary and the attention's qkv stay fp32.  Opt-in for
+ *                   the bf16 configurations (BASELINE configs[4]); tolerance rtol 2e-2 of the output scale.
  *   HOLO_DTYPE_F32_BF16X3  fp32-accurate arithmetic on the bf16 matrix cores: every fp32 operand is split exactly
  *                   into three bf16 terms and each product is assembled from the six leading cross terms (dropped
  *                   terms <= 2^-23 relative, the size of one fp32 rounding), fp32 accumulation.  Opt-in; meets the

@@ -240,8 +240,9 @@ def test_128_cubed_forward_vs_oracle(gu):
 
 @pytest.mark.parametrize("image,mc,mult,attn", [(8, 64, (1, 2), (2,)), (16, 64, (1, 2, 2), (4,)), (16, 32, (1, 1), ())])
 def test_bf16_compute_mode_vs_oracle(gu, image, mc, mult, attn):
-    """Opt-in bf16 products (fp32 accumulate) in the halo convolutions against the fp32 oracle: tolerance of
-    SURVEY.md 8c for the bf16 path (rtol 2e-2 of the tensor scale); the error must also be bf16-sized, not zero."""
+    """Opt-in bf16 mode (bf16 activations in HBM, bf16 products / fp32 accumulate, fp32 GroupNorm statistics) against
+    the fp32 oracle: tolerance of SURVEY.md 8c for the bf16 path (rtol 2e-2 of the tensor scale); the error must also
+    be bf16-sized, not zero."""
     cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
                      channel_mult=mult, attention_resolutions=attn, num_heads=2)
     net, sd = gu.make_unet(cfg, seed=99, compute_dtype="bf16")
@@ -256,9 +257,12 @@ def test_bf16_compute_mode_vs_oracle(gu, image, mc, mult, attn):
 
 
 def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
-    """64^3 x 32 north-star net: bf16-product mode against the (oracle-pinned) fp32 path on the same device."""
+    """64^3 x 32 north-star net: bf16 mode (bf16 storage, wide-tile kernel on the 64^3 level by the planner's own choice)
+    against the (oracle-pinned) fp32 path on the same device."""
     n32, _ = gu.make_unet(NORTH_CFG)
     nbf, _ = gu.make_unet(NORTH_CFG, compute_dtype="bf16")
+    assert any(o.get("kernel") == "conv_bf16t_kernel" for o in nbf.time_ops(1, 1, gu.DEV))
+    assert nbf.workspace_bytes(1, gu.DEV) < 0.8 * n32.workspace_bytes(1, gu.DEV)  # bf16 activations: smaller HBM footprint
     x = seeded_input(NORTH_CFG, 7 + 500).to(gu.DEV)
     t = torch.tensor([500], device=gu.DEV)
     with torch.no_grad():
@@ -279,11 +283,16 @@ def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
         assert ((ym - y32).abs().max() / y32.abs().max()).item() <= tol, mode
 
 
+@pytest.mark.parametrize("form", ["second", "first"])
 @pytest.mark.parametrize("image,mc,mult,attn", [(16, 64, (1, 2, 2), (1, 2)), (16, 128, (1, 2), (2,))])
-def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
-    """The shared-tile bf16 attention kernel (normally used from 8k tokens) forced on at T = 4096 / 512 with head
-    channels 32, 64 and 128, inside the bf16-product mode, against the fp32 oracle (rtol 2e-2 of the scale)."""
+def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, form, monkeypatch):
+    """Both bf16 attention kernels forced on at T = 4096 / 512 with head channels 32, 64 and 128 inside the bf16 mode,
+    against the fp32 oracle (rtol 2e-2 of the scale): the second form (packed operands, transposed V, 32x32x16 tiles,
+    key split + recombination: at these sizes the key range IS split 2-8 ways) and the first form (shared fp32->bf16
+    tiles) it replaces wherever it applies."""
     monkeypatch.setenv("HOLO_BF16_FLASH_MIN_T", "0")
+    if form == "first":
+        monkeypatch.setenv("HOLO_NO_FLASH_V2", "1")
     cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
                      channel_mult=mult, attention_resolutions=attn, num_heads=2)
     net, sd = gu.make_unet(cfg, seed=7, compute_dtype="bf16")
@@ -295,6 +304,32 @@ def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
         y = net(x.to(gu.DEV), t.to(gu.DEV))
     err = gu.rel_err(y, ref)
     assert 1e-5 < err < 2e-2, err
+
+
+@pytest.mark.parametrize("wide_tile", ["0", "1"])
+def test_bf16_storage_mode_blockwise(gu, wide_tile, monkeypatch):
+    """bf16 mode = bf16 activations in HBM: every block output (read back from the bf16 workspace) against the fp32
+    oracle at the bf16 tolerance, once on the 64/128-voxel bf16 halo kernels and once with the wide-tile kernel
+    (8x8x8 tiles, fused skip from global operands, LDS-transposed epilogue, per-tile GroupNorm slabs) forced onto this
+    small grid."""
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+    monkeypatch.setenv("HOLO_CONV_BF16T", wide_tile)
+    cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2,
+                     channel_mult=(1, 2, 2), attention_resolutions=(4,), num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=99, compute_dtype="bf16")
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(11, (2, 16, 16, 16, 16)))
+    t = torch.tensor([321, 17], dtype=torch.int64)
+    trace = {}
+    ref = uo.unet_forward(sd, cfg, x, t, trace)
+    with torch.no_grad():
+        y = net(x.to(gu.DEV), t.to(gu.DEV))
+    assert 1e-5 < gu.rel_err(y, ref) < 2e-2
+    for tag, r in trace.items():
+        if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
+            assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 2e-2, tag
+    kernels = {o.get("kernel") for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv"}
+    assert ("conv_bf16t_kernel" in kernels) == (wide_tile == "1"), kernels
 
 
 @pytest.mark.parametrize("image,mc,mult,attn,batch", [(8, 64, (1, 2), (2,), 1), (16, 64, (1, 2, 2), (4,), 2)])
