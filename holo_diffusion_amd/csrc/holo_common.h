@@ -25,6 +25,8 @@ static inline f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 c) { return e
 static inline float holo_rcp(float x) { return 1.0f / x; }
 static inline float holo_rcp_exact(float x) { return 1.0f / x; }
 static inline float holo_exp2(float x) { return std::exp2(x); }
+static inline float holo_max_xor32(float x) { return std::fmax(x, __shfl_xor(x, 32)); }
+static inline float holo_add_xor32(float x) { return x + __shfl_xor(x, 32); }
 #define HOLO_WAVE_SYNC() emu_wave().bar.wait()
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
@@ -63,6 +65,15 @@ __device__ __forceinline__ f32x16 mfma_bf16_32x32x16(float4 a, float4 b, f32x16 
 __device__ __forceinline__ float holo_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 // v_exp_f32 (2^x, no denormal fix-up: the callers' results are rounded to bf16 or summed in fp32)
 __device__ __forceinline__ float holo_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// x combined with the value of lane ^ 32: v_permlane32_swap (vector pipe) instead of a trip through the LDS crossbar
+__device__ __forceinline__ float holo_max_xor32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float holo_add_xor32(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
 #define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, grid, block, 0, (hipStream_t)(stream), __VA_ARGS__)

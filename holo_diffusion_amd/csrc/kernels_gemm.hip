@@ -8,6 +8,7 @@
 //
 // Same tile machinery as kernels_conv.hip: 128 x 64 block tile, 32-deep K chunks, LDS rows of 36 floats,
 // v_mfma_f32_32x32x2_f32, lane half h owns k in [16h,16h+16) of a chunk.
+#include <stdlib.h>
 #include <string.h>
 
 #include "holo_common.h"
@@ -603,7 +604,7 @@ struct AttnV2 {
 };
 
 // QT: 32-query tiles per wave (2; 1 for head channels 128, whose 64-query wave tile would need 320 registers)
-template <int CH, int QT>
+template <int CH, int QT, bool PIPE = true>
 __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   constexpr int KB = 64;
   constexpr int KW = CH / 2 + 4;  // words per K row
@@ -647,9 +648,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[ct][qt][r] = 0.f;
-  float m_run[QT], l_run[QT];
+  float m_run[QT], d_run[QT], l_run[QT];  // exponent reference, running maximum relative to it, running sum
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) m_run[qt] = -3.0e38f, l_run[qt] = 0.f;
+  for (int qt = 0; qt < QT; ++qt) m_run[qt] = 0.f, d_run[qt] = -3.0e38f, l_run[qt] = 0.f;
 
   float4 kreg[PER], vreg[PER];
   auto stage_load = [&](int blk) {
@@ -682,40 +683,79 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   for (int blk = 0; blk < nblk; ++blk) {
     const int buf = blk & 1;
     if (blk + 1 < nblk) stage_load(blk + 1);
-    // ---- S^T tiles [key tile kt][query tile qt]
+    // ---- S^T tiles [key tile kt][query tile qt]; online softmax per query column (exp2 domain), P^T operands straight
+    // from the registers; O^T += V^T . P^T.  The two query tiles are staggered so that the vector work of one tile's
+    // softmax sits between the MFMAs of the other tile (a wave issues in order: 16 MFMAs followed by 150 vector
+    // instructions leave the matrix pipe idle for the length of the softmax): S(0) | S(1) + softmax(0) |
+    // PV(0) + softmax(1) | PV(1).
     f32x16 sacc[2][QT];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kt][qt][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const float4 ka = *reinterpret_cast<const float4*>(&s_k[buf][(kt * 32 + li) * KW + s * 8 + kg * 4]);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) sacc[kt][qt] = mfma_bf16_32x32x16(ka, qf[qt][s], sacc[kt][qt]);
-      }
-    // ---- online softmax per query column (exp2 domain), P^T operands straight from the registers
     float4 pf[QT][2][2];  // [qt][kt][h]
+    // The exponent reference m_ref of a query is NOT its exact running maximum: S - m_ref comes out of the MFMAs (the
+    // accumulators start at -m_ref), P = 2^(S - m_ref) may exceed 1, and O, l are re-referenced only when the running
+    // maximum has moved more than 2^32 away from m_ref (or in the first block) - any common reference cancels in O / l.
+    // That takes the per-element subtraction and, almost always, the rescaling of O out of the vector work, which is
+    // what bounds this kernel (softmax ~2x the matrix time at 64 head channels).
+    // K / V^T fragments are shared by the two query tiles: read once per block into registers
+    float4 kaf[NKS][2], vaf[2][2][NCT];
+    auto load_k = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
+      for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          kaf[s][kt] = *reinterpret_cast<const float4*>(&s_k[buf][(kt * 32 + li) * KW + s * 8 + kg * 4]);
+    };
+    auto load_v = [&]() {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const uint32_t* vr = &s_v[buf][(ct * 32 + li) * VW + (kt * 32 + 16 * h + 4 * kg) / 2];
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
+            vaf[kt][h][ct] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
+          }
+    };
+    auto s_tile = [&](int qt) {
+      const float init = -m_run[qt];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kt][qt][r] = init;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) sacc[kt][qt] = mfma_bf16_32x32x16(kaf[s][kt], qf[qt][s], sacc[kt][qt]);
+    };
+    auto softmax_tile = [&](int qt) {
       float mx = sacc[0][qt][0];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = holo_exp2(m_run[qt] - m_new);
+      mx = holo_max_xor32(mx);
+      float d = fmaxf(d_run[qt], mx);  // running maximum relative to m_ref
+      if (__any(blk == 0 || d > 32.0f)) {  // re-reference (every lane by its own d: valid for any d)
+        const float sc = holo_exp2(-d);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[kt][qt][r] -= d;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[ct][qt][r] *= sc;
+        l_run[qt] *= sc;
+        m_run[qt] += d;
+        d = 0.f;
+      }
+      d_run[qt] = d;
       float ls = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          sacc[kt][qt][r] = holo_exp2(sacc[kt][qt][r] - m_new);
+          sacc[kt][qt][r] = holo_exp2(sacc[kt][qt][r]);
           ls += sacc[kt][qt][r];
         }
 #pragma unroll
@@ -725,29 +765,46 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
                                       __uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 4], sacc[kt][qt][8 * h + 5])),
                                       __uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 6], sacc[kt][qt][8 * h + 7])));
       }
-      ls += __shfl_xor(ls, 32);
-      l_run[qt] = l_run[qt] * alpha + ls;
-      m_run[qt] = m_new;
-      if (__any(alpha != 1.0f)) {  // (after the first blocks the running maximum rarely moves)
+      l_run[qt] += holo_add_xor32(ls);
+    };
+    auto pv_tile = [&](int qt) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[ct][qt][r] *= alpha;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) oacc[ct][qt] = mfma_bf16_32x32x16(vaf[kt][h][ct], pf[qt][kt][h], oacc[ct][qt]);
+    };
+    // one MFMA, then a slice of the other tile's softmax
+    auto interleave = [&](int n_mfma) {
+#pragma unroll
+      for (int i = 0; i < n_mfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
       }
+    };
+    load_k();
+    s_tile(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (QT == 2) {
+      s_tile(QT - 1);
+      softmax_tile(0);
+      load_v();
+      if (PIPE) interleave(2 * NKS);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_tile(0);
+      softmax_tile(QT - 1);
+      if (PIPE) interleave(4 * NCT);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_tile(QT - 1);
+    } else {
+      load_v();
+      softmax_tile(0);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_tile(0);
     }
-    // ---- O^T += V^T . P^T
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const uint32_t* vr = &s_v[buf][(ct * 32 + li) * VW + (kt * 32 + 16 * h + 4 * kg) / 2];
-          const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
-          const float4 va = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) oacc[ct][qt] = mfma_bf16_32x32x16(va, pf[qt][kt][h], oacc[ct][qt]);
-        }
     if (blk + 1 < nblk) stage_store(buf ^ 1);
     __syncthreads();
   }
@@ -889,6 +946,10 @@ static int attn_v2_ksplit(const AttnParams& p, int num_cus) {
   const int64_t wgs = (int64_t)p.N * p.H * (p.T / (p.C / p.H == 128 ? 128 : 256));
   int ks = 1;
   while (wgs * ks < 2 * (int64_t)num_cus && ks < 8 && (p.T / (ks * 2)) % 64 == 0) ks *= 2;
+  if (const char* e = getenv("HOLO_FLASH_V2_KSPLIT")) {  // development knob
+    const int v = atoi(e);
+    if (v >= 1 && v <= 8 && (p.T / v) % 64 == 0) ks = v;
+  }
   return ks;
 }
 size_t flash_attn_bf16v2_workspace_bytes(const AttnParams& p, int num_cus) {
@@ -926,7 +987,11 @@ int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int 
       break;
     case 64:
       HOLO_LAUNCH(attn_pack_kernel<64>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
+      if (getenv("HOLO_FLASH_V2_NOPIPE")) {  // development knob: the same order without the scheduling pattern
+        HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2, false>), grid, dim3(256), stream, a);
+      } else {
+        HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
+      }
       break;
     default:
       HOLO_LAUNCH(attn_pack_kernel<128>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
