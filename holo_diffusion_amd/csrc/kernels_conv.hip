@@ -753,7 +753,7 @@ __device__ __forceinline__ float4 pack_bf16x8(const float (&f)[8]) {
 }
 
 // SCHED: 2 = one operand request behind each MFMA of a tap (measured 6-7 % faster than 0 = requests in a clump between
-// the taps' MFMA groups; 1 = no scheduling constraints, slowest)
+// the taps' MFMA groups; leaving the order to the compiler was 13 % slower than 0)
 template <int NT, bool SKIP, bool IOBF, int SCHED = 2>
 __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
   constexpr int ES = IOBF ? 2 : 4;  // bytes per activation element in HBM
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
       if (tap + 1 < 27) load_a(A[(tap + 1) & 1], tap + 1);
       if (tap + 2 < 27) load_b(B[(tap + 2) % 3], cc, tap + 2);
       if (tap == 16 && has_next) halo_issue(cc + 1);  // the next chunk's raw halo flies under taps 16..26
-      if (SCHED == 0) __builtin_amdgcn_sched_barrier(0);  // keep the requests above AHEAD of the MFMAs that hide their latency
+      if (SCHED == 0) __builtin_amdgcn_sched_barrier(0);  // (0: all requests AHEAD of the tap's MFMAs)
       mfma_tap(A[tap & 1], B[tap % 3]);
       if (SCHED == 2 && tap != 16) {  // one operand request behind each MFMA instead of a clump after the eighth
 #pragma unroll
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 4 - NT, 0);
       }
-      if (SCHED != 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (has_next) {
       load_b(B[0], cc + 1, 0);
@@ -2567,7 +2567,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   p.bf16t = 0;
-  if (p.mode == 1 && p.bf16 == 1 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.Cout % 32) == 0 &&
+  if (p.mode == 1 && p.bf16 == 1 && p.in_bf16 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.Cout % 32) == 0 &&
       (p.C0 % 8) == 0 && (p.skip_C0 % 8) == 0 && ((p.skip_C0 + p.skip_C1) % 8) == 0 && (p.Cout >= 64 || !p.skip_w)) {
     // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup) where it fills the chip without
     // split-K; HOLO_CONV_BF16T=0 disables it, =1 forces it (tests)
@@ -2693,23 +2693,18 @@ int conv_launch(const ConvParams& p, void* stream) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
     if (p.bf16t) {
-#define HOLO_BF16T(NT_, SK_)                                                                \
-  do {                                                                                      \
-    if (p.in_bf16) {                                                                        \
-      HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, true>), hgrid, block, stream, p);            \
-    } else {                                                                                \
-      HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, false>), hgrid, block, stream, p);           \
-    }                                                                                       \
-  } while (0)
+#define HOLO_BF16T(NT_, SK_) HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, true>), hgrid, block, stream, p)
+      if (!p.in_bf16 || (p.residual && !p.res_bf16)) {
+        set_error("conv_launch: the wide-tile bf16 kernel runs on bf16 activation storage");
+        return -1;
+      }
       if (!wide) {
         HOLO_BF16T(1, false);
       } else if (sk) {
         HOLO_BF16T(2, true);
       } else {
-        const char* sv = getenv("HOLO_BF16T_SCHED");  // development knob: instruction-scheduling variants of the tap loop
-        if (sv && sv[0] == '1' && p.in_bf16) {
-          HOLO_LAUNCH((conv_bf16t_kernel<2, false, true, 1>), hgrid, block, stream, p);
-        } else if (sv && sv[0] == '0' && p.in_bf16) {
+        const char* sv = getenv("HOLO_BF16T_SCHED");  // development knob: 0 = operand requests in a clump between the taps
+        if (sv && sv[0] == '0') {
           HOLO_LAUNCH((conv_bf16t_kernel<2, false, true, 0>), hgrid, block, stream, p);
         } else {
           HOLO_BF16T(2, false);

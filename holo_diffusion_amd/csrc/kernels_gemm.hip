@@ -987,11 +987,7 @@ int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int 
       break;
     case 64:
       HOLO_LAUNCH(attn_pack_kernel<64>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      if (getenv("HOLO_FLASH_V2_NOPIPE")) {  // development knob: the same order without the scheduling pattern
-        HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2, false>), grid, dim3(256), stream, a);
-      } else {
-        HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
-      }
+      HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
       break;
     default:
       HOLO_LAUNCH(attn_pack_kernel<128>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
