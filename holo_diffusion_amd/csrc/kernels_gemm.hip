@@ -652,16 +652,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) m_run[qt] = 0.f, d_run[qt] = -3.0e38f, l_run[qt] = 0.f;
 
-  float4 kreg[PER], vreg[PER];
+  f32x4 kreg[PER], vreg[PER];  // (native vectors: as float4 structs one of the two arrays stayed in scratch memory, and a
+                               //  scratch store of a load still in flight stalls the wave for the whole round trip)
   auto stage_load = [&](int blk) {
     const int k0 = kbeg + blk * KB;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int i = tid + 256 * j;
       const int key = i / (CH / 8), c8 = i - key * (CH / 8);
-      kreg[j] = *reinterpret_cast<const float4*>(p.kb + (hb * p.T + k0 + key) * CH + c8 * 8);
+      kreg[j] = *reinterpret_cast<const f32x4*>(p.kb + (hb * p.T + k0 + key) * CH + c8 * 8);
       const int ch = i >> 3, k8 = i & 7;
-      vreg[j] = *reinterpret_cast<const float4*>(p.vt + (hb * CH + ch) * p.T + k0 + k8 * 8);
+      vreg[j] = *reinterpret_cast<const f32x4*>(p.vt + (hb * CH + ch) * p.T + k0 + k8 * 8);
     }
   };
   auto stage_store = [&](int buf) {
@@ -669,11 +670,11 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     for (int j = 0; j < PER; ++j) {
       const int i = tid + 256 * j;
       const int key = i / (CH / 8), c8 = i - key * (CH / 8);
-      *reinterpret_cast<float4*>(&s_k[buf][key * KW + c8 * 4]) = kreg[j];
+      *reinterpret_cast<f32x4*>(&s_k[buf][key * KW + c8 * 4]) = kreg[j];
       const int ch = i >> 3, k8 = i & 7;
       uint32_t* d = &s_v[buf][ch * VW + k8 * 4];
-      *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(vreg[j].x), __float_as_uint(vreg[j].y));
-      *reinterpret_cast<uint2*>(d + 2) = make_uint2(__float_as_uint(vreg[j].z), __float_as_uint(vreg[j].w));
+      *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(vreg[j][0]), __float_as_uint(vreg[j][1]));
+      *reinterpret_cast<uint2*>(d + 2) = make_uint2(__float_as_uint(vreg[j][2]), __float_as_uint(vreg[j][3]));
     }
   };
 
@@ -682,7 +683,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
   __syncthreads();
   for (int blk = 0; blk < nblk; ++blk) {
     const int buf = blk & 1;
-    if (blk + 1 < nblk) stage_load(blk + 1);
     // ---- S^T tiles [key tile kt][query tile qt]; online softmax per query column (exp2 domain), P^T operands straight
     // from the registers; O^T += V^T . P^T.  The two query tiles are staggered so that the vector work of one tile's
     // softmax sits between the MFMAs of the other tile (a wave issues in order: 16 MFMAs followed by 150 vector
@@ -695,26 +695,16 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     // maximum has moved more than 2^32 away from m_ref (or in the first block) - any common reference cancels in O / l.
     // That takes the per-element subtraction and, almost always, the rescaling of O out of the vector work, which is
     // what bounds this kernel (softmax ~2x the matrix time at 64 head channels).
-    // K / V^T fragments are shared by the two query tiles: read once per block into registers
-    float4 kaf[NKS][2], vaf[2][2][NCT];
+    // the K fragments are shared by the two query tiles (read once per block into registers); the V^T fragments are read
+    // per query tile - holding them too costs 32 registers at the point where the kernel then spills its staging
+    // registers, and a spilled in-flight load stalls the wave for the whole memory round trip
+    float4 kaf[NKS][2];
     auto load_k = [&]() {
 #pragma unroll
       for (int s = 0; s < NKS; ++s)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
           kaf[s][kt] = *reinterpret_cast<const float4*>(&s_k[buf][(kt * 32 + li) * KW + s * 8 + kg * 4]);
-    };
-    auto load_v = [&]() {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            const uint32_t* vr = &s_v[buf][(ct * 32 + li) * VW + (kt * 32 + 16 * h + 4 * kg) / 2];
-            const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
-            vaf[kt][h][ct] = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
-          }
     };
     auto s_tile = [&](int qt) {
       const float init = -m_run[qt];
@@ -773,7 +763,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) oacc[ct][qt] = mfma_bf16_32x32x16(vaf[kt][h][ct], pf[qt][kt][h], oacc[ct][qt]);
+          for (int ct = 0; ct < NCT; ++ct) {
+            const uint32_t* vr = &s_v[buf][(ct * 32 + li) * VW + (kt * 32 + 16 * h + 4 * kg) / 2];
+            const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
+            const float4 va = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
+            oacc[ct][qt] = mfma_bf16_32x32x16(va, pf[qt][kt][h], oacc[ct][qt]);
+          }
     };
     // one MFMA, then a slice of the other tile's softmax
     auto interleave = [&](int n_mfma) {
@@ -791,18 +786,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     if (QT == 2) {
       s_tile(QT - 1);
       softmax_tile(0);
-      load_v();
       if (PIPE) interleave(2 * NKS);
       __builtin_amdgcn_sched_barrier(0);
+      // the next block's K / V^T pieces are requested only now: their 16 staging registers are not live under the S phases,
+      // where the register pressure peaks (requested at the top of the block the kernel spilled Q fragments into the loop)
+      if (blk + 1 < nblk) stage_load(blk + 1);
       pv_tile(0);
       softmax_tile(QT - 1);
       if (PIPE) interleave(4 * NCT);
       __builtin_amdgcn_sched_barrier(0);
       pv_tile(QT - 1);
     } else {
-      load_v();
       softmax_tile(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (blk + 1 < nblk) stage_load(blk + 1);
       pv_tile(0);
     }
     if (blk + 1 < nblk) stage_store(buf ^ 1);
