@@ -753,8 +753,9 @@ __device__ __forceinline__ float4 pack_bf16x8(const float (&f)[8]) {
 }
 
 // SCHED: 2 = one operand request behind each MFMA of a tap (measured 6-7 % faster than 0 = requests in a clump between
-// the taps' MFMA groups; leaving the order to the compiler was 13 % slower than 0)
-template <int NT, bool SKIP, bool IOBF, int SCHED = 2>
+// the taps' MFMA groups; leaving the order to the compiler was 13 % slower than 0).  HT: the tap under which the next
+// chunk's halo is requested (8, 16, 20 and 23 measured within run-to-run noise of each other)
+template <int NT, bool SKIP, bool IOBF, int SCHED = 2, int HT = 16>
 __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
   constexpr int ES = IOBF ? 2 : 4;  // bytes per activation element in HBM
   constexpr int NV = IOBF ? 1 : 2;  // 16-byte loads per staging item
@@ -939,10 +940,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
     for (int tap = 0; tap < 27; ++tap) {
       if (tap + 1 < 27) load_a(A[(tap + 1) & 1], tap + 1);
       if (tap + 2 < 27) load_b(B[(tap + 2) % 3], cc, tap + 2);
-      if (tap == 16 && has_next) halo_issue(cc + 1);  // the next chunk's raw halo flies under taps 16..26
+      if (tap == HT && has_next) halo_issue(cc + 1);  // the next chunk's raw halo flies under taps HT..26
       if (SCHED == 0) __builtin_amdgcn_sched_barrier(0);  // (0: all requests AHEAD of the tap's MFMAs)
       mfma_tap(A[tap & 1], B[tap % 3]);
-      if (SCHED == 2 && tap != 16) {  // one operand request behind each MFMA instead of a clump after the eighth
+      if (SCHED == 2 && tap != HT) {  // one operand request behind each MFMA instead of a clump after the eighth
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
