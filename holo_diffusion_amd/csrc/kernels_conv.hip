@@ -2570,11 +2570,17 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   p.bf16t = 0;
   if (p.mode == 1 && p.bf16 == 1 && p.in_bf16 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.Cout % 32) == 0 &&
       (p.C0 % 8) == 0 && (p.skip_C0 % 8) == 0 && ((p.skip_C0 + p.skip_C1) % 8) == 0 && (p.Cout >= 64 || !p.skip_w)) {
-    // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup) where it fills the chip without
-    // split-K; HOLO_CONV_BF16T=0 disables it, =1 forces it (tests)
+    // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup): where it fills the chip without
+    // split-K, and on the under-filled levels (split over 16-channel chunks) once the K extent is long enough to pay for
+    // the partials - measured at 128^3: from 192 input channels (main + fused skip) it beats the 64/128-voxel halo
+    // kernel (32^3 .. 8^3 levels together 1.96 -> 1.7 ms), below that it loses.  HOLO_CONV_BF16T=0 disables it, =1
+    // forces it everywhere (tests)
     const char* e = getenv("HOLO_CONV_BF16T");
     const int64_t t8 = (M / 512) * cdiv(p.Cout, bn);
-    if (!(e && e[0] == '0') && (t8 >= target || (e && e[0] == '1'))) {
+    const char* lk = getenv("HOLO_CONV_BF16T_LONGK");  // development knob: channel threshold of the rule below (0 = off)
+    const int lk_min = lk ? atoi(lk) : 192;
+    const bool long_k = lk_min > 0 && Cin + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0) >= lk_min;
+    if (!(e && e[0] == '0') && (t8 >= target || long_k || (e && e[0] == '1'))) {
       const int ncc16 = (Cin + 15) / 16;
       const int nsk16 = p.skip_w ? (p.skip_C0 + p.skip_C1 + 15) / 16 : 0;
       if (t8 < target) {
