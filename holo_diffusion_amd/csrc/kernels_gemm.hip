@@ -688,7 +688,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
     // softmax sits between the MFMAs of the other tile (a wave issues in order: 16 MFMAs followed by 150 vector
     // instructions leave the matrix pipe idle for the length of the softmax): S(0) | S(1) + softmax(0) |
     // PV(0) + softmax(1) | PV(1).  (Measured alternatives, all within noise or worse: the plain sequential order; sharing
-    // the V^T fragments too; the minimal-register sequential form at three waves per SIMD: 27 % slower.)
+    // the V^T fragments too; the minimal-register sequential form at three waves per SIMD: 27 % slower; an XCD-aware
+    // workgroup order (each XCD one K / V^T stream): 7 % slower.)
     f32x16 sacc[2][QT];
     float4 pf[QT][2][2];  // [qt][kt][h]
     // The exponent reference m_ref of a query is NOT its exact running maximum: S - m_ref comes out of the MFMAs (the
