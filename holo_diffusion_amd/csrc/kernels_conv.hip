@@ -717,8 +717,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 //   per tap and 16-channel chunk a wave reads 4 A fragments from the LDS halo (ds_read_b128) and NT B fragments
 //   straight from global/L1 (all four waves read the same 1 KB blocks) for 4*NT MFMAs: LDS at 50 %, L1 at 50 % of their
 //   bandwidth when the matrix pipe is saturated.
-// The 10^3 halo of ONE 16-channel chunk is staged per pass (48-byte LDS rows: 32 B of bf16 + 16 B padding, conflict
-// free for the A reads: a 32-row MFMA tile is the y rows {a, a+4, b, b+4} of a plane, 480 words = 32 banks apart);
+// The 10^3 halo of ONE 16-channel chunk is staged per pass: 32-byte LDS rows with no padding, the two 16-byte halves
+// of a voxel swapped on odd halo rows (slot = half ^ (hy & 1)).  A 32-row MFMA tile is 4 consecutive y rows x 8 x: a
+// row's eight voxels cover one 16-byte slot of every 32-byte bank group and the next row covers the other slot, and a
+// tap's ky shifts the parity of every lane alike (two precomputed lane bases).  (The first layout - 48-byte rows,
+// tile rows {a, a+4, b, b+4} - measured LDS bank-conflict cycles of 45 % of the LDS-active cycles.)
 // GroupNorm*FiLM + SiLU, zero padding, nearest-x2 upsampling and the channel concat are applied while staging, as in
 // the halo kernel.  The next chunk's raw halo is requested under tap 16 and committed after the last tap (two barriers
 // per chunk); the activation arithmetic of one workgroup overlaps the tap loop of the other resident workgroup (the bf16
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 constexpr int T_H = 10;                 // halo edge of an 8^3 tile
 constexpr int T_HV = T_H * T_H * T_H;   // halo voxels
 constexpr int T_CK = 16;                // channels per chunk = K of one v_mfma_f32_32x32x16_bf16
-constexpr int T_RS = 12;                // LDS words per halo voxel
+constexpr int T_RS = 8;                 // LDS words per halo voxel (16 bf16, no padding: the halves are swizzled)
 constexpr int T_IT = 8;                 // staging items (voxel, 8-channel half) per thread: 2000 / 256
 
 __device__ __forceinline__ void unpack_bf16x8(const float4& v, float (&f)[8]) {
@@ -760,7 +763,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
   constexpr int ES = IOBF ? 2 : 4;  // bytes per activation element in HBM
   constexpr int NV = IOBF ? 1 : 2;  // 16-byte loads per staging item
   constexpr int BN = 32 * NT;
-  __shared__ __attribute__((aligned(16))) float s_halo[T_HV * T_RS];
+  // (the epilogue re-uses the halo as four 32 x 68-word transposition tiles: 8 704 words)
+  __shared__ __attribute__((aligned(16))) float s_halo[T_HV * T_RS > 4 * 32 * 68 ? T_HV * T_RS : 4 * 32 * 68];
   __shared__ int s_hvox[T_IT * 256];
 
   const int tid = threadIdx.x;
@@ -878,7 +882,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = keep ? f[j] : 0.f;
       const int id = tid + 256 * i;
-      if (id < 2 * T_HV) *reinterpret_cast<float4*>(s_halo + (id >> 1) * T_RS + hh * 4) = pack_bf16x8(f);
+      const int hy_par = (((id >> 1) / T_H) % T_H) & 1;  // halo row parity of the voxel: which slot its halves go to
+      if (id < 2 * T_HV) *reinterpret_cast<float4*>(s_halo + (id >> 1) * T_RS + ((hh ^ hy_par) * 4)) = pack_bf16x8(f);
     }
   };
 
@@ -890,16 +895,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  // A addressing.  MFMA row li of row tile mt (0..3) of this wave: plane z = 2*wave + (mt>>1); with ys = li>>3 the
-  // y row is 2*(mt&1) + (ys>>1) + 4*(ys&1) (so the two 16-lane groups of a ds_read_b128 each cover rows a, a+4), x = li&7.
+  // A addressing.  MFMA row li of row tile mt (0..3) of this wave: plane z = 2*wave + (mt>>1), y row 4*(mt&1) + ys with
+  // ys = li>>3, x = li&7; the lane's 16-byte half sits in slot kg ^ (halo row parity) = kg ^ (ys&1) ^ (kh&1).
   const int ys = li >> 3;
-  const int a_base = (((2 * wave) * T_H + (ys >> 1) + 4 * (ys & 1)) * T_H + (li & 7)) * T_RS + kg * 4;
+  const int a_vox = (((2 * wave) * T_H + ys) * T_H + (li & 7)) * T_RS;
+  const int a_base0 = a_vox + ((kg ^ (ys & 1)) * 4);      // taps with even kh
+  const int a_base1 = a_vox + ((kg ^ (ys & 1) ^ 1) * 4);  // taps with odd kh
   auto load_a = [&](float4 (&a)[4], int tap) {
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
     const int toff = ((kd * T_H + kh) * T_H + kw) * T_RS;
+    const int ab = (kh & 1) ? a_base1 : a_base0;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
-      a[mt] = *reinterpret_cast<const float4*>(s_halo + a_base + ((mt >> 1) * T_H * T_H + 2 * (mt & 1) * T_H) * T_RS + toff);
+      a[mt] = *reinterpret_cast<const float4*>(s_halo + ab + ((mt >> 1) * T_H * T_H + 4 * (mt & 1) * T_H) * T_RS + toff);
   };
   // B addressing: 1 KB blocks [tap][chunk][32-Cout slice], 16 bytes per lane
   const int nsl = p.CoutP >> 5;
@@ -976,10 +984,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
     // tile: channels 8*kg .. +7 of voxel li), four 16-channel k-steps per round trip; no LDS, no barrier.
     const uint16_t* ssrc0 = reinterpret_cast<const uint16_t*>(p.skip_src0);
     const uint16_t* ssrc1 = reinterpret_cast<const uint16_t*>(p.skip_src1);
-    const int64_t vbase = (((int64_t)n * p.OD + tz0 + 2 * wave) * p.OH + ty0 + (ys >> 1) + 4 * (ys & 1)) * p.OW + tx0 + (li & 7);
+    const int64_t vbase = (((int64_t)n * p.OD + tz0 + 2 * wave) * p.OH + ty0 + ys) * p.OW + tx0 + (li & 7);
     int vo[4];  // row tile mt: uniform offsets from the lane's voxel of row tile 0
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) vo[mt] = ((mt >> 1) * p.OH + 2 * (mt & 1)) * p.OW;
+    for (int mt = 0; mt < 4; ++mt) vo[mt] = ((mt >> 1) * p.OH + 4 * (mt & 1)) * p.OW;
     constexpr int SKG = 4;
     for (int g = sk_begin; g < sk_end; g += SKG) {
       float4 SA[SKG][4], SB[SKG][NT];
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
   if (dbg && tid == 0) dbg[2] = HOLO_PROBE_CLOCK();
 
   // ---- epilogue.  D layout of 32x32: column = li (Cout), row i = (r&3) + 8*(r>>2) + 4*kg of the row tile (x = i&7,
-  // ys = i>>3).  Written straight from that layout a lane would issue 128 two-byte stores (measured: 17 of a tile's
+  // y row 4*(mt&1) + (i>>3)).  Written straight from that layout a lane would issue 128 two-byte stores (measured: 17 of a tile's
   // 68 us); instead each wave passes one 32-voxel row tile at a time through its own slice of the (now dead) halo
   // LDS as fp32 [voxel][channel] and leaves with 8 channels of one voxel per lane: bias, residual, GroupNorm
   // statistics and the store are 16-byte operations on that form.
@@ -1050,8 +1058,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int i = ps * VPP + lane / LPV;
-      const int ys = i >> 3;
-      const int y = ty0 + 2 * (mt & 1) + (ys >> 1) + 4 * (ys & 1);
+      const int y = ty0 + 4 * (mt & 1) + (i >> 3);
       o[ps] = ((((int64_t)n * p.OD + z) * p.OH + y) * p.OW + tx0 + (i & 7)) * p.Cout + co8;
       if (p.nsplit == 1 && p.residual) {  // (uniform)
         if (IOBF) {
