@@ -730,7 +730,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(ConvParams p) {
 // so that residual, statistics and stores are 16-byte operations.  Split-K over 16-channel chunks.
 // (A persistent form - each workgroup walking several tiles, the next tile's first halo requested before the
 // epilogue - was measured: the prologue drops from 7 to 4 us per tile but the epilogue's own loads and stores then
-// queue behind the halo loads (in-order vmcnt) and it doubles to 18 us; one tile per workgroup is faster.)
+// queue behind the halo loads (in-order vmcnt) and it doubles to 18 us; one tile per workgroup is faster.  Two halo
+// buffers with one barrier per chunk instead of two: no faster either.)
 // IOBF: activations / residual / output are bf16 in HBM (bf16 storage mode).
 // ---------------------------------------------------------------------------------------------
 constexpr int T_H = 10;                 // halo edge of an 8^3 tile
