@@ -2576,7 +2576,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   p.bf16t = 0;
-  if (p.mode == 1 && p.bf16 == 1 && p.in_bf16 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.Cout % 32) == 0 &&
+  if (p.mode == 1 && p.bf16 == 1 && p.in_bf16 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.Cout % 32) == 0 &&
       (p.C0 % 8) == 0 && (p.skip_C0 % 8) == 0 && ((p.skip_C0 + p.skip_C1) % 8) == 0 && (p.Cout >= 64 || !p.skip_w)) {
     // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup): where it fills the chip without
     // split-K, and on the under-filled levels (split over 16-channel chunks) once the K extent is long enough to pay for
