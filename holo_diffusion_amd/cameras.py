@@ -38,17 +38,29 @@ class PerspectiveCameras:
 
     # A host-side copy of the (tiny) camera parameters travels with the object, so that handing device-resident
     # cameras to the renderer never costs a device->host synchronisation (the launch parameters are built on the host).
+    def _host_key(self):
+        # identity + in-place version of the four parameter tensors: attribute reassignment and in-place edits both
+        # change it, so a stale host copy is never handed to the renderer
+        return tuple((id(t), t._version) for t in (self.R, self.T, self.focal_length, self.principal_point))
+
     def host(self):
-        """(R, T, focal_xy, principal_point) as CPU float32 tensors.  Cached; call ``invalidate_host()`` after
-        modifying the tensors in place."""
+        """(R, T, focal_xy, principal_point) as CPU float32 tensors.  Cached against the identity and ``_version`` of
+        the four tensors: reassigning an attribute or editing a tensor in place refreshes the copy on the next call
+        (one device->host copy for device-resident cameras)."""
         h = self.__dict__.get("_host")
-        if h is None:
+        key = self._host_key()
+        if h is None or self.__dict__.get("_host_key_seen") != key:
             h = tuple(t.detach().to("cpu", torch.float32) for t in (self.R, self.T, self.focal_xy(), self.principal_point))
             self.__dict__["_host"] = h
+            self.__dict__["_host_key_seen"] = key
         return h
 
     def invalidate_host(self) -> None:
         self.__dict__.pop("_host", None)
+
+    def _adopt_host(self, host) -> None:
+        self.__dict__["_host"] = host
+        self.__dict__["_host_key_seen"] = self._host_key()
 
     def __getitem__(self, idx):
         if isinstance(idx, int):
@@ -58,7 +70,7 @@ class PerspectiveCameras:
         c.R, c.T = self.R[idx], self.T[idx]
         c.focal_length, c.principal_point = self.focal_length[idx], self.principal_point[idx]
         if had is not None or not self.R.is_cuda:
-            c.__dict__["_host"] = tuple(t[idx] for t in self.host())
+            c._adopt_host(tuple(t[idx] for t in self.host()))
         return c
 
     def to(self, device):
@@ -66,7 +78,7 @@ class PerspectiveCameras:
         c = PerspectiveCameras.__new__(PerspectiveCameras)
         c.R, c.T = self.R.to(device), self.T.to(device)
         c.focal_length, c.principal_point = self.focal_length.to(device), self.principal_point.to(device)
-        c.__dict__["_host"] = host
+        c._adopt_host(host)
         return c
 
     @property

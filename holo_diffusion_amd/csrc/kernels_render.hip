@@ -523,7 +523,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
       }
     }
     __threadfence();  // cval / cnrm of this tile are read back below (by both lane halves)
-    __builtin_amdgcn_wave_barrier();
+    HOLO_WAVE_SYNC();
 
     // ---- importance-sample depths of all 32 rays, cooperatively: for one ray at a time lane j holds cdf[j] and lane
     //      kk computes the inverse CDF at u_kk = linspace(0,1,nf)[kk] with a binary search over the lanes' values:
@@ -538,7 +538,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
         float cv[8];  // the CDF rows of 8 rays are read together
 #pragma unroll
         for (int q = 0; q < 8; ++q) cv[q] = lane < nb ? czw[(r0 + q) * ZS + lane] : 3.0e38f;
-        __builtin_amdgcn_wave_barrier();  // every lane holds its CDF entries before the rows are overwritten
+        HOLO_WAVE_SYNC();  // every lane holds its CDF entries before the rows are overwritten
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    HOLO_WAVE_SYNC();
 
     if (dbg && lane == 0) dbg[2] += HOLO_PROBE_CLOCK() - dbg[7];
     // ---- fine pass, in lock step.  The reference re-evaluates the coarse points inside its 128-sample fine pass;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // the rows are rewritten by the next tile's coarse pass
+    HOLO_WAVE_SYNC();  // the rows are rewritten by the next tile's coarse pass
     if (dbg && lane == 0) {
       dbg[3] += HOLO_PROBE_CLOCK() - dbg[7];
       dbg[0] += dbg[7] - dbg[6];

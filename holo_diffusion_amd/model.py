@@ -202,12 +202,29 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             assert self.view_pooler_enabled, "view_pooler must be enabled to use image_rgb"
             assert voxel_features is None, "Cannot provide both image_rgb and voxel_features"
             batch_size = len(camera)
+            # safe_slice_sources (:276-298): the source views are the frames of the FIRST frame's sequence minus the
+            # n_targets leading ones; an empty selection falls back to the whole batch
+            if sequence_name is not None and batch_size > 1:
+                ok_ = [si for si, sname in enumerate(sequence_name) if sname == sequence_name[0]]
+                sel = ok_[n_targets:]
+            else:
+                sel = list(range(n_targets, batch_size))
+            if len(sel) == 0 or batch_size <= 1:
+                sel = list(range(batch_size))
             if image_features is None:
                 assert self.image_feature_extractor is not None, "Need an image_feature_extractor"
-                src = slice(n_targets, None) if batch_size > 1 else slice(None)
                 image_features = self.image_feature_extractor(
-                    image_rgb[src], fg_probability[src] if fg_probability is not None else None)
-            source_cameras = camera[list(range(n_targets, batch_size))] if batch_size > 1 else camera
+                    image_rgb[sel], fg_probability[sel] if fg_probability is not None else None)
+            else:
+                # caller-supplied maps are the image feature extractor's output for the batch's source slots (frames
+                # n_targets..) or for the whole batch; either way only the selected frames are pooled
+                n_maps = int(next(iter(image_features.values())).shape[0])
+                if n_maps == batch_size and batch_size > 1:
+                    image_features = {k: v[sel] for k, v in image_features.items()}
+                elif n_maps == batch_size - n_targets and sel != list(range(n_targets, batch_size)):
+                    rel = [si - n_targets for si in sel]
+                    image_features = {k: v[rel] for k, v in image_features.items()}
+            source_cameras = camera[sel]
             voxel_features = self.pool_views_to_voxel_features(image_features, source_cameras)
         if voxel_features is None:
             voxel_features = self.sample_random_voxel_features()

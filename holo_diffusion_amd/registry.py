@@ -98,13 +98,20 @@ class _Registry:
     def __init__(self):
         self._by_base: Dict[Type, Dict[str, Type]] = {}
 
-    def register(self, cls: Type) -> Type:
+    def register_local(self, cls: Type) -> Type:
+        """Package-local registration ONLY.  For config-carrying classes that share their name with a PyTorch3D class
+        they do not replace (e.g. ``AngleWeightedReductionFeatureAggregator``: here a parameter holder of the fused
+        view-pooling kernel, in PyTorch3D an ``nn.Module`` other Implicitron models use).  PyTorch3D's registry maps
+        (base, name) -> class and overwrites silently, so such a class must never be pushed into it."""
+        return self.register(cls, _pytorch3d=False)
+
+    def register(self, cls: Type, _pytorch3d: bool = True) -> Type:
         bases = _replaceable_bases(cls)
         if not bases:
             raise ValueError(f"{cls.__name__} does not derive from a direct subclass of ReplaceableBase")
         for b in bases:
             self._by_base.setdefault(b, {})[cls.__name__] = cls
-        if HAVE_PYTORCH3D:
+        if HAVE_PYTORCH3D and _pytorch3d:
             # the real Implicitron registry: a failure here means experiment.py would NOT resolve to this class,
             # so it is an error, not something to hide
             _P3D_CONFIG.registry.register(cls)

@@ -45,7 +45,7 @@ class ViewSampler(Configurable):
 FeatureAggregatorBase = pt3d_base("implicitron.models.view_pooler.feature_aggregator", "FeatureAggregatorBase")
 
 
-@registry.register
+@registry.register_local  # never into PyTorch3D's registry: it would silently replace PyTorch3D's own aggregator
 class AngleWeightedReductionFeatureAggregator(FeatureAggregatorBase):
     exclude_target_view: bool = True
     exclude_target_view_mask_features: bool = True

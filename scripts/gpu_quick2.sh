@@ -10,7 +10,7 @@ python3 - <<PY
 import json
 d=json.load(open("$OUT/bench.json")); r=d["roofline"]
 print("steps/s %.2f ms/step %.3f | rays/s %.4g ms/frame %.3f"%(d["value"],d["ms_per_step"],d["rays_per_sec"],d["ms_per_frame"]))
-print("dominant:", r["kernel"][:80], "alg TF %.1f exec TF %.1f frac_exec %.3f avg_ms %.4f"%(r["achieved"],r["achieved_executed"],r["frac_executed"],r["avg_launch_ms"]))
+print("dominant:", r["kernel"][:80], "eff TF %.1f exec TF %.1f frac %.3f avg_ms %.4f"%(r["effective_tflops"],r["achieved"],r["frac"],r["avg_launch_ms"]))
 for v in r["by_variant"]: print("  %-20s wc%d tz%d sk%d od%-3d n%-2d ms %.3f TF %.1f exec %.1f"%(v["kernel"],v["wave_cols"],v["tile_depth"],v["fused_skip"],v["out_dim"],v["launches"],v["ms"],v["tflops"],v["tflops_executed"]))
 print("opt-in:", {k:(round(v["denoise_steps_per_s"],1), round(v.get("rays_per_sec",0)/1e6,1)) for k,v in (d.get("opt_in_modes_not_reported") or {}).items()})
 PY

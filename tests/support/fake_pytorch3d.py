@@ -117,5 +117,20 @@ def install():
     mod("pytorch3d.implicitron.models.renderer.base", BaseRenderer=BaseRenderer)
     mod("pytorch3d.implicitron.models.implicit_function")
     mod("pytorch3d.implicitron.models.implicit_function.base", ImplicitFunctionBase=ImplicitFunctionBase)
+    # view pooler side: PyTorch3D ships its OWN AngleWeightedReductionFeatureAggregator (an nn.Module with a forward),
+    # registered at import time; other Implicitron models in the same process depend on it
+    class FeatureAggregatorBase(ReplaceableBase):
+        pass
+
+    class AngleWeightedReductionFeatureAggregator(torch.nn.Module, FeatureAggregatorBase):
+        IS_PYTORCH3D_OWN = True
+
+        def forward(self, *a, **k):
+            return "pytorch3d's own aggregator"
+
+    registry.register(AngleWeightedReductionFeatureAggregator)
+    mod("pytorch3d.implicitron.models.view_pooler")
+    mod("pytorch3d.implicitron.models.view_pooler.feature_aggregator", FeatureAggregatorBase=FeatureAggregatorBase,
+        AngleWeightedReductionFeatureAggregator=AngleWeightedReductionFeatureAggregator)
     sys.modules.update(mods)
     return registry

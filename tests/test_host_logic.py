@@ -140,3 +140,19 @@ def test_flyaround_output_stage(tmp_path):
         assert len(files) == F and files[0] == "frame_00000.ppm"
         head = open(os.path.join(p, files[0]), "rb").read(15)
         assert head.startswith(b"P6\n8 6\n255\n")
+
+
+def test_camera_host_copy_follows_edits():
+    """The host copy the renderer builds its launch parameters from is refreshed when a camera tensor is edited in place
+    or reassigned (the cache is keyed on tensor identity + _version)."""
+    import holo_diffusion_amd as hda
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    moved = cams.to("cpu")
+    T0 = moved.host()[1].clone()
+    moved.T[0, 2] += 1.0
+    assert torch.equal(moved.host()[1][0], T0[0] + torch.tensor([0.0, 0.0, 1.0]))
+    moved.focal_length = torch.full_like(moved.focal_length, 2.0)
+    assert float(moved.host()[2][0, 0]) == 2.0
+    sub = moved[[1, 2]]
+    sub.R.mul_(-1.0)
+    assert torch.equal(sub.host()[0], -moved.host()[0][[1, 2]])

@@ -36,6 +36,17 @@ for c in (hda.HoloDiffusionModel, hda.SimpleUnet3D, hda.HoloVoxelGridImplicitFun
 # the package registry agrees
 assert hda.registry.get(ImplicitronModelBase, "HoloDiffusionModel") is hda.HoloDiffusionModel
 
+# a config-only class that shares its NAME with a PyTorch3D class stays out of PyTorch3D's registry (which overwrites
+# silently): Implicitron's own AngleWeightedReductionFeatureAggregator must survive the import of this package ...
+from pytorch3d.implicitron.models.view_pooler.feature_aggregator import FeatureAggregatorBase
+own = p3d_registry.get(FeatureAggregatorBase, "AngleWeightedReductionFeatureAggregator")
+assert getattr(own, "IS_PYTORCH3D_OWN", False) and hasattr(own, "forward"), own
+# ... while the package resolves the name to its own parameter holder (a member of PyTorch3D's class tree)
+from holo_diffusion_amd.viewpool import AngleWeightedReductionFeatureAggregator as mine, ViewPooler
+assert hda.registry.get(FeatureAggregatorBase, "AngleWeightedReductionFeatureAggregator") is mine and mine is not own
+assert issubclass(mine, FeatureAggregatorBase)
+assert type(ViewPooler().feature_aggregator) is mine
+
 # instantiation goes through PyTorch3D's dataclass processing (ReplaceableBase.__new__) and still builds the plugin
 model = hda.HoloDiffusionModel(resol=8, feature_size=16, render_image_width=12, render_image_height=10,
                                net_3d_SimpleUnet3D_args=dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(2,)),

@@ -126,3 +126,13 @@ def test_model_forward_from_source_views():
     m2.image_feature_extractor = lambda rgb, fg: dfeats
     p3 = m2(camera=cams, image_rgb=torch.zeros(n_src + 1, 3, 8, 8, device=gu.DEV))
     assert torch.equal(p3["images_render"], preds["images_render"])
+    # a mixed-sequence batch (safe_slice_sources, holo_diffusion_model.py:276-298): only the frames of the FIRST frame's
+    # sequence, minus the target, are pooled
+    names = ["seq_a", "seq_a", "seq_b", "seq_a", "seq_b"]
+    feats5, _ = _synthetic_views(n_src + 1, 91)
+    d5 = {k: v.to(gu.DEV) for k, v in feats5.items()}
+    p4 = m2(camera=cams, image_features=d5, sequence_name=names)
+    vf4 = m2.pool_views_to_voxel_features({k: v[[1, 3]] for k, v in d5.items()}, cams[[1, 3]])
+    assert torch.equal(m2(camera=cams[0], voxel_features=vf4)["images_render"], p4["images_render"])
+    p5 = m2(camera=cams, image_features=d5)  # no names: every frame after the target is a source
+    assert not torch.equal(p5["images_render"], p4["images_render"])
