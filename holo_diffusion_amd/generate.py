@@ -218,21 +218,22 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
                                      up: Tuple[float, float, float] = CANONICAL_CO3D_UP_AXIS,
                                      camera_elevation: float = -30.0 * (2 * math.pi / 360),
                                      progressive_sampling_steps_per_render: int = -1, save_frames: bool = True,
-                                     device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+                                     device: Optional[torch.device] = None, load_fn=None) -> Dict[str, torch.Tensor]:
     """``generate_samples(exp_dir=...)`` of the reference script (generate_samples.py:37-138) on the HIP path:
     experiment directory -> model (``checkpoint.load_experiment``) -> sharded sampling + fly-around renders.
 
     Output stage: rank 0 writes ``<output_directory>/sample_%05d_frames.pt`` (images / depths / masks of the
     fly-around as tensors) and, through ``flyaround_output``, one directory of displayable frames per key; video
     encoding and visdom are outside this path."""
-    from .checkpoint import load_experiment
+    if load_fn is None:
+        from .checkpoint import load_experiment as load_fn  # ``load_fn``: same signature (tests inject a stand-in)
     rank, world = dist_info()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     if output_directory is None:
         folder = "generated_samples" if progressive_sampling_steps_per_render == -1 else "generated_samples_denoising"
         output_directory = os.path.join(exp_dir, folder)
-    model, report = load_experiment(exp_dir, render_size=render_size, device=device)
+    model, report = load_fn(exp_dir, render_size=render_size, device=device)
     if not (model.net_3d_enabled and model.diffusion_enabled):
         raise ValueError("Can generate random samples only from a trained HoloDiffusion model "
                          "(net_3d_enabled and diffusion_enabled)")
@@ -249,3 +250,85 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
             export_flyaround_frames({k: v[i] for k, v in out.items()}, output_directory, f"sample_{i:05d}")
     out["load_report"] = report
     return out
+
+
+# ---- command line: `python -m holo_diffusion_amd.generate exp_dir=... key=value ...` ------------------------------
+# OmegaConf-free counterpart of the reference script's `main()` (generate_samples.py:141-149): the arguments are the
+# keyword arguments of `generate_samples` (generate_samples.py:37-51) as `key=value` pairs (values parsed as YAML, like
+# OmegaConf.from_cli).  Launched under `torch.distributed.run` it is the multi-GPU product entry of SURVEY.md 8e: one
+# process per GPU, `init_process_group("nccl")` (= RCCL over xGMI), `set_device(LOCAL_RANK)`, samples sharded over the
+# ranks, one all_gather of the frames at the end.
+CLI_DEFAULTS = dict(exp_dir="", output_directory=None, render_size=None, video_size=(256, 256), camera_path="simple_360",
+                    n_eval_cameras=25 * 3, num_samples=2, seed=3, trajectory_scale=1.3, up=CANONICAL_CO3D_UP_AXIS,
+                    camera_elevation=-30.0 * (2 * math.pi / 360), progressive_sampling_steps_per_render=-1,
+                    save_voxel_features=True)
+
+
+def parse_cli(argv: Sequence[str]) -> Dict[str, object]:
+    import yaml
+    cfg = dict(CLI_DEFAULTS)
+    for a in argv:
+        if "=" not in a:
+            raise SystemExit(f"generate: expected key=value, got '{a}' (keys: {', '.join(CLI_DEFAULTS)})")
+        k, v = a.split("=", 1)
+        if k not in CLI_DEFAULTS:
+            raise SystemExit(f"generate: unknown argument '{k}' (keys: {', '.join(CLI_DEFAULTS)})")
+        val = yaml.safe_load(v) if v != "" else ""
+        if isinstance(CLI_DEFAULTS[k], tuple) and isinstance(val, list):
+            val = tuple(val)
+        cfg[k] = val
+    if cfg["render_size"] is not None:
+        cfg["render_size"] = tuple(int(x) for x in cfg["render_size"])
+    return cfg
+
+
+def init_distributed() -> Tuple[int, int, torch.device]:
+    """One process per GPU under torchrun: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; backend
+    `nccl` (RCCL) on GPUs, `gloo` without (CPU test rigs).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    if use_gpu:
+        torch.cuda.set_device(local)
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if use_gpu:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    return rank, world, device
+
+
+def main(argv: Optional[Sequence[str]] = None, load_fn=None) -> int:
+    import sys
+    cfg = parse_cli(sys.argv[1:] if argv is None else argv)
+    if not cfg["exp_dir"]:
+        raise SystemExit("generate: exp_dir=<experiment directory> is required")
+    if cfg["camera_path"] != "simple_360":
+        raise SystemExit("generate: camera_path must be 'simple_360' (the sampling trajectory, flyaround.py:176-184)")
+    rank, world, device = init_distributed()
+    try:
+        with torch.no_grad():
+            out = generate_samples_from_experiment(
+                cfg["exp_dir"], output_directory=cfg["output_directory"], render_size=cfg["render_size"],
+                n_eval_cameras=int(cfg["n_eval_cameras"]), num_samples=int(cfg["num_samples"]), seed=int(cfg["seed"]),
+                up=tuple(cfg["up"]), camera_elevation=float(cfg["camera_elevation"]),
+                progressive_sampling_steps_per_render=int(cfg["progressive_sampling_steps_per_render"]), device=device,
+                load_fn=load_fn)
+        if rank == 0:
+            img = out["images_render"]
+            print(f"generate: {int(cfg['num_samples'])} samples x {int(cfg['n_eval_cameras'])} frames "
+                  f"{tuple(img.shape[-2:])} on {world} rank(s), backend "
+                  f"{dist.get_backend() if world > 1 else 'none'}")
+    finally:
+        if world > 1 and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

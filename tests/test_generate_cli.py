@@ -1,0 +1,67 @@
+"""The multi-GPU product entry `python -m holo_diffusion_amd.generate` (generate_samples.py:37-51,141-149 of the
+reference as an OmegaConf-free key=value CLI): argument parsing on the host, and the whole entry at world size 2 over
+gloo with a stand-in model (tests/support/generate_cli_stub.py) - on the GPU node the same entry runs over RCCL."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import yaml
+
+from holo_diffusion_amd import generate as gen
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parse_cli_mirrors_generate_samples_arguments():
+    cfg = gen.parse_cli(["exp_dir=/x/y", "n_eval_cameras=40", "render_size=[64,48]", "num_samples=8", "seed=11",
+                         "progressive_sampling_steps_per_render=2", "up=[0.0,-1.0,0.0]"])
+    assert cfg["exp_dir"] == "/x/y" and cfg["n_eval_cameras"] == 40 and cfg["render_size"] == (64, 48)
+    assert cfg["num_samples"] == 8 and cfg["seed"] == 11 and cfg["up"] == (0.0, -1.0, 0.0)
+    assert cfg["camera_path"] == "simple_360" and cfg["video_size"] == (256, 256)  # defaults of generate_samples.py:37-51
+    assert gen.parse_cli([])["n_eval_cameras"] == 75 and gen.parse_cli([])["up"] == gen.CANONICAL_CO3D_UP_AXIS
+    with pytest.raises(SystemExit):
+        gen.parse_cli(["no_such_key=1"])
+    with pytest.raises(SystemExit):
+        gen.parse_cli(["positional"])
+    with pytest.raises(SystemExit):
+        gen.main([])  # exp_dir is required
+
+
+def _experiment(tmp_path):
+    from tests.test_checkpoint_loading import _expconfig
+    d = tmp_path / "exp"
+    d.mkdir()
+    with open(d / "expconfig.yaml", "w") as f:
+        yaml.safe_dump(_expconfig(), f)
+    return str(d)
+
+
+def _run(cmd, env):
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    return res.stdout
+
+
+def test_generate_cli_world2_gloo_equals_single_process(tmp_path):
+    exp = _experiment(tmp_path)
+    script = os.path.join(REPO, "tests", "support", "generate_cli_stub.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    args = ["num_samples=3", "n_eval_cameras=2", "render_size=[12,10]", "seed=5"]
+    port = 29600 + os.getpid() % 1500
+    out2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                 "127.0.0.1", "--master-port", str(port), script, f"exp_dir={exp}",
+                 f"output_directory={tmp_path / 'two'}"] + args, env)
+    assert "on 2 rank(s), backend gloo" in out2
+    out1 = _run([sys.executable, script, f"exp_dir={exp}", f"output_directory={tmp_path / 'one'}"] + args, env)
+    assert "on 1 rank(s)" in out1
+    for i in range(3):  # per-sample seeds: a sample is the same whichever rank drew it
+        a = torch.load(str(tmp_path / "two" / f"sample_{i:05d}_frames.pt"))
+        b = torch.load(str(tmp_path / "one" / f"sample_{i:05d}_frames.pt"))
+        assert a["images_render"].shape == (2, 3, 10, 12)
+        for k in ("images_render", "depths_render", "masks_render"):
+            assert torch.equal(a[k], b[k]), (i, k)
+    a0 = torch.load(str(tmp_path / "two" / "sample_00000_frames.pt"))["images_render"]
+    a1 = torch.load(str(tmp_path / "two" / "sample_00001_frames.pt"))["images_render"]
+    assert not torch.equal(a0, a1)
