@@ -247,8 +247,10 @@ def ea_raymarch(dens: torch.Tensor, feats: torch.Tensor, lengths: torch.Tensor, 
     return rgb, depth, opac, w
 
 
-def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, eps: float = 1e-5) -> torch.Tensor:
-    """Deterministic inverse-CDF sampling (pytorch3d sample_pdf, det=True)."""
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, eps: float = 1e-5,
+               diag: Optional[dict] = None) -> torch.Tensor:
+    """Deterministic inverse-CDF sampling (pytorch3d sample_pdf, det=True).  ``diag`` (test diagnostics) receives the
+    raw ``denom = cdf_above - cdf_below`` of every sample BEFORE the ``denom < eps -> 1`` switch."""
     weights = weights + eps
     pdf = weights / weights.sum(dim=-1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
@@ -260,14 +262,16 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, eps: f
     cdf_b, cdf_a = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
     bin_b, bin_a = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
     denom = cdf_a - cdf_b
+    if diag is not None:
+        diag["denom"] = denom.clone()
     denom = torch.where(denom < eps, torch.ones_like(denom), denom)
     t = (u - cdf_b) / denom
     return bin_b + t * (bin_a - bin_b)
 
 
-def refine_lengths(lengths: torch.Tensor, weights: torch.Tensor, cfg: RenderCfg) -> torch.Tensor:
+def refine_lengths(lengths: torch.Tensor, weights: torch.Tensor, cfg: RenderCfg, diag: Optional[dict] = None) -> torch.Tensor:
     mid = torch.lerp(lengths[..., 1:], lengths[..., :-1], 0.5)
-    z = sample_pdf(mid, weights[..., 1:-1], cfg.n_pts_fine, cfg.sample_pdf_eps)
+    z = sample_pdf(mid, weights[..., 1:-1], cfg.n_pts_fine, cfg.sample_pdf_eps, diag)
     return torch.sort(torch.cat((lengths, z), dim=-1), dim=-1)[0]
 
 
@@ -279,17 +283,18 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
     -> refiner -> fine pass (holo_multipass_ea.py:79-125).  Per-ray outputs: rgb (n,3), depth (n,1), mask (n,1), the
     coarse-pass rgb_c / depth_c / mask_c and the sorted fine lengths; with ``with_normals`` also the rendered normals
     of both passes, sum_i w_i n_i (holo_multipass_ea.py:105-109)."""
-    keys = ["rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c", "fine_lengths"] + (["normals", "normals_c"] if with_normals else [])
+    keys = ["rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c", "fine_lengths", "pdf_denom"] + (["normals", "normals_c"] if with_normals else [])
     outs = {k: [] for k in keys}
     for s in range(0, origins.shape[0], chunk_rays):
         o, d, l = origins[s:s + chunk_rays], dirs[s:s + chunk_rays], lengths[s:s + chunk_rays]
         dens, col = implicit_function(grid, sd, o, d, l, cfg, prefix)
         rgb_c, dep_c, msk_c, w = ea_raymarch(dens, col, l, cfg)
-        lf = refine_lengths(l, w, cfg)
+        diag = {}
+        lf = refine_lengths(l, w, cfg, diag)
         dens, col = implicit_function(grid, sd, o, d, lf, cfg, prefix)
         rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg)
         vals = [("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c), ("mask_c", msk_c),
-                ("fine_lengths", lf)]
+                ("fine_lengths", lf), ("pdf_denom", diag["denom"])]
         if with_normals:
             n_c = implicit_normals(grid, sd, o[:, None, :] + l[:, :, None] * d[:, None, :], cfg, prefix)
             n_f = implicit_normals(grid, sd, o[:, None, :] + lf[:, :, None] * d[:, None, :], cfg, prefix)
