@@ -18,6 +18,7 @@ Host-side torch code on small frame tensors; nothing here is on the measured hot
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Dict, Optional, Sequence
 
@@ -57,18 +58,41 @@ def make_shaded_from_normals(n: torch.Tensor, mask: torch.Tensor, diffuse_streng
     return (shading_ambient * mask + (1 - mask)).clamp(0.0, 1.0)
 
 
+def stack_images(ims: torch.Tensor, size=None) -> torch.Tensor:
+    """``_stack_images`` (flyaround.py:490-502): a batch of source images tiled into a ceil(sqrt(n))^2 mosaic."""
+    ba = ims.shape[0]
+    side = int(math.ceil(math.sqrt(ba)))
+    n_add = side * side - ba
+    if n_add > 0:
+        ims = torch.cat((ims, torch.zeros_like(ims[:1]).repeat(n_add, 1, 1, 1)))
+    ims = ims.view(side, side, *ims.shape[1:])
+    cated = torch.cat([torch.cat(list(row), dim=2) for row in ims], dim=1)
+    if size is not None:
+        cated = Fu.interpolate(cated[None], size=size, mode="bilinear")[0]
+    return cated.clamp(0.0, 1.0)
+
+
 def images_from_preds(preds: Dict[str, torch.Tensor],
-                      extract_keys: Sequence[str] = ("images_render", "masks_render", "depths_render")
+                      extract_keys: Sequence[str] = ("image_rgb", "images_render", "fg_probability", "masks_render",
+                                                     "depths_render", "depth_map", "_all_source_images")
                       ) -> Dict[str, torch.Tensor]:
-    """``_images_from_preds`` for the keys the HIP path produces: every entry becomes an (N,3,H,W) CPU tensor.
-    ``_shaded_depth_render`` needs ``normals_render`` (flyaround.py:440-445)."""
+    """``_images_from_preds`` (flyaround.py:422-488, same default keys): every entry becomes an (N,3,H,W) CPU tensor;
+    keys the predictions lack are skipped.  ``_all_source_images`` tiles ``image_rgb[1:]`` into one mosaic (:437-439);
+    ``_shaded_depth_render`` needs ``normals_render`` (:440-445; the checked-against-the-reference-body fixtures are
+    tests/golden/ref_images_from_preds.npz)."""
     imout = {}
     for k in extract_keys:
+        if k == "_all_source_images" and preds.get("image_rgb") is not None:
+            v = stack_images(preds["image_rgb"][1:].detach().float().cpu().clone(), None)[None]
+            imout[k] = v.repeat(1, 3, 1, 1) if v.shape[1] == 1 else v
+            continue
         if k == "_shaded_depth_render":
             if preds.get("normals_render") is None:
                 continue  # (the depth-map rasterisation fallback of the reference needs PyTorch3D's renderer)
+            # (the reference takes the FIRST mask, `preds["masks_render"][:1]`, and broadcasts it: its predictions hold one
+            # frame; per-frame shading of a stack of frames is `export_flyaround_frames` below)
             v = make_shaded_from_normals(preds["normals_render"].detach().float().cpu().clone(),
-                                         preds["masks_render"].detach().float().cpu().clone())
+                                         preds["masks_render"][:1].detach().float().cpu().clone())
             imout[k] = v.repeat(1, 3, 1, 1)
             continue
         if k not in preds or preds[k] is None:
@@ -99,7 +123,13 @@ def export_flyaround_frames(frames: Dict[str, torch.Tensor], out_dir: str, seque
     frames per key, named like the reference's per-key clips (``<sequence_name>_<key>``).  Returns key -> directory."""
     default_keys = ("images_render", "masks_render", "depths_render") + (
         ("_shaded_depth_render",) if frames.get("normals_render") is not None else ())
-    ims = images_from_preds(frames, tuple(keys) if keys else default_keys)
+    want = tuple(keys) if keys else default_keys
+    ims = images_from_preds(frames, tuple(k for k in want if k != "_shaded_depth_render"))
+    if "_shaded_depth_render" in want and frames.get("normals_render") is not None:  # frame by frame: each its own mask
+        ims["_shaded_depth_render"] = torch.cat([
+            images_from_preds({"normals_render": frames["normals_render"][i:i + 1],
+                               "masks_render": frames["masks_render"][i:i + 1]}, ("_shaded_depth_render",))["_shaded_depth_render"]
+            for i in range(frames["normals_render"].shape[0])])
     dirs = {}
     for k, v in ims.items():
         d = os.path.join(out_dir, f"{sequence_name}_{k}")

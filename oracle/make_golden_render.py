@@ -8,6 +8,11 @@ PyTorch3D at module top, so none of them can be imported; but three pieces are p
                                      the hidden activation lands on the LAST layer only)
   * ``RenderMLP``                    holo_diffusion/holo_voxel_grid_implicit_function.py:48-129
   * ``_make_shaded_from_normals``    holo_diffusion/utils/render_utils/flyaround.py:400-420
+  * ``RenderMLP.get_normals``        holo_voxel_grid_implicit_function.py:131-145 (autograd of the summed density)
+  * ``HoloVoxelGridImplicitFunction.forward``  :182-269 (the in-tree body: dummy directions, normalisation, expansion over the
+                                     points, [colour | view-point independent features] concat, aux normals)
+  * ``MLPMeanFeatureAggregator`` + ``_get_point_to_source_camera_ray_dirs``   custom_modules.py:162-334
+  * ``_images_from_preds`` + ``_stack_images``                               flyaround.py:422-500
 
 This script takes their source text out of the reference files with ``ast`` (nothing is copied into the repository),
 executes exactly those class / function bodies, and records inputs and outputs into ``tests/golden/ref_render_mlp.npz``
@@ -20,6 +25,13 @@ UNPINNED) is only scaffolding:
   * ``_xavier_init``       -> ``torch.nn.init.xavier_uniform_`` (irrelevant: every tensor is overwritten by synthetic weights)
   * ``HarmonicEmbedding``  -> the oracle's restatement (``oracle.render_oracle.harmonic_embedding``: sin | cos | input,
                               frequencies 2^k) - the direction-embedding ORDER therefore remains unpinned
+  * ``VolumeLocator`` / ``FullResolutionVoxelGrid.evaluate_world`` / ``ray_bundle_to_ray_points`` -> the oracle's
+                              ``trilinear`` (cross-checked against ``F.grid_sample``) and ``o + l d``
+  * ``registry`` / ``ImplicitFunctionBase`` / ``FeatureAggregatorBase`` / ``run_auto_creation`` -> no-op registration, plain
+                              base classes carrying PyTorch3D's three aggregator fields, ``create_render_mlp()``
+  * ``_mask_target_view_features`` / ``_get_view_sampling_mask`` / ``_avgmaxstd_reduction_function`` /
+    ``cameras_points_cartesian_product`` -> restated from the published PyTorch3D 0.7.4 source (wmean eps 1e-2)
+  * ``make_depth_image``   -> ``holo_diffusion_amd.flyaround_output.make_depth_image`` (restated, UNPINNED)
 
 Usage:  python oracle/make_golden_render.py
 """
@@ -109,6 +121,251 @@ def build_namespace() -> dict:
     return ns
 
 
+# ---- stand-ins for the second group (implicit function, aggregator, output stage) ----------------------------------
+class _Registry:
+    @staticmethod
+    def register(cls):
+        return cls
+
+
+class ImplicitFunctionBase:
+    pass
+
+
+class FeatureAggregatorBase:  # pytorch3d FeatureAggregatorBase's three fields
+    exclude_target_view: bool = True
+    exclude_target_view_mask_features: bool = True
+    concatenate_output: bool = True
+
+
+class ReductionFunction(enum.Enum):
+    AVG = "avg"
+    MAX = "max"
+    STD = "std"
+    STD_AVG = "std_avg"
+
+
+class VolumeLocator:
+    def __init__(self, batch_size, grid_sizes, device, voxel_size):
+        assert batch_size == 1 and len(set(grid_sizes)) == 1
+        self.cfg = ro.RenderCfg(resol=grid_sizes[0], volume_extent=voxel_size * grid_sizes[0])
+
+
+class FullResolutionVoxelGridValues:
+    def __init__(self, voxel_grid):
+        self.voxel_grid = voxel_grid
+
+
+class FullResolutionVoxelGrid:
+    def __init__(self, n_features):
+        self.n_features = n_features
+
+    def evaluate_world(self, points, values, locator):  # (1,P,3) -> (1,P,C)
+        return ro.trilinear(values.voxel_grid, points[0], locator.cfg)[None]
+
+
+class RayBundle:
+    def __init__(self, origins, directions, lengths):
+        self.origins, self.directions, self.lengths = origins, directions, lengths
+
+
+def ray_bundle_to_ray_points(rb):
+    return rb.origins[..., None, :] + rb.lengths[..., :, None] * rb.directions[..., None, :]
+
+
+class Cameras:
+    def __init__(self, R, T):
+        self.R, self.T = R, T
+
+    def __getitem__(self, idx):
+        return Cameras(self.R[idx], self.T[idx])
+
+
+def cameras_points_cartesian_product(camera, pts):  # pytorch3d view_sampler.py
+    n_cameras, batch_pts = camera.R.shape[0], pts.shape[0]
+    pts_rep = pts.repeat(n_cameras, *[1 for _ in pts.shape[1:]])
+    idx_cams = torch.arange(n_cameras)[:, None].expand(n_cameras, batch_pts).reshape(batch_pts * n_cameras)
+    return camera[idx_cams], pts_rep
+
+
+def _mask_target_view_features(feats_sampled):  # pytorch3d feature_aggregator.py
+    one = next(iter(feats_sampled.values()))
+    pts_batch, n_cameras = one.shape[:2]
+    mask = 1.0 - torch.eye(pts_batch, n_cameras)[:, :, None, None]
+    return {k: f * mask if k == "mask" or k.endswith("mask") else f for k, f in feats_sampled.items()}
+
+
+def _get_view_sampling_mask(n_cameras, pts_batch, device, exclude_target_view):
+    return -torch.eye(pts_batch, n_cameras) + 1.0 if exclude_target_view else torch.ones(pts_batch, n_cameras)
+
+
+def _avgmaxstd_reduction_function(x, w, dim=1, reduction_functions=()):
+    assert list(reduction_functions) == [ReductionFunction.AVG]
+    return (x * w[..., None]).sum(dim=dim, keepdim=True) / w[..., None].sum(dim=dim, keepdim=True).clamp(1e-2)  # wmean
+
+
+def build_namespace2(ns: dict) -> dict:
+    import logging
+    from typing import Any, List, NamedTuple
+    from holo_diffusion_amd.flyaround_output import make_depth_image
+    ns = dict(ns)
+    ns.update(registry=_Registry, ImplicitFunctionBase=ImplicitFunctionBase, FeatureAggregatorBase=FeatureAggregatorBase,
+              ReductionFunction=ReductionFunction, VolumeLocator=VolumeLocator, VoxelGridBase=object,
+              VoxelGridValuesBase=object, FullResolutionVoxelGrid=FullResolutionVoxelGrid,
+              FullResolutionVoxelGridValues=FullResolutionVoxelGridValues, ImplicitronRayBundle=RayBundle,
+              ray_bundle_to_ray_points=ray_bundle_to_ray_points, CamerasBase=Cameras, NamedTuple=NamedTuple, Any=Any,
+              List=List, run_auto_creation=lambda self: self.create_render_mlp(),
+              cameras_points_cartesian_product=cameras_points_cartesian_product,
+              _mask_target_view_features=_mask_target_view_features, _get_view_sampling_mask=_get_view_sampling_mask,
+              _avgmaxstd_reduction_function=_avgmaxstd_reduction_function, make_depth_image=make_depth_image,
+              Fu=torch.nn.functional, np=np, logger=logging.getLogger("ref"))
+    exec(source_of(os.path.join(REF, "holo_voxel_grid_implicit_function.py"),
+                   ["LocalizedVoxelGrid", "HoloVoxelGridImplicitFunction"]), ns)
+    exec(source_of(os.path.join(REF, "custom_modules.py"),
+                   ["LazyLinearWithXavierInit", "MLPMeanFeatureAggregator", "_get_point_to_source_camera_ray_dirs"]), ns)
+    exec(source_of(os.path.join(REF, "utils", "render_utils", "flyaround.py"), ["_images_from_preds", "_stack_images"]), ns)
+    return ns
+
+
+def make_implicit_function(ns, **fields):
+    cls = type("HoloVoxelGridImplicitFunction", (ns["HoloVoxelGridImplicitFunction"],), dict(fields, render_mlp_args={}))
+    obj = cls.__new__(cls)
+    torch.nn.Module.__init__(obj)
+    obj.__post_init__()  # run_auto_creation -> create_render_mlp (:162-172)
+    return obj.eval()
+
+
+def golden_render_mlp_defaults(ns, out):
+    """RenderMLP() with the reference's DEFAULTS (input_dims 128, 64 view-point independent features): the configuration
+    of the reference's own tests/test_voxel_grid_implicit_function.py:17-26."""
+    mlp = ns["RenderMLP"]().eval()
+    assert mlp.input_dims == 128 and mlp.output_vp_independent_feature_dims == 64
+    rcfg = ro.RenderCfg(feature_size=128, feature_dim=64)
+    shapes = ro.render_mlp_param_shapes(rcfg)
+    assert {k: tuple(v.shape) for k, v in mlp.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    assert [type(m).__name__ for m in mlp._feature_net.mlp[0]] == ["Linear", "LeakyReLU"]
+    sd = synth_state_dict(shapes, 4321 + 128)
+    sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(5, (64,)))
+    mlp.load_state_dict(sd)
+    feats = torch.tanh(torch.from_numpy(np_noise(228, (2, 5, 7, 128))))
+    dirs = torch.nn.functional.normalize(torch.from_numpy(np_noise(328, (2, 5, 3))), dim=-1)[..., None, :].expand(2, 5, 7, 3).contiguous()
+    with torch.no_grad():
+        dens, col, vp = mlp(feats, dirs)
+    o_dens, o_col = ro.render_mlp(sd, feats, dirs, rcfg)
+    o_vp = ro.render_mlp_vp_features(sd, feats)
+    for a, b, name in ((o_dens, dens, "dens"), (o_col, col, "col"), (o_vp, vp, "vp")):
+        assert torch.allclose(a, b, rtol=0, atol=3e-6), (name, (a - b).abs().max())
+    out.update({"C128.features": feats.numpy(), "C128.dirs": dirs.numpy(), "C128.densities": dens.numpy(),
+                "C128.colours": col.numpy(), "C128.vp_features": vp.numpy(), "C128.seed": np.array(4321 + 128)})
+    print(f"RenderMLP defaults (C=128, 64 vp features): oracle vs reference class max|d| dens "
+          f"{float((o_dens - dens).abs().max()):.2e} colour {float((o_col - col).abs().max()):.2e} vp {float((o_vp - vp).abs().max()):.2e}")
+
+
+def golden_implicit_function(ns):
+    """HoloVoxelGridImplicitFunction.forward (both entries) + RenderMLP.get_normals, executed from the reference source."""
+    out = {}
+    for tag, R, C, Fd in (("small", 6, 16, 8), ("defaults", 8, 128, 64)):
+        fn = make_implicit_function(ns, resol=R, n_hidden=C, feature_dim=Fd, render_normals=(tag == "small"))
+        rcfg = ro.RenderCfg(resol=R, feature_size=C, feature_dim=Fd)
+        shapes = ro.render_mlp_param_shapes(rcfg)
+        sd = synth_state_dict(shapes, 700 + C)
+        sd["_density_net.mlp.3.0.bias"][-1] += 0.05
+        sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(6, (Fd,)))
+        fn.render_mlp.load_state_dict(sd)
+        grid = torch.tanh(torch.from_numpy(np_noise(40 + C, (1, C, R, R, R))))
+        pts = (torch.from_numpy(np_noise(41 + C, (2, 3, 4, 3))) * 2.2).contiguous()  # some points outside the volume
+        dens, feats, aux = fn(pts_3d=pts, voxel_grid_features=grid)
+        dens, feats = dens.detach(), feats.detach()
+        o_dens, o_feats = ro.implicit_function_pts(grid, sd, pts, rcfg)
+        assert torch.allclose(o_dens, dens, atol=3e-6) and torch.allclose(o_feats, feats, atol=3e-6), \
+            ((o_dens - dens).abs().max(), (o_feats - feats).abs().max())
+        out.update({f"{tag}.cfg": np.array([R, C, Fd]), f"{tag}.seed": np.array(700 + C), f"{tag}.grid_seed": np.array(40 + C),
+                    f"{tag}.pts": pts.numpy(), f"{tag}.densities": dens.numpy(), f"{tag}.features": feats.numpy()})
+        if "normals" in aux:
+            nrm = aux["normals"].detach()
+            o_n = ro.implicit_normals(grid, sd, pts, rcfg)
+            assert torch.allclose(o_n, nrm, atol=1e-5), (o_n - nrm).abs().max()
+            out[f"{tag}.normals"] = nrm.numpy()
+            print(f"get_normals ({tag}): oracle vs reference max|d| {float((o_n - nrm).abs().max()):.2e}")
+        # the ray-bundle entry (:199-201,227-242)
+        o = torch.from_numpy(np_noise(42 + C, (2, 3, 3)))
+        d = torch.from_numpy(np_noise(43 + C, (2, 3, 3)))
+        l = torch.linspace(0.2, 3.0, 5)[None, None].expand(2, 3, 5).contiguous()
+        dens_r, feats_r, _ = fn(ray_bundle=RayBundle(o, d, l), voxel_grid_features=grid)
+        od, oc = ro.implicit_function(grid, sd, o.reshape(-1, 3), d.reshape(-1, 3), l.reshape(-1, 5), rcfg)
+        assert torch.allclose(od.reshape(2, 3, 5, 1), dens_r.detach(), atol=3e-6)
+        assert torch.allclose(oc.reshape(2, 3, 5, 3), feats_r.detach()[..., :3], atol=3e-6)
+        out.update({f"{tag}.ray_origins": o.numpy(), f"{tag}.ray_directions": d.numpy(), f"{tag}.ray_lengths": l.numpy(),
+                    f"{tag}.ray_densities": dens_r.detach().numpy(), f"{tag}.ray_features": feats_r.detach().numpy()})
+        print(f"HoloVoxelGridImplicitFunction.forward ({tag}: R={R} C={C} feature_dim={Fd}): oracle vs reference max|d| "
+              f"dens {float((o_dens - dens).abs().max()):.2e} features {float((o_feats - feats).abs().max()):.2e}")
+    np.savez_compressed(os.path.join(GOLD, "ref_implicit_function.npz"), **out)
+
+
+def golden_mlp_mean(ns):
+    from oracle import viewpool_oracle as vo
+    out = {}
+    n_src, P, Cs = 4, 37, (16, 1, 3)
+    D = sum(Cs) + 21
+    cls = type("MLPMeanFeatureAggregator", (ns["MLPMeanFeatureAggregator"],),
+               dict(exclude_target_view=False, exclude_target_view_mask_features=False, n_hidden=32, dim_out=24,
+                    checkpointed_mlp=True))
+    agg = cls.__new__(cls)
+    agg.__post_init__()
+    agg.eval()
+    cams = ro.simple_360_cameras(n_src, radius=6.0)
+    pts = (torch.from_numpy(np_noise(61, (1, P, 3))) * 1.5).contiguous()
+    feats = {f"f{i}": torch.tanh(torch.from_numpy(np_noise(62 + i, (1, n_src, P, c)))) for i, c in enumerate(Cs)}
+    for case, masks in (("ones", torch.ones(1, n_src, P, 1)),
+                        ("soft", torch.sigmoid(2.0 * torch.from_numpy(np_noise(70, (1, n_src, P, 1)))))):
+        with torch.no_grad():
+            agg(feats, masks, camera=Cameras(cams["R"], cams["T"]), pts=pts)  # materialises the LazyLinear layers
+            shapes = vo.mlp_mean_param_shapes(D, 32, 24)
+            assert {k: tuple(v.shape) for k, v in agg.state_dict().items()} == shapes, agg.state_dict().keys()
+            assert [type(m).__name__ for m in agg._mlp.mlp[0]] == ["Linear", "LeakyReLU"]
+            sd = synth_state_dict(shapes, 808)
+            for k in shapes:
+                if k.endswith("bias"):
+                    sd[k] = 0.1 * torch.from_numpy(np_noise(len(k), shapes[k]))
+            agg.load_state_dict(sd)
+            ref = agg(feats, masks, camera=Cameras(cams["R"], cams["T"]), pts=pts)  # (1,1,P,dim_out)
+            dirs = ns["_get_point_to_source_camera_ray_dirs"](Cameras(cams["R"], cams["T"]), pts)  # (1,n_src,P,3)
+        o_dirs = torch.stack([vo.ray_dirs_to_cameras(pts[0], cams["R"][v], cams["T"][v]) for v in range(n_src)])
+        assert torch.allclose(o_dirs, dirs[0], atol=1e-6), (o_dirs - dirs[0]).abs().max()
+        mine = vo.mlp_mean_aggregate([f[0] for f in feats.values()], o_dirs, masks[0, ..., 0], sd, 3)
+        assert torch.allclose(mine, ref[0, 0], atol=3e-6), (mine - ref[0, 0]).abs().max()
+        out[f"{case}.masks"] = masks.numpy()
+        out[f"{case}.aggregated"] = ref.numpy()
+        print(f"MLPMeanFeatureAggregator ({case} masks): oracle vs reference max|d| {float((mine - ref[0, 0]).abs().max()):.2e}")
+    out.update({"pts": pts.numpy(), "R": cams["R"].numpy(), "T": cams["T"].numpy(), "ray_dirs": dirs.numpy(),
+                "seed": np.array(808), "dims": np.array([n_src, P, 32, 24])})
+    out.update({f"feats.{k}": v.numpy() for k, v in feats.items()})
+    np.savez_compressed(os.path.join(GOLD, "ref_mlp_mean_aggregator.npz"), **out)
+
+
+def golden_images_from_preds(ns):
+    from holo_diffusion_amd.flyaround_output import images_from_preds
+    N, H, W = 2, 6, 8
+    preds = {"images_render": torch.sigmoid(torch.from_numpy(np_noise(81, (N, 3, H, W)))),
+             "masks_render": torch.sigmoid(3.0 * torch.from_numpy(np_noise(82, (N, 1, H, W)))),
+             "depths_render": 8.0 + 2.0 * torch.from_numpy(np_noise(83, (N, 1, H, W))),
+             "normals_render": torch.nn.functional.normalize(torch.from_numpy(np_noise(84, (N, 3, H, W))), dim=1),
+             "image_rgb": torch.sigmoid(torch.from_numpy(np_noise(85, (4, 3, H, W)))),
+             "fg_probability": torch.sigmoid(torch.from_numpy(np_noise(86, (N, 1, H, W)))),
+             "depth_map": 8.0 + torch.from_numpy(np_noise(87, (N, 1, 2 * H, 2 * W)))}
+    keys = ["image_rgb", "images_render", "fg_probability", "masks_render", "depths_render", "depth_map",
+            "_all_source_images", "_shaded_depth_render"]
+    ref = ns["_images_from_preds"]({k: v.clone() for k, v in preds.items()}, keys)
+    mine = images_from_preds({k: v.clone() for k, v in preds.items()}, keys)
+    assert set(ref) == set(mine) == set(keys), (set(ref), set(mine))
+    for k in keys:
+        assert torch.equal(ref[k], mine[k]), (k, (ref[k] - mine[k]).abs().max())
+    out = {f"preds.{k}": v.numpy() for k, v in preds.items()}
+    out.update({f"out.{k}": v.numpy() for k, v in ref.items()})
+    np.savez_compressed(os.path.join(GOLD, "ref_images_from_preds.npz"), **out)
+    print("_images_from_preds: bit-equal on", ", ".join(keys))
+
+
 def main():
     ns = build_namespace()
     out: Dict[str, np.ndarray] = {}
@@ -146,7 +403,12 @@ def main():
         out[f"C{C}.seed"] = np.array(4321 + C)
         print(f"RenderMLP C={C}: oracle vs reference class max|d| dens {float((o_dens - dens).abs().max()):.2e} "
               f"colour {float((o_col - col).abs().max()):.2e}")
+    golden_render_mlp_defaults(ns, out)
     np.savez_compressed(os.path.join(GOLD, "ref_render_mlp.npz"), **out)
+    ns2 = build_namespace2(ns)
+    golden_implicit_function(ns2)
+    golden_mlp_mean(ns2)
+    golden_images_from_preds(ns2)
 
     n = torch.nn.functional.normalize(torch.from_numpy(np_noise(7, (4, 3, 9, 13))), dim=1) * 0.9
     mask = torch.sigmoid(3.0 * torch.from_numpy(np_noise(8, (1, 1, 9, 13))))

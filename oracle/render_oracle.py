@@ -54,6 +54,7 @@ class RenderCfg:
     dnet_hidden_dim: int = 256
     dir_emb_dims: int = 4
     sample_pdf_eps: float = 1e-5
+    feature_dim: int = 0  # RenderMLP.output_vp_independent_feature_dims (0 inside HoloDiffusionModel, 64 by default)
 
 
 # ----------------------------------------------------------------------------
@@ -64,13 +65,17 @@ def render_mlp_param_shapes(cfg: RenderCfg, prefix: str = "") -> Dict[str, Tuple
     C, Hd = cfg.feature_size, cfg.dnet_hidden_dim
     demb = 3 * (2 * cfg.dir_emb_dims + 1)
     p = prefix
-    return {
+    shapes = {
         p + "_density_net.mlp.0.0.weight": (Hd, C), p + "_density_net.mlp.0.0.bias": (Hd,),
         p + "_density_net.mlp.1.0.weight": (Hd, Hd), p + "_density_net.mlp.1.0.bias": (Hd,),
         p + "_density_net.mlp.2.0.weight": (Hd, Hd + C), p + "_density_net.mlp.2.0.bias": (Hd,),
         p + "_density_net.mlp.3.0.weight": (Hd + 1, Hd), p + "_density_net.mlp.3.0.bias": (Hd + 1,),
         p + "_radiance_net.mlp.0.0.weight": (3, Hd + demb), p + "_radiance_net.mlp.0.0.bias": (3,),
     }
+    if cfg.feature_dim > 0:  # the view-point independent feature head (holo_voxel_grid_implicit_function.py:94-105)
+        shapes[p + "_feature_net.mlp.0.0.weight"] = (cfg.feature_dim, Hd)
+        shapes[p + "_feature_net.mlp.0.0.bias"] = (cfg.feature_dim,)
+    return shapes
 
 
 # ----------------------------------------------------------------------------
@@ -206,6 +211,32 @@ def render_mlp(sd: Dict[str, torch.Tensor], feats: torch.Tensor, dirs_normed: to
     e = harmonic_embedding(dirs_normed, cfg.dir_emb_dims)
     rad = F.leaky_relu(F.linear(torch.cat([mlp_feats, e], dim=-1), sd[r + "weight"], sd[r + "bias"]), 0.2)
     return dens, torch.sigmoid(rad)
+
+
+def render_mlp_vp_features(sd: Dict[str, torch.Tensor], feats: torch.Tensor, prefix: str = "") -> torch.Tensor:
+    """The third output of RenderMLP.forward (holo_voxel_grid_implicit_function.py:125-129): ``_feature_net`` - one Linear
+    (rnet_num_layers = 1) followed by the LeakyReLU the construction quirk attaches to a LAST layer - on the density
+    net's hidden features."""
+    p = prefix + "_density_net.mlp."
+    y = F.linear(feats, sd[p + "0.0.weight"], sd[p + "0.0.bias"])
+    y = F.linear(y, sd[p + "1.0.weight"], sd[p + "1.0.bias"])
+    y = torch.cat((y, feats), dim=-1)
+    y = F.linear(y, sd[p + "2.0.weight"], sd[p + "2.0.bias"])
+    y = F.leaky_relu(F.linear(y, sd[p + "3.0.weight"], sd[p + "3.0.bias"]), 0.2)
+    f = prefix + "_feature_net.mlp.0.0."
+    return F.leaky_relu(F.linear(y[..., :-1], sd[f + "weight"], sd[f + "bias"]), 0.2)
+
+
+def implicit_function_pts(grid, sd, pts, cfg: RenderCfg, prefix: str = ""):
+    """The ``pts_3d`` entry of HoloVoxelGridImplicitFunction.forward (holo_voxel_grid_implicit_function.py:182-269):
+    arbitrary world points (...,3), dummy all-ones directions (normalised) -> densities (...,1), features
+    (..., 3 + feature_dim) = [colour | view-point independent features]."""
+    feats = trilinear(grid, pts, cfg)
+    dn = F.normalize(torch.ones_like(pts), dim=-1)
+    dens, col = render_mlp(sd, feats, dn, cfg, prefix)
+    if cfg.feature_dim > 0:
+        col = torch.cat([col, render_mlp_vp_features(sd, feats, prefix)], dim=-1)
+    return dens, col
 
 
 def implicit_function(grid, sd, origins, dirs, lengths, cfg: RenderCfg, prefix: str = ""):

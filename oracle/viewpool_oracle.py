@@ -96,3 +96,58 @@ def voxel_features_from_views(feats: Dict[str, torch.Tensor], cams: dict, mapper
     agg = pool_views(feats, cams, resol, volume_extent, **kw)
     vf = F.linear(agg, mapper_w, mapper_b)                 # (R^3, F)
     return torch.tanh(vf.t().reshape(1, -1, resol, resol, resol))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MLPMeanFeatureAggregator (the REFERENCE's own aggregator, custom_modules.py:162-293; selected by configs/hydrant.yaml:184
+# and old_base_config.yaml:205).  Its body is plain torch and is executed from the reference source by
+# oracle/make_golden_render.py (fixtures tests/golden/ref_mlp_mean_aggregator.npz); the sampling in front of it
+# (ViewSampler) is PyTorch3D's and stays restated.
+# ---------------------------------------------------------------------------------------------------------------------
+def harmonic_embedding(x: torch.Tensor, n: int) -> torch.Tensor:
+    freqs = 2.0 ** torch.arange(n, dtype=torch.float32)
+    e = (x[..., None] * freqs).reshape(*x.shape[:-1], -1)
+    return torch.cat((e.sin(), e.cos(), x), dim=-1)
+
+
+def mlp_mean_param_shapes(in_dim: int, n_hidden: int = 128, dim_out: int = 128, prefix: str = "") -> Dict[str, tuple]:
+    """State-dict names of MLPMeanFeatureAggregator (custom_modules.py:179-196); ``in_dim`` = sum of the sampled
+    feature channels + 3 (2 n_harmonic_functions_ray + 1) (the two LazyLinear layers take their width from it)."""
+    p = prefix
+    return {p + "_first_sampled.weight": (n_hidden, in_dim), p + "_first_sampled.bias": (n_hidden,),
+            p + "_first_mean.weight": (n_hidden, in_dim), p + "_first_mean.bias": (n_hidden,),
+            p + "_last.weight": (dim_out, n_hidden), p + "_last.bias": (dim_out,),
+            p + "_mlp.mlp.0.0.weight": (n_hidden, n_hidden), p + "_mlp.mlp.0.0.bias": (n_hidden,)}
+
+
+def mlp_mean_aggregate(feats_sampled: Sequence[torch.Tensor], ray_dirs: torch.Tensor, weights: torch.Tensor,
+                       sd: Dict[str, torch.Tensor], n_harmonic: int = 3, prefix: str = "") -> torch.Tensor:
+    """``_mlp_pass`` (custom_modules.py:243-262) for one voxel batch.  feats_sampled: list of (n_src, P, C_k); ray_dirs
+    (n_src, P, 3) unit vectors point -> ... from the camera centres; weights (n_src, P).  Returns (P, dim_out)."""
+    x = torch.cat(list(feats_sampled) + [harmonic_embedding(ray_dirs, n_harmonic)], dim=-1) * weights[..., None]
+    mean = (x * weights[..., None]).sum(0, keepdim=True) / weights[..., None].sum(0, keepdim=True).clamp(1e-2)  # wmean
+    p = prefix
+    mlp_in = F.linear(x, sd[p + "_first_sampled.weight"], sd[p + "_first_sampled.bias"]) \
+        + F.linear(mean, sd[p + "_first_mean.weight"], sd[p + "_first_mean.bias"])
+    # MLPWithInputSkips(n_layers=1): the single layer IS the last one -> Linear + LeakyReLU(0.2) (custom_modules.py:108-112)
+    h = F.leaky_relu(F.linear(mlp_in, sd[p + "_mlp.mlp.0.0.weight"], sd[p + "_mlp.mlp.0.0.bias"]), 0.2)
+    out = F.linear(h, sd[p + "_last.weight"], sd[p + "_last.bias"])
+    return (out * torch.softmax(out[..., :1], dim=0)).sum(dim=0)
+
+
+def pool_views_mlp_mean(feats: Dict[str, torch.Tensor], cams: dict, sd: Dict[str, torch.Tensor], resol: int,
+                        volume_extent: float, n_harmonic: int = 3, eps_proj: float = 1e-2, prefix: str = "") -> torch.Tensor:
+    """ViewSampler (restated) + MLPMeanFeatureAggregator at the voxel centres: (R^3, dim_out)."""
+    pts = coord_grid(resol, volume_extent)
+    n = cams["R"].shape[0]
+    dirs = torch.stack([ray_dirs_to_cameras(pts, cams["R"][v], cams["T"][v]) for v in range(n)])
+    ndc = torch.stack([project_ndc(pts, cams["R"][v], cams["T"][v], cams["focal"][v], cams["pp"][v], eps_proj)
+                       for v in range(n)])
+    sampled = [torch.stack([ndc_grid_sample(f[v], ndc[v]) for v in range(n)]) for f in feats.values()]
+    w = torch.ones(n, pts.shape[0])  # masked_sampling false -> masks 1; exclude_target_view forced False (:114-116)
+    return mlp_mean_aggregate(sampled, dirs, w, sd, n_harmonic, prefix)
+
+
+def voxel_features_from_views_mlp_mean(feats, cams, sd, mapper_w, mapper_b, resol, volume_extent, **kw) -> torch.Tensor:
+    agg = pool_views_mlp_mean(feats, cams, sd, resol, volume_extent, **kw)
+    return torch.tanh(F.linear(agg, mapper_w, mapper_b).t().reshape(1, -1, resol, resol, resol))

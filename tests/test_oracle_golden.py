@@ -123,3 +123,97 @@ def test_shaded_from_normals_vs_reference(golden_dir):
     assert torch.equal(make_shaded_from_normals(n, m), ref)
     ims = images_from_preds({"normals_render": n, "masks_render": m}, ("_shaded_depth_render",))
     assert ims["_shaded_depth_render"].shape == (4, 3, 9, 13) and torch.equal(ims["_shaded_depth_render"][:, 1:2], ref)
+
+
+# ---- round 3: more of the render half executed from the reference source (oracle/make_golden_render.py) -------------
+def _implicit_sd(ro, R, C, Fd, seed):
+    from holo_diffusion_amd.weights import synth_state_dict
+    from oracle.common import np_noise
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, feature_dim=Fd)
+    sd = synth_state_dict(ro.render_mlp_param_shapes(rcfg), seed)
+    sd["_density_net.mlp.3.0.bias"][-1] += 0.05
+    sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(6, (Fd,)))
+    return rcfg, sd
+
+
+def test_render_mlp_defaults_vs_reference_class(golden_dir):
+    """RenderMLP() with the reference's DEFAULTS (128 input features, 64 view-point independent output features - the
+    configuration of holo_diffusion/tests/test_voxel_grid_implicit_function.py:17-26): densities, colours and the third
+    output against the reference class."""
+    from holo_diffusion_amd.weights import synth_state_dict
+    from oracle import render_oracle as ro
+    from oracle.common import np_noise
+    g = np.load(os.path.join(golden_dir, "ref_render_mlp.npz"))
+    rcfg = ro.RenderCfg(feature_size=128, feature_dim=64)
+    sd = synth_state_dict(ro.render_mlp_param_shapes(rcfg), int(g["C128.seed"]))
+    sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(5, (64,)))
+    feats, dirs = torch.from_numpy(g["C128.features"]), torch.from_numpy(g["C128.dirs"])
+    dens, col = ro.render_mlp(sd, feats, dirs, rcfg)
+    vp = ro.render_mlp_vp_features(sd, feats)
+    assert (dens - torch.from_numpy(g["C128.densities"])).abs().max() <= 3e-6
+    assert (col - torch.from_numpy(g["C128.colours"])).abs().max() <= 3e-6
+    assert vp.shape[-1] == 64 and (vp - torch.from_numpy(g["C128.vp_features"])).abs().max() <= 3e-6
+
+
+@pytest.mark.parametrize("tag", ["small", "defaults"])
+def test_implicit_function_forward_and_normals_vs_reference_body(golden_dir, tag):
+    """The in-tree body of HoloVoxelGridImplicitFunction.forward (holo_voxel_grid_implicit_function.py:182-269, both the
+    pts_3d and the ray-bundle entry) and RenderMLP.get_normals (:131-145), executed from the reference source."""
+    from oracle import render_oracle as ro
+    from oracle.common import np_noise
+    g = np.load(os.path.join(golden_dir, "ref_implicit_function.npz"))
+    R, C, Fd = (int(v) for v in g[f"{tag}.cfg"])
+    rcfg, sd = _implicit_sd(ro, R, C, Fd, int(g[f"{tag}.seed"]))
+    grid = torch.tanh(torch.from_numpy(np_noise(int(g[f"{tag}.grid_seed"]), (1, C, R, R, R))))
+    pts = torch.from_numpy(g[f"{tag}.pts"])
+    dens, feats = ro.implicit_function_pts(grid, sd, pts, rcfg)
+    assert feats.shape[-1] == 3 + Fd
+    assert (dens - torch.from_numpy(g[f"{tag}.densities"])).abs().max() <= 3e-6
+    assert (feats - torch.from_numpy(g[f"{tag}.features"])).abs().max() <= 3e-6
+    if f"{tag}.normals" in g.files:
+        nrm = ro.implicit_normals(grid, sd, pts, rcfg)
+        assert (nrm - torch.from_numpy(g[f"{tag}.normals"])).abs().max() <= 1e-5
+    o, d, l = (torch.from_numpy(g[f"{tag}.ray_{k}"]) for k in ("origins", "directions", "lengths"))
+    od, oc = ro.implicit_function(grid, sd, o.reshape(-1, 3), d.reshape(-1, 3), l.reshape(-1, l.shape[-1]), rcfg)
+    assert (od.reshape(g[f"{tag}.ray_densities"].shape) - torch.from_numpy(g[f"{tag}.ray_densities"])).abs().max() <= 3e-6
+    assert (oc.reshape(*l.shape, 3) - torch.from_numpy(g[f"{tag}.ray_features"])[..., :3]).abs().max() <= 3e-6
+
+
+@pytest.mark.parametrize("case", ["ones", "soft"])
+def test_mlp_mean_aggregator_vs_reference_class(golden_dir, case):
+    """oracle.viewpool_oracle.mlp_mean_aggregate against the reference's OWN MLPMeanFeatureAggregator and
+    _get_point_to_source_camera_ray_dirs (custom_modules.py:162-334), executed from the reference source: parameter
+    names, the doubly applied aggregation weights, the single-layer-is-the-last-layer LeakyReLU, the softmax over views."""
+    from holo_diffusion_amd.weights import synth_state_dict
+    from oracle import viewpool_oracle as vo
+    from oracle.common import np_noise
+    g = np.load(os.path.join(golden_dir, "ref_mlp_mean_aggregator.npz"))
+    n_src, P, nh, do = (int(v) for v in g["dims"])
+    feats = [torch.from_numpy(g[k])[0] for k in sorted(k for k in g.files if k.startswith("feats."))]
+    D = sum(f.shape[-1] for f in feats) + 21
+    shapes = vo.mlp_mean_param_shapes(D, nh, do)
+    sd = synth_state_dict(shapes, int(g["seed"]))
+    for k in shapes:
+        if k.endswith("bias"):
+            sd[k] = 0.1 * torch.from_numpy(np_noise(len(k), shapes[k]))
+    pts, Rm, T = torch.from_numpy(g["pts"])[0], torch.from_numpy(g["R"]), torch.from_numpy(g["T"])
+    dirs = torch.stack([vo.ray_dirs_to_cameras(pts, Rm[v], T[v]) for v in range(n_src)])
+    assert (dirs - torch.from_numpy(g["ray_dirs"])[0]).abs().max() <= 1e-6
+    out = vo.mlp_mean_aggregate(feats, dirs, torch.from_numpy(g[f"{case}.masks"])[0, ..., 0], sd, 3)
+    assert out.shape == (P, do) and (out - torch.from_numpy(g[f"{case}.aggregated"])[0, 0]).abs().max() <= 3e-6
+
+
+def test_images_from_preds_vs_reference_body(golden_dir):
+    """flyaround_output.images_from_preds against the reference's _images_from_preds / _stack_images (flyaround.py:
+    422-502) executed from the reference source (make_depth_image stood in by the restatement): every key bit-equal,
+    incl. the nearest-resized mask on a depth map of another size, the source-image mosaic and the first-mask shading."""
+    from holo_diffusion_amd.flyaround_output import images_from_preds
+    g = np.load(os.path.join(golden_dir, "ref_images_from_preds.npz"))
+    preds = {k[len("preds."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("preds.")}
+    want = {k[len("out."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("out.")}
+    got = images_from_preds(preds, list(want))
+    assert set(got) == set(want) and len(want) == 8
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    assert set(images_from_preds({"images_render": preds["images_render"], "masks_render": preds["masks_render"]})) == \
+        {"images_render", "masks_render"}  # default keys: the ones the predictions lack are skipped
