@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
 HOLO_DTYPE_F32_BF16X3 = 2
-ABI_VERSION = 2  # include/holo_abi.h HOLO_ABI_VERSION
+ABI_VERSION = 3  # include/holo_abi.h HOLO_ABI_VERSION
 
 
 class HoloError(RuntimeError):
@@ -41,6 +41,7 @@ class HoloRenderCfg(C.Structure):
         ("image_height", C.c_int32), ("image_width", C.c_int32),
         ("bg_color", C.c_float * 3), ("background_opacity", C.c_float),
         ("dnet_hidden_dim", C.c_int32), ("dir_emb_dims", C.c_int32), ("sample_pdf_eps", C.c_float),
+        ("feature_dim", C.c_int32),
     ]
 
 
@@ -100,6 +101,8 @@ SIGNATURES = {
     "holo_render": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               C.c_size_t, _vp]),
     "holo_implicit_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_implicit_workspace_bytes": (C.c_size_t, [_vp, C.c_int64, C.c_int64, C.c_int]),
+    "holo_implicit_eval_features": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_implicit_normals": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp, C.c_size_t, _vp]),
     "holo_view_pool_workspace_bytes": (C.c_size_t, [C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
     "holo_view_pool": (C.c_int, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int,
@@ -167,7 +170,8 @@ def make_unet_cfg(image_size, in_channels, out_channels, model_channels, num_res
 
 def make_render_cfg(resol, feature_size, image_height, image_width, volume_extent=8.0, scene_extent=4.0,
                     scene_center=(0.0, 0.0, 0.0), n_pts_coarse=64, n_pts_fine=64, bg_color=(1.0, 1.0, 1.0),
-                    background_opacity=1e10, dnet_hidden_dim=256, dir_emb_dims=4, sample_pdf_eps=1e-5) -> HoloRenderCfg:
+                    background_opacity=1e10, dnet_hidden_dim=256, dir_emb_dims=4, sample_pdf_eps=1e-5,
+                    feature_dim=0) -> HoloRenderCfg:
     c = HoloRenderCfg()
     c.resol, c.feature_size, c.volume_extent, c.scene_extent = int(resol), int(feature_size), float(volume_extent), float(scene_extent)
     for i in range(3):
@@ -177,4 +181,5 @@ def make_render_cfg(resol, feature_size, image_height, image_width, volume_exten
     c.image_height, c.image_width = int(image_height), int(image_width)
     c.background_opacity = float(background_opacity)
     c.dnet_hidden_dim, c.dir_emb_dims, c.sample_pdf_eps = int(dnet_hidden_dim), int(dir_emb_dims), float(sample_pdf_eps)
+    c.feature_dim = int(feature_dim)
     return c

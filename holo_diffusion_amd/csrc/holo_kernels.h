@@ -251,11 +251,14 @@ struct ImplicitEvalParams {
   const float* pts;
   const float* dirs;
   float* rdir;  // scratch [ceil(n_points / pts_per_dir)][3]: radiance direction term per direction
-  int64_t n_points;
+  int64_t n_points;     // end of the point range of this launch
+  int64_t point0;       // first point of this launch (implicit_points_launch); hidden rows are relative to it
   int64_t pts_per_dir;
   float* densities;
   float* colours;
+  float* hidden;  // optional [n_points][Hd]: hidden features after the LeakyReLU (input of the feature head); null = off
 };
+int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void* stream);
 // view pooling (kernels_viewpool.hip): source-view feature maps -> voxel feature grid
 struct ViewPoolParams {
   static constexpr int MAX_VIEWS = 16, MAX_FEATS = 8, MAX_AGG = 512;
@@ -282,7 +285,9 @@ struct ViewPoolParams {
 int view_pool_launch(const ViewPoolParams& p, void* stream);
 int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
-int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);
+int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);   // = dirs + points
+int implicit_dirs_launch(const ImplicitEvalParams& p, void* stream);
+int implicit_points_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
 int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);
 int render_waves_per_wg(int C, int n_fine, int with_normals);

@@ -149,11 +149,13 @@ __device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy,
 // holo_voxel_grid_implicit_function.py:131-145): the density pre-activation is affine in the interpolated features, so
 // its gradient follows from the eight per-corner scalars s_c = w_dens . F_c and the derivatives of the trilinear
 // weights (zero for corners outside the grid, like grid_sample's backward), times LeakyReLU'.
-template <int CH, bool SP = false, bool NRM = false>
+// HID: also store the sample's hidden features AFTER the LeakyReLU (RenderMLP's `mlp_feats`, the input of the
+// view-point independent feature head) to hid[0..HD) - the lane's 16 rows of a tile are four groups of 4 consecutive rows.
+template <int CH, bool SP = false, bool NRM = false, bool HID = false>
 __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ grid, uint32_t lane_off,
                                            int R, float Rm1, float half_extent, float b_dens, int li, int lh, float px, float py,
                                            float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
-                                           float& cb, float* nrm = nullptr) {
+                                           float& cb, float* nrm = nullptr, float* hid = nullptr) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
   float gx = 0.f, gy = 0.f, gz = 0.f;  // NRM: this lane half's part of d(pre-activation)/d(voxel index)
@@ -310,6 +312,12 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], (k & 1) ? fv[k >> 1].y : fv[k >> 1].x, acc, 0, 0, 0);
     }
     // the MFMA k index runs over both lane halves, so each lane now holds complete hidden units:
+    if (HID && hid) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)  // D row of register 4v+e: t*32 + 8v + 4 lh + e
+        *reinterpret_cast<float4*>(hid + t * 32 + 8 * v + 4 * lh) =
+            make_float4(leaky02(acc[4 * v + 0]), leaky02(acc[4 * v + 1]), leaky02(acc[4 * v + 2]), leaky02(acc[4 * v + 3]));
+    }
     // radiance sums  r_c += 0.4 w_c[row] |h[row]|  on row pairs
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -683,9 +691,11 @@ __global__ __launch_bounds__(256) void dir_term_kernel(MlpParams m, const float*
   rdir_out[i * 3 + 2] = rdir[2];
 }
 
-// (densities, colours) for arbitrary points: grid-stride over groups of 128 points per block
-template <int CH>
-__global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParams p) {
+// (densities, colours) for arbitrary points: grid-stride over groups of 128 points per block.  HID: the hidden features
+// of every point go to p.hidden [n_points][HD] (input of the view-point independent feature head).
+// (128 input features: the LDS image of the folded MLP is 141 KB, one workgroup per CU)
+template <int CH, bool HID>
+__global__ __launch_bounds__(256, (CH <= 32 ? 2 : 1)) void implicit_eval_kernel(ImplicitEvalParams p) {
   __shared__ __attribute__((aligned(16))) MlpLds<CH, false> s_mlp;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -696,17 +706,17 @@ __global__ __launch_bounds__(256, 2) void implicit_eval_kernel(ImplicitEvalParam
   __syncthreads();
   const float Rm1 = (float)(p.R - 1);
   const uint32_t lane_off = (uint32_t)(lh * CH);
-  const int64_t ngroups = (p.n_points + 127) / 128;
+  const int64_t ngroups = (p.n_points - p.point0 + 127) / 128;  // points [point0, n_points)
   for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const int64_t i = g * 128 + wave * 32 + li;
+    const int64_t i = p.point0 + g * 128 + wave * 32 + li;
     const bool active = i < p.n_points;
     const int64_t ii = active ? i : p.n_points - 1;
     const float px = p.pts[ii * 3 + 0], py = p.pts[ii * 3 + 1], pz = p.pts[ii * 3 + 2];
     const int64_t di = ii / p.pts_per_dir;
     const float rdir[3] = {p.rdir[di * 3 + 0], p.rdir[di * 3 + 1], p.rdir[di * 3 + 2]};
     float sg, cr, cg, cb;
-    eval_point<CH, false>(s_mlp, p.grid_cl, lane_off, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz, rdir, sg,
-                          cr, cg, cb);
+    eval_point<CH, false, false, HID>(s_mlp, p.grid_cl, lane_off, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz,
+                                      rdir, sg, cr, cg, cb, nullptr, (HID && active) ? p.hidden + (i - p.point0) * HD : nullptr);
     if (active && lh == 0) {
       p.densities[i] = sg;
       p.colours[i * 3 + 0] = cr;
@@ -795,7 +805,23 @@ __global__ __launch_bounds__(256) void implicit_normals_kernel(ImplicitEvalParam
   }
 }
 
+// y[i][j] = LeakyReLU_0.2(y[i][j] + bias[j]) in place (the LAST-layer activation of the feature head)
+__global__ __launch_bounds__(256) void bias_leaky_kernel(float* __restrict__ y, const float* __restrict__ bias, int64_t total,
+                                                         int cols) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = leaky02(y[i] + bias[i % cols]);
+}
+
 }  // namespace
+
+int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void* stream) {
+  const int64_t total = rows * cols;
+  if (total <= 0) return 0;
+  int64_t blocks = cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  HOLO_LAUNCH(bias_leaky_kernel, dim3((unsigned)blocks), dim3(256), stream, y, bias, total, cols);
+  return 0;
+}
 
 template <int CH, bool SP>
 static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
@@ -847,7 +873,8 @@ int render_launch(const RenderKernelParams& p, void* stream, int n_wgs) {
     case 64:
       return render_launch_t<32, false>(p, stream, n_wgs);
     default:
-      set_error("render: feature_size must be 16, 32 or 64 (got %d)", p.C);
+      set_error("render: the fused renderer is built for feature_size 16, 32 or 64 (got %d; 128 input features are "
+                "supported by the stand-alone implicit function only)", p.C);
       return -1;
   }
 }
@@ -867,14 +894,18 @@ int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* s
     case 64:
       HOLO_LAUNCH(implicit_normals_kernel<32>, grid, dim3(256), stream, p, normals);
       break;
+    case 128:
+      HOLO_LAUNCH(implicit_normals_kernel<64>, grid, dim3(256), stream, p, normals);
+      break;
     default:
-      set_error("implicit_normals: feature_size must be 16, 32 or 64 (got %d)", p.C);
+      set_error("implicit_normals: feature_size must be 16, 32, 64 or 128 (got %d)", p.C);
       return -1;
   }
   return 0;
 }
 
-int implicit_eval_launch(const ImplicitEvalParams& p, void* stream) {
+// radiance direction term of every direction -> p.rdir
+int implicit_dirs_launch(const ImplicitEvalParams& p, void* stream) {
   if (p.mlp.Hd != HD) {
     set_error("implicit_eval: dnet_hidden_dim must be %d (got %d)", HD, p.mlp.Hd);
     return -1;
@@ -882,23 +913,45 @@ int implicit_eval_launch(const ImplicitEvalParams& p, void* stream) {
   if (p.n_points <= 0) return 0;
   const int64_t n_dirs = cdiv(p.n_points, p.pts_per_dir);
   HOLO_LAUNCH(dir_term_kernel, dim3((unsigned)cdiv(n_dirs, 256)), dim3(256), stream, p.mlp, p.dirs, n_dirs, p.rdir);
-  int64_t groups = cdiv(p.n_points, 128);
+  return 0;
+}
+
+int implicit_eval_launch(const ImplicitEvalParams& p, void* stream) {
+  if (implicit_dirs_launch(p, stream)) return -1;
+  return implicit_points_launch(p, stream);
+}
+
+// points [p.point0, p.n_points) with the direction terms already in p.rdir
+int implicit_points_launch(const ImplicitEvalParams& p, void* stream) {
+  if (p.mlp.Hd != HD) {
+    set_error("implicit_eval: dnet_hidden_dim must be %d (got %d)", HD, p.mlp.Hd);
+    return -1;
+  }
+  if (p.n_points - p.point0 <= 0) return 0;
+  int64_t groups = cdiv(p.n_points - p.point0, 128);
   if (groups > 4096) groups = 4096;
   dim3 grid((unsigned)groups);
+#define HOLO_IMPLICIT_CASE(CHV)                                                              \
+  if (p.hidden) {                                                                            \
+    HOLO_LAUNCH((implicit_eval_kernel<CHV, true>), grid, dim3(256), stream, p);              \
+  } else {                                                                                   \
+    HOLO_LAUNCH((implicit_eval_kernel<CHV, false>), grid, dim3(256), stream, p);             \
+  }                                                                                          \
+  break;
   switch (p.C) {
     case 16:
-      HOLO_LAUNCH(implicit_eval_kernel<8>, grid, dim3(256), stream, p);
-      break;
+      HOLO_IMPLICIT_CASE(8)
     case 32:
-      HOLO_LAUNCH(implicit_eval_kernel<16>, grid, dim3(256), stream, p);
-      break;
+      HOLO_IMPLICIT_CASE(16)
     case 64:
-      HOLO_LAUNCH(implicit_eval_kernel<32>, grid, dim3(256), stream, p);
-      break;
+      HOLO_IMPLICIT_CASE(32)
+    case 128:
+      HOLO_IMPLICIT_CASE(64)
     default:
-      set_error("implicit_eval: feature_size must be 16, 32 or 64 (got %d)", p.C);
+      set_error("implicit_eval: feature_size must be 16, 32, 64 or 128 (got %d)", p.C);
       return -1;
   }
+#undef HOLO_IMPLICIT_CASE
   return 0;
 }
 

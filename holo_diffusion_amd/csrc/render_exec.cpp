@@ -35,7 +35,8 @@ struct HoloRenderer {
   HoloRenderCfg cfg;
   std::map<std::string, std::vector<float>> host;        // raw parameters (host copies)
   std::map<std::string, std::vector<int64_t>> expected;  // expected shapes
-  float* packed = nullptr;  // device: w_feat | b_feat | w_dens | w_rad | w_dir | u_rad
+  float* packed = nullptr;  // device: w_feat | b_feat | w_dens | w_rad | w_dir | u_rad | w_fnet [Fd][Hd] | b_fnet [Fd]
+  size_t fnet_off = 0;      // offset (floats) of w_fnet inside `packed`
   float k_rad[3] = {0, 0, 0};
   float b_dens = 0.f;
   float b_rad[3] = {0, 0, 0};
@@ -53,10 +54,11 @@ int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** 
     return HOLO_E_INVALID;
   }
   if (cfg->dnet_hidden_dim != 256 || cfg->dir_emb_dims != 4 ||
-      !(cfg->feature_size == 16 || cfg->feature_size == 32 || cfg->feature_size == 64) || cfg->n_pts_coarse < 3 ||
-      cfg->n_pts_coarse > 64 || cfg->n_pts_fine < 2 || cfg->resol < 2) {
-    set_error("holo_renderer_create: unsupported configuration (hidden 256, dir_emb 4, feature_size 16/32/64, "
-              "3<=n_pts_coarse<=64, n_pts_fine>=2)");
+      !(cfg->feature_size == 16 || cfg->feature_size == 32 || cfg->feature_size == 64 || cfg->feature_size == 128) ||
+      cfg->n_pts_coarse < 3 || cfg->n_pts_coarse > 64 || cfg->n_pts_fine < 2 || cfg->resol < 2 || cfg->feature_dim < 0 ||
+      (cfg->feature_dim & 3)) {
+    set_error("holo_renderer_create: unsupported configuration (hidden 256, dir_emb 4, feature_size 16/32/64/128, "
+              "3<=n_pts_coarse<=64, n_pts_fine>=2, feature_dim a multiple of 4)");
     return HOLO_E_UNSUPPORTED;
   }
   HoloRenderer* r = new HoloRenderer;
@@ -73,7 +75,13 @@ int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** 
   r->expected["_density_net.mlp.3.0.bias"] = {Hd + 1};
   r->expected["_radiance_net.mlp.0.0.weight"] = {3, Hd + De};
   r->expected["_radiance_net.mlp.0.0.bias"] = {3};
-  const size_t n = (size_t)(Hd * C + Hd + C + 3 * Hd + 3 * De + 3 * C + 64);
+  const int64_t Fd = cfg->feature_dim;
+  if (Fd > 0) {  // the view-point independent feature head (holo_voxel_grid_implicit_function.py:94-105,125-129)
+    r->expected["_feature_net.mlp.0.0.weight"] = {Fd, Hd};
+    r->expected["_feature_net.mlp.0.0.bias"] = {Fd};
+  }
+  r->fnet_off = (size_t)(Hd * C + Hd + C + 3 * Hd + 3 * De + 3 * C + 64);
+  const size_t n = r->fnet_off + (size_t)(Fd * Hd + Fd);
   if (hipMalloc((void**)&r->packed, n * sizeof(float)) != hipSuccess) {
     set_error("holo_renderer_create: hipMalloc failed");
     delete r;
@@ -203,6 +211,13 @@ int holo_renderer_commit(HoloRenderer* r, void* stream) {
   r->b_dens = (float)be[Hd];
   for (int c = 0; c < 3; ++c) r->b_rad[c] = br[c];
   HIP_TRY(hipMemcpyAsync(r->packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (r->cfg.feature_dim > 0) {
+    const auto &Wf = W("_feature_net.mlp.0.0.weight"), &bf = W("_feature_net.mlp.0.0.bias");
+    HIP_TRY(hipMemcpyAsync(r->packed + r->fnet_off, Wf.data(), Wf.size() * sizeof(float), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(r->packed + r->fnet_off + Wf.size(), bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  }
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   r->committed = true;
   return 0;
@@ -270,6 +285,11 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   if (!r->committed) {
     set_error("holo_render: call holo_renderer_commit after setting the RenderMLP parameters");
     return HOLO_E_STATE;
+  }
+  if (r->cfg.feature_dim != 0) {
+    set_error("holo_render: rendered view-point independent features are not on this path (HoloDiffusionModel builds its "
+              "implicit function with feature_dim = 0, holo_diffusion_model.py:156)");
+    return HOLO_E_UNSUPPORTED;
   }
   const bool want_nrm = normals != nullptr || normals_coarse != nullptr;
   if (workspace_bytes < holo_render_workspace_bytes(r, n_cameras, want_nrm ? 1 : 0)) {
@@ -392,9 +412,23 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   return 0;
 }
 
-int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
-                       int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
-                       void* stream) {
+// points per pass of the feature head: the hidden features of a pass (Hd floats per point) live in the workspace
+static const int64_t IMPLICIT_CHUNK = 65536;
+
+size_t holo_implicit_workspace_bytes(const HoloRenderer* r, int64_t n_points, int64_t pts_per_dir, int with_features) {
+  if (!r || n_points < 0 || pts_per_dir < 1) return 0;
+  const int64_t n_dirs = (n_points + pts_per_dir - 1) / pts_per_dir;
+  size_t b = grid_cl_bytes(r) + (((size_t)n_dirs * 3 * sizeof(float) + 255) & ~(size_t)255);
+  if (with_features && r->cfg.feature_dim > 0) {
+    const int64_t chunk = n_points < IMPLICIT_CHUNK ? n_points : IMPLICIT_CHUNK;
+    b += (size_t)chunk * r->cfg.dnet_hidden_dim * sizeof(float);
+  }
+  return b + 256;
+}
+
+int holo_implicit_eval_features(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
+                                int64_t pts_per_dir, float* densities, float* colours, float* vp_features, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   if (!r || !grid || !pts || !dirs || !densities || !colours || !workspace || n_points < 0 || pts_per_dir < 1) {
     set_error("holo_implicit_eval: null/invalid argument");
     return HOLO_E_INVALID;
@@ -403,10 +437,14 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
     set_error("holo_implicit_eval: call holo_renderer_commit after setting the RenderMLP parameters");
     return HOLO_E_STATE;
   }
+  if (vp_features && r->cfg.feature_dim <= 0) {
+    set_error("holo_implicit_eval_features: the renderer was created with feature_dim = 0");
+    return HOLO_E_INVALID;
+  }
   const size_t grid_bytes = grid_cl_bytes(r);
   const int64_t n_dirs = (n_points + pts_per_dir - 1) / pts_per_dir;
-  if (workspace_bytes < grid_bytes + (size_t)n_dirs * 3 * sizeof(float)) {
-    set_error("holo_implicit_eval: workspace too small (need holo_render_workspace_bytes + 12 bytes per direction)");
+  if (workspace_bytes < holo_implicit_workspace_bytes(r, n_points, pts_per_dir, vp_features ? 1 : 0) - 256) {
+    set_error("holo_implicit_eval: workspace too small (holo_implicit_workspace_bytes)");
     return HOLO_E_WORKSPACE;
   }
   const HoloRenderCfg& c = r->cfg;
@@ -427,7 +465,46 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
   p.pts_per_dir = pts_per_dir;
   p.densities = densities;
   p.colours = colours;
-  return implicit_eval_launch(p, stream) ? HOLO_E_INVALID : 0;
+  if (!vp_features) return implicit_eval_launch(p, stream) ? HOLO_E_INVALID : 0;
+  // with the feature head: passes of IMPLICIT_CHUNK points (a multiple of pts_per_dir is not needed: the direction of a
+  // point is looked up by its GLOBAL index, so a pass may start anywhere): hidden features -> GEMM with the head's
+  // weight -> bias + LeakyReLU (the activation the construction quirk attaches to a last layer, custom_modules.py:108-112)
+  const int Hd = c.dnet_hidden_dim, Fd = c.feature_dim;
+  float* hidden = (float*)((char*)workspace + grid_bytes + (((size_t)n_dirs * 3 * sizeof(float) + 255) & ~(size_t)255));
+  const float* w_fnet = r->packed + r->fnet_off;
+  const float* b_fnet = w_fnet + (size_t)Fd * Hd;
+  if (implicit_dirs_launch(p, stream)) return HOLO_E_INVALID;
+  for (int64_t s0 = 0; s0 < n_points; s0 += IMPLICIT_CHUNK) {
+    const int64_t m = n_points - s0 < IMPLICIT_CHUNK ? n_points - s0 : IMPLICIT_CHUNK;
+    ImplicitEvalParams q = p;
+    q.point0 = s0;
+    q.n_points = s0 + m;
+    q.hidden = hidden;
+    if (implicit_points_launch(q, stream)) return HOLO_E_INVALID;
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.A = hidden;
+    g.B = w_fnet;
+    g.C = vp_features + s0 * Fd;
+    g.M = (int)m;
+    g.Nn = Fd;
+    g.K = Hd;
+    g.lda = Hd;
+    g.ldb = Hd;
+    g.ldc = Fd;
+    g.nb0 = g.nb1 = 1;
+    g.alpha = 1.f;
+    if (gemm_launch(g, stream)) return HOLO_E_INVALID;
+    if (bias_leaky_launch(vp_features + s0 * Fd, b_fnet, m, Fd, stream)) return HOLO_E_INVALID;
+  }
+  return 0;
+}
+
+int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
+                       int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  return holo_implicit_eval_features(r, grid, pts, dirs, n_points, pts_per_dir, densities, colours, nullptr, workspace,
+                                     workspace_bytes, stream);
 }
 
 int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, int64_t n_points, float* normals,

@@ -145,14 +145,20 @@ class RenderMLP(Configurable, torch.nn.Module):
             unsupported.append("radiance net other than a single layer")
         if self.activation_fn != HiddenActivation.LEAKYRELU:
             unsupported.append("activation_fn other than LEAKYRELU")
-        if self.output_feature_dims != COLOUR_DIMS or self.output_vp_independent_feature_dims != 0:
-            unsupported.append("extra rendered features (HoloDiffusionModel forces feature_dim=0, "
-                               "holo_diffusion_model.py:156)")
+        if self.output_feature_dims != COLOUR_DIMS:
+            unsupported.append("output_feature_dims other than the 3 colour channels")
+        if self.output_vp_independent_feature_dims < 0 or self.output_vp_independent_feature_dims % 4:
+            unsupported.append("output_vp_independent_feature_dims that is not a multiple of 4")
+        if self.dnet_hidden_dim != 256 or self.dir_emb_dims != 4:
+            unsupported.append("dnet_hidden_dim other than 256 / dir_emb_dims other than 4")
+        if self.input_dims not in (16, 32, 64, 128):
+            unsupported.append("input_dims other than 16, 32, 64 or 128")
         if unsupported:
             raise NotImplementedError("RenderMLP: the fused renderer supports the released configuration only; got "
                                       + "; ".join(unsupported))
         self._density_net = _Node()
         self._radiance_net = _Node()
+        self._feature_net = _Node() if self.output_vp_independent_feature_dims > 0 else None
         for name, shape in self.param_shapes().items():
             w = torch.empty(shape)
             if name.endswith("weight"):
@@ -164,13 +170,26 @@ class RenderMLP(Configurable, torch.nn.Module):
     def param_shapes(self) -> Dict[str, Tuple[int, ...]]:
         Cf, Hd = self.input_dims, self.dnet_hidden_dim
         demb = 3 * (2 * self.dir_emb_dims + 1)
-        return {
+        shapes = {
             "_density_net.mlp.0.0.weight": (Hd, Cf), "_density_net.mlp.0.0.bias": (Hd,),
             "_density_net.mlp.1.0.weight": (Hd, Hd), "_density_net.mlp.1.0.bias": (Hd,),
             "_density_net.mlp.2.0.weight": (Hd, Hd + Cf), "_density_net.mlp.2.0.bias": (Hd,),
             "_density_net.mlp.3.0.weight": (Hd + 1, Hd), "_density_net.mlp.3.0.bias": (Hd + 1,),
             "_radiance_net.mlp.0.0.weight": (COLOUR_DIMS, Hd + demb), "_radiance_net.mlp.0.0.bias": (COLOUR_DIMS,),
         }
+        if self.output_vp_independent_feature_dims > 0:  # the feature head (holo_voxel_grid_implicit_function.py:94-105)
+            Fd = self.output_vp_independent_feature_dims
+            shapes["_feature_net.mlp.0.0.weight"] = (Fd, Hd)
+            shapes["_feature_net.mlp.0.0.bias"] = (Fd,)
+        return shapes
+
+    def forward(self, features: torch.Tensor, view_dirs: torch.Tensor):
+        """``RenderMLP.forward(features, view_dirs) -> (densities, radiance, vp_independent_features | None)``
+        (holo_voxel_grid_implicit_function.py:107-129) for features that are ALREADY sampled, (..., input_dims), with one
+        unit view direction per feature row, (..., 3) - the call of the reference's tests/test_voxel_grid_implicit_function.py
+        ::test_RenderMLP_forward.  Runs the same kernel as the implicit function on a one-voxel-per-row grid stand-in:
+        the features are handed over as an (n, C) "grid" whose trilinear fetch at the voxel centres is the identity."""
+        return _render_mlp_forward(self, features, view_dirs)
 
 
 class _NativeRenderMlp:
@@ -216,6 +235,44 @@ class _NativeRenderMlp:
 
     def __del__(self):
         self.close()
+
+
+def _render_mlp_forward(mlp: "RenderMLP", features: torch.Tensor, view_dirs: torch.Tensor):
+    """RenderMLP on already-sampled features through the implicit-function kernel.  The rows are laid out as the voxels
+    of an R^3 grid with R - 1 a power of two, volume_extent = R (voxel size 1, half extent 2^k) and evaluated at the voxel
+    centres i - (R-1)/2: every coordinate, the local coordinate and the voxel index are then EXACT in fp32, so the
+    trilinear fetch returns the row itself (weights exactly 1 and 0)."""
+    runtime.require_device(features, "RenderMLP.forward")
+    dev = features.device
+    Cf, Fd = mlp.input_dims, int(mlp.output_vp_independent_feature_dims)
+    lead = tuple(features.shape[:-1])
+    f = features.reshape(-1, Cf).float()
+    d = view_dirs.expand(*lead, 3).reshape(-1, 3).float().contiguous()
+    n = f.shape[0]
+    R = next(r for r in (3, 5, 9, 17, 33) if r ** 3 >= n or r == 33)
+    if "_native_rows" not in mlp.__dict__:
+        mlp.__dict__["_native_rows"] = _NativeRenderMlp()
+    h = mlp.__dict__["_native_rows"].ensure(dev, mlp, dict(resol=R, feature_size=Cf, image_height=8, image_width=8,
+                                                           volume_extent=float(R), dnet_hidden_dim=mlp.dnet_hidden_dim,
+                                                           dir_emb_dims=mlp.dir_emb_dims, feature_dim=Fd))
+    L = runtime.lib()
+    dens, col = torch.empty(n, device=dev), torch.empty(n, 3, device=dev)
+    vp = torch.empty(n, Fd, device=dev) if Fd > 0 else None
+    cap = R ** 3
+    idx = torch.arange(min(n, cap), device=dev)
+    pts_all = torch.stack([idx % R, (idx // R) % R, idx // (R * R)], dim=-1).float() - 0.5 * (R - 1)
+    grid = torch.zeros(1, Cf, R, R, R, device=dev)
+    for s0 in range(0, n, cap):
+        m = min(cap, n - s0)
+        grid.view(Cf, -1)[:, :m] = f[s0:s0 + m].t()
+        pts = pts_all[:m].contiguous()
+        dd = d[s0:s0 + m].contiguous()
+        ws = runtime.workspace(mlp, dev, L.holo_implicit_workspace_bytes(h, m, 1, 1 if Fd > 0 else 0))
+        _lib.check(L, L.holo_implicit_eval_features(
+            h, runtime.ptr(grid), runtime.ptr(pts), runtime.ptr(dd), m, 1, runtime.ptr(dens[s0:]), runtime.ptr(col[s0:]),
+            runtime.ptr(vp[s0:]) if vp is not None else C.c_void_p(None), runtime.ptr(ws), ws.numel(),
+            runtime.stream_ptr(dev)), "holo_implicit_eval_features")
+    return dens.reshape(*lead, 1), col.reshape(*lead, 3), (vp.reshape(*lead, Fd) if vp is not None else None)
 
 
 def _camera_array(cams):
@@ -310,15 +367,18 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
         h = self._native.ensure(dev, self.render_mlp, dict(
             resol=self.resol, feature_size=self.n_hidden, image_height=8, image_width=8,
             volume_extent=float(self.volume_extent), dnet_hidden_dim=self.render_mlp.dnet_hidden_dim,
-            dir_emb_dims=self.render_mlp.dir_emb_dims))
+            dir_emb_dims=self.render_mlp.dir_emb_dims, feature_dim=self.feature_dim))
         L = runtime.lib()
         dens = torch.empty(n, device=dev)
         col = torch.empty(n, 3, device=dev)
-        nbytes = L.holo_render_workspace_bytes(h, 1, 0) + 12 * dirsf.shape[0] + 256
+        Fd = int(self.feature_dim)
+        vp = torch.empty(n, Fd, device=dev) if Fd > 0 else None
+        nbytes = max(L.holo_implicit_workspace_bytes(h, n, per_dir, 1 if Fd > 0 else 0), L.holo_render_workspace_bytes(h, 1, 0))
         ws = runtime.workspace(self, dev, nbytes)
-        _lib.check(L, L.holo_implicit_eval(h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf),
-                                           runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens), runtime.ptr(col),
-                                           runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_implicit_eval")
+        _lib.check(L, L.holo_implicit_eval_features(
+            h, runtime.ptr(grid.contiguous().float()), runtime.ptr(ptsf), runtime.ptr(dirsf), n, per_dir, runtime.ptr(dens),
+            runtime.ptr(col), runtime.ptr(vp) if vp is not None else C.c_void_p(None), runtime.ptr(ws), ws.numel(),
+            runtime.stream_ptr(dev)), "holo_implicit_eval_features")
         aux = {}
         if self.render_normals:  # RenderMLP.get_normals (:131-145), evaluated analytically in the kernel
             nrm = torch.empty(n, 3, device=dev)
@@ -326,7 +386,10 @@ class HoloVoxelGridImplicitFunction(ImplicitFunctionBase, torch.nn.Module):
                                                   runtime.ptr(nrm), runtime.ptr(ws), ws.numel(),
                                                   runtime.stream_ptr(dev)), "holo_implicit_normals")
             aux["normals"] = nrm.reshape(*spatial, 3)
-        return dens.reshape(*spatial, 1), col.reshape(*spatial, COLOUR_DIMS), aux
+        features = col.reshape(*spatial, COLOUR_DIMS)
+        if vp is not None:  # features = cat(colour, view-point independent features) (:265-269)
+            features = torch.cat([features, vp.reshape(*spatial, Fd)], dim=-1)
+        return dens.reshape(*spatial, 1), features, aux
 
 
 class ImplicitFunctionWrapper(torch.nn.Module):
@@ -470,6 +533,11 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         fn = wrapper._fn
         if not isinstance(fn, HoloVoxelGridImplicitFunction):
             raise NotImplementedError("only HoloVoxelGridImplicitFunction is supported")
+        if fn.feature_dim != 0 or fn.n_hidden not in (16, 32, 64):
+            raise NotImplementedError("the fused renderer composites colours only and is built for 16/32/64 grid features "
+                                      "(HoloDiffusionModel builds its implicit function with feature_dim = 0, "
+                                      "holo_diffusion_model.py:156); feature_dim > 0 / n_hidden = 128 are served by the "
+                                      "stand-alone HoloVoxelGridImplicitFunction.forward")
         grid = wrapper.bound_args.get("voxel_grid_features")
         if grid is None:
             raise ValueError("voxel_grid_features must be bound to the implicit function (bind_args)")

@@ -97,8 +97,8 @@ class SimpleUnet3D(Unet3DBase):
         self._create_parameters()
 
     # ---- parameter tree -------------------------------------------------------------------
-    def _cfg_struct(self):
-        return _lib.make_unet_cfg(self.image_size, self.in_channels, self.out_channels, self.model_channels,
+    def _cfg_struct(self, size: Optional[int] = None):
+        return _lib.make_unet_cfg(size or self.image_size, self.in_channels, self.out_channels, self.model_channels,
                                   self.num_res_blocks, self.channel_mult, self.attention_resolutions, self.num_heads,
                                   self.homogeneous_resample)
 
@@ -136,14 +136,20 @@ class SimpleUnet3D(Unet3DBase):
         self._mark_dirty()
 
     # ---- native handle --------------------------------------------------------------------
-    def _ensure_handle(self, device: torch.device) -> C.c_void_p:
+    def _ensure_handle(self, device: torch.device, size: Optional[int] = None) -> C.c_void_p:
+        """The native handle for inputs of ``size``^3 (default: ``image_size``).  The reference's UNetModel is fully
+        convolutional - ``image_size`` is a stored field, its own test feeds 32^3 grids to a net built with the default
+        64 (tests/test_diffusion_utils.py:16-30) - while the native plan is built for one grid size; a forward at
+        another size switches the handle to a plan of that size (weights are re-bound once per switch)."""
         L = runtime.lib()
-        if self._handle is None or self._handle_device != device:
+        size = int(size or getattr(self, "_handle_size", None) or self.image_size)  # no size: keep the live plan
+        if self._handle is None or self._handle_device != device or getattr(self, "_handle_size", None) != size:
             if self._handle is not None:
                 runtime.sync_before_destroy(self._handle_device)
                 L.holo_unet_destroy(self._handle)
+                self._handle = None
             h = C.c_void_p()
-            cfg = self._cfg_struct()
+            cfg = self._cfg_struct(size)
             _lib.check(L, L.holo_unet_create(runtime.ctx(device), C.byref(cfg), C.byref(h)), "holo_unet_create")
             # cross-check the library's enumeration against the Python tree
             n = L.holo_unet_num_params(h)
@@ -158,7 +164,7 @@ class SimpleUnet3D(Unet3DBase):
                 k = name.value.decode()
                 if tuple(shp[:nd.value]) != tuple(shapes.get(k, ())):
                     raise _lib.HoloError(f"parameter '{k}': library shape {tuple(shp[:nd.value])} != {shapes.get(k)}")
-            self._handle, self._handle_device, self._dirty = h, device, True
+            self._handle, self._handle_device, self._handle_size, self._dirty = h, device, size, True
         code = {"f32": _lib.HOLO_DTYPE_F32, "bf16": _lib.HOLO_DTYPE_BF16,
                 "f32_bf16x3": _lib.HOLO_DTYPE_F32_BF16X3}.get(self.compute_dtype)
         if code is None:
@@ -192,11 +198,12 @@ class SimpleUnet3D(Unet3DBase):
         if cond_features is not None:
             x = torch.cat([x, cond_features], dim=1)
         runtime.require_device(x, "SimpleUnet3D.forward")
-        if x.dim() != 5 or x.shape[1] != self.in_channels or tuple(x.shape[2:]) != (self.image_size,) * 3:
-            raise _lib.HoloError(f"SimpleUnet3D.forward: expected (N,{self.in_channels},{self.image_size}^3), "
-                                 f"got {tuple(x.shape)}")
+        if x.dim() != 5 or x.shape[1] != self.in_channels or len(set(x.shape[2:])) != 1 or \
+                x.shape[2] % (1 << (len(self.channel_mult) - 1)):
+            raise _lib.HoloError(f"SimpleUnet3D.forward: expected (N,{self.in_channels},R,R,R) with R a multiple of "
+                                 f"{1 << (len(self.channel_mult) - 1)}, got {tuple(x.shape)}")
         dev = x.device
-        h = self._ensure_handle(dev)
+        h = self._ensure_handle(dev, int(x.shape[2]))
         L = runtime.lib()
         x = x.contiguous().float()
         t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
@@ -255,7 +262,7 @@ class SimpleUnet3D(Unet3DBase):
         L = runtime.lib()
         nbytes = L.holo_unet_workspace_bytes(h, batch)
         ws = runtime.workspace(self, device, nbytes)
-        R = self.image_size
+        R = getattr(self, "_handle_size", None) or self.image_size
         x = torch.randn(batch, self.in_channels, R, R, R, device=device)
         y = torch.empty(batch, self.out_channels, R, R, R, device=device)
         t = torch.full((batch,), 500, dtype=torch.int64, device=device)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 2
+#define HOLO_ABI_VERSION 3
 
 enum {
   HOLO_OK = 0,
@@ -154,6 +154,10 @@ typedef struct {
   int32_t dnet_hidden_dim;  /* 256 */
   int32_t dir_emb_dims;     /* 4 */
   float sample_pdf_eps;     /* 1e-5 */
+  int32_t feature_dim;      /* RenderMLP.output_vp_independent_feature_dims (HoloVoxelGridImplicitFunction.feature_dim):
+                               0 inside HoloDiffusionModel (holo_diffusion_model.py:156), 64 by default; > 0 adds the
+                               parameters "_feature_net.mlp.0.0.{weight,bias}" and is served by
+                               holo_implicit_eval_features only */
 } HoloRenderCfg;
 
 /* One camera in PyTorch3D PerspectiveCameras/NDC convention (X_cam = X_world R + T), host memory. */
@@ -208,6 +212,15 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
 int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
                        int64_t pts_per_dir, float* densities, float* colours, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The same with RenderMLP's third output (holo_voxel_grid_implicit_function.py:125-129,265-269: the reference returns
+ * features = cat(colour, view-point independent features) when feature_dim > 0 - the configuration of its own tests,
+ * holo_diffusion/tests/test_voxel_grid_implicit_function.py:17-41):
+ *   vp_features : (n_points, feature_dim) = LeakyReLU(Linear(hidden features)), or NULL (= holo_implicit_eval)
+ * Workspace for both entries: holo_implicit_workspace_bytes. */
+size_t holo_implicit_workspace_bytes(const HoloRenderer* r, int64_t n_points, int64_t pts_per_dir, int with_features);
+int holo_implicit_eval_features(HoloRenderer* r, const float* grid, const float* pts, const float* dirs, int64_t n_points,
+                                int64_t pts_per_dir, float* densities, float* colours, float* vp_features, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* Normals of the density field at world points.  Replaces RenderMLP.get_normals as used by
  * HoloVoxelGridImplicitFunction.forward with render_normals=True (holo_voxel_grid_implicit_function.py:131-145,

@@ -41,14 +41,14 @@ def test_python_binding_covers_the_header(lib):
     from holo_diffusion_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     _lib.bind(lib)
-    assert lib.holo_abi_version() == 2
+    assert lib.holo_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
     from holo_diffusion_amd import _lib
     assert ctypes.sizeof(_lib.HoloUnetCfg) == 4 * (5 + 1 + 8 + 1 + 8 + 2)
     assert ctypes.sizeof(_lib.HoloCamera) == 4 * 16
-    assert ctypes.sizeof(_lib.HoloRenderCfg) == 4 * (2 + 1 + 1 + 3 + 2 + 2 + 3 + 1 + 2 + 1)
+    assert ctypes.sizeof(_lib.HoloRenderCfg) == 4 * (2 + 1 + 1 + 3 + 2 + 2 + 3 + 1 + 2 + 1 + 1)
 
 
 def test_error_path_without_gpu(lib):

@@ -98,25 +98,29 @@ def test_north_star_ray_subset_vs_oracle(gu):
     _check_rays(preds, ref, idx, H, W, coarse=preds["rendered"].prev_stage)
     # ---- the control experiment behind the depth quantile of _check_rays -------------------------------------------
     # sample_pdf switches den = cdf_a - cdf_b to 1 below eps = 1e-5.  A ray is FRAGILE when one of its importance
-    # samples has a raw den within +-4 quanta (2^-24 each: cdf values live in [0,1]) of that switch: there the last
-    # bits of the cumulative sums decide on which side the sample falls, and two correct evaluations may differ.
-    # (1) every ray the HIP path has outside 2e-4 x far is fragile; every non-fragile ray is inside, on EVERY ray;
+    # samples has a raw den within 0.3 eps of that switch: the cdf is a normalised running sum of coarse weights that two
+    # correct evaluations reproduce to ~1e-6 (fast exp / sigmoid, reassociated dot products), so there the low bits
+    # decide on which side of the switch the sample falls - and the sample lands elsewhere in an (almost) empty bin.
+    # (1) every ray the HIP path has outside 2e-4 x far is fragile, i.e. every non-fragile ray is inside, on EVERY ray;
     # (2) the SAME holds between the oracle and the oracle on a grid perturbed by 1e-6 (no HIP code involved), with a
     #     disagreement rate of the same order: the quantile is a property of sample_pdf, not of the kernel.
-    margin = 4 * 2.0 ** -24
-    fragile = ((ref["pdf_denom"] - rcfg.sample_pdf_eps).abs() <= margin).any(dim=1)
+    margin = 0.3 * rcfg.sample_pdf_eps
+    gap = (ref["pdf_denom"] - rcfg.sample_pdf_eps).abs().min(dim=1)[0]
+    fragile = gap <= margin
     flat = lambda t: t.reshape(t.shape[1], H * W).t().cpu()[idx]  # noqa: E731
     e_hip = (flat(preds["depths_render"]) - ref["depth"]).abs().flatten()
     bad_hip = e_hip >= 2e-4 * FAR
-    assert not (bad_hip & ~fragile).any(), ("a non-fragile ray misses the depth tolerance", int((bad_hip & ~fragile).sum()))
     pert = grid + 1e-6 * torch.from_numpy(np_noise(8, tuple(grid.shape)))
     ref2 = ro.render_rays(pert, msd, o[idx], d[idx], l[idx], rcfg)
-    fragile2 = fragile | ((ref2["pdf_denom"] - rcfg.sample_pdf_eps).abs() <= margin).any(dim=1)
+    gap2 = torch.minimum(gap, (ref2["pdf_denom"] - rcfg.sample_pdf_eps).abs().min(dim=1)[0])
     bad_ctl = (ref2["depth"] - ref["depth"]).abs().flatten() >= 2e-4 * FAR
-    assert not (bad_ctl & ~fragile2).any(), ("control: a non-fragile ray moved", int((bad_ctl & ~fragile2).sum()))
+    print(f"depth control: {int(fragile.sum())}/{len(idx)} rays fragile (a den within {margin:.1e} of eps); outside 2e-4*far: "
+          f"HIP vs oracle {int(bad_hip.sum())} (largest gap among them {float(gap[bad_hip].max()) if bad_hip.any() else 0:.2e}), "
+          f"oracle vs oracle(grid + 1e-6) {int(bad_ctl.sum())} (largest gap {float(gap2[bad_ctl].max()) if bad_ctl.any() else 0:.2e})")
+    assert not (bad_hip & ~fragile).any(), ("a non-fragile ray misses the depth tolerance", int((bad_hip & ~fragile).sum()),
+                                            float(gap[bad_hip].max()))
+    assert not (bad_ctl & (gap2 > margin)).any(), ("control: a non-fragile ray moved", float(gap2[bad_ctl].max()))
     assert (ref2["rgb"] - ref["rgb"]).abs().max() < 2e-4  # colour and mask barely notice
-    print(f"depth control: {int(fragile.sum())}/{len(idx)} rays fragile; outside 2e-4*far: HIP vs oracle "
-          f"{int(bad_hip.sum())}, oracle vs oracle(grid + 1e-6) {int(bad_ctl.sum())}")
     if not EMU:
         assert int(bad_hip.sum()) <= 3 * int(bad_ctl.sum()) + 0.01 * len(idx)  # same order as the control's own rate
 

@@ -258,3 +258,103 @@ def test_standalone_implicit_function_vs_reference_render_mlp(gu, golden_dir, C)
     ref_c = torch.from_numpy(g[f"C{C}.colours_ones_dir"]).reshape(-1, 3)
     assert (dens.reshape(-1).cpu() - ref_d).abs().max().item() < 1e-4
     assert (col.reshape(-1, 3).cpu() - ref_c).abs().max().item() < 1e-4
+
+
+# ---- round 3: the reference's OWN test configurations (holo_diffusion/tests/test_voxel_grid_implicit_function.py) -----
+def _implicit_fixture_fn(gu, R, C, Fd, seed, render_normals=False):
+    from oracle.common import np_noise
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, feature_dim=Fd)
+    sd = gu.synth_state_dict(ro.render_mlp_param_shapes(rcfg), seed)
+    sd["_density_net.mlp.3.0.bias"][-1] += 0.05
+    if Fd > 0:
+        sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(6, (Fd,)))
+    fn = hda.HoloVoxelGridImplicitFunction(resol=R, n_hidden=C, feature_dim=Fd, render_normals=render_normals)
+    fn.render_mlp.load_state_dict(sd)
+    return fn.to(gu.DEV), sd, rcfg
+
+
+@pytest.mark.parametrize("tag", ["small", "defaults"])
+def test_implicit_function_vs_reference_forward_body(gu, golden_dir, tag):
+    """HoloVoxelGridImplicitFunction.forward on the HIP path against outputs of the REFERENCE's own forward body and
+    RenderMLP.get_normals (tests/golden/ref_implicit_function.npz, executed from the reference source by
+    oracle/make_golden_render.py): pts_3d entry with dummy directions, features = cat(colour, view-point independent
+    features), aux normals; ray-bundle entry.  'defaults' = 128 grid features + 64 feature-head outputs."""
+    import os
+    from holo_diffusion_amd.render import ImplicitronRayBundle
+    from oracle.common import np_noise
+    g = np.load(os.path.join(golden_dir, "ref_implicit_function.npz"))
+    R, C, Fd = (int(v) for v in g[f"{tag}.cfg"])
+    fn, sd, rcfg = _implicit_fixture_fn(gu, R, C, Fd, int(g[f"{tag}.seed"]), render_normals=f"{tag}.normals" in g.files)
+    grid = torch.tanh(torch.from_numpy(np_noise(int(g[f"{tag}.grid_seed"]), (1, C, R, R, R)))).to(gu.DEV)
+    pts = torch.from_numpy(g[f"{tag}.pts"]).to(gu.DEV)
+    dens, feats, aux = fn(pts_3d=pts, voxel_grid_features=grid)
+    assert dens.shape == pts.shape[:-1] + (1,) and feats.shape == pts.shape[:-1] + (3 + Fd,)
+    assert (dens.cpu() - torch.from_numpy(g[f"{tag}.densities"])).abs().max().item() < 1e-4
+    assert (feats.cpu() - torch.from_numpy(g[f"{tag}.features"])).abs().max().item() < 1e-4
+    if f"{tag}.normals" in g.files:
+        # unit vectors; a point whose gradient is ~0 may normalise differently - none in the fixture
+        assert (aux["normals"].cpu() - torch.from_numpy(g[f"{tag}.normals"])).abs().max().item() < 1e-3
+    o, d, l = (torch.from_numpy(g[f"{tag}.ray_{k}"]).to(gu.DEV) for k in ("origins", "directions", "lengths"))
+    rb = ImplicitronRayBundle(camera=None, image_height=o.shape[0], image_width=o.shape[1], n_pts_per_ray=l.shape[-1],
+                              scene_extent=4.0, scene_center=(0.0, 0.0, 0.0), origins=o, directions=d, lengths=l)
+    dens_r, feats_r, _ = fn(ray_bundle=rb, voxel_grid_features=grid)
+    assert (dens_r.cpu() - torch.from_numpy(g[f"{tag}.ray_densities"])).abs().max().item() < 1e-4
+    assert (feats_r.cpu() - torch.from_numpy(g[f"{tag}.ray_features"])).abs().max().item() < 1e-4
+
+
+def test_render_mlp_defaults_forward_vs_reference_class(gu, golden_dir):
+    """`RenderMLP()` with the reference's defaults, called like its test_RenderMLP_forward (features, unit view
+    directions) -> (densities, radiance, view-point independent features), against the reference class's outputs."""
+    import os
+    from oracle.common import np_noise
+    g = np.load(os.path.join(golden_dir, "ref_render_mlp.npz"))
+    mlp = hda.render.RenderMLP()
+    assert mlp.input_dims == 128 and mlp.output_vp_independent_feature_dims == 64
+    sd = gu.synth_state_dict(ro.render_mlp_param_shapes(ro.RenderCfg(feature_size=128, feature_dim=64)), int(g["C128.seed"]))
+    sd["_feature_net.mlp.0.0.bias"] = 0.1 * torch.from_numpy(np_noise(5, (64,)))
+    mlp.load_state_dict(sd)
+    mlp.to(gu.DEV)
+    feats, dirs = torch.from_numpy(g["C128.features"]).to(gu.DEV), torch.from_numpy(g["C128.dirs"]).to(gu.DEV)
+    dens, col, vp = mlp(feats, dirs)
+    assert dens.shape == feats.shape[:-1] + (1,) and vp.shape == feats.shape[:-1] + (64,)
+    for got, key in ((dens, "densities"), (col, "colours"), (vp, "vp_features")):
+        assert (got.cpu() - torch.from_numpy(g[f"C128.{key}"])).abs().max().item() < 1e-4, key
+    # the reference's own test shape: (16, 128) features, (16, 3) unit directions (test_voxel_grid_implicit_function.py:17-26)
+    f16 = torch.from_numpy(np_noise(3, (16, 128))).to(gu.DEV)
+    d16 = torch.nn.functional.normalize(torch.from_numpy(np_noise(4, (16, 3))), dim=-1).to(gu.DEV)
+    d2, c2, v2 = mlp(f16, d16)
+    od, oc = ro.render_mlp(sd, f16.cpu(), d16.cpu(), ro.RenderCfg(feature_size=128, feature_dim=64))
+    ov = ro.render_mlp_vp_features(sd, f16.cpu())
+    assert d2.shape == (16, 1) and c2.shape == (16, 3) and v2.shape == (16, 64)
+    assert not any(torch.isnan(t).any() for t in (d2, c2, v2))  # the reference test's own check
+    sc = od.abs().max().item()
+    assert (d2.cpu() - od).abs().max().item() < 1e-4 * max(1.0, sc) and (c2.cpu() - oc).abs().max().item() < 1e-4
+    assert (v2.cpu() - ov).abs().max().item() < 1e-4 * max(1.0, ov.abs().max().item())
+
+
+def test_implicit_function_reference_test_configuration(gu):
+    """`HoloVoxelGridImplicitFunction()` with the reference's DEFAULTS (resol 32, n_hidden 128, feature_dim 64) on the
+    inputs of its test_VoxelGridImplicitFunction_forward: pts (4, 64, 64, 16, 3) inside the volume, grid (1, 128, 32^3)
+    (holo_diffusion/tests/test_voxel_grid_implicit_function.py:29-41): shapes, no NaNs (the reference's checks), and a
+    strided subset of the 1 M points against the oracle."""
+    import os
+    from oracle.common import np_noise
+    EMU = os.environ.get("HOLO_TEST_EMU") == "1"
+    fn = hda.HoloVoxelGridImplicitFunction()
+    assert (fn.resol, fn.n_hidden, fn.feature_dim) == (32, 128, 64)
+    rcfg = ro.RenderCfg(resol=32, feature_size=128, feature_dim=64)
+    sd = gu.synth_state_dict(ro.render_mlp_param_shapes(rcfg), 31)
+    fn.render_mlp.load_state_dict(sd)
+    fn.to(gu.DEV)
+    shape = (2, 3, 4, 5, 3) if EMU else (4, 64, 64, 16, 3)
+    pts = ((torch.from_numpy(np_noise(9, shape)).clamp(-3, 3) / 3.0) * (fn.volume_extent / 2.0)).contiguous()
+    grid = torch.from_numpy(np_noise(10, (1, 128, 32, 32, 32)))
+    dens, feats, _ = fn(pts_3d=pts.to(gu.DEV), voxel_grid_features=grid.to(gu.DEV))
+    assert dens.shape == shape[:-1] + (1,) and feats.shape == shape[:-1] + (67,)
+    assert not torch.isnan(dens).any() and not torch.isnan(feats).any()
+    flat = pts.reshape(-1, 3)
+    sel = torch.arange(0, flat.shape[0], max(1, flat.shape[0] // 4099))  # incl. points in different 65 536-point passes
+    od, of = ro.implicit_function_pts(grid, sd, flat[sel], rcfg)
+    gd, gf = dens.reshape(-1, 1).cpu()[sel], feats.reshape(-1, 67).cpu()[sel]
+    assert (gd - od).abs().max().item() < 1e-4 * max(1.0, od.abs().max().item())
+    assert (gf - of).abs().max().item() < 1e-4 * max(1.0, of.abs().max().item())

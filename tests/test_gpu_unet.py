@@ -355,3 +355,67 @@ def test_f32_bf16x3_mode_meets_the_fp32_tolerance(gu, image, mc, mult, attn, bat
                 assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 1e-4, tag
     finally:
         del os.environ["HOLO_KEEP_INTERMEDIATES"]
+
+
+@pytest.mark.parametrize("compute,env", [("f32", {}), ("bf16", {}), ("bf16", {"HOLO_BF16_FLASH_MIN_T": "0", "HOLO_NO_FLASH_V2": "1"}),
+                                         ("bf16", {"HOLO_BF16_FLASH_MIN_T": "0"}), ("f32_bf16x3", {})])
+@pytest.mark.parametrize("image,mc,mult,attn", [(16, 128, (1, 2), (2,)), (16, 64, (1, 2, 2), (1, 2))])
+def test_forward_does_not_depend_on_workspace_contents(gu, compute, env, image, mc, mult, attn, monkeypatch):
+    """The caller-owned workspace may hold anything (the caching allocator hands back blocks of earlier work): a forward on
+    a workspace filled with 0xFF bytes (NaN as fp32 and as bf16) must give bit-identical, finite output to one on a zeroed
+    workspace, in every arithmetic mode and with each attention kernel forced on."""
+    from holo_diffusion_amd import runtime
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
+                     channel_mult=mult, attention_resolutions=attn, num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=7, compute_dtype=compute)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(13, (2, 16, image, image, image))).to(gu.DEV)
+    t = torch.tensor([77, 901], dtype=torch.int64, device=gu.DEV)
+    outs = []
+    for fill in (0, 0xFF, 0x7F):
+        ws = runtime.workspace(net, gu.DEV, net.workspace_bytes(2, gu.DEV))
+        ws.fill_(fill)
+        with torch.no_grad():
+            outs.append(net(x, t).clone())
+    assert torch.isfinite(outs[1]).all() and torch.isfinite(outs[2]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = uo.unet_forward(sd, cfg, x.cpu(), t.cpu())
+    assert gu.rel_err(outs[1], ref) < (2e-2 if compute == "bf16" else 2e-3)
+
+
+def test_simple_unet3d_reference_test_configuration(gu):
+    """`SimpleUnet3D()` with the reference's DEFAULTS (128 -> 128 channels, model_channels 128, channel_mult (1,2,4,8),
+    attention_resolutions (8,16), image_size 64) on the input of its own test (holo_diffusion/tests/test_diffusion_utils.py:
+    16-30): a (1, 128, 32, 32, 32) grid - NOT image_size^3: UNetModel is fully convolutional - and a random timestep.
+    Shape and no-NaN (the reference's checks) plus the full forward against the pinned oracle (2e-3 of the output scale,
+    SURVEY.md 8c).  Channel counts up to 1024 and attention with 512 head channels at 4^3 are outside the released YAMLs."""
+    import os
+    if os.environ.get("HOLO_TEST_EMU") == "1":
+        pytest.skip("a 128..1024-channel net is not an emulation size")
+    net = hda.SimpleUnet3D()
+    assert (net.image_size, net.in_channels, net.model_channels, net.channel_mult, net.attention_resolutions) == \
+        (64, 128, 128, (1, 2, 4, 8), (8, 16))
+    cfg = uo.UNetCfg(image_size=32, in_channels=128, out_channels=128, model_channels=128, num_res_blocks=2,
+                     channel_mult=(1, 2, 4, 8), attention_resolutions=(8, 16), num_heads=2)
+    sd = gu.synth_state_dict(uo.unet_param_shapes(cfg), 77)
+    net.load_state_dict({"_net." + k: v for k, v in sd.items()})
+    net.to(gu.DEV)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(21, (1, 128, 32, 32, 32)))
+    t = torch.tensor([437], dtype=torch.int64)
+    with torch.no_grad():
+        y = net(x=x.to(gu.DEV), timesteps=t.to(gu.DEV))
+    assert y.shape == (1, 128, 32, 32, 32) and not torch.isnan(y).any()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref = uo.unet_forward(sd, cfg, x, t)
+    assert (y.cpu() - ref).abs().max() <= 2e-3 * ref.abs().max()
+    # the same object still serves grids of its configured size (the plan follows the input)
+    small = hda.SimpleUnet3D(image_size=8, in_channels=16, out_channels=16, model_channels=32, channel_mult=(1, 2),
+                             attention_resolutions=(2,)).to(gu.DEV)
+    with torch.no_grad():
+        a = small(torch.zeros(1, 16, 8, 8, 8, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
+        b = small(torch.zeros(1, 16, 16, 16, 16, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
+        a2 = small(torch.zeros(1, 16, 8, 8, 8, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
+    assert a.shape[-1] == 8 and b.shape[-1] == 16 and torch.equal(a, a2)
