@@ -54,6 +54,12 @@ class HoloViewFeature(C.Structure):
     _fields_ = [("feats", C.c_void_p), ("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32)]
 
 
+class HoloMlpMeanCfg(C.Structure):
+    _fields_ = [("resol", C.c_int32), ("volume_extent", C.c_float), ("feature_size", C.c_int32), ("n_hidden", C.c_int32),
+                ("dim_out", C.c_int32), ("n_layers", C.c_int32), ("n_harmonic_functions_ray", C.c_int32),
+                ("n_feats", C.c_int32), ("channels", C.c_int32 * 8), ("projection_eps", C.c_float)]
+
+
 class HoloViewPoolCfg(C.Structure):
     _fields_ = [("resol", C.c_int32), ("volume_extent", C.c_float), ("feature_size", C.c_int32),
                 ("weight_by_ray_angle_gamma", C.c_float), ("min_ray_angle_weight", C.c_float),
@@ -107,6 +113,13 @@ SIGNATURES = {
     "holo_view_pool_workspace_bytes": (C.c_size_t, [C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
     "holo_view_pool": (C.c_int, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int,
                                  C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_mlp_mean_create": (C.c_int, [_vp, C.POINTER(HoloMlpMeanCfg), C.POINTER(_vp)]),
+    "holo_mlp_mean_destroy": (C.c_int, [_vp]),
+    "holo_mlp_mean_set_param": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _i64p, _vp]),
+    "holo_mlp_mean_commit": (C.c_int, [_vp, _vp]),
+    "holo_mlp_mean_workspace_bytes": (C.c_size_t, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
+    "holo_mlp_mean_pool": (C.c_int, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.POINTER(HoloCamera), C.c_int, _vp, _vp,
+                                     C.c_size_t, _vp]),
     "holo_event_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "holo_event_timer_start": (C.c_int, [_vp, _vp]),
     "holo_event_timer_stop": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),

@@ -103,11 +103,13 @@ def model_args_from_expconfig(cfg: Dict[str, Any], render_size: Optional[Tuple[i
         ifa["render_mlp_args"] = _filter_fields(
             RenderMLP, ifa["render_mlp_args"],
             f"{MODEL_ARGS_KEY}.implicit_function_HoloVoxelGridImplicitFunction_args.render_mlp_args", ignored)
-    # encoder side (view pooling): kept when the configured pooler is one the fused kernel implements (the released
-    # YAMLs: AngleWeightedReductionFeatureAggregator [AVG, STD], bilinear, unmasked), dropped - and reported - otherwise,
-    # so that sampling from ANY HoloDiffusion checkpoint keeps working
+    # encoder side (view pooling): kept when the configured pooler is one the fused kernels implement (the released
+    # YAMLs: AngleWeightedReductionFeatureAggregator [AVG, STD] or the learnt MLPMeanFeatureAggregator of hydrant.yaml /
+    # old_base_config.yaml; bilinear, unmasked), dropped - and reported - otherwise, so that sampling from ANY
+    # HoloDiffusion checkpoint keeps working
     if kw.get("view_pooler_enabled"):
-        from .viewpool import AngleWeightedReductionFeatureAggregator, ViewPooler, ViewSampler
+        from .viewpool import (AngleWeightedReductionFeatureAggregator, MLPMeanFeatureAggregator, ViewPooler,
+                               ViewSampler)
         vpa = _filter_fields(ViewPooler, kw.get("view_pooler_args") or {}, f"{MODEL_ARGS_KEY}.view_pooler_args", ignored)
         try:
             if vpa.get("view_sampler_args") is not None:
@@ -117,6 +119,10 @@ def model_args_from_expconfig(cfg: Dict[str, Any], render_size: Optional[Tuple[i
             if vpa.get(akey) is not None:
                 vpa[akey] = _filter_fields(AngleWeightedReductionFeatureAggregator, vpa[akey],
                                            f"{MODEL_ARGS_KEY}.view_pooler_args.{akey}", ignored)
+            mkey = "feature_aggregator_MLPMeanFeatureAggregator_args"
+            if vpa.get(mkey) is not None:
+                vpa[mkey] = _filter_fields(MLPMeanFeatureAggregator, vpa[mkey], f"{MODEL_ARGS_KEY}.view_pooler_args.{mkey}",
+                                           ignored)
             ViewPooler(**vpa)  # validates the configuration
             kw["view_pooler_args"] = vpa
         except (NotImplementedError, ValueError, TypeError, KeyError) as e:

@@ -283,6 +283,22 @@ struct ViewPoolParams {
   float* out;         // (1, F, R, R, R)
 };
 int view_pool_launch(const ViewPoolParams& p, void* stream);
+// MLPMeanFeatureAggregator path (kernels_viewpool.hip): the folded aggregator + mapper (viewpool_exec.cpp); vp carries the
+// views, the feature maps (quad0 = first quad in the kernel's padded channel order), R, F, proj_eps and the output
+struct MlpMeanParams {
+  ViewPoolParams vp;
+  const float* a;    // [128][dp]  W1 Ws in the padded channel order
+  const float* am;   // [128][dp]  W1 Wm
+  const float* cb;   // [128]      W1 (bs + bm) + b1
+  const float* g;    // [F][128]   M Wl
+  const float* g0;   // [F]        M bl + mapper bias
+  const float* l;    // [128]      Wl[0]
+  float l0;          // bl[0]
+  int dp;            // padded input width (multiple of 8): sum of the maps' padded channels + padded embedding
+  int emb0;          // first column of the ray-direction embedding
+  int n_harmonic;
+};
+int mlp_mean_pool_launch(const MlpMeanParams& p, int num_cus, void* stream);
 int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);   // = dirs + points

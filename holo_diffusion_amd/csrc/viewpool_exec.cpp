@@ -8,6 +8,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "../../include/holo_abi.h"
 #include "holo_common.h"
 #include "holo_kernels.h"
@@ -101,6 +105,274 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
   p.proj_eps = cfg->projection_eps;
   p.out = voxel_features;
   return view_pool_launch(p, stream) ? HOLO_E_INVALID : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLPMeanFeatureAggregator path (custom_modules.py:162-334; configs/hydrant.yaml:184): parameter binding, the float64
+// fold of the affine stretches (see kernels_viewpool.hip) and the launch.
+// ---------------------------------------------------------------------------------------------------------------------
+struct HoloMlpMeanPooler {
+  HoloCtx* ctx;
+  HoloMlpMeanCfg cfg;
+  std::map<std::string, std::vector<float>> host;
+  std::map<std::string, std::vector<int64_t>> expected;
+  int D = 0, E = 0, dp = 0, emb0 = 0;
+  int quad0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float* dev = nullptr;  // a | am | cb | g | g0 | l
+  float l0 = 0.f;
+  bool committed = false;
+};
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return HOLO_E_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+int holo_mlp_mean_create(HoloCtx* ctx, const HoloMlpMeanCfg* cfg, HoloMlpMeanPooler** out) {
+  if (!ctx || !cfg || !out) {
+    set_error("holo_mlp_mean_create: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (cfg->n_hidden != 128 || cfg->n_layers != 1 || cfg->feature_size < 1 || cfg->feature_size > 32 || cfg->dim_out < 1 ||
+      cfg->n_harmonic_functions_ray < 0 || cfg->n_harmonic_functions_ray > 8 || cfg->n_feats < 1 ||
+      cfg->n_feats > ViewPoolParams::MAX_FEATS || cfg->resol < 2) {
+    set_error("holo_mlp_mean_create: unsupported configuration (n_hidden 128, n_layers 1, feature_size <= 32, "
+              "1..%d feature maps, <= 8 harmonic functions)", ViewPoolParams::MAX_FEATS);
+    return HOLO_E_UNSUPPORTED;
+  }
+  HoloMlpMeanPooler* h = new HoloMlpMeanPooler;
+  h->ctx = ctx;
+  h->cfg = *cfg;
+  int quad = 0;
+  for (int k = 0; k < cfg->n_feats; ++k) {
+    if (cfg->channels[k] < 1) {
+      delete h;
+      set_error("holo_mlp_mean_create: feature map %d has no channels", k);
+      return HOLO_E_INVALID;
+    }
+    h->quad0[k] = quad;
+    quad += (cfg->channels[k] + 3) / 4;
+    h->D += cfg->channels[k];
+  }
+  h->E = 3 * (2 * cfg->n_harmonic_functions_ray + 1);
+  h->D += h->E;
+  h->emb0 = quad * 4;
+  const int dq = h->emb0 + (h->E + 3) / 4 * 4;
+  static const int widths[5] = {32, 48, 64, 96, 128};
+  for (int w : widths)
+    if (!h->dp && dq <= w) h->dp = w;
+  if (!h->dp) {
+    delete h;
+    set_error("holo_mlp_mean_create: %d input channels (padded %d) exceed the kernel's 128", h->D, dq);
+    return HOLO_E_UNSUPPORTED;
+  }
+  const int64_t nh = cfg->n_hidden, D = h->D, dout = cfg->dim_out, F = cfg->feature_size;
+  h->expected["_first_sampled.weight"] = {nh, D};
+  h->expected["_first_sampled.bias"] = {nh};
+  h->expected["_first_mean.weight"] = {nh, D};
+  h->expected["_first_mean.bias"] = {nh};
+  h->expected["_mlp.mlp.0.0.weight"] = {nh, nh};
+  h->expected["_mlp.mlp.0.0.bias"] = {nh};
+  h->expected["_last.weight"] = {dout, nh};
+  h->expected["_last.bias"] = {dout};
+  h->expected["pooled_feature_mapper.weight"] = {F, dout};
+  h->expected["pooled_feature_mapper.bias"] = {F};
+  const size_t n = (size_t)(2 * nh * h->dp + nh + F * nh + F + nh + 64);
+  if (hipMalloc((void**)&h->dev, n * sizeof(float)) != hipSuccess) {
+    delete h;
+    set_error("holo_mlp_mean_create: hipMalloc failed");
+    return HOLO_E_HIP;
+  }
+  *out = h;
+  return 0;
+}
+
+int holo_mlp_mean_destroy(HoloMlpMeanPooler* h) {
+  if (!h) return 0;
+  if (h->dev) (void)hipFree(h->dev);
+  delete h;
+  return 0;
+}
+
+int holo_mlp_mean_set_param(HoloMlpMeanPooler* h, const char* name, const void* dev_ptr, int ndim, const int64_t* shape,
+                            void* stream) {
+  if (!h || !name || !dev_ptr || !shape) {
+    set_error("holo_mlp_mean_set_param: null argument");
+    return HOLO_E_INVALID;
+  }
+  auto it = h->expected.find(name);
+  if (it == h->expected.end()) {
+    set_error("holo_mlp_mean_set_param: unknown parameter '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  bool ok = ndim == (int)it->second.size();
+  int64_t numel = 1;
+  for (int i = 0; ok && i < ndim; ++i) {
+    ok = shape[i] == it->second[i];
+    numel *= shape[i];
+  }
+  if (!ok) {
+    set_error("holo_mlp_mean_set_param: shape mismatch for '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  std::vector<float>& v = h->host[name];
+  v.resize((size_t)numel);
+  HIP_TRY(hipMemcpyAsync(v.data(), dev_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  h->committed = false;
+  return 0;
+}
+
+int holo_mlp_mean_commit(HoloMlpMeanPooler* h, void* stream) {
+  if (!h) {
+    set_error("holo_mlp_mean_commit: null");
+    return HOLO_E_INVALID;
+  }
+  for (auto& kv : h->expected)
+    if (!h->host.count(kv.first)) {
+      set_error("holo_mlp_mean_commit: parameter '%s' has not been set", kv.first.c_str());
+      return HOLO_E_STATE;
+    }
+  const int nh = h->cfg.n_hidden, D = h->D, dp = h->dp, dout = h->cfg.dim_out, F = h->cfg.feature_size;
+  auto W = [&](const char* n) -> const std::vector<float>& { return h->host[n]; };
+  const auto &Ws = W("_first_sampled.weight"), &bs = W("_first_sampled.bias"), &Wm = W("_first_mean.weight"),
+             &bm = W("_first_mean.bias"), &W1 = W("_mlp.mlp.0.0.weight"), &b1 = W("_mlp.mlp.0.0.bias"),
+             &Wl = W("_last.weight"), &bl = W("_last.bias"), &M = W("pooled_feature_mapper.weight"),
+             &mb = W("pooled_feature_mapper.bias");
+  // column of reference channel c (torch.cat order: maps in dict order, then the embedding) in the padded order
+  std::vector<int> col(D);
+  {
+    int c = 0;
+    for (int k = 0; k < h->cfg.n_feats; ++k)
+      for (int j = 0; j < h->cfg.channels[k]; ++j) col[c++] = h->quad0[k] * 4 + j;
+    for (int j = 0; j < h->E; ++j) col[c++] = h->emb0 + j;
+  }
+  std::vector<float> pk((size_t)(2 * nh * dp + nh + F * nh + F + nh), 0.f);
+  float* a = pk.data();
+  float* am = a + (size_t)nh * dp;
+  float* cb = am + (size_t)nh * dp;
+  float* g = cb + nh;
+  float* g0 = g + (size_t)F * nh;
+  float* l = g0 + F;
+  for (int i = 0; i < nh; ++i) {
+    std::vector<double> ra(D, 0.0), rm(D, 0.0);
+    double c = b1[i];
+    for (int k = 0; k < nh; ++k) {
+      const double w = W1[(size_t)i * nh + k];
+      c += w * ((double)bs[k] + (double)bm[k]);
+      for (int j = 0; j < D; ++j) {
+        ra[j] += w * Ws[(size_t)k * D + j];
+        rm[j] += w * Wm[(size_t)k * D + j];
+      }
+    }
+    for (int j = 0; j < D; ++j) {
+      a[(size_t)i * dp + col[j]] = (float)ra[j];
+      am[(size_t)i * dp + col[j]] = (float)rm[j];
+    }
+    cb[i] = (float)c;
+    l[i] = Wl[i];  // row 0 of _last
+  }
+  for (int f = 0; f < F; ++f) {
+    double c = mb[f];
+    std::vector<double> rg(nh, 0.0);
+    for (int o = 0; o < dout; ++o) {
+      const double w = M[(size_t)f * dout + o];
+      c += w * bl[o];
+      for (int k = 0; k < nh; ++k) rg[k] += w * Wl[(size_t)o * nh + k];
+    }
+    for (int k = 0; k < nh; ++k) g[(size_t)f * nh + k] = (float)rg[k];
+    g0[f] = (float)c;
+  }
+  h->l0 = bl[0];
+  HIP_TRY(hipMemcpyAsync(h->dev, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  h->committed = true;
+  return 0;
+}
+
+size_t holo_mlp_mean_workspace_bytes(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views) {
+  if (!h || !feats || n_feats < 1 || n_views < 1) return 0;
+  size_t b = 0;
+  for (int k = 0; k < n_feats; ++k) {
+    const size_t Cp = (size_t)((feats[k].channels + 3) / 4 * 4);
+    b += align256((size_t)n_views * feats[k].height * feats[k].width * Cp * sizeof(float));
+  }
+  return b + 256;
+}
+
+int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras,
+                       int n_views, float* voxel_features, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !feats || !cameras || !voxel_features || !workspace) {
+    set_error("holo_mlp_mean_pool: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (!h->committed) {
+    set_error("holo_mlp_mean_pool: call holo_mlp_mean_commit after setting the parameters");
+    return HOLO_E_STATE;
+  }
+  if (n_feats != h->cfg.n_feats || n_views < 1 || n_views > ViewPoolParams::MAX_VIEWS) {
+    set_error("holo_mlp_mean_pool: %d feature maps (created for %d), 1..%d source views", n_feats, h->cfg.n_feats,
+              ViewPoolParams::MAX_VIEWS);
+    return HOLO_E_INVALID;
+  }
+  if (workspace_bytes < holo_mlp_mean_workspace_bytes(h, feats, n_feats, n_views)) {
+    set_error("holo_mlp_mean_pool: workspace too small");
+    return HOLO_E_WORKSPACE;
+  }
+  MlpMeanParams p;
+  memset(&p, 0, sizeof p);
+  char* ws = (char*)workspace;
+  for (int k = 0; k < n_feats; ++k) {
+    const HoloViewFeature& f = feats[k];
+    if (!f.feats || f.channels != h->cfg.channels[k] || f.height < 1 || f.width < 1) {
+      set_error("holo_mlp_mean_pool: feature map %d must have %d channels", k, h->cfg.channels[k]);
+      return HOLO_E_INVALID;
+    }
+    ViewPoolParams::Feat& o = p.vp.feat[k];
+    o.C = f.channels;
+    o.Cp = (f.channels + 3) / 4 * 4;
+    o.H = f.height;
+    o.W = f.width;
+    o.quad0 = h->quad0[k];
+    o.data = (const float*)ws;
+    if (nchw_to_nhwc_pad_launch(f.feats, (float*)ws, n_views, o.C, o.Cp, (int64_t)o.H * o.W, stream)) return HOLO_E_INVALID;
+    ws += align256((size_t)n_views * o.H * o.W * o.Cp * sizeof(float));
+  }
+  p.vp.n_feats = n_feats;
+  p.vp.n_views = n_views;
+  for (int v = 0; v < n_views; ++v) {
+    const HoloCamera& c = cameras[v];
+    ViewPoolParams::Cam& o = p.vp.cams[v];
+    for (int k = 0; k < 9; ++k) o.Rm[k] = c.R[k];
+    for (int k = 0; k < 3; ++k) o.T[k] = c.T[k];
+    for (int k = 0; k < 2; ++k) {
+      o.focal[k] = c.focal[k];
+      o.pp[k] = c.principal_point[k];
+    }
+    for (int j = 0; j < 3; ++j)  // camera centre C = -T R^T (custom_modules.py:304-312)
+      o.centre[j] = -(c.T[0] * c.R[j * 3 + 0] + c.T[1] * c.R[j * 3 + 1] + c.T[2] * c.R[j * 3 + 2]);
+  }
+  p.vp.R = h->cfg.resol;
+  p.vp.half_extent = 0.5f * (float)(h->cfg.resol - 1) * (h->cfg.volume_extent / (float)h->cfg.resol);
+  p.vp.proj_eps = h->cfg.projection_eps;
+  p.vp.F = h->cfg.feature_size;
+  p.vp.out = voxel_features;
+  const int nh = h->cfg.n_hidden, F = h->cfg.feature_size;
+  p.a = h->dev;
+  p.am = p.a + (size_t)nh * h->dp;
+  p.cb = p.am + (size_t)nh * h->dp;
+  p.g = p.cb + nh;
+  p.g0 = p.g + (size_t)F * nh;
+  p.l = p.g0 + F;
+  p.l0 = h->l0;
+  p.dp = h->dp;
+  p.emb0 = h->emb0;
+  p.n_harmonic = h->cfg.n_harmonic_functions_ray;
+  return mlp_mean_pool_launch(p, h->ctx->num_cus, stream) ? HOLO_E_INVALID : 0;
 }
 
 }  // extern "C"

@@ -68,10 +68,82 @@ class AngleWeightedReductionFeatureAggregator(FeatureAggregatorBase):
         return len(self.reduction_functions) * d
 
 
+@registry.register_local  # (the reference registers ITS class under this name, custom_modules.py:162-163: never overwrite it)
+class MLPMeanFeatureAggregator(torch.nn.Module, FeatureAggregatorBase):
+    """The learnt aggregator of configs/hydrant.yaml:184 / old_base_config.yaml:205 (custom_modules.py:162-293): config
+    fields :171-176 (+ PyTorch3D's three FeatureAggregatorBase fields), parameters under the reference's names
+    ``_first_sampled`` / ``_first_mean`` (LazyLinear: sized by the first checkpoint or pooled batch), ``_mlp.mlp.0.0``,
+    ``_last``.  The arithmetic runs in ``holo_mlp_mean_pool`` (csrc/kernels_viewpool.hip), fused with the sampling in
+    front of it and the model's ``pooled_feature_mapper`` + tanh behind it."""
+    exclude_target_view: bool = True
+    exclude_target_view_mask_features: bool = True
+    concatenate_output: bool = True
+    n_hidden: int = 128
+    dim_out: int = 128
+    n_layers: int = 1
+    n_harmonic_functions_ray: int = 3
+    checkpointed_mlp: bool = True
+
+    def __init__(self, **kwargs):
+        torch.nn.Module.__init__(self)
+        self.__dict__["_native"] = None  # [handle, key, parameter versions] of the folded native copy
+        apply_config(self, kwargs)
+        if self.n_hidden != 128 or self.n_layers != 1 or not self.concatenate_output:
+            raise NotImplementedError("MLPMeanFeatureAggregator: the fused kernel implements the released configuration "
+                                      "(n_hidden 128, n_layers 1, concatenated output; configs/hydrant.yaml:188-196)")
+        nh = self.n_hidden
+        self._first_sampled = torch.nn.LazyLinear(nh)  # LazyLinearWithXavierInit (custom_modules.py:36-41)
+        self._first_mean = torch.nn.LazyLinear(nh)
+        self._last = torch.nn.Linear(nh, self.dim_out)
+        torch.nn.init.xavier_uniform_(self._last.weight)
+        self._mlp = torch.nn.Module()
+        self._mlp.mlp = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(nh, nh))])  # names `_mlp.mlp.0.0.*`
+        torch.nn.init.xavier_uniform_(self._mlp.mlp[0][0].weight)
+        for p in self.parameters():
+            if not isinstance(p, torch.nn.parameter.UninitializedParameter):
+                p.requires_grad_(False)
+
+    def get_aggregated_feature_dim(self, feats_or_feats_dim) -> int:
+        return self.dim_out
+
+    def input_dim(self, feats: Dict[str, torch.Tensor]) -> int:
+        return sum(int(t.shape[1]) for t in feats.values()) + 3 * (2 * self.n_harmonic_functions_ray + 1)
+
+    def materialize(self, in_dim: int, device) -> None:
+        """First use of the two LazyLinear layers (Xavier weights, zero bias: custom_modules.py:36-41)."""
+        for lin in (self._first_sampled, self._first_mean):
+            if isinstance(lin.weight, torch.nn.parameter.UninitializedParameter):
+                lin.in_features = in_dim
+                lin.weight.materialize((self.n_hidden, in_dim), device=device)
+                lin.bias.materialize((self.n_hidden,), device=device)
+                torch.nn.init.xavier_uniform_(lin.weight.data)
+                lin.bias.data.zero_()
+                lin.__class__ = torch.nn.Linear
+                lin.weight.requires_grad_(False)
+                lin.bias.requires_grad_(False)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("MLPMeanFeatureAggregator: aggregation at arbitrary points is not on this path; the model "
+                                  "pools onto its voxel grid through ViewPooler.pool_to_voxel_features() (one fused kernel)")
+
+    def close(self):
+        nat = self.__dict__.get("_native")
+        if nat is not None:
+            try:
+                runtime.lib().holo_mlp_mean_destroy(nat[0])
+            except Exception:
+                pass
+            self.__dict__["_native"] = None
+
+    def __del__(self):
+        self.close()
+
+
 class ViewPooler(Configurable, torch.nn.Module):
     view_sampler_args: Optional[dict] = None
     feature_aggregator_class_type: str = "AngleWeightedReductionFeatureAggregator"
     feature_aggregator_AngleWeightedReductionFeatureAggregator_args: Optional[dict] = None
+    feature_aggregator_MLPMeanFeatureAggregator_args: Optional[dict] = None
 
     def __init__(self, **kwargs):
         torch.nn.Module.__init__(self)
@@ -97,6 +169,8 @@ class ViewPooler(Configurable, torch.nn.Module):
         if agg.exclude_target_view or agg.exclude_target_view_mask_features:
             raise _lib.HoloError("view pooling: exclude_target_view(_mask_features) must be False "
                                  "(HoloDiffusionModel sets both, holo_diffusion_model.py:114-116)")
+        if isinstance(agg, MLPMeanFeatureAggregator):
+            return self._pool_mlp_mean(feats, camera, mapper_weight, mapper_bias, resol, volume_extent)
         from .render import _camera_array
         keys = list(feats)
         if not keys:
@@ -132,4 +206,64 @@ class ViewPooler(Configurable, torch.nn.Module):
         _lib.check(L, L.holo_view_pool(runtime.ctx(dev), C.byref(cfg), arr, len(keys), cams, n_src, runtime.ptr(w),
                                        runtime.ptr(b) if b is not None else C.c_void_p(None), runtime.ptr(out),
                                        runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_view_pool")
+        return out
+
+    @torch.no_grad()
+    def _pool_mlp_mean(self, feats: Dict[str, torch.Tensor], camera, mapper_weight, mapper_bias, resol: int,
+                       volume_extent: float) -> torch.Tensor:
+        from .render import _camera_array
+        agg: MLPMeanFeatureAggregator = self.feature_aggregator
+        keys = list(feats)
+        t0 = feats[keys[0]]
+        runtime.require_device(t0, "ViewPooler.pool_to_voxel_features")
+        dev, n_src = t0.device, int(t0.shape[0])
+        agg.materialize(agg.input_dim(feats), dev)
+        F = int(mapper_weight.shape[0])
+        if tuple(mapper_weight.shape) != (F, agg.dim_out):
+            raise _lib.HoloError(f"pooled_feature_mapper.weight must be ({F}, {agg.dim_out}), got {tuple(mapper_weight.shape)}")
+        arr = (_lib.HoloViewFeature * len(keys))()
+        held = []
+        for i, k in enumerate(keys):
+            t = feats[k]
+            if t.dim() != 4 or t.shape[0] != n_src or t.device != dev:
+                raise _lib.HoloError(f"feature map '{k}' must be (n_src={n_src}, C, H, W) on {dev}, got {tuple(t.shape)}")
+            t = t.contiguous().float()
+            held.append(t)
+            arr[i].feats = t.data_ptr()
+            arr[i].channels, arr[i].height, arr[i].width = int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+        cams = _camera_array(camera)
+        if len(cams) != n_src:
+            raise _lib.HoloError(f"{len(cams)} cameras for {n_src} source views")
+        L = runtime.lib()
+        params = {k: p for k, p in agg.named_parameters()}
+        params["pooled_feature_mapper.weight"] = mapper_weight
+        params["pooled_feature_mapper.bias"] = mapper_bias if mapper_bias is not None else torch.zeros(F, device=dev)
+        key = (dev, int(resol), float(volume_extent), F, tuple(int(a.channels) for a in arr))
+        versions = tuple((k, p.data_ptr(), p._version) for k, p in params.items())
+        if agg._native is None or agg._native[1] != key:
+            agg.close()
+            cfg = _lib.HoloMlpMeanCfg()
+            cfg.resol, cfg.volume_extent, cfg.feature_size = int(resol), float(volume_extent), F
+            cfg.n_hidden, cfg.dim_out, cfg.n_layers = int(agg.n_hidden), int(agg.dim_out), int(agg.n_layers)
+            cfg.n_harmonic_functions_ray, cfg.n_feats, cfg.projection_eps = int(agg.n_harmonic_functions_ray), len(keys), 1e-2
+            for i in range(len(keys)):
+                cfg.channels[i] = int(arr[i].channels)
+            h = C.c_void_p()
+            _lib.check(L, L.holo_mlp_mean_create(runtime.ctx(dev), C.byref(cfg), C.byref(h)), "holo_mlp_mean_create")
+            agg.__dict__["_native"] = [h, key, None]
+        h = agg._native[0]
+        if agg._native[2] != versions:
+            st = runtime.stream_ptr(dev)
+            for k, p in params.items():
+                if p.device != dev or p.dtype != torch.float32:
+                    raise _lib.HoloError(f"aggregator parameter '{k}' is {p.dtype} on {p.device}; expected float32 on {dev}")
+                t = p.detach().contiguous()
+                _lib.check(L, L.holo_mlp_mean_set_param(h, k.encode(), runtime.ptr(t), t.dim(), _lib.shape_array(t.shape), st),
+                           f"holo_mlp_mean_set_param({k})")
+            _lib.check(L, L.holo_mlp_mean_commit(h, st), "holo_mlp_mean_commit")
+            agg._native[2] = versions
+        ws = runtime.workspace(self, dev, L.holo_mlp_mean_workspace_bytes(h, arr, len(keys), n_src))
+        out = torch.empty(1, F, resol, resol, resol, device=dev)
+        _lib.check(L, L.holo_mlp_mean_pool(h, arr, len(keys), cams, n_src, runtime.ptr(out), runtime.ptr(ws), ws.numel(),
+                                           runtime.stream_ptr(dev)), "holo_mlp_mean_pool")
         return out

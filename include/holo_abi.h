@@ -261,6 +261,37 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
                    const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
                    float* voxel_features, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same entry with the reference's own LEARNT aggregator, MLPMeanFeatureAggregator (holo_diffusion/custom_modules.py:
+ * 162-293 + _get_point_to_source_camera_ray_dirs :296-334; selected by configs/hydrant.yaml:184 and
+ * old_base_config.yaml:205): per source view [sampled features | harmonic(ray direction)] -> two LazyLinear layers
+ * (sample, mean over views) -> one Linear + LeakyReLU -> Linear; softmax over the views of output 0; then
+ * pooled_feature_mapper + tanh (holo_diffusion_model.py:368-373).  Parameters by the reference's state-dict names below
+ * `view_pooler.feature_aggregator.`: "_first_sampled.{weight,bias}", "_first_mean.{weight,bias}",
+ * "_mlp.mlp.0.0.{weight,bias}", "_last.{weight,bias}", plus "pooled_feature_mapper.{weight,bias}".  Masks are all ones and
+ * no view is excluded (holo_diffusion_model.py:114-116 forces both exclusions off; masked_sampling false). */
+typedef struct HoloMlpMeanPooler HoloMlpMeanPooler;
+typedef struct {
+  int32_t resol;
+  float volume_extent;
+  int32_t feature_size;             /* rows of pooled_feature_mapper (<= 32) */
+  int32_t n_hidden;                 /* 128 */
+  int32_t dim_out;                  /* 128 */
+  int32_t n_layers;                 /* 1 */
+  int32_t n_harmonic_functions_ray; /* 3 */
+  int32_t n_feats;                  /* feature maps, in the image feature extractor's dict order */
+  int32_t channels[8];              /* channels of each map */
+  float projection_eps;             /* |z| clamp of camera.transform_points (1e-2) */
+} HoloMlpMeanCfg;
+int holo_mlp_mean_create(HoloCtx* ctx, const HoloMlpMeanCfg* cfg, HoloMlpMeanPooler** out);
+int holo_mlp_mean_destroy(HoloMlpMeanPooler* h);
+int holo_mlp_mean_set_param(HoloMlpMeanPooler* h, const char* name, const void* dev_ptr, int ndim, const int64_t* shape,
+                            void* stream);
+/* Folds the affine stretches of the aggregator + mapper in float64 and uploads them (setup time: synchronises). */
+int holo_mlp_mean_commit(HoloMlpMeanPooler* h, void* stream);
+size_t holo_mlp_mean_workspace_bytes(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views);
+int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras,
+                       int n_views, float* voxel_features, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
  * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).

@@ -136,3 +136,71 @@ def test_model_forward_from_source_views():
     assert torch.equal(m2(camera=cams[0], voxel_features=vf4)["images_render"], p4["images_render"])
     p5 = m2(camera=cams, image_features=d5)  # no names: every frame after the target is a source
     assert not torch.equal(p5["images_render"], p4["images_render"])
+
+
+# ---- MLPMeanFeatureAggregator (configs/hydrant.yaml:184) ------------------------------------------------------------
+def test_mlp_mean_config_and_state_dict_names():
+    """The plugin carries the reference's config fields and state-dict names (custom_modules.py:171-196), the LazyLinear
+    layers take their width from a checkpoint, and an experiment config that selects the aggregator keeps view pooling."""
+    from holo_diffusion_amd.viewpool import MLPMeanFeatureAggregator, ViewPooler
+    vp = ViewPooler(feature_aggregator_class_type="MLPMeanFeatureAggregator",
+                    feature_aggregator_MLPMeanFeatureAggregator_args=dict(n_hidden=128, dim_out=128, n_layers=1,
+                                                                          n_harmonic_functions_ray=3, checkpointed_mlp=True))
+    agg = vp.feature_aggregator
+    assert isinstance(agg, MLPMeanFeatureAggregator) and agg.get_aggregated_feature_dim({}) == 128
+    shapes = vo.mlp_mean_param_shapes(89)
+    assert set(agg.state_dict()) == set(shapes)
+    sd = synth_state_dict(shapes, 5)
+    agg.load_state_dict(sd)
+    assert tuple(agg._first_sampled.weight.shape) == (128, 89) and torch.equal(agg._mlp.mlp[0][0].weight, sd["_mlp.mlp.0.0.weight"])
+    from tests.test_checkpoint_loading import _expconfig
+    from holo_diffusion_amd import checkpoint as ck
+    cfg = _expconfig()
+    margs = cfg["model_factory_ImplicitronModelFactory_args"]["model_HoloDiffusionModel_args"]
+    margs["view_pooler_args"] = {"feature_aggregator_class_type": "MLPMeanFeatureAggregator",
+                                 "view_sampler_args": {"masked_sampling": False, "sampling_mode": "bilinear"},
+                                 "feature_aggregator_MLPMeanFeatureAggregator_args": {
+                                     "exclude_target_view": True, "exclude_target_view_mask_features": True,
+                                     "concatenate_output": True, "n_hidden": 128, "dim_out": 128, "n_layers": 1,
+                                     "n_harmonic_functions_ray": 3, "checkpointed_mlp": True}}
+    kw, ignored = ck.model_args_from_expconfig(cfg)
+    assert kw["view_pooler_enabled"] is True and not any("view pooling disabled" in s for s in ignored)
+    model = hda.HoloDiffusionModel(**kw)
+    assert isinstance(model.view_pooler.feature_aggregator, MLPMeanFeatureAggregator)
+    assert model.view_pooler.feature_aggregator.exclude_target_view is False  # forced off (holo_diffusion_model.py:114-116)
+    assert any(k.startswith("view_pooler.feature_aggregator._first_sampled.") for k in model.state_dict())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,n_src,radius,F,dim_out,n_harm", [(8, 3, 10.0, 16, 24, 3), (16, 5, 6.0, 32, 128, 3), (8, 9, 3.0, 16, 128, 2)])
+def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_harm):
+    """holo_mlp_mean_pool (projection + bilinear gather + ray-direction embedding + the folded MLPMeanFeatureAggregator on
+    the matrix cores + softmax over views + mapper + tanh, one kernel) against the oracle, whose aggregator is bit-equal
+    to the reference class (tests/golden/ref_mlp_mean_aggregator.npz); cameras far, near and INSIDE the bounding sphere."""
+    import tests.gpu_utils as gu
+    feats, _ = _synthetic_views(n_src, 150 + R)
+    D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
+    cams_d = _cams(n_src, radius=radius)
+    shapes = vo.mlp_mean_param_shapes(D, 128, dim_out)
+    sd = synth_state_dict(shapes, 21)
+    for k in shapes:
+        if k.endswith("bias"):
+            sd[k] = 0.1 * torch.from_numpy(np_noise(len(k), shapes[k]))
+    w = synth_state_dict({"w": (F, dim_out), "b": (F,)}, 9)
+    w["b"] = 0.1 * torch.from_numpy(np_noise(4, (F,)))
+    ref = vo.voxel_features_from_views_mlp_mean(feats, cams_d, sd, w["w"], w["b"], R, 8.0, n_harmonic=n_harm)
+    model = hda.HoloDiffusionModel(
+        resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False, diffusion_enabled=False,
+        render_image_width=8, render_image_height=8,
+        view_pooler_args=dict(feature_aggregator_class_type="MLPMeanFeatureAggregator",
+                              feature_aggregator_MLPMeanFeatureAggregator_args=dict(dim_out=dim_out, n_harmonic_functions_ray=n_harm)))
+    full = {"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}
+    full.update({"view_pooler.feature_aggregator." + k: v for k, v in sd.items()})
+    res = model.load_state_dict(full, strict=False)
+    assert not res.unexpected_keys
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    got = model.pool_views_to_voxel_features({k: v.to(gu.DEV) for k, v in feats.items()}, cams.to(gu.DEV))
+    assert got.shape == (1, F, R, R, R)
+    assert (got.cpu() - ref).abs().max().item() < 1e-4
+    assert ref.abs().max() <= 1.0 and ref.std() > 0.02
