@@ -69,8 +69,8 @@ def render_flyaround(*args, **kwargs) -> Dict[str, torch.Tensor]:
         ``render_flyaround(dataset, sequence_name, model, output_video_path, ..., sample_mode=True, ...)``:
         ``dataset`` may be ``None`` in sample mode (flyaround.py:150-153), ``trajectory_type`` must be ``simple_360``
         (the only one that needs no training cameras), displayable frames go to ``output_video_frames_dir`` (or next
-        to ``output_video_path``); video encoding / visdom are outside the path.  Reconstruction mode
-        (``sample_mode=False``) needs the encoder side and raises."""
+        to ``output_video_path``); video encoding / visdom are outside the path.  ``sample_mode=False`` is the
+        reconstruction mode of visualize_reconstruction.py:60-162 (see ``_render_flyaround_reconstruction``)."""
     first = args[0] if args else kwargs.get("model", kwargs.get("dataset"))
     if isinstance(first, torch.nn.Module) and "sequence_name" not in kwargs:
         return _render_flyaround(*args, **kwargs)
@@ -92,19 +92,22 @@ def _render_flyaround_reference_form(dataset=None, sequence_name: str = "sample"
                                      save_voxel_features: bool = False) -> Dict[str, torch.Tensor]:
     if model is None:
         raise TypeError("render_flyaround: `model` is required")
-    if not sample_mode:
-        raise NotImplementedError("render_flyaround(sample_mode=False): reconstruction of a dataset sequence needs the "
-                                  "encoder / view-pooling side (SURVEY.md 8f-3), which is outside this path")
     if trajectory_type.lower() != "simple_360":
-        raise NotImplementedError(f"trajectory_type '{trajectory_type}' is fitted to training cameras; sample mode on "
-                                  "this path supports 'simple_360' (flyaround.py:176-184)")
+        raise NotImplementedError(f"trajectory_type '{trajectory_type}' is fitted to training cameras by PyTorch3D's "
+                                  "generate_eval_video_cameras; this path supports 'simple_360' (flyaround.py:176-184)")
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     if dev.type == "cuda" and dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    out = _render_flyaround(model, n_flyaround_poses=n_flyaround_poses, up=tuple(up), camera_elevation=camera_elevation,
-                            camera_focal_length=camera_focal_length, hemispherical_radius=hemispherical_radius,
-                            max_angle=max_angle, device=dev,
-                            progressive_sampling_steps_per_render=progressive_sampling_steps_per_render)
+    if sample_mode:
+        out = _render_flyaround(model, n_flyaround_poses=n_flyaround_poses, up=tuple(up), camera_elevation=camera_elevation,
+                                camera_focal_length=camera_focal_length, hemispherical_radius=hemispherical_radius,
+                                max_angle=max_angle, device=dev,
+                                progressive_sampling_steps_per_render=progressive_sampling_steps_per_render)
+    else:
+        out = _render_flyaround_reconstruction(dataset, sequence_name, model, n_source_views=n_source_views, seed=seed,
+                                               n_flyaround_poses=n_flyaround_poses, up=tuple(up),
+                                               camera_elevation=camera_elevation, camera_focal_length=camera_focal_length,
+                                               hemispherical_radius=hemispherical_radius, max_angle=max_angle, device=dev)
     name = output_video_name or sequence_name
     frames_dir = output_video_frames_dir or (os.path.dirname(output_video_path) if output_video_path else None)
     if frames_dir:
@@ -113,6 +116,66 @@ def _render_flyaround_reference_form(dataset=None, sequence_name: str = "sample"
         export_flyaround_frames({k: v for k, v in out.items() if k in tuple(visualize_preds_keys)}, frames_dir, name)
         if save_voxel_features and out.get("voxel_features") is not None:  # flyaround.py:288-294
             torch.save(out["voxel_features"], os.path.join(frames_dir, f"{sequence_name}_voxel_features.pth"))
+    return out
+
+
+def _frame_field(frame, key):
+    return frame.get(key) if isinstance(frame, dict) else getattr(frame, key, None)
+
+
+def select_source_views(n_frames: int, n_source_views: int, seed) -> List[int]:
+    """The reference's reproducible choice of source frames (flyaround.py:164-167): a seeded random permutation of the
+    sequence's frames under a forked RNG, the first ``n_source_views`` of it."""
+    with torch.random.fork_rng():
+        torch.manual_seed(0 if seed is None else int(seed))
+        return torch.randperm(n_frames)[:n_source_views].tolist()
+
+
+def _render_flyaround_reconstruction(dataset, sequence_name: str, model, n_source_views: int = 9, seed=None,
+                                     n_flyaround_poses: int = 40, up=(0.0, -1.0, 0.0),
+                                     camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
+                                     hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
+                                     device: torch.device = torch.device("cuda")) -> Dict[str, torch.Tensor]:
+    """Reconstruction fly-around (flyaround.py:153-171,219-253; visualize_reconstruction.py:60-162): ``n_source_views``
+    frames of the sequence are drawn reproducibly, their features are pooled onto the voxel grid, the grid goes through
+    ``tanh(net_3d(., 0))`` and is rendered from the fly-around cameras.
+
+    ``dataset``: any object with Implicitron's ``sequence_indices_in_order(sequence_name)`` and ``__getitem__``; a frame
+    (attributes or dict keys) carries ``camera`` (``R, T, focal_length, principal_point``), and either ``image_features``
+    - the image feature extractor's dict for that frame, key -> (C, H, W) - or ``image_rgb`` (3, H, W) (+ optional
+    ``fg_probability``) for ``model.image_feature_extractor``.  The reference re-runs the encoder and the view pooling for
+    every rendered frame with identical inputs (only the target camera changes, flyaround.py:222-224); here the grid is
+    pooled once and all cameras are rendered in one call - the frames are the same."""
+    if dataset is None:
+        raise ValueError("render_flyaround(sample_mode=False) needs the dataset of the sequence to reconstruct")
+    if not getattr(model, "view_pooler_enabled", False):
+        raise ValueError("reconstruction needs a model with view_pooler_enabled")
+    seq_idx = list(dataset.sequence_indices_in_order(sequence_name))
+    if not seq_idx:
+        raise ValueError(f"sequence '{sequence_name}' has no frames")
+    frames = [dataset[seq_idx[i]] for i in select_source_views(len(seq_idx), n_source_views, seed)]
+    cam_fields = {k: torch.cat([torch.as_tensor(getattr(_frame_field(f, "camera"), k), dtype=torch.float32).reshape(
+        (1, 3, 3) if k == "R" else (1, -1)) for f in frames]) for k in ("R", "T", "focal_length", "principal_point")}
+    src_cams = PerspectiveCameras(R=cam_fields["R"], T=cam_fields["T"], focal_length=cam_fields["focal_length"],
+                                  principal_point=cam_fields["principal_point"]).to(device)
+    if all(_frame_field(f, "image_features") is not None for f in frames):
+        keys = list(_frame_field(frames[0], "image_features"))
+        feats = {k: torch.stack([torch.as_tensor(_frame_field(f, "image_features")[k], dtype=torch.float32) for f in frames]
+                                ).to(device) for k in keys}
+    else:
+        if model.image_feature_extractor is None:
+            raise ValueError("the frames carry no `image_features` and the model has no image_feature_extractor "
+                             "(PyTorch3D's ResNetFeatureExtractor is outside this path: attach any callable "
+                             "(image_rgb, fg_probability) -> {key: (n, C, H, W)})")
+        rgb = torch.stack([torch.as_tensor(_frame_field(f, "image_rgb"), dtype=torch.float32) for f in frames]).to(device)
+        fg = [_frame_field(f, "fg_probability") for f in frames]
+        fg = torch.stack([torch.as_tensor(x, dtype=torch.float32) for x in fg]).to(device) if all(x is not None for x in fg) else None
+        feats = model.image_feature_extractor(rgb, fg)
+    voxel_features = model.pool_views_to_voxel_features(feats, src_cams)
+    cams = get_simple_360_camera_trajectory(max_angle, n_flyaround_poses, camera_elevation, hemispherical_radius, up,
+                                            camera_focal_length).to(device)
+    out = model.render_views(voxel_features, cams)
+    out["voxel_features"] = voxel_features
     return out
 
 

@@ -204,3 +204,58 @@ def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_har
     assert got.shape == (1, F, R, R, R)
     assert (got.cpu() - ref).abs().max().item() < 1e-4
     assert ref.abs().max() <= 1.0 and ref.std() > 0.02
+
+
+@pytest.mark.gpu
+def test_reconstruction_flyaround_from_a_dataset_sequence(tmp_path):
+    """render_flyaround(dataset, sequence_name, model, sample_mode=False) - the reconstruction mode of
+    visualize_reconstruction.py:60-162 / flyaround.py:153-171,219-253: source frames drawn with the reference's seeded
+    permutation, pooled once (MLPMeanFeatureAggregator here), refined, rendered from the simple-360 cameras.  Equals the
+    per-frame `model(camera=[target, sources...], image_features=...)` calls the reference's loop makes."""
+    import tests.gpu_utils as gu
+    from holo_diffusion_amd.generate import render_flyaround, select_source_views
+    R, F, n_frames, n_src = 8, 16, 7, 3
+    model, *_ = gu.make_model(R, F, 10, 12, dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2)))
+    m2 = hda.HoloDiffusionModel(resol=R, feature_size=F, render_image_width=12, render_image_height=10, view_pooler_enabled=True,
+                                view_pooler_args=dict(feature_aggregator_class_type="MLPMeanFeatureAggregator"),
+                                net_3d_SimpleUnet3D_args=dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2)))
+    D = 16 + 1 + 3 + 21
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    sd.update({"view_pooler.feature_aggregator." + k: v for k, v in synth_state_dict(vo.mlp_mean_param_shapes(D), 31).items()})
+    sd.update(synth_state_dict({"pooled_feature_mapper.weight": (F, 128), "pooled_feature_mapper.bias": (F,)}, 5))
+    m2.load_state_dict(sd)
+    m2.to(gu.DEV)
+    feats, _ = _synthetic_views(n_frames, 300)
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_frames, -0.4, 9, (0.0, -1.0, 0.0), 3.0)
+
+    class Frame:
+        def __init__(self, i):
+            self.camera = cams[i]
+            self.image_features = {k: v[i] for k, v in feats.items()}
+            self.sequence_name = "seq_a"
+
+    class Dataset:
+        def sequence_indices_in_order(self, name):
+            assert name == "seq_a"
+            return iter(range(100, 100 + n_frames))
+
+        def __getitem__(self, idx):
+            return Frame(idx - 100)
+
+    out = render_flyaround(Dataset(), "seq_a", m2, str(tmp_path / "video"), n_flyaround_poses=3, trajectory_type="simple_360",
+                           n_source_views=n_src, seed=11, sample_mode=False, device=gu.DEV,
+                           output_video_frames_dir=str(tmp_path / "frames"))
+    assert out["images_render"].shape == (3, 3, 10, 12) and torch.isfinite(out["images_render"]).all()
+    assert os.path.isfile(os.path.join(str(tmp_path / "frames"), "seq_a_images_render", "frame_00002.ppm"))
+    sel = select_source_views(n_frames, n_src, 11)
+    assert len(set(sel)) == n_src and sel == select_source_views(n_frames, n_src, 11)
+    test_cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2)
+    src = cams[sel]
+    for n in range(3):  # the reference's loop: batch = [target camera, sources...], one model() call per pose
+        both = hda.PerspectiveCameras(R=torch.cat([test_cams.R[n:n + 1], src.R]), T=torch.cat([test_cams.T[n:n + 1], src.T]),
+                                      focal_length=torch.cat([test_cams.focal_length[n:n + 1], src.focal_length]),
+                                      principal_point=torch.cat([test_cams.principal_point[n:n + 1], src.principal_point]))
+        preds = m2(camera=both.to(gu.DEV), image_features={k: v[sel].to(gu.DEV) for k, v in feats.items()})
+        assert torch.equal(preds["images_render"][0], out["images_render"][n])
+    with pytest.raises(ValueError):
+        render_flyaround(None, "seq_a", m2, "", trajectory_type="simple_360", sample_mode=False, device=gu.DEV)
