@@ -239,6 +239,18 @@ struct RenderKernelParams {
   float* nrm_c;
   unsigned long long* dbg;  // optional per-slot phase clocks [slot][8] (HOLO_RENDER_TIMELINE=1); null in production
   int split3;  // 1: RenderMLP products on the bf16 matrix cores from an exact 3-term bf16 split (feature_size 32 only)
+  // training-mode rendering (n_rays > 0; render2_kernel only): every camera renders the SAME number of rays given as NDC
+  // coordinates; outputs are (n_cams, 3, n_rays) / (n_cams, n_rays) planes.  Optional injected random streams (null =
+  // deterministic): stratified coarse depths, stratified importance samples, density noise of both passes.
+  struct Train {
+    int n_rays;
+    const float* xys;           // (n_cams, n_rays, 2) NDC x, y of every ray (PyTorch3D convention: +x left, +y up)
+    const float* u_coarse;      // (n_cams, n_rays, n_coarse) uniforms in [0,1): stratified depths (_jiggle_within_stratas)
+    const float* u_fine;        // (n_cams, n_rays, n_fine) uniforms: sample_pdf(det = False)
+    const float* noise_coarse;  // (n_cams, n_rays, n_coarse) standard normals: density noise of the coarse pass
+    const float* noise_fine;    // (n_cams, n_rays, n_coarse + n_fine) standard normals of the fine pass, in DEPTH ORDER
+    float noise_std;            // density_noise_std_train
+  } train;
 };
 
 // stand-alone implicit function: densities[P], colours[P][3] at world points pts[P][3];
@@ -306,6 +318,7 @@ int implicit_dirs_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_points_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
 int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);
-int render_waves_per_wg(int C, int n_fine, int with_normals);
+int render_waves_per_wg(int C, int n_fine, int with_normals, int split3 = 0, int train = 0);
+int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int train);
 
 }  // namespace holo

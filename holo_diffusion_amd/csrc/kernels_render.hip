@@ -33,6 +33,7 @@
 // The voxel grid is channels-last so a corner is CH*4 contiguous bytes per lane; the 33.5 MB grid stays
 // resident in the 256 MB Infinity Cache / L2 across the frame.  All eight corner fetches of a sample are
 // issued unconditionally from clamped addresses (zeros padding = zero weight).
+#include <stdlib.h>
 #include <string.h>
 
 #include "holo_common.h"
@@ -679,6 +680,390 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
   }
 }
 
+// =====================================================================================================================
+// render2_kernel - the (ray, depth)-tiled form of the fused renderer (round 3).
+//
+// render_kernel above makes the 32 MFMA columns of a wave 32 RAYS marching in lock step; a ray's state - the (sigma, rgb)
+// of its 64 coarse samples, which the merged fine-pass composite needs again - is then 1 KB x 32 rays per wave and has to
+// go through a global scratch slot (328 of the 549 MB a frame moved through the fabric), and a frame is 5 000 32-ray
+// tiles: 1.63 rounds on the 3 072 resident waves of a single-frame call.
+// Here a wave tile is 4 RAYS and the 32 columns of one implicit-function evaluation are 4 rays x 8 CONSECUTIVE DEPTHS.
+// The evaluation (trilinear fetch + folded RenderMLP on the matrix cores: eval_point, unchanged) no longer carries any
+// per-ray state: it writes (sigma, r, g, b) of its sample into the wave's LDS rows and is done.  All per-ray arithmetic
+// happens afterwards on the rows, one ray at a time with the 64 LANES AS DEPTH INDICES:
+//   coarse composite   x_i = delta_i relu(sigma_i), inclusive wave scan of x in DOUBLE (torch's CPU cumsum accumulates fp32
+//                      in double - measured), T_i = 1 - (1 - e^-S_{i-1}), w_i = (1 - e^-x_i) T_i, wave reductions
+//   cdf                (w_i + eps) / S, second double scan, still in registers: lane j holds cdf[j]
+//   inverse cdf        lane k binary-searches u_k over the lanes' cdf values with shuffles (as before) -> new depth row
+//   merged composite   every sample (lane c: coarse c; lane k: new k, k + 64) finds its RANK in the merged order by binary
+//                      search in the other list (ties: coarse first) and its interval end = the nearer of its own list's
+//                      next depth and the other list's first depth behind it; (x, source id) are scattered by rank into
+//                      the LDS row, three consecutive ranks per lane, double scan, reductions.
+// Per-wave LDS: 4 rays x (64 coarse + ZF new) float4 values + depth / rank rows = 10.6 KB (ZF = 64): 8 waves + the
+// 40 KB RenderMLP image per CU; the coarse values never leave the chip and a frame is 40 000 tiles (13 rounds).
+// TRAIN (training-mode rendering): rays from an explicit NDC list instead of the full pixel grid
+// (mask-sampled rays, configs/apple.yaml:135-146), stratified depths (PyTorch3D _jiggle_within_stratas) and stratified
+// importance samples (sample_pdf det = False) from injected uniforms, density noise from injected normals added to the
+// raw densities of each pass (holo_multipass_ea.py:87-91: the fine pass draws a NEW value for every one of its sorted
+// points - indexed by merged rank here).
+// =====================================================================================================================
+__device__ __forceinline__ float shfl_up1(float v, int lane, float first) {
+  const float r = __shfl(v, lane > 0 ? lane - 1 : 0);
+  return lane > 0 ? r : first;
+}
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  unsigned long long b;
+  memcpy(&b, &v, 8);
+  const float lo = __shfl(__uint_as_float((uint32_t)(b & 0xffffffffull)), src);
+  const float hi = __shfl(__uint_as_float((uint32_t)(b >> 32)), src);
+  b = (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+// inclusive prefix sum over the 64 lanes (Hillis-Steele; the additions of one lane happen in rank order, like a sequential
+// double accumulation up to the last bits of a double)
+__device__ __forceinline__ double wave_scan_incl_d(double v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = shfl_d(v, lane >= d ? lane - d : lane);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+template <int ZF>
+struct Render2Wave {
+  float4 cval[4][64];       // coarse samples (sigma_raw, r, g, b)
+  float4 fval[4][ZF];       // new samples
+  float zf[4][ZF];          // new depths, ascending
+  float mx[64 + ZF];        // merged composite: x by rank
+  int mid[64 + ZF];         // merged composite: source id by rank (< 64 coarse, >= 64 new)
+  float rd[4][4];           // per ray: radiance direction term
+};
+
+// waves per workgroup (= per CU): the per-wave rows are 10.3 KB (64 new samples per ray) / 15.9 KB (128)
+template <int CH, int ZF, bool TRAIN>
+constexpr int render2_waves() { return ZF <= 64 ? 8 : 4; }
+
+template <int CH, int ZF, bool TRAIN>
+__global__ __launch_bounds__((64 * render2_waves<CH, ZF, TRAIN>())) void render2_kernel(RenderKernelParams p) {
+  constexpr int NW = render2_waves<CH, ZF, TRAIN>();
+  struct Smem {
+    MlpLds<CH, false> mlp;  // FIRST: everything the evaluation loop reads sits below 64 KB (16-bit ds_read offsets)
+    Render2Wave<ZF> w[NW];
+  };
+  __shared__ __attribute__((aligned(16))) Smem s_mem;
+  MlpLds<CH, false>& s_mlp = s_mem.mlp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  Render2Wave<ZF>& S = s_mem.w[wave];
+  stage_mlp<CH, false>(s_mlp, p.mlp, tid, 64 * NW);
+  __syncthreads();  // the only workgroup-level synchronisation: from here on the waves are independent workers
+
+  const int npix = p.H * p.W;
+  const int R = p.R;
+  const float Rm1 = (float)(R - 1);
+  const uint32_t lane_off = (uint32_t)lane_channel<CH, false>(lh, 0);
+  const int nc = p.n_coarse, nf = p.n_fine, nb = nc - 1;
+  const int rq = li >> 3, dq = li & 7;  // evaluation mapping: ray of the tile, depth inside the 8-depth column group
+  const int64_t ntiles = p.n_tiles;
+  const int rays_per_cam = TRAIN ? p.train.n_rays : npix;
+  const int tiles_per_cam = (rays_per_cam + 3) / 4;
+  const int xcd = p.xcd > 1 && ((int)gridDim.x % p.xcd) == 0 ? p.xcd : 1;
+  const int wg_in_x = (int)blockIdx.x / xcd, wgs_per_x = (int)gridDim.x / xcd, my_x = (int)blockIdx.x % xcd;
+  const int64_t x_lo = ntiles * my_x / xcd, x_hi = ntiles * (my_x + 1) / xcd;
+
+  for (int64_t t = x_lo + (int64_t)wg_in_x * NW + wave; t < x_hi; t += (int64_t)wgs_per_x * NW) {
+    const int cam_i = (int)(t / tiles_per_cam);
+    const RenderKernelParams::Cam& cam = p.cams[cam_i];
+    const int ray0 = (int)(t - (int64_t)cam_i * tiles_per_cam) * 4;
+    // ---- ray setup; every lane computes the ray it needs in each role (the wave pays per instruction, not per lane)
+    auto ray_of = [&](int rr, float (&org)[3], float (&dir)[3]) {
+      const int ray = min(ray0 + rr, rays_per_cam - 1);
+      float xn, yn;
+      if (TRAIN) {
+        xn = p.train.xys[((int64_t)cam_i * rays_per_cam + ray) * 2 + 0];
+        yn = p.train.xys[((int64_t)cam_i * rays_per_cam + ray) * 2 + 1];
+      } else {
+        const int py = ray / p.W, px = ray - py * p.W;
+        const float hx = p.range_x / (float)p.W, hy = p.range_y / (float)p.H;
+        const float minx = p.range_x - hx, maxx = -p.range_x + hx, miny = p.range_y - hy, maxy = -p.range_y + hy;
+        xn = lin_space(minx, maxx, (maxx - minx) / (float)(p.W - 1), px, p.W);
+        yn = lin_space(miny, maxy, (maxy - miny) / (float)(p.H - 1), py, p.H);
+      }
+      const float dc0 = (xn - cam.pp[0]) / cam.focal[0], dc1 = (yn - cam.pp[1]) / cam.focal[1], dc2 = 1.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float r0 = cam.Rm[j * 3 + 0], r1 = cam.Rm[j * 3 + 1], r2 = cam.Rm[j * 3 + 2];
+        const float p1 = (dc0 - cam.T[0]) * r0 + (dc1 - cam.T[1]) * r1 + (dc2 - cam.T[2]) * r2;
+        const float p2 = (2.f * dc0 - cam.T[0]) * r0 + (2.f * dc1 - cam.T[1]) * r1 + (2.f * dc2 - cam.T[2]) * r2;
+        dir[j] = p2 - p1;
+        org[j] = p1 - dir[j];
+      }
+    };
+    float org[3], dir[3];
+    ray_of(rq, org, dir);
+    // radiance direction term of the 4 rays: lanes (ray = lane >> 4, q = lane & 15) share the 27 embedding entries
+    {
+      const int rr = lane >> 4, q = lane & 15;
+      float o2[3], d2[3];
+      ray_of(rr, o2, d2);
+      const float nrm = fmaxf(sqrtf(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2]), 1e-12f);  // F.normalize eps
+      const float dn[3] = {d2[0] / nrm, d2[1] / nrm, d2[2] / nrm};
+      float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = q + 16 * h;  // entry: [0,12) sin(d_a 2^f), [12,24) cos, [24,27) d_a; a = (j % 12) / 4, f = j % 4
+        const int jj = j < 24 ? j % 12 : 0;
+        const int a = j < 24 ? jj >> 2 : j - 24;
+        const float da = a == 0 ? dn[0] : (a == 1 ? dn[1] : dn[2]);
+        const float arg = da * (float)(1 << (jj & 3));
+        const float e = j < 12 ? sinf(arg) : (j < 24 ? cosf(arg) : da);
+        if (j < 27) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) part[c] = fmaf(p.mlp.w_dir[c * 27 + j], e, part[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) part[c] += __shfl_xor(part[c], d);
+        if (q == 0) S.rd[rr][c] = part[c] + p.mlp.b_rad[c] + p.mlp.k_rad[c];
+      }
+    }
+    HOLO_WAVE_SYNC();
+    const float rdir[3] = {S.rd[rq][0], S.rd[rq][1], S.rd[rq][2]};
+    const float zmin = cam.zmin, zmax = cam.zmax;
+    const float zstep = (zmax - zmin) / (float)(nc - 1);
+    auto zlin = [&](int i) { return lin_space(zmin, zmax, zstep, i, nc); };
+    // coarse depth i of ray rr: the linspace, or (TRAIN) jittered inside its stratum: lower + (upper - lower) u with
+    // lower = [z_0, mids], upper = [mids, z_last], mids = 0.5 (z_i + z_{i+1})   (PyTorch3D _jiggle_within_stratas)
+    auto zcoarse_r = [&](int rr, int i) {
+      const float zi = zlin(i);
+      if (!TRAIN || !p.train.u_coarse) return zi;
+      const float lo = i > 0 ? 0.5f * (zlin(i) + zlin(i - 1)) : zi;
+      const float up = i + 1 < nc ? 0.5f * (zlin(i + 1) + zlin(i)) : zi;
+      const int ray = min(ray0 + rr, rays_per_cam - 1);
+      const float u = p.train.u_coarse[((int64_t)cam_i * rays_per_cam + ray) * nc + i];
+      return lo + (up - lo) * u;
+    };
+    auto eval = [&](float z, float& sg, float& cr, float& cg, float& cb) {
+      eval_point<CH, false, false>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
+                                   org[1] + z * dir[1], org[2] + z * dir[2], rdir, sg, cr, cg, cb);
+    };
+
+    // ---- coarse evaluation: column groups of 8 consecutive depths
+    for (int j0 = 0; j0 < nc; j0 += 8) {
+      const int i = min(j0 + dq, nc - 1);
+      float sg, cr, cg, cb;
+      eval(zcoarse_r(rq, i), sg, cr, cg, cb);
+      if (lh == 0 && j0 + dq < nc) S.cval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+    }
+    HOLO_WAVE_SYNC();
+
+    // ---- per ray: coarse composite, cdf, inverse cdf (lane = depth index)
+    const float ustep = 1.0f / (float)(nf - 1);
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int ray = ray0 + rr;
+      const bool active = ray < rays_per_cam;
+      const int ic = min(lane, nc - 1);
+      const float4 v = S.cval[rr][ic];
+      const float zi = zcoarse_r(rr, ic);
+      const float zn = lane + 1 < nc ? zcoarse_r(rr, min(lane + 1, nc - 1)) : 0.f;
+      float sraw = v.x;
+      if (TRAIN && p.train.noise_coarse)
+        sraw += p.train.noise_std * p.train.noise_coarse[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nc + ic];
+      const float delta = lane + 1 < nc ? zn - zi : p.background_opacity;
+      const float x = lane < nc ? delta * fmaxf(sraw, 0.f) : 0.f;
+      const double Sx = wave_scan_incl_d((double)x, lane);
+      const double Sprev = shfl_d(Sx, lane > 0 ? lane - 1 : 0);
+      const float Tr = lane > 0 ? 1.f - (1.f - __expf(-(float)Sprev)) : 1.f;  // T = 1 - O as the raymarcher forms them
+      const float w = lane < nc ? (1.f - __expf(-x)) * Tr : 0.f;
+      const float O = 1.f - __expf(-(float)shfl_d(Sx, 63));
+      if (p.rgb_c) {
+        const float ar = wave_sum_f(w * v.y), ag = wave_sum_f(w * v.z), ab = wave_sum_f(w * v.w), ad = wave_sum_f(w * zi);
+        if (lane == 0 && active) {
+          const int64_t ob = (int64_t)cam_i * rays_per_cam + ray;
+          float* o = p.rgb_c + (int64_t)cam_i * 3 * rays_per_cam + ray;
+          o[0 * (int64_t)rays_per_cam] = ar + (1.f - O) * p.bg[0];
+          o[1 * (int64_t)rays_per_cam] = ag + (1.f - O) * p.bg[1];
+          o[2 * (int64_t)rays_per_cam] = ab + (1.f - O) * p.bg[2];
+          p.depth_c[ob] = ad;
+          p.mask_c[ob] = O;
+        }
+      }
+      // weights[1:-1] + eps -> pdf -> cdf (nb = nc-1 entries, cdf[0] = 0); running sums in double like torch's
+      const float a = (lane >= 1 && lane <= nc - 2) ? w + p.pdf_eps : 0.f;
+      double Sa = (double)a;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) Sa += shfl_d(Sa, lane ^ d);
+      const float Sf = (float)Sa;
+      const float pdf = (lane >= 1 && lane <= nc - 2) ? a / Sf : 0.f;
+      const double run = wave_scan_incl_d((double)pdf, lane);
+      const float c = lane < nb ? (lane == 0 ? 0.f : (float)run) : 3.0e38f;
+      // bin mids of this ray (TRAIN: of the jittered depths): lerp(z[1:], z[:-1], 0.5)
+      auto mid = [&](int i) {
+        const float a0 = zcoarse_r(rr, i), a1 = zcoarse_r(rr, i + 1);
+        return a0 - (a0 - a1) * 0.5f;
+      };
+      for (int kb = 0; kb < nf; kb += 64) {
+        const int kk = kb + lane;
+        const int kc = kk < nf ? kk : nf - 1;
+        float u = lin_space(0.f, 1.f, ustep, kc, nf);
+        if (TRAIN && p.train.u_fine)  // sample_pdf(det = False): u ~ U[0,1) per sample (unsorted; the merge sorts)
+          u = p.train.u_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nf + kc];
+        int lo = 0, hi = nb;  // ind = #{j < nb : cdf[j] <= u}  (searchsorted right = True)
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+          const int md = (lo + hi) >> 1;
+          const float cm = __shfl(c, md < nb ? md : nb - 1);
+          const bool go = lo < hi && cm <= u;
+          const bool stay = lo < hi && !(cm <= u);
+          if (go) lo = md + 1;
+          if (stay) hi = md;
+        }
+        const int ind = lo;
+        const int below = ind - 1 > 0 ? ind - 1 : 0;
+        const int above = ind < nb - 1 ? ind : nb - 1;
+        const float cb_ = __shfl(c, below), ca_ = __shfl(c, above);
+        float den = ca_ - cb_;
+        if (den < p.pdf_eps) den = 1.f;
+        const float tt = (u - cb_) / den;
+        const float bb = mid(below), ba = mid(above);
+        if (kk < nf) S.zf[rr][kk] = bb + tt * (ba - bb);
+      }
+      if (TRAIN && p.train.u_fine) {
+        // stratified importance samples arrive unsorted: odd-even transposition sort of the row inside the wave (the
+        // deterministic case is already ascending: the inverse cdf of an ascending u)
+        HOLO_WAVE_SYNC();
+        for (int pass = 0; pass < nf; ++pass) {
+          for (int kb = 0; kb < nf; kb += 128) {
+            const int i0 = kb + 2 * lane + (pass & 1);
+            if (i0 + 1 < nf) {
+              const float a0 = S.zf[rr][i0], a1 = S.zf[rr][i0 + 1];
+              if (a1 < a0) {
+                S.zf[rr][i0] = a1;
+                S.zf[rr][i0 + 1] = a0;
+              }
+            }
+          }
+          HOLO_WAVE_SYNC();
+        }
+      }
+    }
+    HOLO_WAVE_SYNC();
+
+    // ---- evaluation of the new samples
+    for (int j0 = 0; j0 < nf; j0 += 8) {
+      const int k = min(j0 + dq, nf - 1);
+      float sg, cr, cg, cb;
+      eval(S.zf[rq][k], sg, cr, cg, cb);
+      if (lh == 0 && j0 + dq < nf) S.fval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+    }
+    HOLO_WAVE_SYNC();
+
+    // ---- per ray: composite of the merged list [coarse | new] in depth order (== torch.sort of the concatenation; a
+    //      coarse sample goes first on a tie)
+    const int nm = nc + nf;
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int ray = ray0 + rr;
+      const bool active = ray < rays_per_cam;
+      const float* zrow = S.zf[rr];
+      // a coarse sample: rank = c + #{new < zc}; interval end = min(next coarse, first new >= zc)
+      if (lane < nc) {
+        const float zc = zcoarse_r(rr, lane);
+        int lo = 0, hi = nf;  // #{k : zf[k] < zc}
+        while (lo < hi) {
+          const int md = (lo + hi) >> 1;
+          if (zrow[md] < zc) lo = md + 1; else hi = md;
+        }
+        const bool more_c = lane + 1 < nc, more_n = lo < nf;
+        float zend = more_c ? zcoarse_r(rr, min(lane + 1, nc - 1)) : 0.f;
+        if (more_n) zend = more_c ? fminf(zend, zrow[lo]) : zrow[lo];
+        const int rank = lane + lo;
+        S.mid[rank] = lane;
+        S.mx[rank] = (more_c || more_n) ? zend - zc : -1.f;  // -1: the last sample of the list (delta = background opacity)
+      }
+      // new samples k = lane (+ 64): rank = k + #{coarse <= zk}; interval end = min(next new, first coarse > zk)
+      for (int kb = 0; kb < nf; kb += 64) {
+        const int k = kb + lane;
+        if (k < nf) {
+          const float zk = zrow[k];
+          int lo = 0, hi = nc;  // #{c : zc <= zk}
+          while (lo < hi) {
+            const int md = (lo + hi) >> 1;
+            if (zcoarse_r(rr, md) <= zk) lo = md + 1; else hi = md;
+          }
+          const bool more_n = k + 1 < nf, more_c = lo < nc;
+          float zend = more_n ? zrow[k + 1] : 0.f;
+          if (more_c) {
+            const float zc = zcoarse_r(rr, min(lo, nc - 1));
+            zend = more_n ? fminf(zend, zc) : zc;
+          }
+          const int rank = k + lo;
+          S.mid[rank] = 64 + k;
+          S.mx[rank] = (more_n || more_c) ? zend - zk : -1.f;
+        }
+      }
+      HOLO_WAVE_SYNC();
+      // three consecutive ranks per lane
+      float xs[3], zz[3];
+      float4 vv[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int q = 3 * lane + e;
+        const int qc = q < nm ? q : nm - 1;
+        const int id = S.mid[qc];
+        const float dl = S.mx[qc];
+        vv[e] = id < 64 ? S.cval[rr][id] : S.fval[rr][id - 64];
+        zz[e] = id < 64 ? zcoarse_r(rr, id) : zrow[id - 64];
+        float sraw = vv[e].x;
+        if (TRAIN && p.train.noise_fine)  // a fresh draw per sorted point of the fine pass
+          sraw += p.train.noise_std * p.train.noise_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nm + qc];
+        xs[e] = q < nm ? (dl < 0.f ? p.background_opacity : dl) * fmaxf(sraw, 0.f) : 0.f;
+      }
+      const double l3 = (double)xs[0] + (double)xs[1] + (double)xs[2];
+      const double incl = wave_scan_incl_d(l3, lane);
+      const double before = shfl_d(incl, lane > 0 ? lane - 1 : 0);
+      double run = lane > 0 ? before : 0.0;  // sum of all x before this lane's first rank
+      float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int q = 3 * lane + e;
+        const float Tr = q > 0 ? 1.f - (1.f - __expf(-(float)run)) : 1.f;
+        const float w = q < nm ? (1.f - __expf(-xs[e])) * Tr : 0.f;
+        ar = fmaf(w, vv[e].y, ar);
+        ag = fmaf(w, vv[e].z, ag);
+        ab = fmaf(w, vv[e].w, ab);
+        ad = fmaf(w, zz[e], ad);
+        run += (double)xs[e];
+      }
+      const float O = 1.f - __expf(-(float)shfl_d(incl, 63));
+      ar = wave_sum_f(ar);
+      ag = wave_sum_f(ag);
+      ab = wave_sum_f(ab);
+      ad = wave_sum_f(ad);
+      if (lane == 0 && active) {
+        const int64_t ob = (int64_t)cam_i * rays_per_cam + ray;
+        float* o = p.rgb + (int64_t)cam_i * 3 * rays_per_cam + ray;
+        o[0 * (int64_t)rays_per_cam] = ar + (1.f - O) * p.bg[0];
+        o[1 * (int64_t)rays_per_cam] = ag + (1.f - O) * p.bg[1];
+        o[2 * (int64_t)rays_per_cam] = ab + (1.f - O) * p.bg[2];
+        p.depth[ob] = ad;
+        p.mask[ob] = O;
+      }
+      HOLO_WAVE_SYNC();  // the rank rows are rewritten for the next ray
+    }
+  }
+}
+
 // radiance direction term per ray direction (one thread per direction)
 __global__ __launch_bounds__(256) void dir_term_kernel(MlpParams m, const float* __restrict__ dirs, int64_t n_dirs,
                                                        float* __restrict__ rdir_out) {
@@ -826,6 +1211,21 @@ int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void*
 template <int CH, bool SP>
 static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
   const bool nrm = p.nrm_ws != nullptr;
+  if (render_rays_per_tile(2 * CH, p.n_fine, nrm ? 1 : 0, SP ? 1 : 0, p.train.n_rays > 0 ? 1 : 0) == 4) {
+    // the (ray, depth)-tiled kernel: no normals, exact fp32
+    if (p.train.n_rays > 0) {
+      if (p.n_fine <= 64) {
+        HOLO_LAUNCH((render2_kernel<CH, 64, true>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 64, true>()), stream, p);
+      } else {
+        HOLO_LAUNCH((render2_kernel<CH, 128, true>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 128, true>()), stream, p);
+      }
+    } else if (p.n_fine <= 64) {
+      HOLO_LAUNCH((render2_kernel<CH, 64, false>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 64, false>()), stream, p);
+    } else {
+      HOLO_LAUNCH((render2_kernel<CH, 128, false>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 128, false>()), stream, p);
+    }
+    return 0;
+  }
   if (p.n_fine <= 64) {
     if (nrm) {
       HOLO_LAUNCH((render_kernel<CH, SP, true, 64>), dim3((unsigned)n_wgs), dim3(64 * render_waves<CH, 64, true>()), stream, p);
@@ -842,9 +1242,24 @@ static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs)
   return 0;
 }
 
+// rays of one wave tile: 4 on the (ray, depth)-tiled kernel, 32 on the ray-per-column kernel (rendered normals, the
+// bf16x3 split arithmetic, and - development knob HOLO_RENDER_V1=1 - everything)
+int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int train) {
+  (void)C;
+  (void)n_fine;
+  if (train) return 4;
+  if (with_normals || split3) return 32;
+#ifndef HOLO_EMU
+  static const bool v1 = getenv("HOLO_RENDER_V1") != nullptr;
+  if (v1) return 32;
+#endif
+  return 4;
+}
+
 // waves per workgroup of the persistent kernel for this configuration (the scratch has one slot per resident wave)
-int render_waves_per_wg(int C, int n_fine, int with_normals) {
+int render_waves_per_wg(int C, int n_fine, int with_normals, int split3, int train) {
   const bool z64 = n_fine <= 64;
+  if (render_rays_per_tile(C, n_fine, with_normals, split3, train) == 4) return z64 ? 8 : 4;
   if (C <= 32) {
     if (with_normals) return z64 ? render_waves<16, 64, true>() : render_waves<16, 128, true>();
     return z64 ? render_waves<16, 64, false>() : render_waves<16, 128, false>();

@@ -253,10 +253,15 @@ static int render_workgroups(const HoloRenderer* r) {
 #endif
   return r->ctx->num_cus > 0 ? r->ctx->num_cus : 256;
 }
+static int split3_active(const HoloRenderer* r) { return (r->split3 && r->cfg.feature_size == 32) ? 1 : 0; }
 static size_t render_slots(const HoloRenderer* r, int with_normals) {
-  return (size_t)render_workgroups(r) * (size_t)render_waves_per_wg(r->cfg.feature_size, r->cfg.n_pts_fine, with_normals);
+  return (size_t)render_workgroups(r) *
+         (size_t)render_waves_per_wg(r->cfg.feature_size, r->cfg.n_pts_fine, with_normals, split3_active(r), 0);
 }
+// scratch of the ray-per-column kernel (rendered normals / split arithmetic): one 32 KB slot per resident wave; the
+// (ray, depth)-tiled kernel keeps every per-ray value in LDS and needs none
 static size_t val_ws_bytes(const HoloRenderer* r, int with_normals) {
+  if (render_rays_per_tile(r->cfg.feature_size, r->cfg.n_pts_fine, with_normals, split3_active(r), 0) == 4) return 256;
   return render_slots(r, with_normals) * 64 * 32 * 4 * sizeof(float);
 }
 
@@ -308,7 +313,9 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   const int n_launches = (n_cameras + RenderKernelParams::MAX_CAMS - 1) / RenderKernelParams::MAX_CAMS;
   const int G = (n_cameras + n_launches - 1) / n_launches;
   const int n_wgs_max = render_workgroups(r);
-  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, want_nrm ? 1 : 0);
+  const int sp3 = split3_active(r);
+  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, want_nrm ? 1 : 0, sp3, 0);
+  const int rays_per_tile = render_rays_per_tile(C, c.n_pts_fine, want_nrm ? 1 : 0, sp3, 0);
 #ifndef HOLO_EMU
   static const bool timeline = getenv("HOLO_RENDER_TIMELINE") != nullptr;  // development probe (synchronises!)
   static const char* xcd_env = getenv("HOLO_RENDER_XCD");
@@ -364,7 +371,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
     p.background_opacity = c.background_opacity;
     p.pdf_eps = c.sample_pdf_eps;
-    p.split3 = (r->split3 && c.feature_size == 32) ? 1 : 0;
+    p.split3 = sp3;
     p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r));
     p.nrm_ws = want_nrm ? (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r, 1)) : nullptr;
     p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets
@@ -377,7 +384,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     }
     p.nrm = normals ? normals + (size_t)c0 * 3 * npix : nullptr;
     p.nrm_c = (normals_coarse && p.rgb_c) ? normals_coarse + (size_t)c0 * 3 * npix : nullptr;
-    p.n_tiles = (int64_t)ng * ((npix + 31) / 32);
+    p.n_tiles = (int64_t)ng * ((npix + rays_per_tile - 1) / rays_per_tile);
     // no more workgroups than there is work for (a tiny launch must not stage the MLP on idle CUs)
     int n_wgs = (int)((p.n_tiles + waves_per_wg - 1) / waves_per_wg);
     if (n_wgs > n_wgs_max) n_wgs = n_wgs_max;

@@ -117,6 +117,13 @@ def test_north_star_ray_subset_vs_oracle(gu):
     print(f"depth control: {int(fragile.sum())}/{len(idx)} rays fragile (a den within {margin:.1e} of eps); outside 2e-4*far: "
           f"HIP vs oracle {int(bad_hip.sum())} (largest gap among them {float(gap[bad_hip].max()) if bad_hip.any() else 0:.2e}), "
           f"oracle vs oracle(grid + 1e-6) {int(bad_ctl.sum())} (largest gap {float(gap2[bad_ctl].max()) if bad_ctl.any() else 0:.2e})")
+    for j in torch.nonzero(bad_hip).flatten().tolist():  # diagnostics of every ray outside the depth tolerance
+        dh, dr_ = float(flat(preds["depths_render"])[j]), float(ref["depth"][j])
+        print(f"  bad ray {j} (pixel {int(idx[j])}): depth HIP {dh:.5f} oracle {dr_:.5f} perturbed-oracle {float(ref2['depth'][j]):.5f} | "
+              f"mask {float(ref['mask'][j]):.5f} (HIP d {float((flat(preds['masks_render'])[j] - ref['mask'][j]).abs()):.1e}) | "
+              f"rgb d {float((flat(preds['images_render'])[j] - ref['rgb'][j]).abs().max()):.1e} | coarse depth d "
+              f"{float((preds['rendered'].prev_stage.depths.reshape(-1)[idx[j]].cpu() - ref['depth_c'][j]).abs()):.1e} | gap {float(gap[j]):.2e} "
+              f"| smallest den {float(ref['pdf_denom'][j].min()):.3e}")
     assert not (bad_hip & ~fragile).any(), ("a non-fragile ray misses the depth tolerance", int((bad_hip & ~fragile).sum()),
                                             float(gap[bad_hip].max()))
     assert not (bad_ctl & (gap2 > margin)).any(), ("control: a non-fragile ray moved", float(gap2[bad_ctl].max()))

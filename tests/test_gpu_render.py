@@ -44,6 +44,8 @@ def _render_pair(gu, resol, C, H, W, n_fine, density_bias, cam_index=1, n_cams=4
     (16, 32, 24, 40, 64, -0.25),   # mostly transparent
     (8, 16, 17, 13, 16, 0.1),      # 16 features, ragged image (partial last workgroup), 16 fine samples
     (8, 64, 16, 16, 64, 0.0),      # 64 features (released YAML feature_size)
+    (8, 16, 9, 11, 128, 0.05),     # 128 new samples per ray (the wide-row variants), ragged 4-ray tiles
+    (8, 32, 6, 7, 100, 0.0),       # new-sample count that is neither a multiple of 8 nor of 64
 ])
 @pytest.mark.parametrize("compute", ["f32", "f32_bf16x3"])  # the split mode is held to the same tolerances
 def test_render_vs_oracle(gu, resol, C, H, W, n_fine, bias, compute):

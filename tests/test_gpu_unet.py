@@ -10,6 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import holo_diffusion_amd as hda  # noqa: E402
 from holo_diffusion_amd import _lib, runtime  # noqa: E402
 from oracle import unet_oracle as uo  # noqa: E402
 from oracle.common import NORTH_CFG, PLUMB_CFG, TINY_CFG, digest, seeded_input  # noqa: E402
@@ -25,7 +26,7 @@ def gu():
 
 def test_native_library_loaded():
     lib = runtime.lib()
-    assert lib.holo_abi_version() == 2
+    assert lib.holo_abi_version() == _lib.ABI_VERSION == 3
     assert os.path.basename(_lib.LIB_PATH) == "libholo_mi355x.so"
 
 
@@ -182,8 +183,9 @@ def test_forward_is_deterministic_and_param_rebind(gu):
 
 def test_wrong_shape_and_unset_errors(gu):
     net, _ = gu.make_unet(TINY_CFG)
-    with pytest.raises(_lib.HoloError):
-        net(torch.zeros(1, 32, 4, 4, 4, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
+    for bad in ((1, 32, 4, 4, 4), (1, 16, 6, 6, 6), (1, 32, 8, 8, 4)):  # channels; not a multiple of 2^(levels-1); not cubic
+        with pytest.raises(_lib.HoloError):
+            net(torch.zeros(*bad, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
 
 
 def test_128_cubed_forward_vs_oracle(gu):
