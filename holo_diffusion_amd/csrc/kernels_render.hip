@@ -739,21 +739,20 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 
 template <int ZF>
 struct Render2Wave {
-  float4 cval[4][64];       // coarse samples (sigma_raw, r, g, b)
-  float4 fval[4][ZF];       // new samples
-  float zf[4][ZF];          // new depths, ascending
-  float mx[64 + ZF];        // merged composite: x by rank
-  int mid[64 + ZF];         // merged composite: source id by rank (< 64 coarse, >= 64 new)
-  float rd[4][4];           // per ray: radiance direction term
+  float4 cval[4][64];               // coarse samples (sigma_raw, r, g, b)
+  float4 fval[4][ZF];               // new samples
+  float zf[4][ZF];                  // new depths, ascending
+  unsigned char isnew[64 + ZF];     // merged composite: 1 where the position of the merged list holds a NEW sample
+  float rd[4][4];                   // per ray: radiance direction term
 };
 
-// waves per workgroup (= per CU): the per-wave rows are 10.3 KB (64 new samples per ray) / 15.9 KB (128)
-template <int CH, int ZF, bool TRAIN>
-constexpr int render2_waves() { return ZF <= 64 ? 8 : 4; }
+// waves per workgroup (= per CU): the per-wave rows are 9.4 KB (64 new samples per ray) / 14.6 KB (128); with the 40 KB
+// RenderMLP image of 32 grid features 12 / 8 waves fit (64 grid features: 73 KB image, 8 / 4 waves)
+template <int CH, int ZF>
+constexpr int render2_waves() { return ZF <= 64 ? (CH <= 16 ? 12 : 8) : (CH <= 16 ? 8 : 4); }
 
-template <int CH, int ZF, bool TRAIN>
-__global__ __launch_bounds__((64 * render2_waves<CH, ZF, TRAIN>())) void render2_kernel(RenderKernelParams p) {
-  constexpr int NW = render2_waves<CH, ZF, TRAIN>();
+template <int CH, int ZF, bool TRAIN, int NW>
+__global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p) {
   struct Smem {
     MlpLds<CH, false> mlp;  // FIRST: everything the evaluation loop reads sits below 64 KB (16-bit ds_read offsets)
     Render2Wave<ZF> w[NW];
@@ -976,63 +975,78 @@ __global__ __launch_bounds__((64 * render2_waves<CH, ZF, TRAIN>())) void render2
       const int ray = ray0 + rr;
       const bool active = ray < rays_per_cam;
       const float* zrow = S.zf[rr];
-      // a coarse sample: rank = c + #{new < zc}; interval end = min(next coarse, first new >= zc)
-      if (lane < nc) {
-        const float zc = zcoarse_r(rr, lane);
-        int lo = 0, hi = nf;  // #{k : zf[k] < zc}
-        while (lo < hi) {
-          const int md = (lo + hi) >> 1;
-          if (zrow[md] < zc) lo = md + 1; else hi = md;
-        }
-        const bool more_c = lane + 1 < nc, more_n = lo < nf;
-        float zend = more_c ? zcoarse_r(rr, min(lane + 1, nc - 1)) : 0.f;
-        if (more_n) zend = more_c ? fminf(zend, zrow[lo]) : zrow[lo];
-        const int rank = lane + lo;
-        S.mid[rank] = lane;
-        S.mx[rank] = (more_c || more_n) ? zend - zc : -1.f;  // -1: the last sample of the list (delta = background opacity)
-      }
-      // new samples k = lane (+ 64): rank = k + #{coarse <= zk}; interval end = min(next new, first coarse > zk)
+      // positions of the NEW samples in the merged order: rank of new sample k = k + #{coarse c : zc <= z_k}.  The coarse
+      // depths are a linspace, so the count is arithmetic (one floor + a fix-up against the exact linspace values);
+      // with jittered coarse depths (TRAIN) it is a binary search.
+      const bool jitter = TRAIN && p.train.u_coarse != nullptr;
+      for (int i = lane; i < (nm + 3) / 4; i += 64) reinterpret_cast<uint32_t*>(S.isnew)[i] = 0u;
+      HOLO_WAVE_SYNC();
       for (int kb = 0; kb < nf; kb += 64) {
         const int k = kb + lane;
         if (k < nf) {
           const float zk = zrow[k];
-          int lo = 0, hi = nc;  // #{c : zc <= zk}
-          while (lo < hi) {
-            const int md = (lo + hi) >> 1;
-            if (zcoarse_r(rr, md) <= zk) lo = md + 1; else hi = md;
+          int b;
+          if (jitter) {
+            int lo = 0, hi = nc;  // #{c : zc <= zk}
+            while (lo < hi) {
+              const int md = (lo + hi) >> 1;
+              if (zcoarse_r(rr, md) <= zk) lo = md + 1; else hi = md;
+            }
+            b = lo;
+          } else {
+            b = (int)fminf(fmaxf(floorf((zk - zmin) / zstep) + 1.f, 0.f), (float)nc);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              if (b > 0 && zlin(b - 1) > zk) --b;
+              if (b < nc && zlin(b) <= zk) ++b;
+            }
           }
-          const bool more_n = k + 1 < nf, more_c = lo < nc;
-          float zend = more_n ? zrow[k + 1] : 0.f;
-          if (more_c) {
-            const float zc = zcoarse_r(rr, min(lo, nc - 1));
-            zend = more_n ? fminf(zend, zc) : zc;
-          }
-          const int rank = k + lo;
-          S.mid[rank] = 64 + k;
-          S.mx[rank] = (more_n || more_c) ? zend - zk : -1.f;
+          S.isnew[k + b] = 1;
         }
       }
       HOLO_WAVE_SYNC();
-      // three consecutive ranks per lane
-      float xs[3], zz[3];
+      // three consecutive positions per lane: which are new, how many new ones lie before (integer wave scan), hence
+      // the sample behind every position; its interval ends at the NEXT position's depth
+      int f[3], cnt = 0;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int q = 3 * lane + e;
+        f[e] = q < nm ? (int)S.isnew[q] : 0;
+        cnt += f[e];
+      }
+      int incl_i = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)incl_i), lane >= d ? lane - d : lane));
+        if (lane >= d) incl_i += o;
+      }
+      int nbefore = incl_i - cnt;
+      float xs[3], zz[4];
       float4 vv[3];
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int q = 3 * lane + e;
         const int qc = q < nm ? q : nm - 1;
-        const int id = S.mid[qc];
-        const float dl = S.mx[qc];
-        vv[e] = id < 64 ? S.cval[rr][id] : S.fval[rr][id - 64];
-        zz[e] = id < 64 ? zcoarse_r(rr, id) : zrow[id - 64];
+        const int id = f[e] ? min(nbefore, nf - 1) : min(max(qc - nbefore, 0), nc - 1);
+        vv[e] = f[e] ? S.fval[rr][id] : S.cval[rr][id];
+        zz[e] = f[e] ? zrow[id] : zcoarse_r(rr, id);
+        nbefore += f[e];
+      }
+      zz[3] = __shfl(zz[0], lane < 63 ? lane + 1 : lane);  // first depth of the next lane
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int q = 3 * lane + e;
         float sraw = vv[e].x;
         if (TRAIN && p.train.noise_fine)  // a fresh draw per sorted point of the fine pass
-          sraw += p.train.noise_std * p.train.noise_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nm + qc];
-        xs[e] = q < nm ? (dl < 0.f ? p.background_opacity : dl) * fmaxf(sraw, 0.f) : 0.f;
+          sraw += p.train.noise_std *
+                  p.train.noise_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nm + (q < nm ? q : nm - 1)];
+        const float dl = q + 1 < nm ? zz[e + 1] - zz[e] : p.background_opacity;
+        xs[e] = q < nm ? dl * fmaxf(sraw, 0.f) : 0.f;
       }
       const double l3 = (double)xs[0] + (double)xs[1] + (double)xs[2];
       const double incl = wave_scan_incl_d(l3, lane);
       const double before = shfl_d(incl, lane > 0 ? lane - 1 : 0);
-      double run = lane > 0 ? before : 0.0;  // sum of all x before this lane's first rank
+      double run = lane > 0 ? before : 0.0;  // sum of all x before this lane's first position
       float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -1059,7 +1073,7 @@ __global__ __launch_bounds__((64 * render2_waves<CH, ZF, TRAIN>())) void render2
         p.depth[ob] = ad;
         p.mask[ob] = O;
       }
-      HOLO_WAVE_SYNC();  // the rank rows are rewritten for the next ray
+      HOLO_WAVE_SYNC();  // the flag row is rewritten for the next ray
     }
   }
 }
@@ -1208,22 +1222,37 @@ int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void*
   return 0;
 }
 
+// waves per workgroup of render2_kernel at run time (HOLO_RENDER2_NW=8: development knob, the 8-wave form of the
+// 12-wave configurations)
+static int render2_waves_rt(int C, int n_fine) {
+  const int ch = C / 2;
+  int nw = n_fine <= 64 ? (ch <= 16 ? 12 : 8) : (ch <= 16 ? 8 : 4);
+#ifndef HOLO_EMU
+  static const char* e = getenv("HOLO_RENDER2_NW");
+  if (e && atoi(e) == 8 && nw == 12) nw = 8;
+#endif
+  return nw;
+}
+
 template <int CH, bool SP>
 static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
   const bool nrm = p.nrm_ws != nullptr;
   if (render_rays_per_tile(2 * CH, p.n_fine, nrm ? 1 : 0, SP ? 1 : 0, p.train.n_rays > 0 ? 1 : 0) == 4) {
     // the (ray, depth)-tiled kernel: no normals, exact fp32
+    const int nw = render2_waves_rt(2 * CH, p.n_fine);
+#define HOLO_R2(ZFV, TRV, NWV) HOLO_LAUNCH((render2_kernel<CH, ZFV, TRV, NWV>), dim3((unsigned)n_wgs), dim3(64 * NWV), stream, p)
     if (p.train.n_rays > 0) {
       if (p.n_fine <= 64) {
-        HOLO_LAUNCH((render2_kernel<CH, 64, true>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 64, true>()), stream, p);
+        if (nw == 12) HOLO_R2(64, true, (render2_waves<CH, 64>())); else HOLO_R2(64, true, 8);
       } else {
-        HOLO_LAUNCH((render2_kernel<CH, 128, true>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 128, true>()), stream, p);
+        HOLO_R2(128, true, (render2_waves<CH, 128>()));
       }
     } else if (p.n_fine <= 64) {
-      HOLO_LAUNCH((render2_kernel<CH, 64, false>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 64, false>()), stream, p);
+      if (nw == 12) HOLO_R2(64, false, (render2_waves<CH, 64>())); else HOLO_R2(64, false, 8);
     } else {
-      HOLO_LAUNCH((render2_kernel<CH, 128, false>), dim3((unsigned)n_wgs), dim3(64 * render2_waves<CH, 128, false>()), stream, p);
+      HOLO_R2(128, false, (render2_waves<CH, 128>()));
     }
+#undef HOLO_R2
     return 0;
   }
   if (p.n_fine <= 64) {
@@ -1259,7 +1288,7 @@ int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int tr
 // waves per workgroup of the persistent kernel for this configuration (the scratch has one slot per resident wave)
 int render_waves_per_wg(int C, int n_fine, int with_normals, int split3, int train) {
   const bool z64 = n_fine <= 64;
-  if (render_rays_per_tile(C, n_fine, with_normals, split3, train) == 4) return z64 ? 8 : 4;
+  if (render_rays_per_tile(C, n_fine, with_normals, split3, train) == 4) return render2_waves_rt(C, n_fine);
   if (C <= 32) {
     if (with_normals) return z64 ? render_waves<16, 64, true>() : render_waves<16, 128, true>();
     return z64 ? render_waves<16, 64, false>() : render_waves<16, 128, false>();

@@ -265,6 +265,27 @@ static size_t val_ws_bytes(const HoloRenderer* r, int with_normals) {
   return render_slots(r, with_normals) * 64 * 32 * 4 * sizeof(float);
 }
 
+static void fill_cam(const HoloRenderCfg& c, const HoloCamera& cam, RenderKernelParams::Cam& pc) {
+  for (int k = 0; k < 9; ++k) pc.Rm[k] = cam.R[k];
+  for (int k = 0; k < 3; ++k) pc.T[k] = cam.T[k];
+  for (int k = 0; k < 2; ++k) {
+    pc.focal[k] = cam.focal[k];
+    pc.pp[k] = cam.principal_point[k];
+  }
+  // AdaptiveRaySampler: near/far from the camera centre C = -T R^T (fp32, as torch computes it)
+  float d2 = 0.f;
+  for (int j = 0; j < 3; ++j) {
+    float cj = -(cam.T[0] * cam.R[j * 3 + 0] + cam.T[1] * cam.R[j * 3 + 1] + cam.T[2] * cam.R[j * 3 + 2]);
+    const float d = cj - c.scene_center[j];
+    d2 += d * d;
+  }
+  if (d2 < 0.001f) d2 = 0.001f;
+  float dist = sqrtf(d2);
+  if (dist < c.scene_extent + 1e-3f) dist = c.scene_extent + 1e-3f;
+  pc.zmin = dist - c.scene_extent;
+  pc.zmax = dist + c.scene_extent;
+}
+
 int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
   if (!r || (dtype != HOLO_DTYPE_F32 && dtype != HOLO_DTYPE_F32_BF16X3)) {
     set_error("holo_renderer_set_compute_dtype: HOLO_DTYPE_F32 or HOLO_DTYPE_F32_BF16X3");
@@ -335,28 +356,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.half_extent = 0.5f * (float)(R - 1) * voxel_size;
     fill_mlp(r, p.mlp);
     p.n_cams = ng;
-    for (int g = 0; g < ng; ++g) {
-      const HoloCamera& cam = cameras[c0 + g];
-      RenderKernelParams::Cam& pc = p.cams[g];
-      for (int k = 0; k < 9; ++k) pc.Rm[k] = cam.R[k];
-      for (int k = 0; k < 3; ++k) pc.T[k] = cam.T[k];
-      for (int k = 0; k < 2; ++k) {
-        pc.focal[k] = cam.focal[k];
-        pc.pp[k] = cam.principal_point[k];
-      }
-      // AdaptiveRaySampler: near/far from the camera centre C = -T R^T (fp32, as torch computes it)
-      float d2 = 0.f;
-      for (int j = 0; j < 3; ++j) {
-        float cj = -(cam.T[0] * cam.R[j * 3 + 0] + cam.T[1] * cam.R[j * 3 + 1] + cam.T[2] * cam.R[j * 3 + 2]);
-        const float d = cj - c.scene_center[j];
-        d2 += d * d;
-      }
-      if (d2 < 0.001f) d2 = 0.001f;
-      float dist = sqrtf(d2);
-      if (dist < c.scene_extent + 1e-3f) dist = c.scene_extent + 1e-3f;
-      pc.zmin = dist - c.scene_extent;
-      pc.zmax = dist + c.scene_extent;
-    }
+    for (int g = 0; g < ng; ++g) fill_cam(c, cameras[c0 + g], p.cams[g]);
     p.H = H;
     p.W = Wd;
     if (Wd >= H) {
@@ -512,6 +512,79 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
                        void* stream) {
   return holo_implicit_eval_features(r, grid, pts, dirs, n_points, pts_per_dir, densities, colours, nullptr, workspace,
                                      workspace_bytes, stream);
+}
+
+// Training-mode rendering: an explicit list of rays per camera, optional injected random streams.
+int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
+                     const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                     const float* noise_fine, float density_noise_std, float* images, float* depths, float* masks,
+                     float* images_coarse, float* depths_coarse, float* masks_coarse, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  if (!r || !grid || !cameras || n_cameras < 1 || n_rays < 1 || !xys || !images || !depths || !masks || !workspace) {
+    set_error("holo_render_rays: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_render_rays: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  if (r->cfg.feature_dim != 0 || r->cfg.feature_size > 64) {
+    set_error("holo_render_rays: colours only, feature_size 16/32/64");
+    return HOLO_E_UNSUPPORTED;
+  }
+  if (workspace_bytes < grid_cl_bytes(r) + 256) {
+    set_error("holo_render_rays: workspace too small (holo_render_workspace_bytes)");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  const int R = c.resol, C = c.feature_size;
+  float* grid_cl = (float*)workspace;
+  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream)) return HOLO_E_INVALID;
+  const int G = RenderKernelParams::MAX_CAMS;
+  const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, 0, 0, 1);
+  const int n_wgs_max = render_workgroups(r);
+  const int64_t nm = (int64_t)c.n_pts_coarse + c.n_pts_fine;
+  for (int c0 = 0; c0 < n_cameras; c0 += G) {
+    const int ng = n_cameras - c0 < G ? n_cameras - c0 : G;
+    RenderKernelParams p;
+    memset(&p, 0, sizeof p);
+    p.grid_cl = grid_cl;
+    p.R = R;
+    p.C = C;
+    p.half_extent = 0.5f * (float)(R - 1) * (c.volume_extent / (float)R);
+    fill_mlp(r, p.mlp);
+    p.n_cams = ng;
+    for (int g = 0; g < ng; ++g) fill_cam(c, cameras[c0 + g], p.cams[g]);
+    p.H = c.image_height;
+    p.W = c.image_width;
+    p.n_coarse = c.n_pts_coarse;
+    p.n_fine = c.n_pts_fine;
+    for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
+    p.background_opacity = c.background_opacity;
+    p.pdf_eps = c.sample_pdf_eps;
+    const int64_t o = (int64_t)c0 * n_rays;
+    p.train.n_rays = n_rays;
+    p.train.xys = xys + o * 2;
+    p.train.u_coarse = u_coarse ? u_coarse + o * c.n_pts_coarse : nullptr;
+    p.train.u_fine = u_fine ? u_fine + o * c.n_pts_fine : nullptr;
+    p.train.noise_coarse = (noise_coarse && density_noise_std > 0.f) ? noise_coarse + o * c.n_pts_coarse : nullptr;
+    p.train.noise_fine = (noise_fine && density_noise_std > 0.f) ? noise_fine + o * nm : nullptr;
+    p.train.noise_std = density_noise_std;
+    p.rgb = images + o * 3;
+    p.depth = depths + o;
+    p.mask = masks + o;
+    if (images_coarse && depths_coarse && masks_coarse) {
+      p.rgb_c = images_coarse + o * 3;
+      p.depth_c = depths_coarse + o;
+      p.mask_c = masks_coarse + o;
+    }
+    p.n_tiles = (int64_t)ng * ((n_rays + 3) / 4);
+    int n_wgs = (int)((p.n_tiles + waves_per_wg - 1) / waves_per_wg);
+    if (n_wgs > n_wgs_max) n_wgs = n_wgs_max;
+    p.xcd = 1;
+    if (render_launch(p, stream, n_wgs)) return HOLO_E_INVALID;
+  }
+  return 0;
 }
 
 int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, int64_t n_points, float* normals,

@@ -189,19 +189,26 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
                 depth_map=None, sequence_name=None, frame_timestamp=None,
                 evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION,
                 voxel_features: Optional[torch.Tensor] = None, **kwargs) -> Dict[str, Any]:
-        if evaluation_mode != EvaluationMode.EVALUATION:
-            raise NotImplementedError("training-mode forward (mask-sampled rays, density noise, losses) is outside this path")
         image_features = kwargs.pop("image_features", None)
-        n_targets = 1  # EVALUATION renders one target camera per call (:263-269)
+        rng_streams = kwargs.pop("rng_streams", None)
+        training = evaluation_mode == EvaluationMode.TRAINING
+        batch_size = len(camera)
+        # number of target views (holo_diffusion_model.py:262-274): 1 in evaluation; in training the first
+        # n_train_target_views cameras of the batch (all of them when <= 0), 1 when the batch is not larger than that
+        if not training:
+            n_targets = 1
+        else:
+            n_targets = batch_size if self.n_train_target_views <= 0 else min(self.n_train_target_views, batch_size)
+        if batch_size <= n_targets:
+            n_targets = 1
         target_cameras = camera[list(range(n_targets))]
-        sampling_mode = RenderSamplingMode(self.sampling_mode_evaluation)
-        if sampling_mode != RenderSamplingMode.FULL_GRID:
+        sampling_mode = RenderSamplingMode(self.sampling_mode_training if training else self.sampling_mode_evaluation)
+        if not training and sampling_mode != RenderSamplingMode.FULL_GRID:
             raise NotImplementedError("evaluation uses full_grid sampling")
         if image_rgb is not None or image_features is not None:
             # ---- view pooling: views -> voxel grid (:327-374), one fused kernel behind the image feature extractor
             assert self.view_pooler_enabled, "view_pooler must be enabled to use image_rgb"
             assert voxel_features is None, "Cannot provide both image_rgb and voxel_features"
-            batch_size = len(camera)
             # safe_slice_sources (:276-298): the source views are the frames of the FIRST frame's sequence minus the
             # n_targets leading ones; an empty selection falls back to the whole batch
             if sequence_name is not None and batch_size > 1:
@@ -227,17 +234,30 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             source_cameras = camera[sel]
             voxel_features = self.pool_views_to_voxel_features(image_features, source_cameras)
         if voxel_features is None:
+            assert not training, "training needs image_rgb / image_features or voxel_features"
             voxel_features = self.sample_random_voxel_features()
         if self.check_ranges:
             assert voxel_features.min() >= -1.0 and voxel_features.max() <= 1.0
         if self.net_3d_enabled:
-            voxel_features = self._refine(voxel_features)
+            if self.diffusion_enabled and training:
+                voxel_features = self._diffuse_and_denoise(voxel_features, rng_streams)
+            else:
+                voxel_features = self._refine(voxel_features)
         assert voxel_features.shape[1] == self.feature_size, "Wrong voxel feature size!"
         for func in self._implicit_functions:
             func.bind_args(voxel_grid_features=voxel_features)
-        ray_bundle = self.raysampler(target_cameras, evaluation_mode, mask=None)
-        rendered = self.renderer(ray_bundle=ray_bundle, implicit_functions=list(self._implicit_functions),
-                                 evaluation_mode=evaluation_mode)
+        if training:
+            rs = rng_streams or {}
+            ray_bundle = self.raysampler(
+                target_cameras, evaluation_mode, sampling_mode=sampling_mode, xys=rs.get("xys"),
+                mask=mask_crop[list(range(n_targets))] if mask_crop is not None
+                and sampling_mode == RenderSamplingMode.MASK_SAMPLE else None)
+            rendered = self.renderer(ray_bundle=ray_bundle, implicit_functions=list(self._implicit_functions),
+                                     evaluation_mode=evaluation_mode, rng_streams=rs)
+        else:
+            ray_bundle = self.raysampler(target_cameras, evaluation_mode, mask=None)
+            rendered = self.renderer(ray_bundle=ray_bundle, implicit_functions=list(self._implicit_functions),
+                                     evaluation_mode=evaluation_mode)
         for func in self._implicit_functions:
             func.unbind_args()
         preds: Dict[str, Any] = {"rendered": rendered, "ray_bundle": ray_bundle}
@@ -250,6 +270,33 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             # for (flyaround.py:440-445, _make_shaded_from_normals)
             preds["normals_render"] = rendered.normals.permute(0, 3, 1, 2)
         return preds
+
+    @torch.no_grad()
+    def _diffuse_and_denoise(self, voxel_features: torch.Tensor, rng_streams: Optional[dict]) -> torch.Tensor:
+        """The diffusion mechanism of the TRAINING branch (holo_diffusion_model.py:386-418), forward only: sample a
+        timestep, diffuse the clean grid (q_sample), predict it back (pred_xstart of p_mean_variance, clamped) - and, with
+        probability ``bootstrap_prob``, once more on the prediction ("bootstrap").  Random draws may be injected through
+        ``rng_streams``: ``timesteps`` / ``q_noise`` (first round), ``bootstrap`` (bool), ``timesteps2`` / ``q_noise2``."""
+        import numpy as np
+        rs = rng_streams or {}
+        dev = voxel_features.device
+
+        def one_round(x0, t_key, n_key):
+            t = rs.get(t_key)
+            if t is None:
+                t, _ = self.diffusion.sample_timesteps(x0.shape[0], dev)
+            t = torch.as_tensor(t, device=dev, dtype=torch.int64).reshape(x0.shape[0])
+            nz = rs.get(n_key)
+            x_t = self.diffusion.q_sample(x0, t, noise=nz.to(dev) if nz is not None else None)
+            return self.diffusion.p_mean_variance(model=self.net_3d, x=x_t, t=t, clip_denoised=True, model_kwargs={})["pred_xstart"]
+
+        out = one_round(voxel_features, "timesteps", "q_noise")
+        boot = rs.get("bootstrap")
+        if boot is None:
+            boot = self.enable_bootstrap and (np.random.uniform() < self.bootstrap_prob)
+        if boot:
+            out = one_round(out, "timesteps2", "q_noise2")
+        return out
 
     @torch.no_grad()
     def pool_views_to_voxel_features(self, image_features: Dict[str, torch.Tensor], source_cameras) -> torch.Tensor:

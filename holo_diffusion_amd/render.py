@@ -61,6 +61,10 @@ class ImplicitronRayBundle:
     directions: Optional[torch.Tensor] = None
     lengths: Optional[torch.Tensor] = None
     xys: Optional[torch.Tensor] = None
+    # training mode: `xys` (n_cam, n_rays, 1, 2) is the explicit ray list (mask-sampled rays); `stratified` asks the
+    # renderer for stratified depths (stratified_point_sampling_training)
+    training: bool = False
+    stratified: bool = False
 
     def materialize(self) -> "ImplicitronRayBundle":
         """Fill origins (n,H,W,3), directions (n,H,W,3), lengths (n,H,W,P), xys (n,H,W,2) with plain torch ops
@@ -425,14 +429,38 @@ class AdaptiveRaySampler(Configurable):
     def __init__(self, **kwargs):
         apply_config(self, kwargs)
 
-    def __call__(self, cameras: PerspectiveCameras, evaluation_mode: EvaluationMode, mask=None) -> ImplicitronRayBundle:
-        if evaluation_mode != EvaluationMode.EVALUATION:
-            raise NotImplementedError("training-mode (mask-sampled, stratified) ray sampling is out of scope")
-        if self.stratified_point_sampling_evaluation:
-            raise NotImplementedError("stratified sampling at evaluation time is not supported")
-        return ImplicitronRayBundle(camera=cameras, image_height=self.image_height, image_width=self.image_width,
-                                    n_pts_per_ray=self.n_pts_per_ray_evaluation, scene_extent=self.scene_extent,
-                                    scene_center=tuple(self.scene_center))
+    def __call__(self, cameras: PerspectiveCameras, evaluation_mode: EvaluationMode, mask=None,
+                 sampling_mode: Optional[RenderSamplingMode] = None, xys: Optional[torch.Tensor] = None) -> ImplicitronRayBundle:
+        """EVALUATION: the full pixel grid (regenerated inside the kernel).  TRAINING: ``mask_sample`` draws
+        ``n_rays_per_image_sampled_from_mask`` pixels per camera from the (nearest-resized) mask as a multinomial
+        distribution, without replacement while the mask has enough support (PyTorch3D MultinomialRaysampler._sample_mask /
+        _safe_multinomial, restated - a random draw, UNPINNED by nature); ``xys`` (n_cam, n_rays, 2) overrides the draw."""
+        training = evaluation_mode == EvaluationMode.TRAINING
+        if not training:
+            if self.stratified_point_sampling_evaluation:
+                raise NotImplementedError("stratified sampling at evaluation time is not supported")
+            return ImplicitronRayBundle(camera=cameras, image_height=self.image_height, image_width=self.image_width,
+                                        n_pts_per_ray=self.n_pts_per_ray_evaluation, scene_extent=self.scene_extent,
+                                        scene_center=tuple(self.scene_center))
+        n_cam = len(cameras)
+        H, W = self.image_height, self.image_width
+        if xys is None:
+            if sampling_mode == RenderSamplingMode.MASK_SAMPLE and mask is not None:
+                n_rays = self.n_rays_per_image_sampled_from_mask
+                wts = torch.nn.functional.interpolate(mask.float(), size=[H, W], mode="nearest").reshape(n_cam, -1)
+                enough = (wts > 0).sum(dim=1) >= n_rays
+                idx = torch.stack([torch.multinomial(wts[i] if bool(wts[i].sum() > 0) else torch.ones_like(wts[i]), n_rays,
+                                                     replacement=not bool(enough[i])) for i in range(n_cam)])
+            else:  # full grid in training mode
+                idx = torch.arange(H * W, device=cameras.R.device)[None].expand(n_cam, -1)
+            rx, ry = (W / H, 1.0) if W >= H else (1.0, H / W)
+            xs = torch.linspace(rx - rx / W, -rx + rx / W, W, dtype=torch.float32, device=idx.device)
+            ys = torch.linspace(ry - ry / H, -ry + ry / H, H, dtype=torch.float32, device=idx.device)
+            xys = torch.stack([xs[idx % W], ys[idx // W]], dim=-1)
+        xys = xys.reshape(n_cam, -1, 1, 2).float()
+        return ImplicitronRayBundle(camera=cameras, image_height=H, image_width=W, n_pts_per_ray=self.n_pts_per_ray_training,
+                                    scene_extent=self.scene_extent, scene_center=tuple(self.scene_center), xys=xys,
+                                    training=True, stratified=bool(self.stratified_point_sampling_training))
 
 
 BaseRenderer = pt3d_base("implicitron.models.renderer.base", "BaseRenderer")
@@ -523,10 +551,82 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         except Exception:
             pass
 
+    def _forward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams) -> RendererOutput:
+        """Training-mode forward of the two-pass renderer (holo_multipass_ea.py:79-125 with
+        evaluation_mode = TRAINING): explicit ray list, ``n_pts_per_ray_training`` coarse + ``n_pts_per_ray_fine_training``
+        new samples, stratified depths / importance samples, density noise of std ``density_noise_std_train`` on both
+        passes.  The random streams are drawn with torch on the device unless injected through ``rng_streams`` (keys
+        ``u_coarse (n_cam,n_rays,P)``, ``u_fine (n_cam,n_rays,Pf)``, ``noise_coarse (n_cam,n_rays,P)``,
+        ``noise_fine (n_cam,n_rays,P+Pf)`` - the parity tests inject them).  Forward only: no autograd graph is built."""
+        if not bundle.training or bundle.xys is None:
+            raise ValueError("training-mode rendering needs the ray sampler's training bundle (explicit xys)")
+        wrapper = implicit_functions[0]
+        fn = wrapper._fn
+        grid = wrapper.bound_args.get("voxel_grid_features")
+        if grid is None:
+            raise ValueError("voxel_grid_features must be bound to the implicit function (bind_args)")
+        runtime.require_device(grid, "HoloMultiPassEmissionAbsorptionRenderer.forward")
+        dev = grid.device
+        if not isinstance(fn, HoloVoxelGridImplicitFunction) or fn.feature_dim != 0 or fn.n_hidden not in (16, 32, 64):
+            raise NotImplementedError("training-mode rendering: HoloVoxelGridImplicitFunction with 16/32/64 grid features, colours only")
+        cams = bundle.camera
+        n_cam, n_rays = len(cams), int(bundle.xys.shape[1])
+        P, Pf = int(bundle.n_pts_per_ray), int(self.n_pts_per_ray_fine_training)
+        two_pass = len(implicit_functions) > 1
+        # the handle is keyed on the sample counts: a training handle next to the evaluation one
+        eval_bundle = ImplicitronRayBundle(camera=cams, image_height=bundle.image_height, image_width=bundle.image_width,
+                                           n_pts_per_ray=P, scene_extent=bundle.scene_extent, scene_center=bundle.scene_center)
+        saved = (self._handle, self._handle_key, self._param_versions, self.n_pts_per_ray_fine_evaluation)
+        if "_train_state" not in self.__dict__:
+            self.__dict__["_train_state"] = (None, None, None)
+        self._handle, self._handle_key, self._param_versions = self.__dict__["_train_state"]
+        self.n_pts_per_ray_fine_evaluation = Pf
+        try:
+            h = self._ensure_handle(fn, eval_bundle, dev)
+        finally:
+            self.__dict__["_train_state"] = (self._handle, self._handle_key, self._param_versions)
+            self._handle, self._handle_key, self._param_versions, self.n_pts_per_ray_fine_evaluation = saved
+        rs = dict(rng_streams or {})
+        std = float(self.density_noise_std_train)
+
+        def stream(key, shape, normal, wanted):
+            if not wanted:
+                return None
+            t = rs.get(key)
+            if t is None:
+                t = torch.randn(shape, device=dev) if normal else torch.rand(shape, device=dev)
+            if tuple(t.shape) != tuple(shape):
+                raise _lib.HoloError(f"rng_streams['{key}'] must have shape {tuple(shape)}, got {tuple(t.shape)}")
+            return t.to(dev, torch.float32).contiguous()
+
+        u_c = stream("u_coarse", (n_cam, n_rays, P), False, bundle.stratified and self.stratified_sampling_coarse_training)
+        u_f = stream("u_fine", (n_cam, n_rays, Pf), False, two_pass and self.stratified_sampling_coarse_training)
+        nz_c = stream("noise_coarse", (n_cam, n_rays, P), True, std > 0.0)
+        nz_f = stream("noise_fine", (n_cam, n_rays, P + Pf), True, std > 0.0 and two_pass)
+        L = runtime.lib()
+        xys = bundle.xys.reshape(n_cam, n_rays, 2).to(dev, torch.float32).contiguous()
+        grid = grid.contiguous().float()
+        img = torch.empty(n_cam, 3, n_rays, device=dev)
+        dep, msk = torch.empty(n_cam, n_rays, device=dev), torch.empty(n_cam, n_rays, device=dev)
+        imgc, depc, mskc = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(msk)
+        ws = runtime.workspace(self, dev, L.holo_render_workspace_bytes(h, n_cam, 0))
+        nul = C.c_void_p(None)
+        opt = lambda t: runtime.ptr(t) if t is not None else nul  # noqa: E731
+        _lib.check(L, L.holo_render_rays(h, runtime.ptr(grid), _camera_array(cams), n_cam, n_rays, runtime.ptr(xys), opt(u_c),
+                                         opt(u_f), opt(nz_c), opt(nz_f), std, runtime.ptr(img), runtime.ptr(dep),
+                                         runtime.ptr(msk), runtime.ptr(imgc), runtime.ptr(depc), runtime.ptr(mskc),
+                                         runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_render_rays")
+        shp = lambda t, c: t.reshape(n_cam, c, n_rays, 1).permute(0, 2, 3, 1)  # noqa: E731  -> (n_cam, n_rays, 1, c)
+        coarse = RendererOutput(features=shp(imgc, 3), depths=shp(depc, 1), masks=shp(mskc, 1))
+        if not two_pass:
+            return coarse
+        return RendererOutput(features=shp(img, 3), depths=shp(dep, 1), masks=shp(msk, 1), prev_stage=coarse)
+
     def forward(self, ray_bundle: ImplicitronRayBundle, implicit_functions: List[ImplicitFunctionWrapper],
-                evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION, **kwargs) -> RendererOutput:
+                evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION, rng_streams: Optional[dict] = None,
+                **kwargs) -> RendererOutput:
         if evaluation_mode != EvaluationMode.EVALUATION:
-            raise NotImplementedError("training-mode rendering (density noise, stratified sampling) is out of scope")
+            return self._forward_training(ray_bundle, implicit_functions, rng_streams)
         if not implicit_functions:
             raise ValueError("EA renderer expects implicit functions")
         wrapper = implicit_functions[0]

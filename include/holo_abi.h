@@ -204,6 +204,24 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
                 float* depths, float* masks, float* images_coarse, float* depths_coarse, float* masks_coarse,
                 float* normals, float* normals_coarse, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training-mode rendering: the same two-pass renderer on an EXPLICIT list of rays per camera with the
+ * random streams of the reference's training branch injected by the caller:
+ *   xys           (n_cameras, n_rays, 2) NDC coordinates of the rays (mask-sampled rays of the AdaptiveRaySampler,
+ *                 configs/apple.yaml:135-146; PyTorch3D convention +x left, +y up)
+ *   u_coarse      (n_cameras, n_rays, n_pts_coarse) uniforms in [0,1) or NULL: stratified depths (PyTorch3D
+ *                 _jiggle_within_stratas; stratified_point_sampling_training)
+ *   u_fine        (n_cameras, n_rays, n_pts_fine) uniforms or NULL: stratified importance samples (sample_pdf det=False)
+ *   noise_coarse  (n_cameras, n_rays, n_pts_coarse), noise_fine (n_cameras, n_rays, n_pts_coarse + n_pts_fine, in DEPTH
+ *                 ORDER) standard normals or NULL: raw density += density_noise_std * noise before the ReLU
+ *                 (holo_multipass_ea.py:77,87-91; the fine pass draws a new value for each of its sorted points)
+ *   images (n_cameras, 3, n_rays), depths / masks (n_cameras, n_rays); *_coarse optional (all three or none).
+ * n_pts_coarse / n_pts_fine come from the renderer's configuration (the training values of the YAML). */
+int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
+                     const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                     const float* noise_fine, float density_noise_std, float* images, float* depths, float* masks,
+                     float* images_coarse, float* depths_coarse, float* masks_coarse, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* Stand-alone implicit function.  Replaces HoloVoxelGridImplicitFunction.forward
  * (holo_voxel_grid_implicit_function.py:182-269): trilinear fetch of `grid` at the world points, RenderMLP.
  *   pts        : (n_points, 3) world coordinates; dirs : (n_points / pts_per_dir, 3) ray directions

@@ -260,10 +260,16 @@ def implicit_normals(grid, sd, pts, cfg: RenderCfg, prefix: str = ""):
 # ----------------------------------------------------------------------------
 # raymarcher + refiner
 # ----------------------------------------------------------------------------
-def ea_raymarch(dens: torch.Tensor, feats: torch.Tensor, lengths: torch.Tensor, cfg: RenderCfg):
+def ea_raymarch(dens: torch.Tensor, feats: torch.Tensor, lengths: torch.Tensor, cfg: RenderCfg,
+                noise: Optional[torch.Tensor] = None, noise_std: float = 0.0):
+    """``noise`` (rays, P) standard normals: the raymarcher's ``density_noise_std`` branch (training mode,
+    holo_multipass_ea.py:87-91): densities + randn_like * std BEFORE the ReLU, with the draw injected."""
     deltas = torch.cat((torch.diff(lengths, dim=-1),
                         torch.full_like(lengths[..., :1], cfg.background_opacity)), dim=-1)
-    d = torch.relu(dens[..., 0])
+    raw = dens[..., 0]
+    if noise is not None and noise_std > 0.0:
+        raw = raw + noise * noise_std
+    d = torch.relu(raw)
     wd = deltas * d
     capped = 1.0 - torch.exp(-wd)
     ray_op = 1.0 - torch.exp(-torch.cumsum(wd, dim=-1))
@@ -279,14 +285,17 @@ def ea_raymarch(dens: torch.Tensor, feats: torch.Tensor, lengths: torch.Tensor, 
 
 
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, eps: float = 1e-5,
-               diag: Optional[dict] = None) -> torch.Tensor:
+               diag: Optional[dict] = None, u: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Deterministic inverse-CDF sampling (pytorch3d sample_pdf, det=True).  ``diag`` (test diagnostics) receives the
     raw ``denom = cdf_above - cdf_below`` of every sample BEFORE the ``denom < eps -> 1`` switch."""
     weights = weights + eps
     pdf = weights / weights.sum(dim=-1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    u = torch.linspace(0.0, 1.0, n_samples, dtype=cdf.dtype).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
+    if u is None:  # det = True
+        u = torch.linspace(0.0, 1.0, n_samples, dtype=cdf.dtype).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
+    else:          # det = False (training): u = torch.rand(...), injected
+        u = u.contiguous()
     inds = torch.searchsorted(cdf, u, right=True)
     below = (inds - 1).clamp(0)
     above = inds.clamp(max=cdf.shape[-1] - 1)
@@ -300,16 +309,42 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, eps: f
     return bin_b + t * (bin_a - bin_b)
 
 
-def refine_lengths(lengths: torch.Tensor, weights: torch.Tensor, cfg: RenderCfg, diag: Optional[dict] = None) -> torch.Tensor:
+def jiggle_within_stratas(bin_centers: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """PyTorch3D ``_jiggle_within_stratas`` with the uniform draw injected: one sample per stratum, strata bounded by
+    the mid points of neighbouring depths (and the first / last depth itself)."""
+    mids = 0.5 * (bin_centers[..., 1:] + bin_centers[..., :-1])
+    upper = torch.cat((mids, bin_centers[..., -1:]), dim=-1)
+    lower = torch.cat((bin_centers[..., :1], mids), dim=-1)
+    return lower + (upper - lower) * u
+
+
+def rays_from_xys(cam: dict, xys: torch.Tensor, cfg: RenderCfg):
+    """Rays of ONE camera through the NDC points xys (n,2) (mask-sampled rays of the training branch): the same
+    un-projection as the full grid (make_rays)."""
+    R, T = cam["R"].reshape(-1, 3, 3)[0].float(), cam["T"].reshape(-1, 3)[0].float()
+    f, pp = cam["focal"].reshape(-1, 2)[0].float(), cam["pp"].reshape(-1, 2)[0].float()
+    d_cam = torch.stack([(xys[:, 0] - pp[0]) / f[0], (xys[:, 1] - pp[1]) / f[1], torch.ones(xys.shape[0])], dim=-1)
+    p1 = (d_cam * 1.0 - T[None]) @ R.t()
+    p2 = (d_cam * 2.0 - T[None]) @ R.t()
+    dirs = p2 - p1
+    zmin, zmax = depth_bounds(R, T, cfg)
+    lengths = torch.linspace(zmin, zmax, cfg.n_pts_coarse, dtype=torch.float32)[None].expand(xys.shape[0], -1)
+    return p1 - dirs, dirs, lengths
+
+
+def refine_lengths(lengths: torch.Tensor, weights: torch.Tensor, cfg: RenderCfg, diag: Optional[dict] = None,
+                   u: Optional[torch.Tensor] = None) -> torch.Tensor:
     mid = torch.lerp(lengths[..., 1:], lengths[..., :-1], 0.5)
-    z = sample_pdf(mid, weights[..., 1:-1], cfg.n_pts_fine, cfg.sample_pdf_eps, diag)
+    z = sample_pdf(mid, weights[..., 1:-1], cfg.n_pts_fine, cfg.sample_pdf_eps, diag, u)
     return torch.sort(torch.cat((lengths, z), dim=-1), dim=-1)[0]
 
 
 @torch.no_grad()
 def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.Tensor, dirs: torch.Tensor,
                 lengths: torch.Tensor, cfg: RenderCfg, prefix: str = "", chunk_rays: int = 4096,
-                with_normals: bool = False) -> Dict[str, torch.Tensor]:
+                with_normals: bool = False, u_coarse: Optional[torch.Tensor] = None, u_fine: Optional[torch.Tensor] = None,
+                noise_coarse: Optional[torch.Tensor] = None, noise_fine: Optional[torch.Tensor] = None,
+                noise_std: float = 0.0) -> Dict[str, torch.Tensor]:
     """Two-pass render of an ARBITRARY set of rays (origins (n,3), directions (n,3), coarse lengths (n,P)): coarse pass
     -> refiner -> fine pass (holo_multipass_ea.py:79-125).  Per-ray outputs: rgb (n,3), depth (n,1), mask (n,1), the
     coarse-pass rgb_c / depth_c / mask_c and the sorted fine lengths; with ``with_normals`` also the rendered normals
@@ -317,13 +352,17 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
     keys = ["rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c", "fine_lengths", "pdf_denom"] + (["normals", "normals_c"] if with_normals else [])
     outs = {k: [] for k in keys}
     for s in range(0, origins.shape[0], chunk_rays):
-        o, d, l = origins[s:s + chunk_rays], dirs[s:s + chunk_rays], lengths[s:s + chunk_rays]
+        sl = slice(s, s + chunk_rays)
+        o, d, l = origins[sl], dirs[sl], lengths[sl]
+        # training-mode streams, all injected: stratified depths, density noise, stratified importance samples
+        if u_coarse is not None:
+            l = jiggle_within_stratas(l, u_coarse[sl])
         dens, col = implicit_function(grid, sd, o, d, l, cfg, prefix)
-        rgb_c, dep_c, msk_c, w = ea_raymarch(dens, col, l, cfg)
+        rgb_c, dep_c, msk_c, w = ea_raymarch(dens, col, l, cfg, noise_coarse[sl] if noise_coarse is not None else None, noise_std)
         diag = {}
-        lf = refine_lengths(l, w, cfg, diag)
+        lf = refine_lengths(l, w, cfg, diag, u_fine[sl] if u_fine is not None else None)
         dens, col = implicit_function(grid, sd, o, d, lf, cfg, prefix)
-        rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg)
+        rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg, noise_fine[sl] if noise_fine is not None else None, noise_std)
         vals = [("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c), ("mask_c", msk_c),
                 ("fine_lengths", lf), ("pdf_denom", diag["denom"])]
         if with_normals:

@@ -1,0 +1,139 @@
+"""GPU parity of the TRAINING-mode forward (first half): mask-sampled / explicit ray lists, stratified
+depths and importance samples, density noise on both passes (holo_multipass_ea.py:77,87-91), and the model's diffusion
+mechanism with the bootstrap round (holo_diffusion_model.py:386-418) - every random stream injected on both sides, HIP
+path against the oracle.  (Backward kernels are the second half of 8f-4.)"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import holo_diffusion_amd as hda  # noqa: E402
+from holo_diffusion_amd.render import EvaluationMode  # noqa: E402
+from oracle import diffusion_oracle as do  # noqa: E402
+from oracle import render_oracle as ro  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+from oracle.common import np_noise  # noqa: E402
+
+EMU = os.environ.get("HOLO_TEST_EMU") == "1"
+TINY_UNET = dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2))
+FAR = 14.0
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import tests.gpu_utils as g
+    return g
+
+
+def _streams(n_cam, n_rays, P, Pf, seed):
+    u = lambda s, shp: torch.from_numpy(np_noise(s, shp)).mul(0.5).erf().add(1).mul(0.5).clamp(0, 0.999999)  # noqa: E731  U[0,1)
+    return {"u_coarse": u(seed, (n_cam, n_rays, P)), "u_fine": u(seed + 1, (n_cam, n_rays, Pf)),
+            "noise_coarse": torch.from_numpy(np_noise(seed + 2, (n_cam, n_rays, P))),
+            "noise_fine": torch.from_numpy(np_noise(seed + 3, (n_cam, n_rays, P + Pf)))}
+
+
+def _oracle_training_render(grid, msd, cams, xys, rs, rcfg, noise_std, gu):
+    outs = []
+    for i in range(xys.shape[0]):
+        o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
+        outs.append(ro.render_rays(grid, msd, o, d, l, rcfg, u_coarse=rs.get("u_coarse", [None] * 99)[i] if "u_coarse" in rs else None,
+                                   u_fine=rs["u_fine"][i] if "u_fine" in rs else None,
+                                   noise_coarse=rs["noise_coarse"][i] if "noise_coarse" in rs else None,
+                                   noise_fine=rs["noise_fine"][i] if "noise_fine" in rs else None, noise_std=noise_std))
+    return {k: torch.stack([o[k] for o in outs]) for k in ("rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c")}
+
+
+@pytest.mark.parametrize("P,Pf,C,which", [(24, 20, 16, "all"), (64, 64, 32, "all"), (24, 20, 32, "noise_only"), (16, 100, 16, "strat_only")])
+def test_training_mode_render_vs_oracle(gu, P, Pf, C, which):
+    """holo_render_rays through the renderer plugin's TRAINING branch: explicit NDC ray lists per camera (ragged 4-ray
+    tiles), P stratified coarse depths, Pf stratified importance samples (unsorted draws: the kernel sorts them), density
+    noise of std 1 on both passes with the fine pass's noise indexed by merged depth order."""
+    R, n_cam, n_rays = 8, 3, 37
+    model, _, _, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    grid = torch.tanh(torch.from_numpy(np_noise(7, (1, C, R, R, R))))
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_cam, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    xys = (torch.from_numpy(np_noise(11, (n_cam, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = _streams(n_cam, n_rays, P, Pf, 500 + P)
+    std = 1.0
+    if which == "noise_only":
+        model.raysampler.stratified_point_sampling_training = False
+        model.renderer.stratified_sampling_coarse_training = False
+        rs = {k: v for k, v in rs.items() if k.startswith("noise")}
+    if which == "strat_only":
+        model.renderer.density_noise_std_train = std = 0.0
+        rs = {k: v for k, v in rs.items() if k.startswith("u_")}
+    for fn in model._implicit_functions:
+        fn.bind_args(voxel_grid_features=grid.to(gu.DEV))
+    bundle = model.raysampler(cams.to(gu.DEV), EvaluationMode.TRAINING, xys=xys.to(gu.DEV))
+    assert bundle.xys.shape == (n_cam, n_rays, 1, 2)
+    out = model.renderer(ray_bundle=bundle, implicit_functions=list(model._implicit_functions),
+                         evaluation_mode=EvaluationMode.TRAINING, rng_streams={k: v.to(gu.DEV) for k, v in rs.items()})
+    assert out.features.shape == (n_cam, n_rays, 1, 3) and out.depths.shape == (n_cam, n_rays, 1, 1)
+    ref = _oracle_training_render(grid, msd, cams, xys, rs, rcfg, std, gu)
+    g = lambda t: t.reshape(n_cam, n_rays, -1).cpu()  # noqa: E731
+    for name, got, want, tol in (("rgb", out.features, ref["rgb"], 2e-4), ("mask", out.masks, ref["mask"], 2e-4),
+                                 ("rgb_c", out.prev_stage.features, ref["rgb_c"], 2e-4),
+                                 ("mask_c", out.prev_stage.masks, ref["mask_c"], 2e-4),
+                                 ("depth_c", out.prev_stage.depths, ref["depth_c"], 2e-4 * FAR),
+                                 ("depth", out.depths, ref["depth"], 1e-3 * FAR)):
+        err = (g(got) - want.reshape(n_cam, n_rays, -1)).abs().max().item()
+        assert err < tol, (name, err)
+    # the streams matter: a different draw changes the frame
+    rs2 = {k: v.flip(1).to(gu.DEV) for k, v in rs.items()}
+    out2 = model.renderer(ray_bundle=bundle, implicit_functions=list(model._implicit_functions),
+                          evaluation_mode=EvaluationMode.TRAINING, rng_streams=rs2)
+    assert (out2.features - out.features).abs().max().item() > 1e-3
+
+
+def test_training_mode_model_forward_vs_oracle(gu):
+    """HoloDiffusionModel.forward(evaluation_mode=TRAINING) with a clean grid: timestep draw, q_sample, pred_xstart, the
+    bootstrap round, then the training-mode render of the first n_train_target_views cameras - against the oracle
+    pipeline with the same injected draws."""
+    R, C, P, Pf, n_rays = 8, 16, 16, 16, 21
+    model, ucfg, usd, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.n_train_target_views = 2
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    vf = torch.tanh(torch.from_numpy(np_noise(3, (1, C, R, R, R))))
+    xys = (torch.from_numpy(np_noise(12, (2, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = _streams(2, n_rays, P, Pf, 900)
+    rs.update({"xys": xys, "timesteps": torch.tensor([700]), "q_noise": torch.from_numpy(np_noise(31, tuple(vf.shape))),
+               "bootstrap": True, "timesteps2": torch.tensor([150]), "q_noise2": torch.from_numpy(np_noise(32, tuple(vf.shape)))})
+    dev_rs = {k: (v.to(gu.DEV) if torch.is_tensor(v) else v) for k, v in rs.items()}
+    preds = model(camera=cams.to(gu.DEV), evaluation_mode=EvaluationMode.TRAINING, voxel_features=vf.to(gu.DEV),
+                  rng_streams=dev_rs)
+    assert preds["images_render"].shape == (2, 3, n_rays, 1)
+    orc = do.DiffusionOracle(1000)
+    net = lambda a, b: uo.unet_forward(usd, ucfg, a, b)  # noqa: E731
+    x0 = vf
+    for tk, nk in (("timesteps", "q_noise"), ("timesteps2", "q_noise2")):
+        x0 = orc.p_mean_variance(net, orc.q_sample(x0, rs[tk], rs[nk]), rs[tk], True)["pred_xstart"]
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    ref = _oracle_training_render(x0, msd, cams, xys, rs, rcfg, 1.0, gu)
+    got = preds["images_render"].reshape(2, 3, n_rays).permute(0, 2, 1).cpu()
+    assert (got - ref["rgb"]).abs().max().item() < 1e-3
+    assert (preds["masks_render"].reshape(2, n_rays).cpu() - ref["mask"].reshape(2, n_rays)).abs().max().item() < 1e-3
+    # without the bootstrap round the grid - and the frame - differ
+    p2 = model(camera=cams.to(gu.DEV), evaluation_mode=EvaluationMode.TRAINING, voxel_features=vf.to(gu.DEV),
+               rng_streams={**dev_rs, "bootstrap": False})
+    assert (p2["images_render"] - preds["images_render"]).abs().max().item() > 1e-4
+    # mask sampling draws n_rays_per_image_sampled_from_mask pixels from the mask's support
+    model.raysampler.n_rays_per_image_sampled_from_mask = 9
+    mask = torch.zeros(4, 1, 16, 16)
+    mask[:, :, 4:9, 5:11] = 1.0
+    torch.manual_seed(0)
+    p3 = model(camera=cams.to(gu.DEV), evaluation_mode=EvaluationMode.TRAINING, voxel_features=vf.to(gu.DEV),
+               mask_crop=mask.to(gu.DEV), rng_streams={k: v for k, v in dev_rs.items() if k in ("timesteps", "q_noise", "bootstrap")})
+    assert p3["images_render"].shape == (2, 3, 9, 1) and torch.isfinite(p3["images_render"]).all()
+    b = p3["ray_bundle"].xys.reshape(2, 9, 2).cpu()
+    gridx = torch.linspace(1 - 1 / 16, -1 + 1 / 16, 16)
+    assert all(min((gridx[5:11] - float(v)).abs()) < 1e-6 for v in b[..., 0].flatten())
+    assert all(min((gridx[4:9] - float(v)).abs()) < 1e-6 for v in b[..., 1].flatten())

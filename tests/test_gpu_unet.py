@@ -183,7 +183,7 @@ def test_forward_is_deterministic_and_param_rebind(gu):
 
 def test_wrong_shape_and_unset_errors(gu):
     net, _ = gu.make_unet(TINY_CFG)
-    for bad in ((1, 32, 4, 4, 4), (1, 16, 6, 6, 6), (1, 32, 8, 8, 4)):  # channels; not a multiple of 2^(levels-1); not cubic
+    for bad in ((1, 16, 8, 8, 8), (1, 32, 7, 7, 7), (1, 32, 8, 8, 4)):  # channels; not a multiple of 2^(levels-1); not cubic
         with pytest.raises(_lib.HoloError):
             net(torch.zeros(*bad, device=gu.DEV), torch.zeros(1, dtype=torch.long, device=gu.DEV))
 
