@@ -777,7 +777,18 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
   const int wg_in_x = (int)blockIdx.x / xcd, wgs_per_x = (int)gridDim.x / xcd, my_x = (int)blockIdx.x % xcd;
   const int64_t x_lo = ntiles * my_x / xcd, x_hi = ntiles * (my_x + 1) / xcd;
 
+  unsigned long long* dbg = p.dbg ? p.dbg + ((int64_t)blockIdx.x * NW + wave) * 8 : nullptr;  // development probe
+  unsigned long long tk = 0;
+  auto stamp = [&](int slot) {
+    if (dbg && lane == 0) {
+      const unsigned long long now = HOLO_PROBE_CLOCK();
+      dbg[slot] += now - tk;
+      tk = now;
+    }
+  };
+
   for (int64_t t = x_lo + (int64_t)wg_in_x * NW + wave; t < x_hi; t += (int64_t)wgs_per_x * NW) {
+    if (dbg && lane == 0) tk = HOLO_PROBE_CLOCK();
     const int cam_i = (int)(t / tiles_per_cam);
     const RenderKernelParams::Cam& cam = p.cams[cam_i];
     const int ray0 = (int)(t - (int64_t)cam_i * tiles_per_cam) * 4;
@@ -856,6 +867,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
                                    org[1] + z * dir[1], org[2] + z * dir[2], rdir, sg, cr, cg, cb);
     };
 
+    stamp(0);
     // ---- coarse evaluation: column groups of 8 consecutive depths
     for (int j0 = 0; j0 < nc; j0 += 8) {
       const int i = min(j0 + dq, nc - 1);
@@ -864,6 +876,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       if (lh == 0 && j0 + dq < nc) S.cval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
     }
     HOLO_WAVE_SYNC();
+    stamp(1);
 
     // ---- per ray: coarse composite, cdf, inverse cdf (lane = depth index)
     const float ustep = 1.0f / (float)(nf - 1);
@@ -957,6 +970,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       }
     }
     HOLO_WAVE_SYNC();
+    stamp(2);
 
     // ---- evaluation of the new samples
     for (int j0 = 0; j0 < nf; j0 += 8) {
@@ -966,6 +980,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       if (lh == 0 && j0 + dq < nf) S.fval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
     }
     HOLO_WAVE_SYNC();
+    stamp(3);
 
     // ---- per ray: composite of the merged list [coarse | new] in depth order (== torch.sort of the concatenation; a
     //      coarse sample goes first on a tie)
@@ -1075,6 +1090,8 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       }
       HOLO_WAVE_SYNC();  // the flag row is rewritten for the next ray
     }
+    stamp(5);
+    if (dbg && lane == 0) dbg[4] += 1;
   }
 }
 

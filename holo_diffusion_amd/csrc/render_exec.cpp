@@ -404,15 +404,20 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
       HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
       HIP_TRY(hipMemcpy(d.data(), p.dbg, d.size() * 8, hipMemcpyDeviceToHost));
       (void)hipFree(p.dbg);
-      double ph[4] = {0, 0, 0, 0}, tiles = 0;
+      double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tiles = 0;
       for (int w = 0; w < nslots; ++w) {
-        for (int k = 0; k < 4; ++k) ph[k] += (double)d[w * 8 + k];
+        for (int k = 0; k < 8; ++k) ph[k] += (double)d[w * 8 + k];
         tiles += (double)d[w * 8 + 4];
       }
       if (tiles < 1) tiles = 1;
-      fprintf(stderr, "[render timeline] frames %d slots %d tiles %.0f | per tile: setup %.1f  coarse %.1f  cdf+inverse-cdf %.1f  "
-              "fine+composite %.1f us\n", ng, nslots, tiles, ph[0] / tiles * 0.01, ph[1] / tiles * 0.01,
-              (ph[2] - ph[1]) / tiles * 0.01, (ph[3] - ph[2]) / tiles * 0.01);
+      if (rays_per_tile == 4)
+        fprintf(stderr, "[render timeline] frames %d slots %d 4-ray tiles %.0f | per tile (us): setup %.2f  coarse eval %.2f  "
+                "coarse composite+cdf+inverse-cdf %.2f  new-sample eval %.2f  merged composite %.2f\n", ng, nslots, tiles,
+                ph[0] / tiles * 0.01, ph[1] / tiles * 0.01, ph[2] / tiles * 0.01, ph[3] / tiles * 0.01, ph[5] / tiles * 0.01);
+      else
+        fprintf(stderr, "[render timeline] frames %d slots %d tiles %.0f | per tile: setup %.1f  coarse %.1f  cdf+inverse-cdf %.1f  "
+                "fine+composite %.1f us\n", ng, nslots, tiles, ph[0] / tiles * 0.01, ph[1] / tiles * 0.01,
+                (ph[2] - ph[1]) / tiles * 0.01, (ph[3] - ph[2]) / tiles * 0.01);
     }
 #endif
   }
