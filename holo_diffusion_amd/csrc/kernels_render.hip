@@ -707,10 +707,65 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
 // raw densities of each pass (holo_multipass_ea.py:87-91: the fine pass draws a NEW value for every one of its sorted
 // points - indexed by merged rank here).
 // =====================================================================================================================
-__device__ __forceinline__ float shfl_up1(float v, int lane, float first) {
-  const float r = __shfl(v, lane > 0 ? lane - 1 : 0);
-  return lane > 0 ? r : first;
+// ---- wave-wide (64 lanes) scans and reductions.  On the device they run on DPP (data-parallel primitives: the source
+// lane is selected inside the VALU instruction, no trip through the LDS crossbar that __shfl = ds_bpermute takes):
+// Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8; a lane without a source inside its row adds the `old` value
+// 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  A disabled or source-less lane receives
+// `old` = 0 bits = +0.0.  The host emulation of the tests uses shuffles.
+#ifndef HOLO_EMU
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROW_MASK, 0xf, false));
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+  unsigned long long b;
+  memcpy(&b, &v, 8);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b & 0xffffffffull), CTRL, ROW_MASK, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  b = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+#define HOLO_DPP_SCAN(v, F)        \
+  v += F<0x111, 0xf>(v);           \
+  v += F<0x112, 0xf>(v);           \
+  v += F<0x114, 0xf>(v);           \
+  v += F<0x118, 0xf>(v);           \
+  v += F<0x142, 0xa>(v);           \
+  v += F<0x143, 0xc>(v)
+__device__ __forceinline__ double wave_scan_incl_d(double v, int) {
+  HOLO_DPP_SCAN(v, dpp_d);
+  return v;
+}
+__device__ __forceinline__ int wave_scan_incl_i(int v, int) {
+  HOLO_DPP_SCAN(v, dpp_i);
+  return v;
+}
+// totals: the inclusive scan's last lane, broadcast through a scalar register
+__device__ __forceinline__ float wave_sum_f(float v) {
+  HOLO_DPP_SCAN(v, dpp_f);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+__device__ __forceinline__ double wave_last_d(double incl) {  // value of lane 63
+  unsigned long long b;
+  memcpy(&b, &incl, 8);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b & 0xffffffffull), 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+  b = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+// value of the previous lane (wave_shr:1), 0 for lane 0
+__device__ __forceinline__ double wave_prev_d(double v, int) { return dpp_d<0x138, 0xf>(v); }
+__device__ __forceinline__ int wave_prev_i(int v, int) { return dpp_i<0x138, 0xf>(v); }
+#else
 __device__ __forceinline__ double shfl_d(double v, int src) {
   unsigned long long b;
   memcpy(&b, &v, 8);
@@ -721,21 +776,34 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
   memcpy(&r, &b, 8);
   return r;
 }
-// inclusive prefix sum over the 64 lanes (Hillis-Steele; the additions of one lane happen in rank order, like a sequential
-// double accumulation up to the last bits of a double)
 __device__ __forceinline__ double wave_scan_incl_d(double v, int lane) {
-#pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const double o = shfl_d(v, lane >= d ? lane - d : lane);
     if (lane >= d) v += o;
   }
   return v;
 }
+__device__ __forceinline__ int wave_scan_incl_i(int v, int lane) {
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)v), lane >= d ? lane - d : lane));
+    if (lane >= d) v += o;
+  }
+  return v;
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
+__device__ __forceinline__ double wave_last_d(double incl) { return shfl_d(incl, 63); }
+__device__ __forceinline__ double wave_prev_d(double v, int lane) {
+  const double r = shfl_d(v, lane > 0 ? lane - 1 : 0);
+  return lane > 0 ? r : 0.0;
+}
+__device__ __forceinline__ int wave_prev_i(int v, int lane) {
+  const int r = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)v), lane > 0 ? lane - 1 : 0));
+  return lane > 0 ? r : 0;
+}
+#endif
 
 template <int ZF>
 struct Render2Wave {
@@ -894,10 +962,10 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const float delta = lane + 1 < nc ? zn - zi : p.background_opacity;
       const float x = lane < nc ? delta * fmaxf(sraw, 0.f) : 0.f;
       const double Sx = wave_scan_incl_d((double)x, lane);
-      const double Sprev = shfl_d(Sx, lane > 0 ? lane - 1 : 0);
+      const double Sprev = wave_prev_d(Sx, lane);
       const float Tr = lane > 0 ? 1.f - (1.f - __expf(-(float)Sprev)) : 1.f;  // T = 1 - O as the raymarcher forms them
       const float w = lane < nc ? (1.f - __expf(-x)) * Tr : 0.f;
-      const float O = 1.f - __expf(-(float)shfl_d(Sx, 63));
+      const float O = 1.f - __expf(-(float)wave_last_d(Sx));
       if (p.rgb_c) {
         const float ar = wave_sum_f(w * v.y), ag = wave_sum_f(w * v.z), ab = wave_sum_f(w * v.w), ad = wave_sum_f(w * zi);
         if (lane == 0 && active) {
@@ -912,10 +980,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       }
       // weights[1:-1] + eps -> pdf -> cdf (nb = nc-1 entries, cdf[0] = 0); running sums in double like torch's
       const float a = (lane >= 1 && lane <= nc - 2) ? w + p.pdf_eps : 0.f;
-      double Sa = (double)a;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) Sa += shfl_d(Sa, lane ^ d);
-      const float Sf = (float)Sa;
+      const float Sf = (float)wave_last_d(wave_scan_incl_d((double)a, lane));
       const float pdf = (lane >= 1 && lane <= nc - 2) ? a / Sf : 0.f;
       const double run = wave_scan_incl_d((double)pdf, lane);
       const float c = lane < nb ? (lane == 0 ? 0.f : (float)run) : 3.0e38f;
@@ -1029,13 +1094,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         f[e] = q < nm ? (int)S.isnew[q] : 0;
         cnt += f[e];
       }
-      int incl_i = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)incl_i), lane >= d ? lane - d : lane));
-        if (lane >= d) incl_i += o;
-      }
-      int nbefore = incl_i - cnt;
+      int nbefore = wave_scan_incl_i(cnt, lane) - cnt;
       float xs[3], zz[4];
       float4 vv[3];
 #pragma unroll
@@ -1060,8 +1119,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       }
       const double l3 = (double)xs[0] + (double)xs[1] + (double)xs[2];
       const double incl = wave_scan_incl_d(l3, lane);
-      const double before = shfl_d(incl, lane > 0 ? lane - 1 : 0);
-      double run = lane > 0 ? before : 0.0;  // sum of all x before this lane's first position
+      double run = wave_prev_d(incl, lane);  // sum of all x before this lane's first position
       float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
@@ -1074,7 +1132,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         ad = fmaf(w, zz[e], ad);
         run += (double)xs[e];
       }
-      const float O = 1.f - __expf(-(float)shfl_d(incl, 63));
+      const float O = 1.f - __expf(-(float)wave_last_d(incl));
       ar = wave_sum_f(ar);
       ag = wave_sum_f(ag);
       ab = wave_sum_f(ab);
