@@ -511,7 +511,7 @@ def main():
         mlp_flops_per_ray = samples * (2 * 257 * C + 2 * 3 * 256 + 2 * 3 * 27)
         render_traffic = None
         try:  # fabric-side bytes per FRAME of the render kernel from the committed PMC pass
-            ent = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("render_kernel<16, false, false, 64>")
+            ent = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("render2_kernel<16, 64, false, 12>")
             if ent and args.workload == "north":
                 fpl = ent.get("frames_per_launch", 1)
                 render_traffic = {"bytes_per_frame": (ent["fetch_bytes"] + ent["write_bytes"]) / fpl,
@@ -543,8 +543,8 @@ def main():
             "unet_workspace_bytes": net.workspace_bytes(1, device),
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,
-                                "kernel": "render_kernel<16, false, false, 64> (persistent: one 12-wave workgroup per CU walks "
-                                          "the 32-ray wave tiles of all frames of the call)",
+                                "kernel": "render2_kernel<16, 64, false, 12> (persistent: one 12-wave workgroup per CU walks the "
+                                          "4-ray x 8-depth wave tiles of all frames of the call; per-ray values stay in LDS)",
                                 "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,
                                 "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,
                                 "peak_hbm_GBps": PEAK_HBM_GBPS,

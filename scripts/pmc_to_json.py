@@ -47,9 +47,9 @@ for (k, grid), (n, f_kib) in fetch.items():
         if mw.group(3) == "2":
             continue  # the 32-channel two-wave-row variant: its grid is not distinguishable from the 64-channel one here
         label = f"conv_wino{mw.group(1)}_kernel<{mw.group(2)}> at {od}^3 output"
-    elif "render_kernel" in k:
-        mr = re.search(r"render_kernel<([^>]*)>", k)
-        label = f"render_kernel<{mr.group(1)}>"
+    elif "render2_kernel" in k or "render_kernel" in k:
+        mr = re.search(r"(render2?_kernel)<([^>]*)>", k)
+        label = f"{mr.group(1)}<{mr.group(2)}>"
         frames = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # frames per launch of the profiled command
     else:
         continue
