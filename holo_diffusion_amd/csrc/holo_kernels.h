@@ -239,6 +239,7 @@ struct RenderKernelParams {
   float* nrm_c;
   unsigned long long* dbg;  // optional per-slot phase clocks [slot][8] (HOLO_RENDER_TIMELINE=1); null in production
   int split3;  // 1: RenderMLP products on the bf16 matrix cores from an exact 3-term bf16 split (feature_size 32 only)
+  int* tile_ctr;  // render2_kernel: 8 zeroed counters (one per XCD range) for the dynamic tile hand-out; null = static stride
   // training-mode rendering (n_rays > 0; render2_kernel only): every camera renders the SAME number of rays given as NDC
   // coordinates; outputs are (n_cams, 3, n_rays) / (n_cams, n_rays) planes.  Optional injected random streams (null =
   // deterministic): stratified coarse depths, stratified importance samples, density noise of both passes.

@@ -389,6 +389,15 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     int n_wgs = (int)((p.n_tiles + waves_per_wg - 1) / waves_per_wg);
     if (n_wgs > n_wgs_max) n_wgs = n_wgs_max;
     p.xcd = (xcd > 1 && n_wgs == n_wgs_max && n_wgs % xcd == 0) ? xcd : 1;
+#ifndef HOLO_EMU
+    static const bool static_tiles = getenv("HOLO_RENDER_STATIC_TILES") != nullptr;  // development knob
+#else
+    const bool static_tiles = false;
+#endif
+    if (rays_per_tile == 4 && !static_tiles) {  // dynamic tile hand-out: the counters live in the (otherwise unused) scratch area
+      p.tile_ctr = (int*)p.val_ws;
+      HIP_TRY(hipMemsetAsync(p.tile_ctr, 0, 8 * sizeof(int), (hipStream_t)stream));
+    }
     const int nslots = n_wgs * waves_per_wg;
 #ifndef HOLO_EMU
     if (timeline) {

@@ -266,6 +266,12 @@ static inline double atomicAdd(double* p, double v) {
   *p = o + v;
   return o;
 }
+static inline int atomicAdd(int* p, int v) {
+  std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
+  int o = *p;
+  *p = o + v;
+  return o;
+}
 static inline float atomicAdd(float* p, float v) {
   std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
   float o = *p;
