@@ -155,7 +155,8 @@ int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, vo
 // (unet.py:248-250): y = GN(x)*(1+scale)+shift.  Channels [0,C0) use part0 (B0 slabs), [C0,C0+C1) part1.
 int gn_finalize_launch(const double* part0, int C0, int B0, const double* part1, int C1, int B1, int N, int64_t V,
                        int groups, float eps, const float* gamma, const float* beta, const float* film,
-                       int film_stride, int film_cout, float* coef, void* stream);
+                       int film_stride, int film_cout, float* coef, void* stream, float* moments = nullptr);
+// moments (training forward): [N][C0 + C1][2] = (mean, rstd) of the channel's group, for the backward pass
 
 // emb = Linear2(SiLU(Linear1(timestep_embedding(t, mc))));  writes silu(emb) (all consumers apply SiLU first:
 // unet.py:199-205) and emb itself.
@@ -314,6 +315,65 @@ struct MlpMeanParams {
 int mlp_mean_pool_launch(const MlpMeanParams& p, int num_cus, void* stream);
 int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
+// ---------------------------------------------------------------------------------------------
+// backward of the denoiser (kernels_bwd.hip)
+// ---------------------------------------------------------------------------------------------
+struct WgradParams {   // dW[co][ci][tap] = sum_m gy[m][co] act(coef . x)[m + tap][ci]; geometry as ConvParams
+  const float* gy;     // [M_out][Cout]
+  const float* src0;
+  const float* src1;   // virtual concat (may be null); C0 % 32 == 0 then
+  int C0, C1;
+  int N, ID, IH, IW, ups, OD, OH, OW, stride, pad, ksz, ntaps;
+  int Cout;
+  const float* coef;   // [N][Cin][2] or null
+  int act;
+  float* partial;      // [splits][Cout][Cin][ntaps] scratch (wgrad_partial_bytes)
+};
+int wgrad_splits(const WgradParams& p, int num_cus);
+size_t wgrad_partial_bytes(const WgradParams& p, int num_cus);
+int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_cus, void* stream);
+int flip_transpose_weight_launch(const float* in, float* out, int Co, int Ci, int T, void* stream);
+int weight_tco_ci_launch(const float* in, float* out, int Co, int Ci, int T, void* stream);
+size_t colsum_scratch_bytes(int C);
+int colsum_launch(const float* g, int64_t M, int C, double* scratch, float* out, int accumulate, void* stream);
+struct GnBwdParams {   // GroupNorm32 (+ FiLM) (+ SiLU) backward over the virtual concat [x0 | x1]
+  const float* x0;
+  const float* x1;
+  int C0, C1, N;
+  int64_t V;
+  const float* ga;     // [N][V][C0 + C1] gradient w.r.t. the activated tensor
+  const float* coef;   // forward (a, b)
+  const float* mom;    // forward (mean, rstd) per channel
+  const float* gamma;
+  const float* beta;
+  const float* film;   // [N][film_stride]: scale at +c, shift at +film_cout + c (null: no FiLM)
+  int film_stride, film_cout;
+  int act;
+  double* part;        // scratch (gn_bwd_scratch_bytes)
+  float* grp;          // scratch [N][Cin][2]
+  float* dgamma;
+  float* dbeta;
+  float* dfilm;        // [N][film_stride] gradient of the FiLM rows (null without FiLM)
+  int acc_params;
+  float* gx0;          // gradient w.r.t. x0 / x1 (raw tensors)
+  float* gx1;
+  int acc0, acc1;      // accumulate into gx0 / gx1 instead of overwriting
+};
+size_t gn_bwd_scratch_bytes(const GnBwdParams& p);
+int gn_bwd_launch(const GnBwdParams& p, void* stream);
+int add_launch(float* dst, const float* src, int64_t n, int accumulate, void* stream);
+int split_cat_launch(const float* g, float* g0, float* g1, int64_t M, int C0, int C1, int acc0, int acc1, void* stream);
+int sumpool2_launch(const float* gup, float* gin, int N, int R, int C, int accumulate, void* stream);
+int conv_dgrad_s2_launch(const float* gy, const float* wt, float* gx, int N, int RI, int RO, int Ci, int Co, int accumulate,
+                         void* stream);
+int attn_ds_launch(const float* P, float* dP, int64_t rows, int cols, void* stream);
+int transpose_launch(const float* in, float* out, int batch, int T, void* stream);
+int film_bwd_launch(const float* dfilm, const float* embs, const float* w, float* dw, float* db, float* gembs, int N, int rows,
+                    int K, void* stream);
+int time_embed_bwd_launch(const int64_t* t, int N, int mc, int ted, const float* w1, const float* b1, const float* w2,
+                          const float* b2, const float* gembs, float* dw1, float* db1, float* dw2, float* db2, void* stream);
+int fill_launch(float* dst, float v, int64_t n, void* stream);
+
 int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);   // = dirs + points
 int implicit_dirs_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_points_launch(const ImplicitEvalParams& p, void* stream);

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           int groups, float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ film, int film_stride,
-                                                          int film_cout, float* __restrict__ coef) {
+                                                          int film_cout, float* __restrict__ coef,
+                                                          float* __restrict__ moments) {
   __shared__ double rs[256], rq[256];
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int Cin = C0 + C1;
@@ -229,6 +230,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
     coef[((int64_t)n * Cin + c) * 2 + 0] = (float)a;
     coef[((int64_t)n * Cin + c) * 2 + 1] = (float)b;
+    if (moments) {  // training forward: the backward needs the group's mean and 1/std
+      moments[((int64_t)n * Cin + c) * 2 + 0] = (float)mean;
+      moments[((int64_t)n * Cin + c) * 2 + 1] = (float)rstd;
+    }
   }
 }
 
@@ -496,7 +501,7 @@ int gn_stats_launch(const float* x, double* partial, int N, int C, int64_t V, vo
 
 int gn_finalize_launch(const double* part0, int C0, int B0, const double* part1, int C1, int B1, int N, int64_t V,
                        int groups, float eps, const float* gamma, const float* beta, const float* film,
-                       int film_stride, int film_cout, float* coef, void* stream) {
+                       int film_stride, int film_cout, float* coef, void* stream, float* moments) {
   const int Cin = C0 + C1;
   if (Cin % groups || Cin / groups > 256) {
     set_error("gn_finalize: C=%d not compatible with %d groups", Cin, groups);
@@ -504,7 +509,7 @@ int gn_finalize_launch(const double* part0, int C0, int B0, const double* part1,
   }
   dim3 grid((unsigned)groups, (unsigned)N);
   HOLO_LAUNCH(gn_finalize_kernel, grid, dim3(256), stream, part0, C0, B0, part1, C1, B1, V, groups, eps, gamma, beta,
-              film, film_stride, film_cout, coef);
+              film, film_stride, film_cout, coef, moments);
   return 0;
 }
 

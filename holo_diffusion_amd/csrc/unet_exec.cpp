@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -129,6 +130,17 @@ struct Act {  // channels-last activation [N][R][R][R][C]
   int refs = 0;
 };
 
+struct Tape {  // one layer of the training forward (what its backward needs)
+  int kind = 0;  // BlockKind, or 100 = the output head (GroupNorm + SiLU + conv), 101 = input conv
+  Block b;
+  Act x0, x1, h1, out;
+  bool has_x1 = false;
+  size_t coefA = 0, coefB = 0, momA = 0, momB = 0;
+  const float* film = nullptr;
+  size_t qkv = 0, a = 0;
+  bool has_skip = false;
+};
+
 enum OpKind { OP_MEMSET, OP_IN, OP_TEMB, OP_EMBLIN, OP_STATS, OP_FINAL, OP_CONV, OP_GEMM, OP_SOFTMAX, OP_FLASH, OP_OUT };
 struct Op {
   OpKind kind;
@@ -186,6 +198,21 @@ struct HoloUnet {
   size_t ws_need = 0;
   std::map<std::string, Act> block_outputs;
   std::map<int, size_t> ws_cache;
+  // ---- training (holo_unet_backward): weights of the transposed convolutions, packed like the forward ones
+  // ([Cin][Cout] flipped taps for the stride-1 convs; [tap][Cout][Cin] for the stride-2 Downsample convs), supplied by
+  // holo_unet_set_dgrad_weight; the training plan (forward with every intermediate kept + backward op list)
+  std::map<std::string, float*> dgrad_w;
+  float* dgrad_tmp = nullptr;
+  size_t dgrad_tmp_floats = 0;
+  int tplan_batch = -1;
+  void* tplan_ws = nullptr;
+  std::vector<Op> tops;                                      // training forward
+  std::vector<std::function<int(void*)>> bops;               // backward, in execution order
+  std::vector<size_t> grad_off;                              // per parameter: byte offset of its gradient in the workspace
+  size_t tws_need = 0;
+  size_t gy_off = 0, gx_off = 0, y_off = 0;
+  const int64_t* t_dev = nullptr;                            // timesteps of the running call (time_embed backward)
+  std::map<int, size_t> tws_cache;
 };
 
 namespace {
@@ -354,11 +381,13 @@ struct Planner {
   size_t stats_cap, small_cap;
   size_t stats_base, small_base, arena_base;
   std::vector<Op>& ops;
+  std::vector<Tape>* tape = nullptr;  // training forward: every layer is recorded, nothing is released
+  size_t last_mom = 0;                // moments buffer of the last emit_finalize (training)
 
   Planner(HoloUnet* u_, int N_, void* ws, std::vector<Op>& ops_) : u(u_), N(N_), base((char*)ws), ops(ops_) {
     // generous fixed regions for the small buffers
     stats_cap = 0;
-    small_cap = Arena::al((size_t)N * 8 * 1024 * 256 + (size_t)N * (u->emb_rows + 4 * u->ted) * 4 + 65536);
+    small_cap = Arena::al((size_t)N * 8 * 1024 * 256 * 2 + (size_t)N * (u->emb_rows + 4 * u->ted) * 4 * 2 + 65536);
     stats_base = 0;
     small_base = stats_cap;
     arena_base = stats_cap + small_cap;
@@ -417,6 +446,10 @@ struct Planner {
     size_t coef = small_alloc((size_t)N * Cin * 2 * sizeof(float));
     Op op;
     op.kind = OP_FINAL;
+    if (tape) {
+      last_mom = small_alloc((size_t)N * Cin * 2 * sizeof(float));
+      op.o1 = ptr<float>(last_mom);
+    }
     op.d0 = ptr<double>(x0.stats_off);
     op.i0 = x0.C;
     op.d1 = x1 ? ptr<double>(x1->stats_off) : nullptr;
@@ -520,12 +553,14 @@ struct Planner {
     const std::string& p = b.prefix;
     const int R = x0.R;
     size_t coefA = emit_finalize(x0, x1, P(u, p + ".in_layers.0.weight"), P(u, p + ".in_layers.0.bias"), nullptr, 0);
+    const size_t momA = last_mom;
     Act h1 = new_act(b.cout, R);
     emit_conv(x0, x1, R, 0, R, 1, 3, P(u, p + ".in_layers.2.weight"), P(u, p + ".in_layers.2.bias"), coefA, true, 1,
               nullptr, ptr<float>(h1.off), b.cout, &h1);
     const float* film = ptr<float>(eml_off) + u->emb_row_off[p];
     size_t coefB =
         emit_finalize(h1, nullptr, P(u, p + ".out_layers.0.weight"), P(u, p + ".out_layers.0.bias"), film, b.cout);
+    const size_t momB = last_mom;
     Act s;
     const float* residual;
     const bool has_skip = b.cin != b.cout;
@@ -552,6 +587,23 @@ struct Planner {
                 true, 1, residual, ptr<float>(out.off), b.cout, &out);
     release(h1);
     if (has_skip && !fuse_skip) release(s);
+    if (tape) {
+      Tape t;
+      t.kind = B_RES;
+      t.b = b;
+      t.x0 = x0;
+      t.has_x1 = x1 != nullptr;
+      if (x1) t.x1 = *x1;
+      t.h1 = h1;
+      t.out = out;
+      t.coefA = coefA;
+      t.coefB = coefB;
+      t.momA = momA;
+      t.momB = momB;
+      t.film = film;
+      t.has_skip = has_skip;
+      tape->push_back(t);
+    }
     return out;
   }
 
@@ -560,6 +612,7 @@ struct Planner {
     const int C = x.C, R = x.R, H = u->cfg.num_heads, ch = C / H;
     const int64_t T = vox(R);
     size_t coef = emit_finalize(x, nullptr, P(u, p + ".norm.weight"), P(u, p + ".norm.bias"), nullptr, 0);
+    const size_t momX = last_mom;
     const size_t qkv_bytes = (size_t)N * T * 3 * C * sizeof(float);
     const size_t s_bytes = (size_t)N * H * T * T * sizeof(float);
     const size_t a_bytes = (size_t)N * T * C * sizeof(float);
@@ -677,10 +730,23 @@ struct Planner {
     if (v2_bytes) scratch_free(v2_work, v2_bytes);
     scratch_free(qkv, qkv_bytes);
     scratch_free(a, a_bytes);
+    if (tape) {
+      Tape t;
+      t.kind = B_ATTN;
+      t.b = b;
+      t.x0 = x;
+      t.out = out;
+      t.coefA = coef;
+      t.momA = momX;
+      t.qkv = qkv;
+      t.a = a;
+      tape->push_back(t);
+    }
     return out;
   }
 
-  size_t eml_off = 0;
+  size_t eml_off = 0, embs_off = 0;
+  Act x_in, y_out;
 
   // runs a TimestepEmbedSequential; consumes (releases) the input activation(s)
   Act run_layers(const std::vector<Block>& layers, Act h, Act* skip, bool release_h) {
@@ -711,6 +777,14 @@ struct Planner {
                     P(u, b.prefix + ".conv.bias"), 0, false, 0, nullptr, ptr<float>(out.off), b.cout, &out);
           break;
       }
+      if (tape && (b.kind == B_CONV || b.kind == B_DOWN || b.kind == B_UP)) {
+        Tape t;
+        t.kind = b.kind;
+        t.b = b;
+        t.x0 = h;
+        t.out = out;
+        tape->push_back(t);
+      }
       if (!first || release_h) release(h);
       if (first && skip) release(*skip);
       h = out;
@@ -728,6 +802,7 @@ struct Planner {
     size_t emb = small_alloc((size_t)N * u->ted * 4);
     size_t embs = small_alloc((size_t)N * u->ted * 4);
     eml_off = small_alloc((size_t)N * u->emb_rows * 4);
+    embs_off = embs;
     {
       Op op;
       op.kind = OP_TEMB;
@@ -749,6 +824,7 @@ struct Planner {
       ops.push_back(op);
     }
     Act x = new_act(c.in_channels, R);
+    x_in = x;
     {
       Op op;
       op.kind = OP_IN;
@@ -780,8 +856,19 @@ struct Planner {
     }
     size_t coef = emit_finalize(h, nullptr, P(u, "out.0.weight"), P(u, "out.0.bias"), nullptr, 0);
     Act y = new_act(c.out_channels, R, /*f32=*/true);  // the network output stays fp32
+    if (tape) {
+      Tape t;
+      t.kind = 100;
+      t.b = Block{B_CONV, "out", u->final_ch, c.out_channels};
+      t.x0 = h;
+      t.out = y;
+      t.coefA = coef;
+      t.momA = last_mom;
+      tape->push_back(t);
+    }
     emit_conv(h, nullptr, R, 0, R, 1, 3, P(u, "out.2.weight"), P(u, "out.2.bias"), coef, true, 1, nullptr,
               ptr<float>(y.off), c.out_channels, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true);
+    y_out = y;
     release(h);
     {
       Op op;
@@ -796,6 +883,405 @@ struct Planner {
   size_t total_bytes() const { return arena_base + arena.peak; }
   bool regions_ok() const { return stats_top <= stats_cap && small_top <= small_cap; }
 };
+
+// ---------------------------------------------------------------------------------------------
+// training plan (second half): the forward with every intermediate kept and every layer recorded,
+// then the backward as a list of launches in reverse layer order.  fp32 mode only.
+//   * dgrad of a stride-1 convolution = the forward conv kernels on the flipped / transposed weights
+//     (holo_unet_set_dgrad_weight);  Downsample: conv_dgrad_s2_kernel;  Upsample: dgrad at the fine size + sumpool2
+//   * wgrad: conv_wgrad_kernel re-applies GroupNorm . FiLM . SiLU to the raw input like the forward's staging does
+//   * GroupNorm (+ FiLM + SiLU): gn_bwd_launch;  attention: batched fp32 MFMA GEMMs around the softmax rows
+// Gradients of activations are allocated on first use and ACCUMULATED by later consumers (skip connections, the
+// identity branches of ResBlock / AttentionBlock).  Parameter gradients live in the workspace in the reference's layouts.
+// ---------------------------------------------------------------------------------------------
+struct TrainPlanner {
+  HoloUnet* u;
+  int N;
+  Planner pl;
+  std::vector<Tape> tape;
+  std::vector<std::function<int(void*)>>& bops;
+  std::map<size_t, std::pair<size_t, bool>> grads;  // activation offset -> (gradient offset, already written)
+  std::string err;
+
+  TrainPlanner(HoloUnet* u_, int N_, void* ws, std::vector<Op>& fops, std::vector<std::function<int(void*)>>& b)
+      : u(u_), N(N_), pl(u_, N_, ws, fops), bops(b) {
+    pl.arena.keep = true;
+    pl.tape = &tape;
+  }
+  template <class T>
+  T* ptr(size_t off) {
+    return pl.ptr<T>(off);
+  }
+  size_t alloc(size_t bytes) { return pl.scratch_alloc(bytes); }
+  int64_t vox(int R) const { return (int64_t)R * R * R; }
+  // gradient buffer of an activation; `acc` tells the caller whether to accumulate (a consumer wrote it before)
+  float* grad_of(const Act& a, int* acc) {
+    auto it = grads.find(a.off);
+    if (it == grads.end()) {
+      const size_t off = alloc((size_t)N * vox(a.R) * a.C * sizeof(float));
+      grads[a.off] = std::make_pair(off, true);
+      *acc = 0;
+      return ptr<float>(off);
+    }
+    *acc = 1;
+    return ptr<float>(it->second.first);
+  }
+  float* grad_ready(const Act& a) {  // gradient of a layer OUTPUT: must have been written by its consumers
+    auto it = grads.find(a.off);
+    if (it == grads.end()) {
+      err = "internal: a layer output has no gradient";
+      return nullptr;
+    }
+    return ptr<float>(it->second.first);
+  }
+  float* pgrad(const std::string& name) {
+    auto it = u->pindex.find(name);
+    return it == u->pindex.end() ? nullptr : reinterpret_cast<float*>(pl.base + u->grad_off[it->second]);
+  }
+  const float* dgw(const std::string& name) {
+    auto it = u->dgrad_w.find(name);
+    if (it == u->dgrad_w.end()) {
+      err = "holo_unet_backward: call holo_unet_set_dgrad_weight for '" + name + "' first";
+      return nullptr;
+    }
+    return it->second;
+  }
+
+  // dgrad of a stride-1 conv (3x3x3 pad 1 or 1x1x1): out[M][cin] = conv(gy[M][cout], flipped weights)
+  void emit_dgrad(const float* gy, int cout, int R, const std::string& wname, int cin, int ksz, float* out) {
+    const float* w = dgw(wname);
+    if (!w) return;
+    Act g;
+    g.off = (size_t)((const char*)gy - pl.base);
+    g.C = cout;
+    g.R = R;
+    pl.emit_conv(g, nullptr, R, 0, R, 1, ksz, w, nullptr, 0, false, 0, nullptr, out, cin);
+    Op op = pl.ops.back();
+    pl.ops.pop_back();
+    ConvParams cp = op.conv;
+    bops.push_back([cp](void* st) { return conv_launch(cp, st); });
+  }
+  void emit_wgrad(const float* gy, int cout, const Act& x0, const Act* x1, int in_R, int ups, int out_R, int stride, int ksz,
+                  size_t coef, bool has_coef, int act, const std::string& wname, const std::string& bname) {
+    WgradParams w;
+    memset(&w, 0, sizeof w);
+    w.gy = gy;
+    w.src0 = ptr<float>(x0.off);
+    w.src1 = x1 ? ptr<float>(x1->off) : nullptr;
+    w.C0 = x0.C;
+    w.C1 = x1 ? x1->C : 0;
+    w.N = N;
+    w.ID = w.IH = w.IW = in_R;
+    w.ups = ups;
+    w.OD = w.OH = w.OW = out_R;
+    w.stride = stride;
+    w.pad = ksz == 3 ? 1 : 0;
+    w.ksz = ksz;
+    w.ntaps = ksz == 3 ? 27 : 1;
+    w.Cout = cout;
+    w.coef = has_coef ? ptr<float>(coef) : nullptr;
+    w.act = act;
+    const size_t pb = wgrad_partial_bytes(w, u->ctx->num_cus);
+    w.partial = ptr<float>(alloc(pb));
+    float* dw = pgrad(wname);
+    float* db = pgrad(bname);
+    double* cs = ptr<double>(alloc(colsum_scratch_bytes(cout)));
+    const int ncu = u->ctx->num_cus;
+    const int64_t M = (int64_t)N * vox(out_R);
+    bops.push_back([w, dw, ncu](void* st) { return conv_wgrad_launch(w, dw, 0, ncu, st); });
+    bops.push_back([gy, M, cout, cs, db](void* st) { return colsum_launch(gy, M, cout, cs, db, 0, st); });
+  }
+  // GroupNorm (+FiLM) (+SiLU) backward of the (virtual concat) input of a conv: ga [M][Cin] -> gradients of x0 / x1
+  void emit_gn_bwd(const Act& x0, const Act* x1, const float* ga, size_t coef, size_t mom, const std::string& gname,
+                   const std::string& bname, const float* film, int film_cout, float* dfilm, int act) {
+    GnBwdParams g;
+    memset(&g, 0, sizeof g);
+    g.x0 = ptr<float>(x0.off);
+    g.x1 = x1 ? ptr<float>(x1->off) : nullptr;
+    g.C0 = x0.C;
+    g.C1 = x1 ? x1->C : 0;
+    g.N = N;
+    g.V = vox(x0.R);
+    g.ga = ga;
+    g.coef = ptr<float>(coef);
+    g.mom = ptr<float>(mom);
+    g.gamma = P(u, gname);
+    g.beta = P(u, bname);
+    g.film = film;
+    g.film_stride = u->emb_rows;
+    g.film_cout = film_cout;
+    g.act = act;
+    g.part = ptr<double>(alloc(gn_bwd_scratch_bytes(g)));
+    g.grp = ptr<float>(alloc((size_t)N * (g.C0 + g.C1) * 2 * sizeof(float)));
+    g.dgamma = pgrad(gname);
+    g.dbeta = pgrad(bname);
+    g.dfilm = dfilm;
+    g.gx0 = grad_of(x0, &g.acc0);
+    if (x1) g.gx1 = grad_of(*x1, &g.acc1);
+    bops.push_back([g](void* st) { return gn_bwd_launch(g, st); });
+  }
+
+  void bwd_res(const Tape& t, float* dfilm_base) {
+    const std::string& p = t.b.prefix;
+    const int R = t.x0.R, cin = t.b.cin, cout = t.b.cout;
+    const int64_t M = (int64_t)N * vox(R);
+    float* gout = grad_ready(t.out);
+    if (!gout) return;
+    const Act* x1 = t.has_x1 ? &t.x1 : nullptr;
+    // second conv: out = skip(x) + conv2(silu(film(gn2(h1))))
+    float* ga2 = ptr<float>(alloc((size_t)M * cout * sizeof(float)));
+    emit_dgrad(gout, cout, R, p + ".out_layers.3.weight", cout, 3, ga2);
+    emit_wgrad(gout, cout, t.h1, nullptr, R, 0, R, 1, 3, t.coefB, true, 1, p + ".out_layers.3.weight", p + ".out_layers.3.bias");
+    const int row = u->emb_row_off[p];
+    emit_gn_bwd(t.h1, nullptr, ga2, t.coefB, t.momB, p + ".out_layers.0.weight", p + ".out_layers.0.bias", t.film, cout,
+                dfilm_base + row, 1);
+    float* gh1 = grad_ready(t.h1);
+    // first conv: h1 = conv1(silu(gn1([x0 | x1])))
+    float* ga1 = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
+    emit_dgrad(gh1, cout, R, p + ".in_layers.2.weight", cin, 3, ga1);
+    emit_wgrad(gh1, cout, t.x0, x1, R, 0, R, 1, 3, t.coefA, true, 1, p + ".in_layers.2.weight", p + ".in_layers.2.bias");
+    emit_gn_bwd(t.x0, x1, ga1, t.coefA, t.momA, p + ".in_layers.0.weight", p + ".in_layers.0.bias", nullptr, 0, nullptr, 1);
+    // skip connection: identity, or a 1x1x1 conv of the raw input
+    int a0 = 0, a1 = 0;
+    float* gx0 = grad_of(t.x0, &a0);
+    float* gx1 = x1 ? grad_of(*x1, &a1) : nullptr;
+    if (!t.has_skip) {
+      const int64_t n = M * cin;
+      bops.push_back([gx0, gout, n, a0](void* st) { return add_launch(gx0, gout, n, a0, st); });
+    } else {
+      float* gs = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
+      emit_dgrad(gout, cout, R, p + ".skip_connection.weight", cin, 1, gs);
+      emit_wgrad(gout, cout, t.x0, x1, R, 0, R, 1, 1, 0, false, 0, p + ".skip_connection.weight", p + ".skip_connection.bias");
+      if (x1) {
+        const int C0 = t.x0.C, C1 = t.x1.C;
+        bops.push_back([gs, gx0, gx1, M, C0, C1, a0, a1](void* st) { return split_cat_launch(gs, gx0, gx1, M, C0, C1, a0, a1, st); });
+      } else {
+        const int64_t n = M * cin;
+        bops.push_back([gx0, gs, n, a0](void* st) { return add_launch(gx0, gs, n, a0, st); });
+      }
+    }
+  }
+
+  void bwd_attn(const Tape& t) {
+    const std::string& p = t.b.prefix;
+    const int C = t.x0.C, R = t.x0.R, H = u->cfg.num_heads, ch = C / H;
+    const int64_t T = vox(R), M = (int64_t)N * T;
+    float* gout = grad_ready(t.out);
+    if (!gout) return;
+    int ax = 0;
+    float* gx = grad_of(t.x0, &ax);
+    {  // identity branch
+      const int64_t n = M * C;
+      bops.push_back([gx, gout, n, ax](void* st) { return add_launch(gx, gout, n, ax, st); });
+    }
+    // proj_out (1x1 over the attention output a)
+    Act av;
+    av.off = t.a;
+    av.C = C;
+    av.R = R;
+    float* ga = ptr<float>(alloc((size_t)M * C * sizeof(float)));
+    emit_dgrad(gout, C, R, p + ".proj_out.weight", C, 1, ga);
+    emit_wgrad(gout, C, av, nullptr, R, 0, R, 1, 1, 0, false, 0, p + ".proj_out.weight", p + ".proj_out.bias");
+    // attention core: P = softmax(s2 q k^T); dP = ga v^T; dS = P (dP - rowsum(dP P)); dv = P^T ga; dq = s2 dS k; dk = s2 dS^T q
+    const size_t sb = (size_t)N * H * T * T * sizeof(float);
+    float* Pm = ptr<float>(alloc(sb));
+    float* dS = ptr<float>(alloc(sb));
+    float* Tm = ptr<float>(alloc(sb));
+    float* gqkv = ptr<float>(alloc((size_t)M * 3 * C * sizeof(float)));
+    const float* qkv = ptr<float>(t.qkv);
+    const double sc = 1.0 / sqrt(sqrt((double)ch));
+    const float s2 = (float)(sc * sc);
+    auto gemm = [&](const float* A, int lda, int64_t sa0, int64_t sa1, const float* B, int ldb, int64_t sb0, int64_t sb1,
+                    int kmajor, float* Cc, int ldc, int64_t sc0, int64_t sc1, int Mm, int Nn, int K, float alpha) {
+      GemmParams g;
+      memset(&g, 0, sizeof g);
+      g.A = A;
+      g.B = B;
+      g.C = Cc;
+      g.M = Mm;
+      g.Nn = Nn;
+      g.K = K;
+      g.lda = lda;
+      g.ldb = ldb;
+      g.ldc = ldc;
+      g.nb0 = N;
+      g.nb1 = H;
+      g.sa0 = sa0;
+      g.sa1 = sa1;
+      g.sb0 = sb0;
+      g.sb1 = sb1;
+      g.sc0 = sc0;
+      g.sc1 = sc1;
+      g.b_kmajor = kmajor;
+      g.alpha = alpha;
+      bops.push_back([g](void* st) { return gemm_launch(g, st); });
+    };
+    const int64_t TT = T * T, q3 = T * 3 * C;
+    const int Ti = (int)T;
+    gemm(qkv, 3 * C, q3, 3 * ch, qkv + ch, 3 * C, q3, 3 * ch, 0, Pm, Ti, (int64_t)H * TT, TT, Ti, Ti, ch, s2);
+    {
+      const int64_t rows = (int64_t)N * H * T;
+      bops.push_back([Pm, rows, Ti](void* st) { return softmax_rows_launch(Pm, rows, Ti, st); });
+    }
+    gemm(ga, C, T * C, ch, qkv + 2 * ch, 3 * C, q3, 3 * ch, 0, dS, Ti, (int64_t)H * TT, TT, Ti, Ti, ch, 1.0f);
+    {
+      const int64_t rows = (int64_t)N * H * T;
+      bops.push_back([Pm, dS, rows, Ti](void* st) { return attn_ds_launch(Pm, dS, rows, Ti, st); });
+    }
+    const int NH = N * H;
+    bops.push_back([Pm, Tm, NH, Ti](void* st) { return transpose_launch(Pm, Tm, NH, Ti, st); });
+    gemm(Tm, Ti, (int64_t)H * TT, TT, ga, C, T * C, ch, 1, gqkv + 2 * ch, 3 * C, q3, 3 * ch, Ti, ch, Ti, 1.0f);           // dv
+    gemm(dS, Ti, (int64_t)H * TT, TT, qkv + ch, 3 * C, q3, 3 * ch, 1, gqkv, 3 * C, q3, 3 * ch, Ti, ch, Ti, s2);           // dq
+    bops.push_back([dS, Tm, NH, Ti](void* st) { return transpose_launch(dS, Tm, NH, Ti, st); });
+    gemm(Tm, Ti, (int64_t)H * TT, TT, qkv, 3 * C, q3, 3 * ch, 1, gqkv + ch, 3 * C, q3, 3 * ch, Ti, ch, Ti, s2);            // dk
+    // qkv conv (1x1, C -> 3C, GroupNorm applied on load, no activation)
+    float* gxn = ptr<float>(alloc((size_t)M * C * sizeof(float)));
+    emit_dgrad(gqkv, 3 * C, R, p + ".qkv.weight", C, 1, gxn);
+    emit_wgrad(gqkv, 3 * C, t.x0, nullptr, R, 0, R, 1, 1, t.coefA, true, 0, p + ".qkv.weight", p + ".qkv.bias");
+    emit_gn_bwd(t.x0, nullptr, gxn, t.coefA, t.momA, p + ".norm.weight", p + ".norm.bias", nullptr, 0, nullptr, 0);
+  }
+
+  void bwd_conv(const Tape& t) {  // input conv / Downsample / Upsample / output head
+    const int cin = t.b.cin, cout = t.b.cout, Ri = t.x0.R, Ro = t.out.R;
+    float* gout = grad_ready(t.out);
+    if (!gout) return;
+    if (t.kind == 100) {  // y = conv(silu(gn(h)))
+      const int64_t M = (int64_t)N * vox(Ri);
+      float* ga = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
+      emit_dgrad(gout, cout, Ri, "out.2.weight", cin, 3, ga);
+      emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ri, 1, 3, t.coefA, true, 1, "out.2.weight", "out.2.bias");
+      emit_gn_bwd(t.x0, nullptr, ga, t.coefA, t.momA, "out.0.weight", "out.0.bias", nullptr, 0, nullptr, 1);
+      return;
+    }
+    int ax = 0;
+    float* gx = grad_of(t.x0, &ax);
+    const std::string wn = t.b.prefix + (t.kind == B_DOWN ? ".op.weight" : t.kind == B_UP ? ".conv.weight" : ".weight");
+    const std::string bn = t.b.prefix + (t.kind == B_DOWN ? ".op.bias" : t.kind == B_UP ? ".conv.bias" : ".bias");
+    if (t.kind == B_CONV) {
+      if (ax) {
+        err = "internal: the input conv's source already has a gradient";
+        return;
+      }
+      emit_dgrad(gout, cout, Ri, wn, cin, 3, gx);
+      emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ro, 1, 3, 0, false, 0, wn, bn);
+    } else if (t.kind == B_DOWN) {
+      const float* wt = dgw(wn);
+      if (!wt) return;
+      const int Nn = N;
+      bops.push_back([gout, wt, gx, Nn, Ri, Ro, cin, cout, ax](void* st) {
+        return conv_dgrad_s2_launch(gout, wt, gx, Nn, Ri, Ro, cin, cout, ax, st);
+      });
+      emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ro, 2, 3, 0, false, 0, wn, bn);
+    } else {  // B_UP: conv at the fine size of the nearest-upsampled input
+      const int64_t Mf = (int64_t)N * vox(Ro);
+      float* gup = ptr<float>(alloc((size_t)Mf * cin * sizeof(float)));
+      emit_dgrad(gout, cout, Ro, wn, cin, 3, gup);
+      const int Nn = N;
+      bops.push_back([gup, gx, Nn, Ri, cin, ax](void* st) { return sumpool2_launch(gup, gx, Nn, Ri, cin, ax, st); });
+      emit_wgrad(gout, cout, t.x0, nullptr, Ro, 1, Ro, 1, 3, 0, false, 0, wn, bn);
+    }
+  }
+
+  int build() {
+    const HoloUnetCfg& c = u->cfg;
+    pl.build();
+    // parameter gradients: one region in the reference's layouts; emb_layers rows alias the concatenated matrix
+    u->grad_off.assign(u->params.size(), 0);
+    const size_t gembw = alloc((size_t)u->emb_rows * u->ted * sizeof(float));
+    const size_t gembb = alloc((size_t)u->emb_rows * sizeof(float));
+    for (size_t i = 0; i < u->params.size(); ++i) {
+      const ParamSlot& s = u->params[i];
+      if (s.kind == P_EMB_W || s.kind == P_EMB_B) {
+        const int row = u->emb_row_off[s.name.substr(0, s.name.rfind(".emb_layers"))];
+        u->grad_off[i] = s.kind == P_EMB_W ? gembw + (size_t)row * u->ted * sizeof(float) : gembb + (size_t)row * sizeof(float);
+      } else {
+        u->grad_off[i] = alloc((size_t)s.numel * sizeof(float));
+      }
+    }
+    // the gradient of the output arrives NCDHW and is laid out channels-last as the gradient of y
+    const int R = c.image_size;
+    const int64_t V = vox(R);
+    const size_t gy = alloc((size_t)N * V * c.out_channels * sizeof(float));
+    grads[pl.y_out.off] = std::make_pair(gy, true);
+    u->gy_off = gy;
+    u->y_off = pl.y_out.off;
+    const size_t dfilm = alloc((size_t)N * u->emb_rows * sizeof(float));
+    float* dfilm_base = ptr<float>(dfilm);
+    for (int i = (int)tape.size() - 1; i >= 0 && err.empty(); --i) {
+      const Tape& t = tape[i];
+      if (t.kind == B_RES)
+        bwd_res(t, dfilm_base);
+      else if (t.kind == B_ATTN)
+        bwd_attn(t);
+      else
+        bwd_conv(t);
+    }
+    if (!err.empty()) {
+      set_error("%s", err.c_str());
+      return HOLO_E_STATE;
+    }
+    // embedding path
+    {
+      const float* embs = ptr<float>(pl.embs_off);
+      float* gembs = ptr<float>(alloc((size_t)N * u->ted * sizeof(float)));
+      float* dw = ptr<float>(gembw);
+      float* db = ptr<float>(gembb);
+      const float* w = u->emb_w;
+      const int rows = u->emb_rows, K = u->ted, Nn = N;
+      bops.push_back([dfilm_base, embs, w, dw, db, gembs, Nn, rows, K](void* st) {
+        return film_bwd_launch(dfilm_base, embs, w, dw, db, gembs, Nn, rows, K, st);
+      });
+      HoloUnet* uu = u;
+      const int mc = c.model_channels;
+      const float *w1 = P(u, "time_embed.0.weight"), *b1 = P(u, "time_embed.0.bias"), *w2 = P(u, "time_embed.2.weight"),
+                  *b2 = P(u, "time_embed.2.bias");
+      float *dw1 = pgrad("time_embed.0.weight"), *db1 = pgrad("time_embed.0.bias"), *dw2 = pgrad("time_embed.2.weight"),
+            *db2 = pgrad("time_embed.2.bias");
+      bops.push_back([uu, Nn, mc, K, w1, b1, w2, b2, gembs, dw1, db1, dw2, db2](void* st) {
+        return time_embed_bwd_launch(uu->t_dev, Nn, mc, K, w1, b1, w2, b2, gembs, dw1, db1, dw2, db2, st);
+      });
+    }
+    auto gi = grads.find(pl.x_in.off);
+    if (gi == grads.end()) {
+      set_error("internal: the network input has no gradient");
+      return HOLO_E_STATE;
+    }
+    u->gx_off = gi->second.first;
+    return 0;
+  }
+  size_t total_bytes() const { return pl.total_bytes(); }
+};
+
+int ensure_train_plan(HoloUnet* u, int batch, void* ws) {
+  if (u->tplan_batch == batch && u->tplan_ws == ws && !u->tops.empty()) return 0;
+  if (u->compute_mode != 0) {
+    set_error("holo_unet_backward: the backward pass runs in the fp32 mode only");
+    return HOLO_E_UNSUPPORTED;
+  }
+  for (auto& s : u->params)
+    if (!s.set) {
+      set_error("holo_unet_backward: parameter '%s' has not been set", s.name.c_str());
+      return HOLO_E_STATE;
+    }
+  u->tops.clear();
+  u->bops.clear();
+  TrainPlanner tp(u, batch, ws, u->tops, u->bops);
+  int rc = tp.build();
+  if (rc) {
+    u->tops.clear();
+    u->bops.clear();
+    return rc;
+  }
+  if (!tp.pl.regions_ok()) {
+    set_error("internal: small-buffer regions overflow");
+    return HOLO_E_INVALID;
+  }
+  u->tws_need = tp.total_bytes();
+  u->tplan_batch = batch;
+  u->tplan_ws = ws;
+  u->plan_batch = -1;  // block_outputs were rewritten
+  return 0;
+}
 
 int ensure_plan(HoloUnet* u, int batch, void* ws) {
   if (u->plan_batch == batch && u->plan_ws == ws && !u->ops.empty()) return 0;
@@ -831,7 +1317,7 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
       return gn_stats_launch(op.f0, op.dout, N, op.i0, op.l0, stream, op.i1);
     case OP_FINAL:
       return gn_finalize_launch(op.d0, op.i0, op.i4, op.d1, op.i1, op.i5, N, op.l0, 32, 1e-5f, op.f0, op.f1, op.f2,
-                                op.i2, op.i3, op.o0, stream);
+                                op.i2, op.i3, op.o0, stream, op.o1);
     case OP_CONV:
       return conv_launch(op.conv, stream);
     case OP_GEMM:
@@ -1002,6 +1488,9 @@ int holo_unet_destroy(HoloUnet* net) {
   if (net->pstore) (void)hipFree(net->pstore);
   if (net->pstore_bf) (void)hipFree(net->pstore_bf);
   if (net->pstore_wino) (void)hipFree(net->pstore_wino);
+  for (auto& kv : net->dgrad_w)
+    if (kv.second) (void)hipFree(kv.second);
+  if (net->dgrad_tmp) (void)hipFree(net->dgrad_tmp);
   delete net;
   return 0;
 }
@@ -1255,6 +1744,120 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *n_ops = n;
+  return 0;
+}
+
+// ---- training: backward of the denoiser -----------------------------------------------------------------------------
+int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_ptr, void* stream) {
+  if (!net || !name || !dev_ptr) {
+    set_error("holo_unet_set_dgrad_weight: null argument");
+    return HOLO_E_INVALID;
+  }
+  auto it = net->pindex.find(name);
+  if (it == net->pindex.end() || (net->params[it->second].kind != P_CONV3 && net->params[it->second].kind != P_CONV1)) {
+    set_error("holo_unet_set_dgrad_weight: '%s' is not a convolution weight", name);
+    return HOLO_E_INVALID;
+  }
+  const ParamSlot& s = net->params[it->second];
+  const int Co = (int)s.shape[0], Ci = (int)s.shape[1], T = s.kind == P_CONV3 ? 27 : 1;
+  const std::string nm(name);
+  const bool down = nm.size() > 10 && nm.compare(nm.size() - 10, 10, ".op.weight") == 0;  // Downsample: stride 2
+  // transposed convolution: Cout' = Ci, Cin' = Co
+  const size_t packed = down ? (size_t)T * Co * Ci : (size_t)T * pad_cout(Ci) * pad_cin(Co);
+  float*& dst = net->dgrad_w[nm];
+  if (!dst) HIP_TRY(hipMalloc((void**)&dst, packed * sizeof(float)));
+  if (down) return weight_tco_ci_launch((const float*)dev_ptr, dst, Co, Ci, T, stream) ? HOLO_E_INVALID : 0;
+  if (net->dgrad_tmp_floats < (size_t)s.numel) {
+    if (net->dgrad_tmp) {
+      HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+      (void)hipFree(net->dgrad_tmp);
+    }
+    HIP_TRY(hipMalloc((void**)&net->dgrad_tmp, (size_t)s.numel * sizeof(float)));
+    net->dgrad_tmp_floats = (size_t)s.numel;
+  }
+  if (flip_transpose_weight_launch((const float*)dev_ptr, net->dgrad_tmp, Co, Ci, T, stream)) return HOLO_E_INVALID;
+  return repack_conv_weight_launch(net->dgrad_tmp, dst, Ci, Co, T, pad_cout(Ci), pad_cin(Co), stream) ? HOLO_E_INVALID : 0;
+}
+
+size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch) {
+  if (!net || batch < 1) return 0;
+  auto it = net->tws_cache.find(batch);
+  if (it != net->tws_cache.end()) return it->second;
+  std::vector<Op> fo;
+  std::vector<std::function<int(void*)>> bo;
+  std::vector<size_t> keep = net->grad_off;
+  TrainPlanner tp(net, batch, nullptr, fo, bo);
+  // a sizing pass must not fail on missing transposed weights: it only allocates
+  std::map<std::string, float*> saved = net->dgrad_w;
+  for (auto& s : net->params)
+    if ((s.kind == P_CONV3 || s.kind == P_CONV1) && !net->dgrad_w.count(s.name)) net->dgrad_w[s.name] = (float*)(uintptr_t)256;
+  tp.build();
+  net->dgrad_w = saved;
+  net->grad_off = keep;
+  const size_t b = tp.total_bytes();
+  net->tws_cache[batch] = b;
+  net->tplan_batch = -1;
+  net->plan_batch = -1;
+  net->ops.clear();
+  return b;
+}
+
+int holo_unet_backward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, const float* grad_out, float* y,
+                       float* grad_x, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!net || !x || !timesteps || !grad_out || !workspace || batch < 1) {
+    set_error("holo_unet_backward: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  int rc = ensure_train_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->tws_need) {
+    set_error("holo_unet_backward: workspace too small (%zu < %zu)", workspace_bytes, net->tws_need);
+    net->tplan_batch = -1;
+    return HOLO_E_WORKSPACE;
+  }
+  net->t_dev = timesteps;
+  float ydummy;
+  (void)ydummy;
+  for (const Op& op : net->tops) {
+    if (op.kind == OP_OUT && !y) continue;
+    rc = run_op(net, op, batch, x, timesteps, y, stream);
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  const HoloUnetCfg& c = net->cfg;
+  const int64_t V = (int64_t)c.image_size * c.image_size * c.image_size;
+  if (ncdhw_to_ndhwc_launch(grad_out, (float*)((char*)workspace + net->gy_off), batch, c.out_channels, V, 0, stream))
+    return HOLO_E_INVALID;
+  for (auto& f : net->bops) {
+    rc = f(stream);
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  if (grad_x &&
+      ndhwc_to_ncdhw_launch((const float*)((char*)workspace + net->gx_off), grad_x, batch, c.in_channels, V, stream))
+    return HOLO_E_INVALID;
+  return 0;
+}
+
+int holo_unet_get_grad(HoloUnet* net, const char* name, float* dst, int64_t numel, const void* workspace, void* stream) {
+  if (!net || !name || !dst || !workspace) {
+    set_error("holo_unet_get_grad: null argument");
+    return HOLO_E_INVALID;
+  }
+  auto it = net->pindex.find(name);
+  if (it == net->pindex.end()) {
+    set_error("holo_unet_get_grad: unknown parameter '%s'", name);
+    return HOLO_E_INVALID;
+  }
+  if (net->tplan_ws != workspace || net->grad_off.size() != net->params.size()) {
+    set_error("holo_unet_get_grad: no backward pass has run on this workspace");
+    return HOLO_E_STATE;
+  }
+  const ParamSlot& s = net->params[it->second];
+  if (numel != s.numel) {
+    set_error("holo_unet_get_grad: '%s' has %lld elements, not %lld", name, (long long)s.numel, (long long)numel);
+    return HOLO_E_INVALID;
+  }
+  HIP_TRY(hipMemcpyAsync(dst, (const char*)workspace + net->grad_off[it->second], (size_t)numel * sizeof(float),
+                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 

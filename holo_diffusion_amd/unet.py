@@ -197,6 +197,14 @@ class SimpleUnet3D(Unet3DBase):
     def forward(self, x, timesteps, cond_features=None, **kwargs):
         if cond_features is not None:
             x = torch.cat([x, cond_features], dim=1)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self._net.parameters())):
+            # differentiable call: `loss.backward()` reaches holo_unet_backward through the autograd node below
+            names = list(self._param_names)
+            sd = dict(self._net.named_parameters())
+            return _HoloUnetFn.apply(self, x, timesteps, names, *[sd[k] for k in names])
+        return self._forward_impl(x, timesteps)
+
+    def _forward_impl(self, x, timesteps):
         runtime.require_device(x, "SimpleUnet3D.forward")
         if x.dim() != 5 or x.shape[1] != self.in_channels or len(set(x.shape[2:])) != 1 or \
                 x.shape[2] % (1 << (len(self.channel_mult) - 1)):
@@ -216,6 +224,62 @@ class SimpleUnet3D(Unet3DBase):
         _lib.check(L, L.holo_unet_forward(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
                                           ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
         return y
+
+    # ---- backward -------------------------------------------------------------
+    def _ensure_dgrad_weights(self, device: torch.device) -> None:
+        """Weights of the transposed convolutions (holo_unet_set_dgrad_weight), re-prepared when a parameter changed."""
+        h = self._ensure_handle(device)
+        key = tuple((k, p.data_ptr(), p._version) for k, p in self._net.named_parameters() if p.dim() >= 3)
+        if self.__dict__.get("_dgrad_key") == (h.value, key):
+            return
+        L = runtime.lib()
+        st = runtime.stream_ptr(device)
+        keep = []
+        for k, p in self._net.named_parameters():
+            if p.dim() >= 3:
+                t = p.detach().contiguous()
+                keep.append(t)
+                _lib.check(L, L.holo_unet_set_dgrad_weight(h, k.encode(), runtime.ptr(t), st), f"holo_unet_set_dgrad_weight({k})")
+        torch.cuda.current_stream(device).synchronize()
+        self.__dict__["_dgrad_key"] = (h.value, key)
+
+    @torch.no_grad()
+    def backward(self, x: torch.Tensor, timesteps: torch.Tensor, grad_output: torch.Tensor, params=None):
+        """Gradients of ``(forward(x, timesteps) * grad_output).sum()``: returns ``(y, grad_x, {parameter name: gradient})``
+        with the gradients in the reference's parameter layouts (``_net.<guided-diffusion name>`` without the prefix).
+        ``params``: names to fetch (default: all).  The forward is re-run inside the call with every intermediate kept
+        (``holo_unet_backward``); fp32 mode only."""
+        runtime.require_device(x, "SimpleUnet3D.backward")
+        if self.compute_dtype != "f32":
+            raise _lib.HoloError("SimpleUnet3D.backward runs in the fp32 mode only")
+        dev = x.device
+        h = self._ensure_handle(dev, int(x.shape[2]))
+        self._ensure_dgrad_weights(dev)
+        L = runtime.lib()
+        x = x.contiguous().float()
+        g = grad_output.contiguous().float()
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        B = x.shape[0]
+        if tuple(g.shape) != (B, self.out_channels) + tuple(x.shape[2:]):
+            raise _lib.HoloError(f"grad_output must be {(B, self.out_channels) + tuple(x.shape[2:])}, got {tuple(g.shape)}")
+        nbytes = L.holo_unet_backward_workspace_bytes(h, B)
+        held = self.__dict__.get("_holo_train_ws")
+        if held is None or held.device != dev or held.numel() < nbytes:
+            held = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            self.__dict__["_holo_train_ws"] = held
+        y = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), device=dev)
+        gx = torch.empty_like(x)
+        st = runtime.stream_ptr(dev)
+        _lib.check(L, L.holo_unet_backward(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(g), runtime.ptr(y), runtime.ptr(gx),
+                                           runtime.ptr(held), held.numel(), st), "holo_unet_backward")
+        grads = {}
+        shapes = self.param_shapes()
+        for k in (params if params is not None else self._param_names):
+            out = torch.empty(shapes[k], device=dev)
+            _lib.check(L, L.holo_unet_get_grad(h, k.encode(), runtime.ptr(out), out.numel(), runtime.ptr(held), st),
+                       f"holo_unet_get_grad({k})")
+            grads[k] = out
+        return y, gx, grads
 
     def workspace_bytes(self, batch: int, device: torch.device) -> int:
         """Caller-owned HBM workspace of one forward at this batch size in the current compute mode (activations, GroupNorm
@@ -282,3 +346,23 @@ class SimpleUnet3D(Unet3DBase):
                          nsplit=a.nsplit, stride=a.stride, upsample=bool(a.upsample), ksz=a.ksz)
             ops.append(d)
         return ops
+
+
+class _HoloUnetFn(torch.autograd.Function):
+    """Autograd node of the HIP denoiser: forward = holo_unet_forward, backward = holo_unet_backward (which re-runs the
+    forward with every intermediate kept).  The parameters are inputs of the node so that their ``.grad`` is filled."""
+
+    @staticmethod
+    def forward(ctx, net, x, timesteps, names, *params):
+        ctx.net, ctx.names = net, names
+        ctx.save_for_backward(x.detach(), timesteps.detach())
+        ctx.x_needs = x.requires_grad
+        with torch.no_grad():
+            return net._forward_impl(x.detach(), timesteps)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, t = ctx.saved_tensors
+        want = [k for k, need in zip(ctx.names, ctx.needs_input_grad[4:]) if need]
+        _, gx, grads = ctx.net.backward(x, t, grad_y, params=want)
+        return (None, gx if ctx.x_needs else None, None, None) + tuple(grads.get(k) for k in ctx.names)

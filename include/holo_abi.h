@@ -113,6 +113,25 @@ int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t ds
                           void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the denoiser.  Replaces autograd through UNetModel.forward
+ * (holo_diffusion/guided_diffusion/unet.py:800-837): what `output.mean().backward()` does in the reference's own backward
+ * test (holo_diffusion/tests/test_diffusion_utils.py:47-66) and what the training step needs from net_3d
+ * (holo_diffusion_model.py:386-418).  fp32 mode.
+ *   holo_unet_set_dgrad_weight   per convolution weight (same names / OIDHW tensors as holo_unet_set_param): prepares the
+ *                                weight of the transposed convolution; call again whenever the parameter changes
+ *   holo_unet_backward           runs the forward (every intermediate kept in the workspace) and the backward for
+ *                                grad_out = dL/dy (N, Cout, R, R, R); y (optional) receives the forward output, grad_x
+ *                                (optional) dL/dx.  Parameter gradients stay in the workspace ...
+ *   holo_unet_get_grad           ... and are copied out by name, in the reference's parameter layouts, from the
+ *                                workspace of the last backward call.
+ * No allocation / synchronisation inside holo_unet_backward; workspace size from holo_unet_backward_workspace_bytes. */
+int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_ptr, void* stream);
+size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch);
+int holo_unet_backward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, const float* grad_out, float* y,
+                       float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
+int holo_unet_get_grad(HoloUnet* net, const char* name, float* dst, int64_t numel, const void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * DDPM ancestral step.  Replaces the elementwise tail of GaussianDiffusion.p_sample:
  *   gaussian_diffusion.py:314-343 (clamp, START_X), :237-240 (posterior mean), :499-506 (noise add)
  *   tables   : (T, 4) fp32 on the device: {posterior_mean_coef1, posterior_mean_coef2,
