@@ -25,8 +25,9 @@ def gu():
 def _oracle_grads(sd, cfg, x, t, G):
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     xr = x.clone().requires_grad_(True)
-    y = uo.unet_forward(sdr, cfg, xr, t)
-    (y * G).sum().backward()
+    with torch.enable_grad():  # (the oracle's entry point is decorated no_grad: call the undecorated function)
+        y = uo.unet_forward.__wrapped__(sdr, cfg, xr, t)
+        (y * G).sum().backward()
     return y.detach(), xr.grad, {k: v.grad for k, v in sdr.items()}
 
 
