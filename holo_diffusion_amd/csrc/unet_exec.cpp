@@ -1791,9 +1791,10 @@ size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch) {
   std::map<std::string, float*> saved = net->dgrad_w;
   for (auto& s : net->params)
     if ((s.kind == P_CONV3 || s.kind == P_CONV1) && !net->dgrad_w.count(s.name)) net->dgrad_w[s.name] = (float*)(uintptr_t)256;
-  tp.build();
+  const int rc = tp.build();
   net->dgrad_w = saved;
   net->grad_off = keep;
+  if (rc) return 0;  // the message is in holo_last_error()
   const size_t b = tp.total_bytes();
   net->tws_cache[batch] = b;
   net->tplan_batch = -1;

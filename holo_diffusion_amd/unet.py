@@ -263,6 +263,8 @@ class SimpleUnet3D(Unet3DBase):
         if tuple(g.shape) != (B, self.out_channels) + tuple(x.shape[2:]):
             raise _lib.HoloError(f"grad_output must be {(B, self.out_channels) + tuple(x.shape[2:])}, got {tuple(g.shape)}")
         nbytes = L.holo_unet_backward_workspace_bytes(h, B)
+        if nbytes == 0:
+            raise _lib.HoloError("holo_unet_backward_workspace_bytes: " + (L.holo_last_error() or b"").decode())
         held = self.__dict__.get("_holo_train_ws")
         if held is None or held.device != dev or held.numel() < nbytes:
             held = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)

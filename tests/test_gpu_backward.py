@@ -31,11 +31,14 @@ def _oracle_grads(sd, cfg, x, t, G):
     return y.detach(), xr.grad, {k: v.grad for k, v in sdr.items()}
 
 
-def _check(got, ref, name, rtol=1e-3):
+def _check(got, ref, name, rtol=1e-3, floor=1e-12):
+    """|got - ref| <= rtol * max(scale of ref, floor).  `floor`: a gradient that is mathematically ZERO (a bias in front of
+    a GroupNorm whose groups are single channels) is roundoff on both sides; it is held to rtol of the net's typical
+    gradient scale instead of its own."""
     assert ref is not None, name
     scale = ref.abs().max().item()
     err = (got.cpu() - ref).abs().max().item()
-    assert err <= rtol * max(scale, 1e-12), (name, err, scale)
+    assert err <= rtol * max(scale, floor), (name, err, scale)
 
 
 @pytest.mark.parametrize("cfg_name,batch", [("tiny", 2), ("wide", 1), ("deep", 1)])
@@ -60,10 +63,11 @@ def test_unet_backward_vs_oracle_autograd(gu, cfg_name, batch):
     _check(y, y_ref, "forward output", 2e-3)
     _check(gx, gx_ref, "grad_x")
     assert set(grads) == set(sd)
-    worst = max(((grads[k].cpu() - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), 1e-12), k) for k in sd)
+    floor = 1e-2 * float(np.median([g_ref[k].abs().max().item() for k in sd]))
+    worst = max(((grads[k].cpu() - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), floor), k) for k in sd)
     print(f"backward {cfg_name}: worst relative gradient error {worst[0]:.2e} ({worst[1]})")
     for k in sd:
-        _check(grads[k], g_ref[k], k)
+        _check(grads[k], g_ref[k], k, floor=floor)
 
 
 def test_loss_backward_through_the_plugin(gu):
@@ -84,9 +88,10 @@ def test_loss_backward_through_the_plugin(gu):
     out.mean().backward()
     G = torch.full((1, cfg.out_channels) + (cfg.image_size,) * 3, 1.0 / out.numel())
     _, _, g_ref = _oracle_grads(sd, cfg, x, t, G)
+    floor = 1e-2 * float(np.median([g_ref[k].abs().max().item() for k in sd]))
     for k, p in net._net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
-        _check(p.grad, g_ref[k], k)
+        _check(p.grad, g_ref[k], k, floor=floor)
     # inference calls are unaffected
     with torch.no_grad():
         y2 = net(x.to(gu.DEV), t.to(gu.DEV))
