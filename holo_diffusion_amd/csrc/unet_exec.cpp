@@ -915,24 +915,27 @@ struct TrainPlanner {
   size_t alloc(size_t bytes) { return pl.scratch_alloc(bytes); }
   int64_t vox(int R) const { return (int64_t)R * R * R; }
   // gradient buffer of an activation; `acc` tells the caller whether to accumulate (a consumer wrote it before)
-  float* grad_of(const Act& a, int* acc) {
+  // (all bookkeeping is in workspace OFFSETS: the sizing pass runs with a null base, and pointer differences against a
+  // null base are undefined behaviour that an optimising compiler does exploit)
+  static constexpr size_t NONE = ~(size_t)0;
+  size_t grad_of(const Act& a, int* acc) {
     auto it = grads.find(a.off);
     if (it == grads.end()) {
       const size_t off = alloc((size_t)N * vox(a.R) * a.C * sizeof(float));
       grads[a.off] = std::make_pair(off, true);
       *acc = 0;
-      return ptr<float>(off);
+      return off;
     }
     *acc = 1;
-    return ptr<float>(it->second.first);
+    return it->second.first;
   }
-  float* grad_ready(const Act& a) {  // gradient of a layer OUTPUT: must have been written by its consumers
+  size_t grad_ready(const Act& a) {  // gradient of a layer OUTPUT: must have been written by its consumers
     auto it = grads.find(a.off);
     if (it == grads.end()) {
       err = "internal: a layer output has no gradient";
-      return nullptr;
+      return NONE;
     }
-    return ptr<float>(it->second.first);
+    return it->second.first;
   }
   float* pgrad(const std::string& name) {
     auto it = u->pindex.find(name);
@@ -948,21 +951,22 @@ struct TrainPlanner {
   }
 
   // dgrad of a stride-1 conv (3x3x3 pad 1 or 1x1x1): out[M][cin] = conv(gy[M][cout], flipped weights)
-  void emit_dgrad(const float* gy, int cout, int R, const std::string& wname, int cin, int ksz, float* out) {
+  void emit_dgrad(size_t gy_off, int cout, int R, const std::string& wname, int cin, int ksz, size_t out_off) {
     const float* w = dgw(wname);
     if (!w) return;
     Act g;
-    g.off = (size_t)((const char*)gy - pl.base);
+    g.off = gy_off;
     g.C = cout;
     g.R = R;
-    pl.emit_conv(g, nullptr, R, 0, R, 1, ksz, w, nullptr, 0, false, 0, nullptr, out, cin);
+    pl.emit_conv(g, nullptr, R, 0, R, 1, ksz, w, nullptr, 0, false, 0, nullptr, ptr<float>(out_off), cin);
     Op op = pl.ops.back();
     pl.ops.pop_back();
     ConvParams cp = op.conv;
     bops.push_back([cp](void* st) { return conv_launch(cp, st); });
   }
-  void emit_wgrad(const float* gy, int cout, const Act& x0, const Act* x1, int in_R, int ups, int out_R, int stride, int ksz,
+  void emit_wgrad(size_t gy_off, int cout, const Act& x0, const Act* x1, int in_R, int ups, int out_R, int stride, int ksz,
                   size_t coef, bool has_coef, int act, const std::string& wname, const std::string& bname) {
+    const float* gy = ptr<float>(gy_off);
     WgradParams w;
     memset(&w, 0, sizeof w);
     w.gy = gy;
@@ -992,7 +996,7 @@ struct TrainPlanner {
     bops.push_back([gy, M, cout, cs, db](void* st) { return colsum_launch(gy, M, cout, cs, db, 0, st); });
   }
   // GroupNorm (+FiLM) (+SiLU) backward of the (virtual concat) input of a conv: ga [M][Cin] -> gradients of x0 / x1
-  void emit_gn_bwd(const Act& x0, const Act* x1, const float* ga, size_t coef, size_t mom, const std::string& gname,
+  void emit_gn_bwd(const Act& x0, const Act* x1, size_t ga_off, size_t coef, size_t mom, const std::string& gname,
                    const std::string& bname, const float* film, int film_cout, float* dfilm, int act) {
     GnBwdParams g;
     memset(&g, 0, sizeof g);
@@ -1002,7 +1006,7 @@ struct TrainPlanner {
     g.C1 = x1 ? x1->C : 0;
     g.N = N;
     g.V = vox(x0.R);
-    g.ga = ga;
+    g.ga = ptr<float>(ga_off);
     g.coef = ptr<float>(coef);
     g.mom = ptr<float>(mom);
     g.gamma = P(u, gname);
@@ -1016,8 +1020,8 @@ struct TrainPlanner {
     g.dgamma = pgrad(gname);
     g.dbeta = pgrad(bname);
     g.dfilm = dfilm;
-    g.gx0 = grad_of(x0, &g.acc0);
-    if (x1) g.gx1 = grad_of(*x1, &g.acc1);
+    g.gx0 = ptr<float>(grad_of(x0, &g.acc0));
+    if (x1) g.gx1 = ptr<float>(grad_of(*x1, &g.acc1));
     bops.push_back([g](void* st) { return gn_bwd_launch(g, st); });
   }
 
@@ -1025,32 +1029,35 @@ struct TrainPlanner {
     const std::string& p = t.b.prefix;
     const int R = t.x0.R, cin = t.b.cin, cout = t.b.cout;
     const int64_t M = (int64_t)N * vox(R);
-    float* gout = grad_ready(t.out);
-    if (!gout) return;
+    const size_t gout = grad_ready(t.out);
+    if (gout == NONE) return;
     const Act* x1 = t.has_x1 ? &t.x1 : nullptr;
     // second conv: out = skip(x) + conv2(silu(film(gn2(h1))))
-    float* ga2 = ptr<float>(alloc((size_t)M * cout * sizeof(float)));
+    const size_t ga2 = alloc((size_t)M * cout * sizeof(float));
     emit_dgrad(gout, cout, R, p + ".out_layers.3.weight", cout, 3, ga2);
     emit_wgrad(gout, cout, t.h1, nullptr, R, 0, R, 1, 3, t.coefB, true, 1, p + ".out_layers.3.weight", p + ".out_layers.3.bias");
     const int row = u->emb_row_off[p];
     emit_gn_bwd(t.h1, nullptr, ga2, t.coefB, t.momB, p + ".out_layers.0.weight", p + ".out_layers.0.bias", t.film, cout,
                 dfilm_base + row, 1);
-    float* gh1 = grad_ready(t.h1);
+    const size_t gh1 = grad_ready(t.h1);
+    if (gh1 == NONE) return;
     // first conv: h1 = conv1(silu(gn1([x0 | x1])))
-    float* ga1 = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
+    const size_t ga1 = alloc((size_t)M * cin * sizeof(float));
     emit_dgrad(gh1, cout, R, p + ".in_layers.2.weight", cin, 3, ga1);
     emit_wgrad(gh1, cout, t.x0, x1, R, 0, R, 1, 3, t.coefA, true, 1, p + ".in_layers.2.weight", p + ".in_layers.2.bias");
     emit_gn_bwd(t.x0, x1, ga1, t.coefA, t.momA, p + ".in_layers.0.weight", p + ".in_layers.0.bias", nullptr, 0, nullptr, 1);
     // skip connection: identity, or a 1x1x1 conv of the raw input
     int a0 = 0, a1 = 0;
-    float* gx0 = grad_of(t.x0, &a0);
-    float* gx1 = x1 ? grad_of(*x1, &a1) : nullptr;
+    float* gx0 = ptr<float>(grad_of(t.x0, &a0));
+    float* gx1 = x1 ? ptr<float>(grad_of(*x1, &a1)) : nullptr;
+    const float* goutp = ptr<float>(gout);
     if (!t.has_skip) {
       const int64_t n = M * cin;
-      bops.push_back([gx0, gout, n, a0](void* st) { return add_launch(gx0, gout, n, a0, st); });
+      bops.push_back([gx0, goutp, n, a0](void* st) { return add_launch(gx0, goutp, n, a0, st); });
     } else {
-      float* gs = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
-      emit_dgrad(gout, cout, R, p + ".skip_connection.weight", cin, 1, gs);
+      const size_t gso = alloc((size_t)M * cin * sizeof(float));
+      const float* gs = ptr<float>(gso);
+      emit_dgrad(gout, cout, R, p + ".skip_connection.weight", cin, 1, gso);
       emit_wgrad(gout, cout, t.x0, x1, R, 0, R, 1, 1, 0, false, 0, p + ".skip_connection.weight", p + ".skip_connection.bias");
       if (x1) {
         const int C0 = t.x0.C, C1 = t.x1.C;
@@ -1066,28 +1073,31 @@ struct TrainPlanner {
     const std::string& p = t.b.prefix;
     const int C = t.x0.C, R = t.x0.R, H = u->cfg.num_heads, ch = C / H;
     const int64_t T = vox(R), M = (int64_t)N * T;
-    float* gout = grad_ready(t.out);
-    if (!gout) return;
+    const size_t gout = grad_ready(t.out);
+    if (gout == NONE) return;
     int ax = 0;
-    float* gx = grad_of(t.x0, &ax);
+    float* gx = ptr<float>(grad_of(t.x0, &ax));
     {  // identity branch
       const int64_t n = M * C;
-      bops.push_back([gx, gout, n, ax](void* st) { return add_launch(gx, gout, n, ax, st); });
+      const float* goutp = ptr<float>(gout);
+      bops.push_back([gx, goutp, n, ax](void* st) { return add_launch(gx, goutp, n, ax, st); });
     }
     // proj_out (1x1 over the attention output a)
     Act av;
     av.off = t.a;
     av.C = C;
     av.R = R;
-    float* ga = ptr<float>(alloc((size_t)M * C * sizeof(float)));
-    emit_dgrad(gout, C, R, p + ".proj_out.weight", C, 1, ga);
+    const size_t ga_off = alloc((size_t)M * C * sizeof(float));
+    float* ga = ptr<float>(ga_off);
+    emit_dgrad(gout, C, R, p + ".proj_out.weight", C, 1, ga_off);
     emit_wgrad(gout, C, av, nullptr, R, 0, R, 1, 1, 0, false, 0, p + ".proj_out.weight", p + ".proj_out.bias");
     // attention core: P = softmax(s2 q k^T); dP = ga v^T; dS = P (dP - rowsum(dP P)); dv = P^T ga; dq = s2 dS k; dk = s2 dS^T q
     const size_t sb = (size_t)N * H * T * T * sizeof(float);
     float* Pm = ptr<float>(alloc(sb));
     float* dS = ptr<float>(alloc(sb));
     float* Tm = ptr<float>(alloc(sb));
-    float* gqkv = ptr<float>(alloc((size_t)M * 3 * C * sizeof(float)));
+    const size_t gqkv_off = alloc((size_t)M * 3 * C * sizeof(float));
+    float* gqkv = ptr<float>(gqkv_off);
     const float* qkv = ptr<float>(t.qkv);
     const double sc = 1.0 / sqrt(sqrt((double)ch));
     const float s2 = (float)(sc * sc);
@@ -1135,26 +1145,28 @@ struct TrainPlanner {
     bops.push_back([dS, Tm, NH, Ti](void* st) { return transpose_launch(dS, Tm, NH, Ti, st); });
     gemm(Tm, Ti, (int64_t)H * TT, TT, qkv, 3 * C, q3, 3 * ch, 1, gqkv + ch, 3 * C, q3, 3 * ch, Ti, ch, Ti, s2);            // dk
     // qkv conv (1x1, C -> 3C, GroupNorm applied on load, no activation)
-    float* gxn = ptr<float>(alloc((size_t)M * C * sizeof(float)));
-    emit_dgrad(gqkv, 3 * C, R, p + ".qkv.weight", C, 1, gxn);
-    emit_wgrad(gqkv, 3 * C, t.x0, nullptr, R, 0, R, 1, 1, t.coefA, true, 0, p + ".qkv.weight", p + ".qkv.bias");
+    const size_t gxn = alloc((size_t)M * C * sizeof(float));
+    emit_dgrad(gqkv_off, 3 * C, R, p + ".qkv.weight", C, 1, gxn);
+    emit_wgrad(gqkv_off, 3 * C, t.x0, nullptr, R, 0, R, 1, 1, t.coefA, true, 0, p + ".qkv.weight", p + ".qkv.bias");
     emit_gn_bwd(t.x0, nullptr, gxn, t.coefA, t.momA, p + ".norm.weight", p + ".norm.bias", nullptr, 0, nullptr, 0);
   }
 
   void bwd_conv(const Tape& t) {  // input conv / Downsample / Upsample / output head
     const int cin = t.b.cin, cout = t.b.cout, Ri = t.x0.R, Ro = t.out.R;
-    float* gout = grad_ready(t.out);
-    if (!gout) return;
+    const size_t gout = grad_ready(t.out);
+    if (gout == NONE) return;
     if (t.kind == 100) {  // y = conv(silu(gn(h)))
       const int64_t M = (int64_t)N * vox(Ri);
-      float* ga = ptr<float>(alloc((size_t)M * cin * sizeof(float)));
+      const size_t ga = alloc((size_t)M * cin * sizeof(float));
       emit_dgrad(gout, cout, Ri, "out.2.weight", cin, 3, ga);
       emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ri, 1, 3, t.coefA, true, 1, "out.2.weight", "out.2.bias");
       emit_gn_bwd(t.x0, nullptr, ga, t.coefA, t.momA, "out.0.weight", "out.0.bias", nullptr, 0, nullptr, 1);
       return;
     }
     int ax = 0;
-    float* gx = grad_of(t.x0, &ax);
+    const size_t gx_off = grad_of(t.x0, &ax);
+    float* gx = ptr<float>(gx_off);
+    const float* goutp = ptr<float>(gout);
     const std::string wn = t.b.prefix + (t.kind == B_DOWN ? ".op.weight" : t.kind == B_UP ? ".conv.weight" : ".weight");
     const std::string bn = t.b.prefix + (t.kind == B_DOWN ? ".op.bias" : t.kind == B_UP ? ".conv.bias" : ".bias");
     if (t.kind == B_CONV) {
@@ -1162,20 +1174,21 @@ struct TrainPlanner {
         err = "internal: the input conv's source already has a gradient";
         return;
       }
-      emit_dgrad(gout, cout, Ri, wn, cin, 3, gx);
+      emit_dgrad(gout, cout, Ri, wn, cin, 3, gx_off);
       emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ro, 1, 3, 0, false, 0, wn, bn);
     } else if (t.kind == B_DOWN) {
       const float* wt = dgw(wn);
       if (!wt) return;
       const int Nn = N;
-      bops.push_back([gout, wt, gx, Nn, Ri, Ro, cin, cout, ax](void* st) {
-        return conv_dgrad_s2_launch(gout, wt, gx, Nn, Ri, Ro, cin, cout, ax, st);
+      bops.push_back([goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax](void* st) {
+        return conv_dgrad_s2_launch(goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax, st);
       });
       emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ro, 2, 3, 0, false, 0, wn, bn);
     } else {  // B_UP: conv at the fine size of the nearest-upsampled input
       const int64_t Mf = (int64_t)N * vox(Ro);
-      float* gup = ptr<float>(alloc((size_t)Mf * cin * sizeof(float)));
-      emit_dgrad(gout, cout, Ro, wn, cin, 3, gup);
+      const size_t gup_off = alloc((size_t)Mf * cin * sizeof(float));
+      float* gup = ptr<float>(gup_off);
+      emit_dgrad(gout, cout, Ro, wn, cin, 3, gup_off);
       const int Nn = N;
       bops.push_back([gup, gx, Nn, Ri, cin, ax](void* st) { return sumpool2_launch(gup, gx, Nn, Ri, cin, ax, st); });
       emit_wgrad(gout, cout, t.x0, nullptr, Ro, 1, Ro, 1, 3, 0, false, 0, wn, bn);
