@@ -218,16 +218,74 @@ def gen_full_digests():
     print("full_unet_digests.npz written")
 
 
+def grad_probe(g: torch.Tensor) -> np.ndarray:
+    """Fixture form of a gradient tensor: the whole tensor when small, else its first 2048 values + 2048 strided probes."""
+    f = g.detach().reshape(-1)
+    if f.numel() <= 4096:
+        return f.numpy().copy()
+    idx = torch.cat([torch.arange(2048), torch.linspace(2048, f.numel() - 1, 2048).long()])
+    return f[idx].numpy().copy()
+
+
+def gen_backward():
+    """Gradients of the REFERENCE UNetModel (autograd through the reference module itself): the reference's own backward
+    test (holo_diffusion/tests/test_diffusion_utils.py:47-66) takes `output.mean().backward()`; a second loss weights the
+    output with a fixed random tensor so that no gradient is accidentally small.  Also asserts that autograd through the
+    ORACLE's forward gives the same gradients (the `-m gpu` backward tests compare the HIP path with the oracle's)."""
+    cfg = TINY_CFG
+    net = build_reference(cfg)
+    sd = load_synth(net, cfg, 5)
+    shape = (2, cfg.in_channels) + (cfg.image_size,) * 3
+    x = torch.from_numpy(np_noise(1, shape))
+    t = torch.tensor([437, 12])
+    G = torch.from_numpy(np_noise(2, (2, cfg.out_channels) + (cfg.image_size,) * 3))
+    out = {"seed": np.array(5), "x_seed": np.array(1), "g_seed": np.array(2), "t": t.numpy()}
+    for loss_name in ("mean", "weighted"):
+        net.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        y = net(xr, t)
+        loss = y.mean() if loss_name == "mean" else (y * G).sum()
+        loss.backward()
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xo = x.clone().requires_grad_(True)
+        with torch.enable_grad():
+            yo = uo.unet_forward.__wrapped__(sdr, cfg, xo, t)
+            (yo.mean() if loss_name == "mean" else (yo * G).sum()).backward()
+        worst = 0.0
+        scales = []
+        for k, p in net.named_parameters():
+            scales.append(p.grad.abs().max().item())
+        floor = 1e-2 * float(np.median(scales))
+        for k, p in net.named_parameters():
+            e = (sdr[k].grad - p.grad).abs().max().item() / max(p.grad.abs().max().item(), floor)
+            worst = max(worst, e)
+            out[f"{loss_name}.{k}"] = grad_probe(p.grad)
+            out[f"{loss_name}.scale.{k}"] = np.array(p.grad.abs().max().item())
+        e = (xo.grad - xr.grad).abs().max().item() / xr.grad.abs().max().item()
+        worst = max(worst, e)
+        out[f"{loss_name}.grad_x"] = grad_probe(xr.grad)
+        out[f"{loss_name}.scale.grad_x"] = np.array(xr.grad.abs().max().item())
+        out[f"{loss_name}.floor"] = np.array(floor)
+        print(f"  backward [{loss_name}]: oracle autograd vs reference autograd, worst relative gradient error {worst:.2e}")
+        assert worst < 1e-4, worst
+    np.savez_compressed(os.path.join(GOLD, "ref_unet_backward.npz"), **out)
+    print("ref_unet_backward.npz written")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only-backward", action="store_true", help="write tests/golden/ref_unet_backward.npz only")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if args.only_backward:
+        return gen_backward()
     gen_schedule()
     gen_timestep_embedding()
     net, sd = gen_tiny_unet()
     gen_sampler(net, sd)
+    gen_backward()
     if args.full:
         gen_full_digests()
 

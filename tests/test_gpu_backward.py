@@ -96,3 +96,76 @@ def test_loss_backward_through_the_plugin(gu):
     with torch.no_grad():
         y2 = net(x.to(gu.DEV), t.to(gu.DEV))
     assert not y2.requires_grad and torch.equal(y2, out.detach())
+
+
+def _probe(g):
+    f = g.detach().reshape(-1).cpu()
+    if f.numel() <= 4096:
+        return f
+    idx = torch.cat([torch.arange(2048), torch.linspace(2048, f.numel() - 1, 2048).long()])
+    return f[idx]
+
+
+@pytest.mark.parametrize("loss", ["mean", "weighted"])
+def test_unet_backward_vs_reference_module_gradients(gu, golden_dir, loss):
+    """The HIP backward against gradients recorded from the REFERENCE UNetModel's own autograd (tests/golden/
+    ref_unet_backward.npz, written by oracle/make_golden.py from /root/reference): `output.mean().backward()` - the loss of
+    the reference's backward test - and a randomly weighted sum; every parameter (whole tensor or 4096 probes) and grad_x at
+    rtol 1e-3."""
+    g = np.load(os.path.join(golden_dir, "ref_unet_backward.npz"))
+    cfg = TINY_CFG
+    net, sd = gu.make_unet(cfg, seed=int(g["seed"]))
+    shape = (2, cfg.in_channels) + (cfg.image_size,) * 3
+    x = torch.from_numpy(np_noise(int(g["x_seed"]), shape))
+    t = torch.from_numpy(g["t"])
+    G = torch.from_numpy(np_noise(int(g["g_seed"]), (2, cfg.out_channels) + (cfg.image_size,) * 3))
+    if loss == "mean":
+        G = torch.full_like(G, 1.0 / G.numel())
+    _, gx, grads = net.backward(x.to(gu.DEV), t.to(gu.DEV), G.to(gu.DEV))
+    floor = float(g[f"{loss}.floor"])
+    for k in list(sd) + ["grad_x"]:
+        got = _probe(gx if k == "grad_x" else grads[k])
+        want = torch.from_numpy(g[f"{loss}.{k}"])
+        scale = max(float(g[f"{loss}.scale.{k}"]), floor)
+        assert (got - want).abs().max().item() <= 1e-3 * scale, (loss, k)
+
+
+def test_plumbing_size_backward_vs_oracle_and_north_star_timing(gu):
+    """The 32^3 x 16 net of BASELINE configs[0] (model_channels 64, five levels, attention at 8^3 / 4^3 / 2^3: Winograd forward
+    kernels, LDS-halo dgrad kernels, split-K) against autograd through the oracle on the host cores; then one backward of
+    the NORTH-STAR net (64^3 x 32) - finite gradients and the wall time of forward + backward, printed."""
+    import time
+    from oracle.common import NORTH_CFG, PLUMB_CFG
+    if os.environ.get("HOLO_TEST_EMU") == "1":
+        pytest.skip("not an emulation size")
+    cfg = PLUMB_CFG
+    net, sd = gu.make_unet(cfg, seed=1234)
+    shape = (1, cfg.in_channels) + (cfg.image_size,) * 3
+    x = torch.from_numpy(np_noise(1, shape))
+    t = torch.tensor([321], dtype=torch.int64)
+    G = torch.from_numpy(np_noise(2, (1, cfg.out_channels) + (cfg.image_size,) * 3))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    y_ref, gx_ref, g_ref = _oracle_grads(sd, cfg, x, t, G)
+    y, gx, grads = net.backward(x.to(gu.DEV), t.to(gu.DEV), G.to(gu.DEV))
+    floor = 1e-2 * float(np.median([g_ref[k].abs().max().item() for k in sd]))
+    _check(gx, gx_ref, "grad_x")
+    worst = max(((grads[k].cpu() - g_ref[k]).abs().max().item() / max(g_ref[k].abs().max().item(), floor), k) for k in sd)
+    print(f"backward 32^3x16: worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+    for k in sd:
+        _check(grads[k], g_ref[k], k, floor=floor)
+    del net
+    torch.cuda.empty_cache()
+    net, _ = gu.make_unet(NORTH_CFG, seed=1234)
+    shape = (1, 32, 64, 64, 64)
+    xd = torch.randn(*shape, device=gu.DEV)
+    gd = torch.randn(*shape, device=gu.DEV)
+    td = torch.tensor([500], device=gu.DEV)
+    names = ["input_blocks.0.0.weight", "middle_block.0.in_layers.2.weight", "out.2.weight", "time_embed.0.weight"]
+    net.backward(xd, td, gd, params=names)  # plan + transposed weights
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y, gx, grads = net.backward(xd, td, gd, params=names)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(gx).all() and all(torch.isfinite(v).all() for v in grads.values())
+    print(f"north-star net (64^3x32, 165 M parameters): forward + backward {dt * 1e3:.1f} ms")

@@ -217,3 +217,23 @@ def test_images_from_preds_vs_reference_body(golden_dir):
         assert torch.equal(got[k], want[k]), k
     assert set(images_from_preds({"images_render": preds["images_render"], "masks_render": preds["masks_render"]})) == \
         {"images_render", "masks_render"}  # default keys: the ones the predictions lack are skipped
+
+
+def test_oracle_autograd_vs_reference_module_gradients(golden_dir):
+    """Autograd through the oracle's forward reproduces the gradients of the REFERENCE UNetModel (ref_unet_backward.npz):
+    this is what lets the `-m gpu` backward tests use the oracle as their gradient reference for other net shapes."""
+    g = np.load(os.path.join(golden_dir, "ref_unet_backward.npz"))
+    cfg = TINY_CFG
+    sd = synth_state_dict(uo.unet_param_shapes(cfg), int(g["seed"]))
+    x = torch.from_numpy(np_noise(int(g["x_seed"]), (2, cfg.in_channels) + (cfg.image_size,) * 3))
+    t = torch.from_numpy(g["t"])
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        uo.unet_forward.__wrapped__(sdr, cfg, xr, t).mean().backward()
+    for k in list(sd) + ["grad_x"]:
+        f = (xr.grad if k == "grad_x" else sdr[k].grad).reshape(-1)
+        if f.numel() > 4096:
+            f = f[torch.cat([torch.arange(2048), torch.linspace(2048, f.numel() - 1, 2048).long()])]
+        scale = max(float(g[f"mean.scale.{k}"]), float(g["mean.floor"]))
+        assert (f - torch.from_numpy(g[f"mean.{k}"])).abs().max().item() <= 1e-5 * scale, k
