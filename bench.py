@@ -179,6 +179,32 @@ def side_donut128(usd, device, warm=3, timed=5):
             "workload": "donut.yaml size: 128^3x32 grid, batch-1 DDPM steps (UNet forward + posterior + noise)"}
 
 
+def side_batched_chains(net, diff, w, device, batches=(2, 4), warm=5, timed=20):
+    """B independent ancestral chains advanced together (one UNet call on a batch of B grids per step): the tail of tiny
+    launches (1x1 convs, 4^3 / 8^3 levels, GroupNorm finalisation) is paid once per call rather than once per grid."""
+    res = {}
+    for B in batches:
+        x = torch.randn(B, w["feature_size"], *(w["resol"],) * 3, device=device)
+        ts = torch.arange(999, 999 - (warm + timed), -1, device=device, dtype=torch.int64)[:, None].repeat(1, B).contiguous()
+        with torch.no_grad():
+            for k in range(warm + timed):
+                if k == warm:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                out = net(x, ts[k])
+                x, _ = diff._step(x, ts[k], out, torch.randn_like(x), True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert torch.isfinite(x).all()
+        res[f"batch{B}"] = {"grid_steps_per_s": B * timed / dt, "ms_per_call": 1e3 * dt / timed, "calls": timed, "warmup": warm,
+                            "unet_workspace_bytes": net.workspace_bytes(B, device)}
+        del x
+    res["workload"] = ("north-star net, B independent chains per GPU advanced by one batched UNet call per step "
+                       "(generate_samples draws its samples one chain at a time; this is the throughput form)")
+    torch.cuda.empty_cache()
+    return res
+
+
 def respawn_under_torchrun(n: int) -> None:
     """``python bench.py --gpus N`` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
@@ -469,7 +495,7 @@ def main():
     # same weights (the UNet's parameters do not depend on the grid size): 3 warm + 5 timed DDPM steps
     side = None
     if world == 1 and args.workload == "north" and args.compute_dtype == "f32" and not args.no_side:
-        side = {"donut128_bf16": side_donut128(usd, device)}
+        side = {"donut128_bf16": side_donut128(usd, device), "batched_chains_f32": side_batched_chains(net, diff, w, device)}
 
     # ---------------- the one exchange of the path: all_gather of the rendered frames over RCCL / xGMI.
     # Every rank contributes the frames of its own sample (the timed render call's output); timed separately from the

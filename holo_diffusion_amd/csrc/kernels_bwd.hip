@@ -145,48 +145,114 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ---- column sums (bias gradients): part[b][c] = sum over the block's rows; then reduced
+// threads = (channel, sub-row): with C < 256 the 256 / C sub-rows of a thread block stride the rows together and are summed
+// through LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ g, double* __restrict__ part, int64_t M, int C) {
+  __shared__ double red[256];
   const int64_t rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int64_t m0 = (int64_t)blockIdx.x * rows_per, m1 = m0 + rows_per < M ? m0 + rows_per : M;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int nsub = C >= 256 ? 1 : 256 / C;
+  const int sub = threadIdx.x / C, c0 = threadIdx.x - sub * C;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int c = cb + c0;
     double s = 0.0;
-    for (int64_t m = m0; m < m1; ++m) s += (double)g[m * C + c];
-    part[(int64_t)blockIdx.x * C + c] = s;
+    if (sub < nsub && c < C) {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      int64_t m = m0 + sub;
+      for (; m + 3 * nsub < m1; m += 4 * nsub) {  // 4 independent loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] = g[(m + u * nsub) * C + c];
+        s += ((double)s4[0] + (double)s4[1]) + ((double)s4[2] + (double)s4[3]);
+      }
+      for (; m < m1; m += nsub) s += (double)g[m * C + c];
+    }
+    if (nsub > 1) {
+      red[threadIdx.x] = s;
+      __syncthreads();
+      if (sub == 0 && c < C)
+        for (int k = 1; k < nsub; ++k) s += red[k * C + c0];
+      __syncthreads();
+    }
+    if (sub == 0 && c < C) part[(int64_t)blockIdx.x * C + c] = s;
   }
 }
+// one block per 32 channels: 8 lanes per channel stride the partials, summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int nb, int C,
                                                           int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  if (c < C)
+    for (int b = sub; b < nb; b += 8) s += part[(int64_t)b * C + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    for (int k = 1; k < 8; ++k) s += red[k * 32 + cl];
+    out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  }
 }
 
 // ---- GroupNorm + FiLM + SiLU backward --------------------------------------------------------------------------------
 // u = a x + b (the forward's coefficients), act: SiLU.  gu = ga * silu'(u) (or ga).  xhat = (x - mean) rstd.
 // stage 1: part[blk][n][c] = (sum gu, sum gu xhat) over the block's voxels
 __global__ __launch_bounds__(256) void gn_bwd_part_kernel(GnBwdParams p) {
+  __shared__ double red[2][256];
   const int Cin = p.C0 + p.C1;
   const int n = blockIdx.y;
   const int64_t v_per = (p.V + gridDim.x - 1) / gridDim.x;
   const int64_t v0 = (int64_t)blockIdx.x * v_per, v1 = v0 + v_per < p.V ? v0 + v_per : p.V;
-  for (int c = threadIdx.x; c < Cin; c += blockDim.x) {
-    const float* src = c < p.C0 ? p.x0 + c : p.x1 + (c - p.C0);
-    const int Cs = c < p.C0 ? p.C0 : p.C1;
-    const float a = p.coef[((int64_t)n * Cin + c) * 2], b = p.coef[((int64_t)n * Cin + c) * 2 + 1];
-    const float mean = p.mom[((int64_t)n * Cin + c) * 2], rstd = p.mom[((int64_t)n * Cin + c) * 2 + 1];
+  // threads = (channel, sub-voxel): with Cin < 256 the 256 / Cin sub-voxels stride the block's voxels together
+  const int nsub = Cin >= 256 ? 1 : 256 / Cin;
+  const int sub = threadIdx.x / Cin, c0 = threadIdx.x - sub * Cin;
+  for (int cb = 0; cb < Cin; cb += 256) {
+    const int c = cb + c0;
+    const bool live = sub < nsub && c < Cin;
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t v = v0; v < v1; ++v) {
-      const float x = src[((int64_t)n * p.V + v) * Cs];
-      float g = p.ga[((int64_t)n * p.V + v) * Cin + c];
-      if (p.act) g *= dsilu(fmaf(x, a, b));
-      s1 += (double)g;
-      s2 += (double)(g * ((x - mean) * rstd));
+    if (live) {
+      const float* src = c < p.C0 ? p.x0 + c : p.x1 + (c - p.C0);
+      const int Cs = c < p.C0 ? p.C0 : p.C1;
+      const float a = p.coef[((int64_t)n * Cin + c) * 2], b = p.coef[((int64_t)n * Cin + c) * 2 + 1];
+      const float mean = p.mom[((int64_t)n * Cin + c) * 2], rstd = p.mom[((int64_t)n * Cin + c) * 2 + 1];
+      int64_t v = v0 + sub;
+      for (; v + 3 * nsub < v1; v += 4 * nsub) {  // 8 independent loads in flight
+        float xs[4], gs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xs[u] = src[((int64_t)n * p.V + v + u * nsub) * Cs];
+          gs[u] = p.ga[((int64_t)n * p.V + v + u * nsub) * Cin + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (p.act) gs[u] *= dsilu(fmaf(xs[u], a, b));
+          s1 += (double)gs[u];
+          s2 += (double)(gs[u] * ((xs[u] - mean) * rstd));
+        }
+      }
+      for (; v < v1; v += nsub) {
+        const float x = src[((int64_t)n * p.V + v) * Cs];
+        float g = p.ga[((int64_t)n * p.V + v) * Cin + c];
+        if (p.act) g *= dsilu(fmaf(x, a, b));
+        s1 += (double)g;
+        s2 += (double)(g * ((x - mean) * rstd));
+      }
     }
-    double* d = p.part + (((int64_t)blockIdx.x * p.N + n) * Cin + c) * 2;
-    d[0] = s1;
-    d[1] = s2;
+    if (nsub > 1) {
+      red[0][threadIdx.x] = s1;
+      red[1][threadIdx.x] = s2;
+      __syncthreads();
+      if (sub == 0 && c < Cin)
+        for (int k = 1; k < nsub; ++k) {
+          s1 += red[0][k * Cin + c0];
+          s2 += red[1][k * Cin + c0];
+        }
+      __syncthreads();
+    }
+    if (sub == 0 && c < Cin) {
+      double* d = p.part + (((int64_t)blockIdx.x * p.N + n) * Cin + c) * 2;
+      d[0] = s1;
+      d[1] = s2;
+    }
   }
 }
 // stage 2 (one block per sample): channel sums, group terms, parameter and FiLM gradients.
@@ -194,20 +260,38 @@ __global__ __launch_bounds__(256) void gn_bwd_part_kernel(GnBwdParams p) {
 //   block of sample n handles ... one block handles ALL samples sequentially so the accumulation order is fixed)
 __global__ __launch_bounds__(256) void gn_bwd_group_kernel(GnBwdParams p, int nblk) {
   __shared__ double sh[2 * 2048 + 64];  // [Cin][2] sums, then per group (A, B)
+  __shared__ double R[512];
   const int Cin = p.C0 + p.C1;
   const int cpg = Cin / 32;
   double* S = sh;
   double* G = sh + 2 * Cin;
   for (int n = 0; n < p.N; ++n) {
-    for (int c = threadIdx.x; c < Cin; c += blockDim.x) {
+    // threads = (channel, sub-block) as in stage 1; the sub-blocks' sums meet in LDS in a fixed order
+    const int nsub = Cin >= 256 ? 1 : 256 / Cin;
+    const int sub = threadIdx.x / Cin, c0 = threadIdx.x - sub * Cin;
+    for (int cb = 0; cb < Cin; cb += 256) {
+      const int c = cb + c0;
       double s1 = 0.0, s2 = 0.0;
-      for (int b = 0; b < nblk; ++b) {
-        const double* d = p.part + (((int64_t)b * p.N + n) * Cin + c) * 2;
-        s1 += d[0];
-        s2 += d[1];
+      if (sub < nsub && c < Cin)
+        for (int b = sub; b < nblk; b += nsub) {
+          const double* d = p.part + (((int64_t)b * p.N + n) * Cin + c) * 2;
+          s1 += d[0];
+          s2 += d[1];
+        }
+      if (nsub > 1) {
+        R[2 * threadIdx.x] = s1;
+        R[2 * threadIdx.x + 1] = s2;
+        __syncthreads();
+        if (sub == 0 && c < Cin)
+          for (int k = 1; k < nsub; ++k) {
+            s1 += R[2 * (k * Cin + c0)];
+            s2 += R[2 * (k * Cin + c0) + 1];
+          }
       }
-      S[2 * c] = s1;
-      S[2 * c + 1] = s2;
+      if (sub == 0 && c < Cin) {
+        S[2 * c] = s1;
+        S[2 * c + 1] = s2;
+      }
     }
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -403,14 +487,34 @@ __global__ __launch_bounds__(256) void film_bwd_w_kernel(const float* __restrict
     db[r] = s;
   }
 }
+// one block per (4 columns k, sample): 64 row lanes per column stride the rows, summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void film_bwd_x_kernel(const float* __restrict__ dfilm, const float* __restrict__ w,
                                                         float* __restrict__ gembs, int rows, int K) {
+  __shared__ double red[256];
   const int n = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+  const int kl = threadIdx.x & 3, sub = threadIdx.x >> 2;
+  const int k = blockIdx.x * 4 + kl;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)dfilm[(int64_t)n * rows + r] * (double)w[(int64_t)r * K + k];
-  gembs[(int64_t)n * K + k] = (float)s;
+  if (k < K) {
+    int r = sub;
+    for (; r + 3 * 64 < rows; r += 4 * 64) {
+      float d4[4], w4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d4[u] = dfilm[(int64_t)n * rows + r + u * 64];
+        w4[u] = w[(int64_t)(r + u * 64) * K + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += (double)d4[u] * (double)w4[u];
+    }
+    for (; r < rows; r += 64) s += (double)dfilm[(int64_t)n * rows + r] * (double)w[(int64_t)r * K + k];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sub == 0 && k < K) {
+    for (int j = 1; j < 64; ++j) s += red[j * 4 + kl];
+    gembs[(int64_t)n * K + k] = (float)s;
+  }
 }
 // time_embed (unet.py:645-650) backward, one block: recomputes the forward of every sample, accumulates over the samples
 __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const int64_t* __restrict__ t, int N, int mc, int ted,
@@ -523,13 +627,13 @@ int colsum_launch(const float* g, int64_t M, int C, double* scratch, float* out,
   int nb = (int)(M < 256 ? M : 256);
   if (nb < 1) nb = 1;
   HOLO_LAUNCH(colsum_part_kernel, dim3((unsigned)nb), dim3(256), stream, g, scratch, M, C);
-  HOLO_LAUNCH(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), stream, scratch, out, nb, C, accumulate);
+  HOLO_LAUNCH(colsum_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), stream, scratch, out, nb, C, accumulate);
   return 0;
 }
 
 int gn_bwd_blocks(int64_t V) {
   int64_t b = V / 64;
-  if (b > 128) b = 128;
+  if (b > 512) b = 512;
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -579,7 +683,7 @@ int transpose_launch(const float* in, float* out, int batch, int T, void* stream
 int film_bwd_launch(const float* dfilm, const float* embs, const float* w, float* dw, float* db, float* gembs, int N, int rows,
                     int K, void* stream) {
   HOLO_LAUNCH(film_bwd_w_kernel, dim3((unsigned)rows), dim3(256), stream, dfilm, embs, dw, db, N, rows, K);
-  HOLO_LAUNCH(film_bwd_x_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)N), dim3(256), stream, dfilm, w, gembs, rows, K);
+  HOLO_LAUNCH(film_bwd_x_kernel, dim3((unsigned)((K + 3) / 4), (unsigned)N), dim3(256), stream, dfilm, w, gembs, rows, K);
   return 0;
 }
 int time_embed_bwd_launch(const int64_t* t, int N, int mc, int ted, const float* w1, const float* b1, const float* w2,

@@ -1029,6 +1029,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
   constexpr int LPV = BN / 8;      // lanes per voxel
   constexpr int VPP = 64 / LPV;    // voxels per pass
   constexpr int NPASS = 32 / VPP;
+  static_assert(VPP % 8 == 0, "a pass covers whole x rows of the tile (uniform per-pass output offsets)");
   float* s_ep = s_halo + wave * (32 * EW);
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int ch8 = (lane % LPV) * 8;
@@ -1046,6 +1047,26 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
     bv[0] += b0.x, bv[1] += b0.y, bv[2] += b0.z, bv[3] += b0.w, bv[4] += b1.x, bv[5] += b1.y, bv[6] += b1.z, bv[7] += b1.w;
   }
   float* pp = p.nsplit > 1 ? p.partial + (int64_t)blockIdx.z * M * p.Cout : nullptr;
+  // output offsets: the lane's voxel of (row tile 0, pass 0) + an offset per (row tile, pass) that is uniform over the wave
+  const int i0 = lane / LPV;
+  // (32-bit lane part: conv_plan keeps an output sample below 4 GB on this path; the sample base and the pass offset are scalars)
+  const unsigned obase = (unsigned)((((tz0 + 2 * wave) * p.OH + ty0 + (i0 >> 3)) * p.OW + tx0 + (i0 & 7)) * p.Cout + co8);
+  const int64_t nbase = (int64_t)n * p.OD * p.OH * p.OW * p.Cout;
+  auto uoff = [&](int mt, int ps) {
+    return nbase + (int64_t)(((mt >> 1) * p.OH + 4 * (mt & 1) + ((ps * VPP) >> 3)) * p.OW) * p.Cout;
+  };
+  // bf16 storage: the residual of ALL four row tiles is requested up front (one memory latency instead of four in a row;
+  // the staging and operand registers of the tap loop are dead here)
+  constexpr bool HOIST = IOBF;
+  float4 res_all[HOIST ? 4 : 1][NPASS];
+  const bool with_res = p.nsplit == 1 && p.residual;  // (uniform)
+  if (HOIST && with_res) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+        res_all[mt][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const uint16_t*>(p.residual) + uoff(mt, ps) + obase);
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -1053,16 +1074,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16t_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_ep[((r & 3) + 8 * (r >> 2) + 4 * kg) * EW + nt * 32 + li] = acc[mt][nt][r];
     HOLO_WAVE_SYNC();  // (the transposition tile is private to the wave)
-    const int z = tz0 + 2 * wave + (mt >> 1);
     int64_t o[NPASS];
     float4 res[NPASS][2];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      const int i = ps * VPP + lane / LPV;
-      const int y = ty0 + 4 * (mt & 1) + (i >> 3);
-      o[ps] = ((((int64_t)n * p.OD + z) * p.OH + y) * p.OW + tx0 + (i & 7)) * p.Cout + co8;
-      if (p.nsplit == 1 && p.residual) {  // (uniform)
-        if (IOBF) {
+      o[ps] = uoff(mt, ps) + obase;
+      if (with_res) {
+        if (HOIST) {
+          res[ps][0] = res_all[mt][ps];
+        } else if (IOBF) {
           res[ps][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const uint16_t*>(p.residual) + o[ps]);
         } else {
           res[ps][0] = *reinterpret_cast<const float4*>(p.residual + o[ps]);
@@ -2556,7 +2576,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   const int64_t src_vox = (int64_t)p.ID * p.IH * p.IW;  // the halo kernel addresses a source sample with 32-bit byte offsets
   const int cmax = p.C0 > p.C1 ? p.C0 : p.C1;
   const int skmax = p.skip_C0 > p.skip_C1 ? p.skip_C0 : p.skip_C1;
-  const bool fits32 = src_vox * (cmax > skmax ? cmax : skmax) * 4 < ((int64_t)1 << 32);
+  const bool fits32 = src_vox * (cmax > skmax ? cmax : skmax) * 4 < ((int64_t)1 << 32) &&
+                      (int64_t)p.OD * p.OH * p.OW * p.Cout * 4 < ((int64_t)1 << 32);  // (the wide-tile epilogue: output sample too)
   p.mode = (p.ksz == 3 && p.stride == 1 && p.pad == 1 && (p.OD % 2) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 &&  // (TZ=1 tiles need no z divisibility)
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1

@@ -1,8 +1,9 @@
 // conv_timeline — per-workgroup timeline of one LDS-halo conv3d launch (development probe, not part of the library).
 // Build: hipcc -O2 --offload-arch=gfx950 tools/conv_timeline.cpp holo_diffusion_amd/csrc/kernels_conv.o \
-//              holo_diffusion_amd/csrc/kernels_misc.o holo_diffusion_amd/csrc/err.o -o tools/conv_timeline
+//              holo_diffusion_amd/csrc/kernels_misc.o -o tools/conv_timeline
 // Usage: conv_timeline [R=64] [Cin=64] [Cout=64] [kernel: 0 direct, 2 = (z,y) Winograd, 3 = bf16 wide-tile (bf16 storage)]
 //                      [tile_depth=0 (planner)] [stagger_us=0] [act=0: 1 = GroupNorm affine + SiLU while staging]
+//                      [epi=0: 1 = residual + bias + GroupNorm statistics in the epilogue]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,6 +11,8 @@
 #include <map>
 #include <vector>
 #include "../holo_diffusion_amd/csrc/holo_kernels.h"
+#include <stdarg.h>
+namespace holo { void set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vprintf(fmt, a); va_end(a); printf("\n"); } }
 using namespace holo;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
@@ -48,6 +51,13 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> hwb((size_t)27 * CinP * CoutP); for (auto& x : hwb) x = (uint16_t)(0x3800 + rand() % 0x300) | (rand() & 1 ? 0x8000 : 0);
     CK(hipMemcpy(wb, hwb.data(), hwb.size() * 2, hipMemcpyHostToDevice));
     p.bf16 = 1; p.w_bf = wb; p.w_bft = wb; p.in_bf16 = p.res_bf16 = p.out_bf16 = 1;
+  }
+  if (argc > 8 && atoi(argv[8])) {  // the epilogue of a resblock's second conv: residual, bias, statistics of the output
+    float *res, *bias; double* stats;
+    CK(hipMalloc(&res, V * Cout * 4)); CK(hipMemset(res, 0, V * Cout * 4));
+    CK(hipMalloc(&bias, Cout * 4)); CK(hipMemset(bias, 0, Cout * 4));
+    CK(hipMalloc(&stats, (size_t)(V / 64) * Cout * 2 * 8));
+    p.residual = res; p.bias = bias; p.stats = stats;
   }
   conv_plan(p, 256);
   if (tzo > 0) { p.tz = tzo; p.grid_x = (int)(V / (64 * p.tz)); }
