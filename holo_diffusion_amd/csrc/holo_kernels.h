@@ -252,8 +252,65 @@ struct RenderKernelParams {
     const float* noise_coarse;  // (n_cams, n_rays, n_coarse) standard normals: density noise of the coarse pass
     const float* noise_fine;    // (n_cams, n_rays, n_coarse + n_fine) standard normals of the fine pass, in DEPTH ORDER
     float noise_std;            // density_noise_std_train
+    float* z_merged;            // optional out (n_cams, n_rays, n_coarse + n_fine): the fine pass's depths, in depth order
+    unsigned char* new_flags;   // optional out, same shape: 1 where the merged position holds an importance sample
   } train;
 };
+
+// ---- backward of the training-mode renderer (kernels_render_bwd.hip) ----
+// per ray record (36 floats): origin 3 | direction 3 | W_dir e(dir) + b_rad 3 | harmonic embedding of the normalised direction 27
+struct RenderBwdRays {
+  RenderKernelParams::Cam cams[RenderKernelParams::MAX_CAMS];
+  int n_cams, n_rays;
+  int64_t ray0;        // global index of the first ray of this camera group
+  const float* xys;    // (all cameras, n_rays, 2)
+  float* rays;         // (all rays, 36)
+  const float* w_dir;  // [3][27]
+  float b_rad[3];
+};
+// one chunk of whole rays; feature-major buffers have `ld` (= chunk capacity, a multiple of 64) columns
+struct RenderBwdChunk {
+  const float* grid_cl;
+  float* ggrid_cl;
+  int R, C;
+  float half_extent;
+  int Hd, Hp;
+  int nm, n_coarse, rays_per_cam;
+  int64_t ray0;      // global index of the chunk's first ray
+  int n_rays_chunk;
+  int64_t n, n_pad, ld;
+  const float* rays;
+  const float* z_merged;           // (all rays, nm) merged depths in depth order
+  const unsigned char* new_flags;  // (all rays, nm) 1 = importance sample, 0 = coarse sample
+  float* F;    // [n_pad][C]
+  float* YT;   // [Hp][ld]
+  float* AT;   // [Hp][ld]
+  float* GFT;  // [C][ld]
+  float4* val;
+  float4* drad;
+  float4* gval;
+  float4* GR;
+  float* tmp;     // [n][4]
+  float* gr_ray;  // (all rays, 4)
+  const float* be;     // [Hp]
+  const float* w_rad;  // [3][Hd]
+  const float* noise_fine;
+  const float* noise_coarse;
+  float noise_std;
+  const float *g_rgb, *g_depth, *g_mask, *g_rgb_c, *g_depth_c, *g_mask_c;  // any may be null (= zero)
+  float bg[3];
+  float background_opacity;
+};
+int rbwd_rays_launch(const RenderBwdRays& p, void* stream);
+int rbwd_gather_launch(const RenderBwdChunk& p, void* stream);
+int rbwd_point_fwd_launch(const RenderBwdChunk& p, void* stream);
+int rbwd_composite_launch(const RenderBwdChunk& p, void* stream);
+int rbwd_point_bwd_launch(const RenderBwdChunk& p, void* stream);
+int rbwd_dir_grad_launch(const float* gr_ray, const float* rays, int64_t n_rays_total, float* out, void* stream);
+int rbwd_rowsum_launch(const float* YT, int64_t ld, int64_t n, int rows, float* out, int accumulate, void* stream);
+int rbwd_scatter_launch(const RenderBwdChunk& p, void* stream);
+// dw[i] (+)= sum_s partial[s][i] (kernels_bwd.hip)
+int partial_reduce_launch(const float* partial, float* dw, int64_t n, int splits, int accumulate, void* stream);
 
 // stand-alone implicit function: densities[P], colours[P][3] at world points pts[P][3];
 // direction of point i is dirs[i / pts_per_dir] (pts_per_dir = 1: one direction per point)

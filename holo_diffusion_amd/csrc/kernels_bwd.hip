@@ -622,6 +622,11 @@ int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_c
   return 0;
 }
 
+int partial_reduce_launch(const float* partial, float* dw, int64_t n, int splits, int accumulate, void* stream) {
+  HOLO_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), stream, partial, dw, n, splits, accumulate);
+  return 0;
+}
+
 size_t colsum_scratch_bytes(int C) { return (size_t)256 * C * sizeof(double); }
 int colsum_launch(const float* g, int64_t M, int C, double* scratch, float* out, int accumulate, void* stream) {
   int nb = (int)(M < 256 ? M : 256);

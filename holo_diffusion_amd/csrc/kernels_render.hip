@@ -1117,6 +1117,17 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         nbefore += f[e];
       }
       zz[3] = __shfl(zz[0], lane < 63 ? lane + 1 : lane);  // first depth of the next lane
+      if (TRAIN && p.train.z_merged && active) {  // the merged list of the ray, for the backward pass (kernels_render_bwd.hip)
+        const int64_t mb = ((int64_t)cam_i * rays_per_cam + ray) * nm;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const int q = 3 * lane + e;
+          if (q < nm) {
+            p.train.z_merged[mb + q] = zz[e];
+            p.train.new_flags[mb + q] = (unsigned char)f[e];
+          }
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int q = 3 * lane + e;

@@ -42,6 +42,12 @@ struct HoloRenderer {
   float b_rad[3] = {0, 0, 0};
   bool committed = false;
   int split3 = 0;  // holo_renderer_set_compute_dtype
+  // backward of the training-mode renderer: the float64 stages of the density-net fold (kept by holo_renderer_commit),
+  // device copies of the folded weights in the GEMM layouts, the parameter gradients of the last backward (host)
+  std::vector<double> fA1, fc1, fA2, fc2, fWe, fbe;
+  float* bwd_pack = nullptr;  // WeP [Hp][C] | WeT [C][Hp] | be [Hp]
+  bool bwd_pack_valid = false;
+  std::map<std::string, std::vector<float>> grads;
 };
 
 static int dir_emb(const HoloRenderCfg& c) { return 3 * (2 * c.dir_emb_dims + 1); }
@@ -94,6 +100,7 @@ int holo_renderer_create(HoloCtx* ctx, const HoloRenderCfg* cfg, HoloRenderer** 
 int holo_renderer_destroy(HoloRenderer* r) {
   if (!r) return 0;
   if (r->packed) (void)hipFree(r->packed);
+  if (r->bwd_pack) (void)hipFree(r->bwd_pack);
   delete r;
   return 0;
 }
@@ -210,6 +217,9 @@ int holo_renderer_commit(HoloRenderer* r, void* stream) {
   }
   r->b_dens = (float)be[Hd];
   for (int c = 0; c < 3; ++c) r->b_rad[c] = br[c];
+  r->fA1 = A1, r->fc1 = c1, r->fA2 = A2, r->fc2 = c2, r->fWe = We, r->fbe = be;
+  r->bwd_pack_valid = false;
+  r->grads.clear();
   HIP_TRY(hipMemcpyAsync(r->packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
   if (r->cfg.feature_dim > 0) {
     const auto &Wf = W("_feature_net.mlp.0.0.weight"), &bf = W("_feature_net.mlp.0.0.bias");
@@ -529,31 +539,16 @@ int holo_implicit_eval(HoloRenderer* r, const float* grid, const float* pts, con
 }
 
 // Training-mode rendering: an explicit list of rays per camera, optional injected random streams.
-int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
-                     const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
-                     const float* noise_fine, float density_noise_std, float* images, float* depths, float* masks,
-                     float* images_coarse, float* depths_coarse, float* masks_coarse, void* workspace, size_t workspace_bytes,
-                     void* stream) {
-  if (!r || !grid || !cameras || n_cameras < 1 || n_rays < 1 || !xys || !images || !depths || !masks || !workspace) {
-    set_error("holo_render_rays: null/invalid argument");
-    return HOLO_E_INVALID;
-  }
-  if (!r->committed) {
-    set_error("holo_render_rays: call holo_renderer_commit after setting the RenderMLP parameters");
-    return HOLO_E_STATE;
-  }
-  if (r->cfg.feature_dim != 0 || r->cfg.feature_size > 64) {
-    set_error("holo_render_rays: colours only, feature_size 16/32/64");
-    return HOLO_E_UNSUPPORTED;
-  }
-  if (workspace_bytes < grid_cl_bytes(r) + 256) {
-    set_error("holo_render_rays: workspace too small (holo_render_workspace_bytes)");
-    return HOLO_E_WORKSPACE;
-  }
+}  // extern "C"
+
+// grid_cl: the channels-last grid, already converted.  z_merged / new_flags: optional outputs for the backward pass.
+static int render_rays_impl(HoloRenderer* r, const float* grid_cl, const HoloCamera* cameras, int n_cameras, int n_rays,
+                            const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                            const float* noise_fine, float density_noise_std, float* images, float* depths, float* masks,
+                            float* images_coarse, float* depths_coarse, float* masks_coarse, float* z_merged,
+                            unsigned char* new_flags, void* stream) {
   const HoloRenderCfg& c = r->cfg;
   const int R = c.resol, C = c.feature_size;
-  float* grid_cl = (float*)workspace;
-  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream)) return HOLO_E_INVALID;
   const int G = RenderKernelParams::MAX_CAMS;
   const int waves_per_wg = render_waves_per_wg(C, c.n_pts_fine, 0, 0, 1);
   const int n_wgs_max = render_workgroups(r);
@@ -584,6 +579,8 @@ int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* camer
     p.train.noise_coarse = (noise_coarse && density_noise_std > 0.f) ? noise_coarse + o * c.n_pts_coarse : nullptr;
     p.train.noise_fine = (noise_fine && density_noise_std > 0.f) ? noise_fine + o * nm : nullptr;
     p.train.noise_std = density_noise_std;
+    p.train.z_merged = z_merged ? z_merged + o * nm : nullptr;
+    p.train.new_flags = new_flags ? new_flags + o * nm : nullptr;
     p.rgb = images + o * 3;
     p.depth = depths + o;
     p.mask = masks + o;
@@ -599,6 +596,38 @@ int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* camer
     if (render_launch(p, stream, n_wgs)) return HOLO_E_INVALID;
   }
   return 0;
+}
+
+extern "C" {
+
+int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
+                     const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                     const float* noise_fine, float density_noise_std, float* images, float* depths, float* masks,
+                     float* images_coarse, float* depths_coarse, float* masks_coarse, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  if (!r || !grid || !cameras || n_cameras < 1 || n_rays < 1 || !xys || !images || !depths || !masks || !workspace) {
+    set_error("holo_render_rays: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_render_rays: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  if (r->cfg.feature_dim != 0 || r->cfg.feature_size > 64) {
+    set_error("holo_render_rays: colours only, feature_size 16/32/64");
+    return HOLO_E_UNSUPPORTED;
+  }
+  if (workspace_bytes < grid_cl_bytes(r) + 256) {
+    set_error("holo_render_rays: workspace too small (holo_render_workspace_bytes)");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  const int R = c.resol, C = c.feature_size;
+  float* grid_cl = (float*)workspace;
+  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream)) return HOLO_E_INVALID;
+  return render_rays_impl(r, grid_cl, cameras, n_cameras, n_rays, xys, u_coarse, u_fine, noise_coarse, noise_fine,
+                          density_noise_std, images, depths, masks, images_coarse, depths_coarse, masks_coarse, nullptr, nullptr,
+                          stream);
 }
 
 int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, int64_t n_points, float* normals,
@@ -630,6 +659,348 @@ int holo_implicit_normals(HoloRenderer* r, const float* grid, const float* pts, 
   p.pts = pts;
   p.n_points = n_points;
   return implicit_normals_launch(p, normals, stream) ? HOLO_E_INVALID : 0;
+}
+
+}  // extern "C"
+
+// ---- backward of the training-mode renderer (kernels_render_bwd.hip) ------------------------------------
+namespace {
+struct RbwdLayout {
+  int64_t NR, nm, cap, rays_per_chunk;
+  int Hd, Hp, C, S;
+  size_t o_ggrid, o_fwd, o_zm, o_flags, o_rays, o_grray, o_F, o_YT, o_AT, o_GFT, o_val, o_drad, o_gval, o_GR, o_tmp, o_part,
+      o_dWe, o_dbe, o_partr, o_dWrh, o_dir, total;
+};
+size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+RbwdLayout rbwd_layout(const HoloRenderer* r, int n_cameras, int n_rays) {
+  RbwdLayout L;
+  const HoloRenderCfg& c = r->cfg;
+  L.NR = (int64_t)n_cameras * n_rays;
+  L.nm = (int64_t)c.n_pts_coarse + c.n_pts_fine;
+  L.Hd = c.dnet_hidden_dim;
+  L.Hp = (L.Hd + 1 + 3) & ~3;
+  L.C = c.feature_size;
+  L.S = 16;  // splits of the products over the points
+  L.rays_per_chunk = 65536 / L.nm;
+  if (L.rays_per_chunk < 1) L.rays_per_chunk = 1;
+  if (L.rays_per_chunk > L.NR) L.rays_per_chunk = L.NR;
+  L.cap = (L.rays_per_chunk * L.nm + 63) & ~(int64_t)63;  // a multiple of 4 * S
+  size_t o = grid_cl_bytes(r);
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += al256(bytes);
+    return at;
+  };
+  L.o_ggrid = take(grid_cl_bytes(r));
+  L.o_fwd = take((size_t)L.NR * 10 * sizeof(float));
+  L.o_zm = take((size_t)L.NR * L.nm * sizeof(float));
+  L.o_flags = take((size_t)L.NR * L.nm);
+  L.o_rays = take((size_t)L.NR * 36 * sizeof(float));
+  L.o_grray = take((size_t)L.NR * 4 * sizeof(float));
+  L.o_F = take((size_t)L.cap * L.C * sizeof(float));
+  L.o_YT = take((size_t)L.Hp * L.cap * sizeof(float));
+  L.o_AT = take((size_t)L.Hp * L.cap * sizeof(float));
+  L.o_GFT = take((size_t)L.C * L.cap * sizeof(float));
+  L.o_val = take((size_t)L.cap * 16);
+  L.o_drad = take((size_t)L.cap * 16);
+  L.o_gval = take((size_t)L.cap * 16);
+  L.o_GR = take((size_t)L.cap * 16);
+  L.o_tmp = take((size_t)L.cap * 16);
+  L.o_part = take((size_t)L.S * L.Hp * L.C * sizeof(float));
+  L.o_dWe = take((size_t)L.Hp * L.C * sizeof(float));
+  L.o_dbe = take((size_t)L.Hp * sizeof(float));
+  L.o_partr = take((size_t)L.S * L.Hd * 4 * sizeof(float));
+  L.o_dWrh = take((size_t)L.Hd * 4 * sizeof(float));
+  L.o_dir = take(128 * sizeof(float));
+  L.total = o + 256;
+  return L;
+}
+}  // namespace
+
+extern "C" {
+
+size_t holo_render_rays_backward_workspace_bytes(const HoloRenderer* r, int n_cameras, int n_rays) {
+  if (!r || n_cameras < 1 || n_rays < 1) return 0;
+  return rbwd_layout(r, n_cameras, n_rays).total;
+}
+
+int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
+                              const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                              const float* noise_fine, float density_noise_std, const float* grad_images,
+                              const float* grad_depths, const float* grad_masks, const float* grad_images_coarse,
+                              const float* grad_depths_coarse, const float* grad_masks_coarse, float* grad_grid,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!r || !grid || !cameras || n_cameras < 1 || n_rays < 1 || !xys || !grad_grid || !workspace) {
+    set_error("holo_render_rays_backward: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!r->committed) {
+    set_error("holo_render_rays_backward: call holo_renderer_commit after setting the RenderMLP parameters");
+    return HOLO_E_STATE;
+  }
+  if (r->cfg.feature_dim != 0 || r->cfg.feature_size > 64) {
+    set_error("holo_render_rays_backward: colours only, feature_size 16/32/64");
+    return HOLO_E_UNSUPPORTED;
+  }
+  const RbwdLayout L = rbwd_layout(r, n_cameras, n_rays);
+  if (workspace_bytes < L.total) {
+    set_error("holo_render_rays_backward: workspace too small (holo_render_rays_backward_workspace_bytes)");
+    return HOLO_E_WORKSPACE;
+  }
+  const HoloRenderCfg& c = r->cfg;
+  const int R = c.resol, C = c.feature_size, Hd = L.Hd, Hp = L.Hp, De = dir_emb(c);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* grid_cl = (float*)ws;
+  float* ggrid_cl = (float*)(ws + L.o_ggrid);
+  // folded weights in the GEMM layouts (once per commit)
+  if (!r->bwd_pack_valid) {
+    if (!r->bwd_pack) HIP_TRY(hipMalloc((void**)&r->bwd_pack, ((size_t)2 * Hp * C + Hp) * sizeof(float)));
+    std::vector<float> pk((size_t)2 * Hp * C + Hp, 0.f);
+    for (int i = 0; i <= Hd; ++i)
+      for (int j = 0; j < C; ++j) {
+        pk[(size_t)i * C + j] = (float)r->fWe[(size_t)i * C + j];
+        pk[(size_t)Hp * C + (size_t)j * Hp + i] = (float)r->fWe[(size_t)i * C + j];
+      }
+    for (int i = 0; i <= Hd; ++i) pk[(size_t)2 * Hp * C + i] = (float)r->fbe[i];
+    HIP_TRY(hipMemcpyAsync(r->bwd_pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    r->bwd_pack_valid = true;
+  }
+  const float* WeP = r->bwd_pack;
+  const float* WeT = WeP + (size_t)Hp * C;
+  const float* be = WeT + (size_t)Hp * C;
+  MlpParams mlp;
+  fill_mlp(r, mlp);
+
+  if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream)) return HOLO_E_INVALID;
+  HIP_TRY(hipMemsetAsync(ggrid_cl, 0, grid_cl_bytes(r), st));
+  HIP_TRY(hipMemsetAsync(ws + L.o_AT, 0, (size_t)Hp * L.cap * sizeof(float), st));
+  // 1. the forward pass once more: the merged depth list of every ray
+  float* fwd = (float*)(ws + L.o_fwd);
+  float* z_merged = (float*)(ws + L.o_zm);
+  unsigned char* flags = (unsigned char*)(ws + L.o_flags);
+  int rc = render_rays_impl(r, grid_cl, cameras, n_cameras, n_rays, xys, u_coarse, u_fine, noise_coarse, noise_fine,
+                            density_noise_std, fwd, fwd + L.NR * 3, fwd + L.NR * 4, fwd + L.NR * 5, fwd + L.NR * 8, fwd + L.NR * 9,
+                            z_merged, flags, stream);
+  if (rc) return rc;
+  // 2. per-ray records
+  float* rays = (float*)(ws + L.o_rays);
+  for (int c0 = 0; c0 < n_cameras; c0 += RenderKernelParams::MAX_CAMS) {
+    const int ng = n_cameras - c0 < RenderKernelParams::MAX_CAMS ? n_cameras - c0 : RenderKernelParams::MAX_CAMS;
+    RenderBwdRays q;
+    memset(&q, 0, sizeof q);
+    for (int g = 0; g < ng; ++g) fill_cam(c, cameras[c0 + g], q.cams[g]);
+    q.n_cams = ng;
+    q.n_rays = n_rays;
+    q.ray0 = (int64_t)c0 * n_rays;
+    q.xys = xys;
+    q.rays = rays;
+    q.w_dir = mlp.w_dir;
+    for (int k = 0; k < 3; ++k) q.b_rad[k] = r->b_rad[k];
+    if (rbwd_rays_launch(q, stream)) return HOLO_E_INVALID;
+  }
+  // 3. chunks of whole rays
+  RenderBwdChunk p;
+  memset(&p, 0, sizeof p);
+  p.grid_cl = grid_cl;
+  p.ggrid_cl = ggrid_cl;
+  p.R = R;
+  p.C = C;
+  p.half_extent = 0.5f * (float)(R - 1) * (c.volume_extent / (float)R);
+  p.Hd = Hd;
+  p.Hp = Hp;
+  p.nm = (int)L.nm;
+  p.n_coarse = c.n_pts_coarse;
+  p.rays_per_cam = n_rays;
+  p.ld = L.cap;
+  p.n_pad = L.cap;
+  p.rays = rays;
+  p.z_merged = z_merged;
+  p.new_flags = flags;
+  p.F = (float*)(ws + L.o_F);
+  p.YT = (float*)(ws + L.o_YT);
+  p.AT = (float*)(ws + L.o_AT);
+  p.GFT = (float*)(ws + L.o_GFT);
+  p.val = (float4*)(ws + L.o_val);
+  p.drad = (float4*)(ws + L.o_drad);
+  p.gval = (float4*)(ws + L.o_gval);
+  p.GR = (float4*)(ws + L.o_GR);
+  p.tmp = (float*)(ws + L.o_tmp);
+  p.gr_ray = (float*)(ws + L.o_grray);
+  p.be = be;
+  p.w_rad = mlp.w_rad;
+  const bool noisy = density_noise_std > 0.f;
+  p.noise_fine = noisy ? noise_fine : nullptr;
+  p.noise_coarse = noisy ? noise_coarse : nullptr;
+  p.noise_std = density_noise_std;
+  p.g_rgb = grad_images, p.g_depth = grad_depths, p.g_mask = grad_masks;
+  p.g_rgb_c = grad_images_coarse, p.g_depth_c = grad_depths_coarse, p.g_mask_c = grad_masks_coarse;
+  for (int k = 0; k < 3; ++k) p.bg[k] = c.bg_color[k];
+  p.background_opacity = c.background_opacity;
+  float* part = (float*)(ws + L.o_part);
+  float* dWe = (float*)(ws + L.o_dWe);
+  float* dbe = (float*)(ws + L.o_dbe);
+  float* partr = (float*)(ws + L.o_partr);
+  float* dWrh = (float*)(ws + L.o_dWrh);
+  float* ddir = (float*)(ws + L.o_dir);
+  const int Ks = (int)(L.cap / L.S);
+  int first = 1;
+  for (int64_t r0 = 0; r0 < L.NR; r0 += L.rays_per_chunk) {
+    const int64_t nr = L.NR - r0 < L.rays_per_chunk ? L.NR - r0 : L.rays_per_chunk;
+    p.ray0 = r0;
+    p.n_rays_chunk = (int)nr;
+    p.n = nr * L.nm;
+    if (rbwd_gather_launch(p, stream)) return HOLO_E_INVALID;
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.alpha = 1.f;
+    g.nb0 = g.nb1 = 1;
+    // YT [Hp][cap] = WeP [Hp][C] . F[cap][C]^T
+    g.A = WeP, g.lda = C, g.B = p.F, g.ldb = C, g.b_kmajor = 0, g.C = p.YT, g.ldc = (int)L.cap;
+    g.M = Hp, g.Nn = (int)L.cap, g.K = C;
+    if (gemm_launch(g, stream)) return HOLO_E_INVALID;
+    if (rbwd_point_fwd_launch(p, stream)) return HOLO_E_INVALID;
+    if (rbwd_composite_launch(p, stream)) return HOLO_E_INVALID;
+    if (rbwd_point_bwd_launch(p, stream)) return HOLO_E_INVALID;
+    // GFT [C][cap] = WeT [C][Hp] . YT [Hp][cap]
+    g.A = WeT, g.lda = Hp, g.B = p.YT, g.ldb = (int)L.cap, g.b_kmajor = 1, g.C = p.GFT, g.ldc = (int)L.cap;
+    g.M = C, g.Nn = (int)L.cap, g.K = Hp;
+    if (gemm_launch(g, stream)) return HOLO_E_INVALID;
+    // dWe partials [S][Hp][C] = YT[:, split] . F[split, :]
+    g.A = p.YT, g.lda = (int)L.cap, g.sa0 = Ks, g.B = p.F, g.ldb = C, g.sb0 = (int64_t)Ks * C, g.b_kmajor = 1;
+    g.C = part, g.ldc = C, g.sc0 = (int64_t)Hp * C, g.nb0 = L.S, g.M = Hp, g.Nn = C, g.K = Ks;
+    if (gemm_launch(g, stream)) return HOLO_E_INVALID;
+    if (partial_reduce_launch(part, dWe, (int64_t)Hp * C, L.S, first ? 0 : 1, stream)) return HOLO_E_INVALID;
+    if (rbwd_rowsum_launch(p.YT, L.cap, L.cap, Hp, dbe, first ? 0 : 1, stream)) return HOLO_E_INVALID;
+    // dWr_h partials [S][Hd][4] = AT[:, split] . GR[split, :]
+    g.A = p.AT, g.lda = (int)L.cap, g.sa0 = Ks, g.B = (const float*)p.GR, g.ldb = 4, g.sb0 = (int64_t)Ks * 4, g.b_kmajor = 1;
+    g.C = partr, g.ldc = 4, g.sc0 = (int64_t)Hd * 4, g.nb0 = L.S, g.M = Hd, g.Nn = 4, g.K = Ks;
+    if (gemm_launch(g, stream)) return HOLO_E_INVALID;
+    if (partial_reduce_launch(partr, dWrh, (int64_t)Hd * 4, L.S, first ? 0 : 1, stream)) return HOLO_E_INVALID;
+    if (rbwd_scatter_launch(p, stream)) return HOLO_E_INVALID;
+    first = 0;
+  }
+  if (rbwd_dir_grad_launch(p.gr_ray, rays, L.NR, ddir, stream)) return HOLO_E_INVALID;
+  if (ndhwc_to_ncdhw_launch(ggrid_cl, grad_grid, 1, C, (int64_t)R * R * R, stream)) return HOLO_E_INVALID;
+  // 4. unfold the gradients of the folded density net to its four Linear layers (float64, host)
+  std::vector<float> hWe((size_t)Hp * C), hbe(Hp), hWrh((size_t)Hd * 4), hdir(84);
+  HIP_TRY(hipMemcpyAsync(hWe.data(), dWe, hWe.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hbe.data(), dbe, hbe.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hWrh.data(), dWrh, hWrh.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hdir.data(), ddir, hdir.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int H1 = Hd + 1, L2 = Hd + C;
+  auto W = [&](const char* n) -> const std::vector<float>& { return r->host[n]; };
+  const auto &W0 = W("_density_net.mlp.0.0.weight"), &b0 = W("_density_net.mlp.0.0.bias");
+  const auto& W1 = W("_density_net.mlp.1.0.weight");
+  const auto& W2 = W("_density_net.mlp.2.0.weight");
+  const auto& W3 = W("_density_net.mlp.3.0.weight");
+  std::vector<double> G((size_t)H1 * C), gv(H1);
+  for (int i = 0; i < H1; ++i) {
+    gv[i] = hbe[i];
+    for (int j = 0; j < C; ++j) G[(size_t)i * C + j] = hWe[(size_t)i * C + j];
+  }
+  auto out = [&](const char* n, size_t sz) -> std::vector<float>& {
+    std::vector<float>& v = r->grads[n];
+    v.assign(sz, 0.f);
+    return v;
+  };
+  {  // layer 3: y3 = A2 f + c2
+    auto& dW3 = out("_density_net.mlp.3.0.weight", (size_t)H1 * Hd);
+    auto& db3 = out("_density_net.mlp.3.0.bias", H1);
+    for (int i = 0; i < H1; ++i) {
+      db3[i] = (float)gv[i];
+      for (int k = 0; k < Hd; ++k) {
+        double s = gv[i] * r->fc2[k];
+        for (int j = 0; j < C; ++j) s += G[(size_t)i * C + j] * r->fA2[(size_t)k * C + j];
+        dW3[(size_t)i * Hd + k] = (float)s;
+      }
+    }
+  }
+  std::vector<double> G3((size_t)Hd * C, 0.0), g3(Hd, 0.0);  // W3^T G, W3^T g
+  for (int i = 0; i < H1; ++i)
+    for (int k = 0; k < Hd; ++k) {
+      const double w = W3[(size_t)i * Hd + k];
+      g3[k] += w * gv[i];
+      for (int j = 0; j < C; ++j) G3[(size_t)k * C + j] += w * G[(size_t)i * C + j];
+    }
+  {  // layer 2: input [y2 = A1 f + c1 ; f]
+    auto& dW2 = out("_density_net.mlp.2.0.weight", (size_t)Hd * L2);
+    auto& db2 = out("_density_net.mlp.2.0.bias", Hd);
+    for (int i = 0; i < Hd; ++i) {
+      db2[i] = (float)g3[i];
+      for (int k = 0; k < Hd; ++k) {
+        double s = g3[i] * r->fc1[k];
+        for (int j = 0; j < C; ++j) s += G3[(size_t)i * C + j] * r->fA1[(size_t)k * C + j];
+        dW2[(size_t)i * L2 + k] = (float)s;
+      }
+      for (int j = 0; j < C; ++j) dW2[(size_t)i * L2 + Hd + j] = (float)G3[(size_t)i * C + j];
+    }
+  }
+  std::vector<double> G2((size_t)Hd * C, 0.0), g2(Hd, 0.0);  // W2a^T G3, W2a^T g3
+  for (int i = 0; i < Hd; ++i)
+    for (int k = 0; k < Hd; ++k) {
+      const double w = W2[(size_t)i * L2 + k];
+      g2[k] += w * g3[i];
+      for (int j = 0; j < C; ++j) G2[(size_t)k * C + j] += w * G3[(size_t)i * C + j];
+    }
+  {  // layer 1: input y1 = W0 f + b0
+    auto& dW1 = out("_density_net.mlp.1.0.weight", (size_t)Hd * Hd);
+    auto& db1 = out("_density_net.mlp.1.0.bias", Hd);
+    for (int i = 0; i < Hd; ++i) {
+      db1[i] = (float)g2[i];
+      for (int k = 0; k < Hd; ++k) {
+        double s = g2[i] * b0[k];
+        for (int j = 0; j < C; ++j) s += G2[(size_t)i * C + j] * W0[(size_t)k * C + j];
+        dW1[(size_t)i * Hd + k] = (float)s;
+      }
+    }
+  }
+  {  // layer 0
+    auto& dW0 = out("_density_net.mlp.0.0.weight", (size_t)Hd * C);
+    auto& db0 = out("_density_net.mlp.0.0.bias", Hd);
+    std::vector<double> G1((size_t)Hd * C, 0.0), g1(Hd, 0.0);
+    for (int i = 0; i < Hd; ++i)
+      for (int k = 0; k < Hd; ++k) {
+        const double w = W1[(size_t)i * Hd + k];
+        g1[k] += w * g2[i];
+        for (int j = 0; j < C; ++j) G1[(size_t)k * C + j] += w * G2[(size_t)i * C + j];
+      }
+    for (int k = 0; k < Hd; ++k) {
+      db0[k] = (float)g1[k];
+      for (int j = 0; j < C; ++j) dW0[(size_t)k * C + j] = (float)G1[(size_t)k * C + j];
+    }
+  }
+  {  // radiance layer: [hidden | direction embedding]
+    auto& dWr = out("_radiance_net.mlp.0.0.weight", (size_t)3 * (Hd + De));
+    auto& dbr = out("_radiance_net.mlp.0.0.bias", 3);
+    for (int j = 0; j < 3; ++j) {
+      for (int h = 0; h < Hd; ++h) dWr[(size_t)j * (Hd + De) + h] = hWrh[(size_t)h * 4 + j];
+      for (int e = 0; e < De; ++e) dWr[(size_t)j * (Hd + De) + Hd + e] = hdir[j * 28 + e];
+      dbr[j] = hdir[j * 28 + 27];
+    }
+  }
+  return 0;
+}
+
+int holo_renderer_get_grad(HoloRenderer* r, const char* name, float* out_dev, int64_t numel, void* stream) {
+  if (!r || !name || !out_dev) {
+    set_error("holo_renderer_get_grad: null argument");
+    return HOLO_E_INVALID;
+  }
+  auto it = r->grads.find(name);
+  if (it == r->grads.end()) {
+    set_error("holo_renderer_get_grad: no gradient for '%s' (run holo_render_rays_backward first)", name);
+    return HOLO_E_STATE;
+  }
+  if ((int64_t)it->second.size() != numel) {
+    set_error("holo_renderer_get_grad: '%s' has %lld elements, not %lld", name, (long long)it->second.size(), (long long)numel);
+    return HOLO_E_INVALID;
+  }
+  HIP_TRY(hipMemcpyAsync(out_dev, it->second.data(), (size_t)numel * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
 }
 
 }  // extern "C"

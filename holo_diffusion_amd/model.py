@@ -272,6 +272,64 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         return preds
 
     @torch.no_grad()
+    def training_backward(self, *, camera: PerspectiveCameras, voxel_features: torch.Tensor, rng_streams: dict,
+                          grads: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        """``loss.backward()`` of the TRAINING branch for a loss on the rendered outputs: the gradients that
+        autograd leaves in the reference on the denoiser's and the RenderMLP's parameters and on the clean grid when
+        ``forward(evaluation_mode=TRAINING)`` (holo_diffusion_model.py:384-457) is followed by losses on
+        ``images_render / depths_render / masks_render`` and their prev_stage (coarse) counterparts (:458-489).
+          rng_streams : the draws of the forward call - ``timesteps``, ``q_noise``, ``bootstrap`` (+ ``timesteps2``,
+                        ``q_noise2``), ``xys`` and the renderer's ``u_coarse / u_fine / noise_coarse / noise_fine``
+          grads       : d loss / d output, any of ``features (n_targets, n_rays, 1, 3)``, ``depths``, ``masks`` and
+                        ``features_coarse`` / ``depths_coarse`` / ``masks_coarse``
+        Chain: renderer backward (holo_render_rays_backward) -> the clamp of pred_xstart -> denoiser backward
+        (holo_unet_backward) -> q_sample's sqrt(alpha_bar_t) -> (bootstrap) the first round's clamp and denoiser again; the
+        parameter gradients of the two rounds add up, as the reference's shared ``net_3d`` accumulates them.
+        Returns ``{"unet": {name: grad}, "render_mlp": {name: grad}, "voxel_features": grad of the clean grid,
+        "voxel_grid": grad of the rendered grid}``.  The view-pooling branch (image_rgb inputs) has no backward here."""
+        assert self.net_3d_enabled and self.diffusion_enabled, "training_backward: the diffusion branch"
+        rs = dict(rng_streams)
+        for k in ("timesteps", "q_noise", "bootstrap", "xys"):
+            if k not in rs:
+                raise ValueError(f"training_backward: rng_streams['{k}'] is needed (the draw of the forward pass)")
+        dev = voxel_features.device
+        batch_size = len(camera)
+        n_targets = batch_size if self.n_train_target_views <= 0 else min(self.n_train_target_views, batch_size)
+        if batch_size <= n_targets:
+            n_targets = 1
+        target_cameras = camera[list(range(n_targets))]
+        rounds = []
+
+        def one_round(x0, t_key, n_key):
+            t = torch.as_tensor(rs[t_key], device=dev, dtype=torch.int64).reshape(x0.shape[0])
+            x_t = self.diffusion.q_sample(x0, t, noise=rs[n_key].to(dev))
+            y = self.net_3d(x_t, t)
+            rounds.append((x_t, t, y))
+            return y.clamp(-1.0, 1.0)
+
+        grid = one_round(voxel_features.float(), "timesteps", "q_noise")
+        if rs["bootstrap"]:
+            grid = one_round(grid, "timesteps2", "q_noise2")
+        for func in self._implicit_functions:
+            func.bind_args(voxel_grid_features=grid)
+        try:
+            bundle = self.raysampler(target_cameras, EvaluationMode.TRAINING,
+                                     sampling_mode=RenderSamplingMode(self.sampling_mode_training), xys=rs["xys"])
+            g_grid, render_grads = self.renderer.backward_training(bundle, list(self._implicit_functions), rs, grads)
+        finally:
+            for func in self._implicit_functions:
+                func.unbind_args()
+        unet_grads: Dict[str, torch.Tensor] = {}
+        g = g_grid
+        for x_t, t, y in reversed(rounds):
+            g_y = g * ((y >= -1.0) & (y <= 1.0)).to(g.dtype)  # torch.clamp passes the gradient inside [min, max]
+            _, g_x, ug = self.net_3d.backward(x_t, t, g_y)
+            for k, v in ug.items():
+                unet_grads[k] = v if k not in unet_grads else unet_grads[k] + v
+            g = self.diffusion._extract(self.diffusion.sqrt_alphas_cumprod, t, g_x.shape) * g_x  # d q_sample / d x_start
+        return {"unet": unet_grads, "render_mlp": render_grads, "voxel_features": g, "voxel_grid": g_grid}
+
+    @torch.no_grad()
     def _diffuse_and_denoise(self, voxel_features: torch.Tensor, rng_streams: Optional[dict]) -> torch.Tensor:
         """The diffusion mechanism of the TRAINING branch (holo_diffusion_model.py:386-418), forward only: sample a
         timestep, diffuse the clean grid (q_sample), predict it back (pred_xstart of p_mean_variance, clamped) - and, with

@@ -551,13 +551,10 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         except Exception:
             pass
 
-    def _forward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams) -> RendererOutput:
-        """Training-mode forward of the two-pass renderer (SURVEY 8f-4; holo_multipass_ea.py:79-125 with
-        evaluation_mode = TRAINING): explicit ray list, ``n_pts_per_ray_training`` coarse + ``n_pts_per_ray_fine_training``
-        new samples, stratified depths / importance samples, density noise of std ``density_noise_std_train`` on both
-        passes.  The random streams are drawn with torch on the device unless injected through ``rng_streams`` (keys
-        ``u_coarse (n_cam,n_rays,P)``, ``u_fine (n_cam,n_rays,Pf)``, ``noise_coarse (n_cam,n_rays,P)``,
-        ``noise_fine (n_cam,n_rays,P+Pf)`` - the parity tests inject them).  Forward only: no autograd graph is built."""
+    def _training_setup(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams, draw: bool = True):
+        """Arguments shared by the training-mode forward and its backward: handle (keyed on the training sample counts),
+        grid, ray list, random streams (``draw = False``: every stream in use must be injected - the backward pass has to
+        see the draws of the forward pass)."""
         if not bundle.training or bundle.xys is None:
             raise ValueError("training-mode rendering needs the ray sampler's training bundle (explicit xys)")
         wrapper = implicit_functions[0]
@@ -594,6 +591,8 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
                 return None
             t = rs.get(key)
             if t is None:
+                if not draw:
+                    raise _lib.HoloError(f"rng_streams['{key}'] is needed: the backward pass takes the draws of the forward pass")
                 t = torch.randn(shape, device=dev) if normal else torch.rand(shape, device=dev)
             if tuple(t.shape) != tuple(shape):
                 raise _lib.HoloError(f"rng_streams['{key}'] must have shape {tuple(shape)}, got {tuple(t.shape)}")
@@ -603,9 +602,22 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         u_f = stream("u_fine", (n_cam, n_rays, Pf), False, two_pass and self.stratified_sampling_coarse_training)
         nz_c = stream("noise_coarse", (n_cam, n_rays, P), True, std > 0.0)
         nz_f = stream("noise_fine", (n_cam, n_rays, P + Pf), True, std > 0.0 and two_pass)
-        L = runtime.lib()
         xys = bundle.xys.reshape(n_cam, n_rays, 2).to(dev, torch.float32).contiguous()
         grid = grid.contiguous().float()
+        return dict(h=h, fn=fn, grid=grid, dev=dev, cams=cams, n_cam=n_cam, n_rays=n_rays, P=P, Pf=Pf, two_pass=two_pass,
+                    u_c=u_c, u_f=u_f, nz_c=nz_c, nz_f=nz_f, std=std, xys=xys)
+
+    def _forward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams) -> RendererOutput:
+        """Training-mode forward of the two-pass renderer (SURVEY 8f-4; holo_multipass_ea.py:79-125 with
+        evaluation_mode = TRAINING): explicit ray list, ``n_pts_per_ray_training`` coarse + ``n_pts_per_ray_fine_training``
+        new samples, stratified depths / importance samples, density noise of std ``density_noise_std_train`` on both
+        passes.  The random streams are drawn with torch on the device unless injected through ``rng_streams`` (keys
+        ``u_coarse (n_cam,n_rays,P)``, ``u_fine (n_cam,n_rays,Pf)``, ``noise_coarse (n_cam,n_rays,P)``,
+        ``noise_fine (n_cam,n_rays,P+Pf)`` - the parity tests inject them).  Forward only: no autograd graph is built."""
+        a = self._training_setup(bundle, implicit_functions, rng_streams)
+        h, grid, dev, cams, n_cam, n_rays, two_pass = a["h"], a["grid"], a["dev"], a["cams"], a["n_cam"], a["n_rays"], a["two_pass"]
+        u_c, u_f, nz_c, nz_f, std, xys = a["u_c"], a["u_f"], a["nz_c"], a["nz_f"], a["std"], a["xys"]
+        L = runtime.lib()
         img = torch.empty(n_cam, 3, n_rays, device=dev)
         dep, msk = torch.empty(n_cam, n_rays, device=dev), torch.empty(n_cam, n_rays, device=dev)
         imgc, depc, mskc = torch.empty_like(img), torch.empty_like(dep), torch.empty_like(msk)
@@ -621,6 +633,47 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         if not two_pass:
             return coarse
         return RendererOutput(features=shp(img, 3), depths=shp(dep, 1), masks=shp(msk, 1), prev_stage=coarse)
+
+    def backward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams: dict, grads: dict):
+        """Backward of the training-mode forward: what autograd computes in the reference for losses on
+        the renderer's outputs (holo_diffusion_model.py:458-489).  ``rng_streams``: the draws of the forward call (all
+        streams in use must be given).  ``grads``: gradients of the loss w.r.t. the forward's outputs, any subset of
+        ``features (n_cam,n_rays,1,3)``, ``depths``, ``masks (n_cam,n_rays,1,1)`` and ``features_coarse`` / ``depths_coarse``
+        / ``masks_coarse`` (the prev_stage outputs).  Returns ``(grad_grid (1,C,R,R,R), {RenderMLP parameter name: grad})``
+        with the reference's state_dict names (``_density_net.mlp.<i>.0.weight`` ...).  The importance sampling carries no
+        gradient (PyTorch3D's RayPointRefiner samples under torch.no_grad())."""
+        a = self._training_setup(bundle, implicit_functions, rng_streams, draw=False)
+        h, grid, dev, cams, n_cam, n_rays = a["h"], a["grid"], a["dev"], a["cams"], a["n_cam"], a["n_rays"]
+        if not a["two_pass"]:
+            raise NotImplementedError("backward_training: the two-pass renderer (coarse + fine implicit function)")
+        L = runtime.lib()
+        nul = C.c_void_p(None)
+        opt = lambda t: runtime.ptr(t) if t is not None else nul  # noqa: E731
+
+        def g(key, c):
+            t = grads.get(key)
+            if t is None:
+                return None
+            if tuple(t.shape) != (n_cam, n_rays, 1, c):
+                raise _lib.HoloError(f"grads['{key}'] must have shape {(n_cam, n_rays, 1, c)}, got {tuple(t.shape)}")
+            return t.to(dev, torch.float32).permute(0, 3, 1, 2).reshape(n_cam, c, n_rays).contiguous()
+
+        gi, gd, gm = g("features", 3), g("depths", 1), g("masks", 1)
+        gic, gdc, gmc = g("features_coarse", 3), g("depths_coarse", 1), g("masks_coarse", 1)
+        grad_grid = torch.empty_like(grid)
+        ws = runtime.workspace(self, dev, L.holo_render_rays_backward_workspace_bytes(h, n_cam, n_rays))
+        _lib.check(L, L.holo_render_rays_backward(h, runtime.ptr(grid), _camera_array(cams), n_cam, n_rays, runtime.ptr(a["xys"]),
+                                                  opt(a["u_c"]), opt(a["u_f"]), opt(a["nz_c"]), opt(a["nz_f"]), a["std"],
+                                                  opt(gi), opt(gd), opt(gm), opt(gic), opt(gdc), opt(gmc), runtime.ptr(grad_grid),
+                                                  runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)),
+                   "holo_render_rays_backward")
+        pgrads = {}
+        for name, prm in a["fn"].render_mlp.named_parameters():
+            out = torch.empty_like(prm, dtype=torch.float32, device=dev)
+            _lib.check(L, L.holo_renderer_get_grad(h, name.encode(), runtime.ptr(out), out.numel(), runtime.stream_ptr(dev)),
+                       "holo_renderer_get_grad")
+            pgrads[name] = out
+        return grad_grid, pgrads
 
     def forward(self, ray_bundle: ImplicitronRayBundle, implicit_functions: List[ImplicitFunctionWrapper],
                 evaluation_mode: EvaluationMode = EvaluationMode.EVALUATION, rng_streams: Optional[dict] = None,

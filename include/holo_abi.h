@@ -241,6 +241,26 @@ int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* camer
                      float* images_coarse, float* depths_coarse, float* masks_coarse, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Backward of holo_render_rays: what autograd computes for the reference's rendering losses
+ * (holo_diffusion_model.py:458-489 on the outputs of holo_multipass_ea.py:79-125) - the gradients of BOTH passes' rgb /
+ * depth / mask with respect to the voxel grid (grid_sample's scatter-add, holo_voxel_grid_implicit_function.py:221-243)
+ * and the RenderMLP parameters (:73-129).  Same ray / random-stream arguments as the forward call; the importance
+ * sampling carries no gradient (PyTorch3D RayPointRefiner samples under torch.no_grad()).
+ *   grad_images (n_cameras, 3, n_rays), grad_depths / grad_masks (n_cameras, n_rays), *_coarse the same for the coarse
+ *   pass; any of the six may be NULL (= zero)
+ *   grad_grid   : (1, C, R, R, R) fp32, overwritten
+ * The parameter gradients of the call are fetched with holo_renderer_get_grad (names of holo_renderer_set_param; device
+ * destination of `numel` floats).  The call synchronises the stream (the gradients of the folded density net are unfolded
+ * to its four Linear layers on the host in float64, like holo_renderer_commit folds them). */
+size_t holo_render_rays_backward_workspace_bytes(const HoloRenderer* r, int n_cameras, int n_rays);
+int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, int n_rays,
+                              const float* xys, const float* u_coarse, const float* u_fine, const float* noise_coarse,
+                              const float* noise_fine, float density_noise_std, const float* grad_images,
+                              const float* grad_depths, const float* grad_masks, const float* grad_images_coarse,
+                              const float* grad_depths_coarse, const float* grad_masks_coarse, float* grad_grid,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int holo_renderer_get_grad(HoloRenderer* r, const char* name, float* out_dev, int64_t numel, void* stream);
+
 /* Stand-alone implicit function.  Replaces HoloVoxelGridImplicitFunction.forward
  * (holo_voxel_grid_implicit_function.py:182-269): trilinear fetch of `grid` at the world points, RenderMLP.
  *   pts        : (n_points, 3) world coordinates; dirs : (n_points / pts_per_dir, 3) ray directions

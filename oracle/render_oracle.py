@@ -360,7 +360,8 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
         dens, col = implicit_function(grid, sd, o, d, l, cfg, prefix)
         rgb_c, dep_c, msk_c, w = ea_raymarch(dens, col, l, cfg, noise_coarse[sl] if noise_coarse is not None else None, noise_std)
         diag = {}
-        lf = refine_lengths(l, w, cfg, diag, u_fine[sl] if u_fine is not None else None)
+        # (the refiner samples under torch.no_grad() in PyTorch3D's RayPointRefiner: the importance samples carry no gradient)
+        lf = refine_lengths(l, w.detach(), cfg, diag, u_fine[sl] if u_fine is not None else None).detach()
         dens, col = implicit_function(grid, sd, o, d, lf, cfg, prefix)
         rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg, noise_fine[sl] if noise_fine is not None else None, noise_std)
         vals = [("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c), ("mask_c", msk_c),
@@ -372,6 +373,23 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
         for k, v in vals:
             outs[k].append(v)
     return {k: torch.cat(v) for k, v in outs.items()}
+
+
+def render_rays_grad(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.Tensor, dirs: torch.Tensor,
+                     lengths: torch.Tensor, cfg: RenderCfg, out_grads: Dict[str, torch.Tensor], prefix: str = "", **streams):
+    """Backward of ``render_rays`` by autograd (the checker of holo_render_rays_backward): gradients of
+    sum_k <out_grads[k], out[k]> over k in rgb / depth / mask / rgb_c / depth_c / mask_c with respect to the grid and
+    every RenderMLP parameter - what ``loss.backward()`` leaves on them in the reference for a loss on the renderer's
+    outputs (holo_diffusion_model.py:458-489).  Returns (grad_grid, {name: grad}, outputs)."""
+    with torch.enable_grad():
+        g = grid.detach().clone().requires_grad_(True)
+        psd = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+        out = render_rays.__wrapped__(g, psd, origins, dirs, lengths, cfg, prefix, **streams)
+        loss = sum((out[k] * out_grads[k].reshape(out[k].shape)).sum() for k in out_grads)
+        names = [k for k in psd if k.startswith(prefix + "_density_net") or k.startswith(prefix + "_radiance_net")]
+        gs = torch.autograd.grad(loss, [g] + [psd[k] for k in names], allow_unused=True)
+    pg = {k: (v if v is not None else torch.zeros_like(psd[k])) for k, v in zip(names, gs[1:])}
+    return gs[0], pg, {k: v.detach() for k, v in out.items()}
 
 
 @torch.no_grad()

@@ -1,0 +1,172 @@
+"""GPU parity of the renderer's backward pass (second half): holo_render_rays_backward - gradients of both
+passes' rgb / depth / mask w.r.t. the voxel grid (grid_sample's scatter-add) and every RenderMLP parameter - against
+autograd through the oracle's training-mode renderer with the same injected random streams (the importance sampling is
+detached on both sides, as PyTorch3D's RayPointRefiner samples under torch.no_grad())."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import holo_diffusion_amd as hda  # noqa: E402
+from holo_diffusion_amd.render import EvaluationMode  # noqa: E402
+from oracle import render_oracle as ro  # noqa: E402
+from oracle.common import np_noise  # noqa: E402
+
+EMU = os.environ.get("HOLO_TEST_EMU") == "1"
+TINY_UNET = dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2))
+
+
+@pytest.fixture(scope="module")
+def gu():
+    import tests.gpu_utils as g
+    return g
+
+
+def _streams(n_cam, n_rays, P, Pf, seed):
+    u = lambda s, shp: torch.from_numpy(np_noise(s, shp)).mul(0.5).erf().add(1).mul(0.5).clamp(0, 0.999999)  # noqa: E731  U[0,1)
+    return {"u_coarse": u(seed, (n_cam, n_rays, P)), "u_fine": u(seed + 1, (n_cam, n_rays, Pf)),
+            "noise_coarse": torch.from_numpy(np_noise(seed + 2, (n_cam, n_rays, P))),
+            "noise_fine": torch.from_numpy(np_noise(seed + 3, (n_cam, n_rays, P + Pf)))}
+
+
+def _rel(got, want, floor):
+    return ((got - want).abs().max() / max(float(want.abs().max()), floor)).item()
+
+
+CASES = [(12, 10, 16, 8, 3, 13, "all")] if EMU else [(12, 10, 16, 8, 3, 13, "all"), (24, 20, 32, 16, 3, 37, "all"),
+                                                     (64, 64, 32, 32, 2, 300, "all"), (24, 20, 16, 16, 2, 41, "fine_only"),
+                                                     (16, 100, 16, 16, 2, 29, "no_noise"), (64, 64, 32, 32, 4, 700, "chunks")]
+
+
+@pytest.mark.parametrize("P,Pf,C,R,n_cam,n_rays,which", CASES)
+def test_render_rays_backward_vs_oracle_autograd(gu, P, Pf, C, R, n_cam, n_rays, which):
+    """Losses on all six outputs (random cotangents), stratified depths / importance samples and density noise of std 1
+    injected; `chunks`: more points than one 65 536-point chunk, `fine_only`: no gradient on the coarse outputs (NULL
+    pointers), `no_noise`: deterministic depths, no density noise (16 + 100 samples: a 116-point merged list)."""
+    model, _, _, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    grid = torch.tanh(torch.from_numpy(np_noise(7, (1, C, R, R, R))))
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_cam, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    xys = (torch.from_numpy(np_noise(11, (n_cam, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = _streams(n_cam, n_rays, P, Pf, 500 + P)
+    std = 1.0
+    if which == "no_noise":
+        model.raysampler.stratified_point_sampling_training = False
+        model.renderer.stratified_sampling_coarse_training = False
+        model.renderer.density_noise_std_train = std = 0.0
+        rs = {}
+    keys = {"features": ("rgb", 3), "depths": ("depth", 1), "masks": ("mask", 1), "features_coarse": ("rgb_c", 3),
+            "depths_coarse": ("depth_c", 1), "masks_coarse": ("mask_c", 1)}
+    if which == "fine_only":
+        keys = {k: v for k, v in keys.items() if not k.endswith("_coarse")}
+    cot = {k: torch.from_numpy(np_noise(900 + i, (n_cam, n_rays, 1, c))) * (0.05 if "depth" in k else 1.0)
+           for i, (k, (_, c)) in enumerate(keys.items())}
+    for fn in model._implicit_functions:
+        fn.bind_args(voxel_grid_features=grid.to(gu.DEV))
+    bundle = model.raysampler(cams.to(gu.DEV), EvaluationMode.TRAINING, xys=xys.to(gu.DEV))
+    dev_rs = {k: v.to(gu.DEV) for k, v in rs.items()}
+    ggrid, pg = model.renderer.backward_training(bundle, list(model._implicit_functions), dev_rs,
+                                                 {k: v.to(gu.DEV) for k, v in cot.items()})
+    assert ggrid.shape == grid.shape and torch.isfinite(ggrid).all()
+    # oracle: autograd per camera, summed
+    want_grid = torch.zeros_like(grid)
+    want_p = None
+    for i in range(n_cam):
+        o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
+        og = {keys[k][0]: cot[k][i] for k in keys}
+        g, p, _ = ro.render_rays_grad(grid, msd, o, d, l, rcfg, og, u_coarse=rs["u_coarse"][i] if rs else None,
+                                      u_fine=rs["u_fine"][i] if rs else None,
+                                      noise_coarse=rs["noise_coarse"][i] if rs else None,
+                                      noise_fine=rs["noise_fine"][i] if rs else None, noise_std=std)
+        want_grid += g
+        want_p = p if want_p is None else {k: want_p[k] + p[k] for k in p}
+    assert float(want_grid.abs().max()) > 1e-3
+    worst = ("grid", _rel(ggrid.cpu(), want_grid, 1e-6))
+    scale = sorted(float(v.abs().max()) for v in want_p.values())[len(want_p) // 2]
+    assert set(pg) == set(want_p)
+    for k in want_p:
+        e = _rel(pg[k].cpu(), want_p[k], 1e-2 * scale)
+        if e > worst[1]:
+            worst = (k, e)
+    print(f"\nrender backward P={P} Pf={Pf} C={C} R={R} rays={n_cam}x{n_rays} [{which}]: worst relative gradient error "
+          f"{worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-3, worst
+
+
+def test_render_backward_needs_the_forward_draws(gu):
+    """The backward pass must see the draws of the forward pass: a missing stream is an error, not a fresh draw."""
+    model, _, _, _, _ = gu.make_model(8, 16, 16, 16, TINY_UNET, n_fine=64)
+    model.raysampler.n_pts_per_ray_training = 12
+    model.renderer.n_pts_per_ray_fine_training = 10
+    grid = torch.zeros(1, 16, 8, 8, 8, device=gu.DEV)
+    for fn in model._implicit_functions:
+        fn.bind_args(voxel_grid_features=grid)
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 2, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    bundle = model.raysampler(cams.to(gu.DEV), EvaluationMode.TRAINING, xys=torch.zeros(2, 5, 2, device=gu.DEV))
+    with pytest.raises(hda._lib.HoloError):
+        model.renderer.backward_training(bundle, list(model._implicit_functions), {}, {"features": torch.zeros(2, 5, 1, 3)})
+
+
+@pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
+@pytest.mark.parametrize("bootstrap", [False, True])
+def test_training_backward_chain_vs_oracle_autograd(gu, bootstrap):
+    """HoloDiffusionModel.training_backward: renderer backward -> clamp of pred_xstart -> denoiser backward -> q_sample
+    (-> the bootstrap round's clamp and denoiser once more), against autograd through the oracle pipeline (diffusion
+    oracle + UNet oracle + training-mode render oracle) with every draw injected: gradients of the UNet parameters (the
+    two rounds accumulate), the RenderMLP parameters and the clean grid."""
+    from oracle import diffusion_oracle as do
+    from oracle import unet_oracle as uo
+    R, C, P, Pf, n_rays = 8, 16, 16, 16, 33
+    model, ucfg, usd, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.n_train_target_views = 2
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 4, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    vf = torch.tanh(torch.from_numpy(np_noise(3, (1, C, R, R, R))))
+    xys = (torch.from_numpy(np_noise(12, (2, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = _streams(2, n_rays, P, Pf, 900)
+    rs.update({"xys": xys, "timesteps": torch.tensor([700]), "q_noise": torch.from_numpy(np_noise(31, tuple(vf.shape))),
+               "bootstrap": bootstrap, "timesteps2": torch.tensor([150]), "q_noise2": torch.from_numpy(np_noise(32, tuple(vf.shape)))})
+    keys = {"features": ("rgb", 3), "masks": ("mask", 1), "depths": ("depth", 1), "features_coarse": ("rgb_c", 3)}
+    cot = {k: torch.from_numpy(np_noise(700 + i, (2, n_rays, 1, c))) * (0.05 if "depth" in k else 1.0)
+           for i, (k, (_, c)) in enumerate(keys.items())}
+    dev_rs = {k: (v.to(gu.DEV) if torch.is_tensor(v) else v) for k, v in rs.items()}
+    out = model.training_backward(camera=cams.to(gu.DEV), voxel_features=vf.to(gu.DEV), rng_streams=dev_rs,
+                                  grads={k: v.to(gu.DEV) for k, v in cot.items()})
+    # ---- oracle: autograd through the whole training branch
+    orc = do.DiffusionOracle(1000)
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    with torch.enable_grad():
+        x0 = vf.clone().requires_grad_(True)
+        pu = {k: v.detach().clone().requires_grad_(True) for k, v in usd.items()}
+        pm = {k: v.detach().clone().requires_grad_(True) for k, v in msd.items()}
+        g = x0
+        for tk, nk in (("timesteps", "q_noise"), ("timesteps2", "q_noise2"))[: 2 if bootstrap else 1]:
+            g = uo.unet_forward.__wrapped__(pu, ucfg, orc.q_sample(g, rs[tk], rs[nk]), rs[tk]).clamp(-1, 1)
+        loss = 0.0
+        for i in range(2):
+            o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
+            r = ro.render_rays.__wrapped__(g, pm, o, d, l, rcfg, "", u_coarse=rs["u_coarse"][i], u_fine=rs["u_fine"][i],
+                                           noise_coarse=rs["noise_coarse"][i], noise_fine=rs["noise_fine"][i], noise_std=1.0)
+            loss = loss + sum((r[keys[k][0]] * cot[k][i].reshape(r[keys[k][0]].shape)).sum() for k in keys)
+        mnames = [k for k in pm if k.startswith("_density_net") or k.startswith("_radiance_net")]
+        unames = list(pu)
+        gs = torch.autograd.grad(loss, [x0] + [pu[k] for k in unames] + [pm[k] for k in mnames], allow_unused=True)
+    want_x0 = gs[0]
+    want_u = {k: (v if v is not None else torch.zeros_like(pu[k])) for k, v in zip(unames, gs[1:1 + len(unames)])}
+    want_m = dict(zip(mnames, gs[1 + len(unames):]))
+    worst = ("voxel_features", _rel(out["voxel_features"].cpu(), want_x0, 1e-9))
+    for group, want in (("unet", want_u), ("render_mlp", want_m)):
+        scale = sorted(float(v.abs().max()) for v in want.values())[len(want) // 2]
+        assert set(out[group]) >= set(want), (group, set(want) - set(out[group]))
+        for k in want:
+            e = _rel(out[group][k].cpu(), want[k], 1e-2 * scale)
+            if e > worst[1]:
+                worst = (group + "." + k, e)
+    print(f"\ntraining backward chain (bootstrap={bootstrap}): worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-3, worst
