@@ -114,7 +114,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_render_rays_backward_workspace_bytes": (C.c_size_t, [_vp, C.c_int, C.c_int]),
     "holo_render_rays_backward": (C.c_int, [_vp, _vp, C.POINTER(HoloCamera), C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_float,
-                                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+                                            _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_renderer_get_grad": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
     "holo_implicit_eval": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_implicit_workspace_bytes": (C.c_size_t, [_vp, C.c_int64, C.c_int64, C.c_int]),

@@ -729,7 +729,8 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
                               const float* noise_fine, float density_noise_std, const float* grad_images,
                               const float* grad_depths, const float* grad_masks, const float* grad_images_coarse,
                               const float* grad_depths_coarse, const float* grad_masks_coarse, float* grad_grid,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              float* merged_depths, unsigned char* merged_is_new, void* workspace, size_t workspace_bytes,
+                              void* stream) {
   if (!r || !grid || !cameras || n_cameras < 1 || n_rays < 1 || !xys || !grad_grid || !workspace) {
     set_error("holo_render_rays_backward: null/invalid argument");
     return HOLO_E_INVALID;
@@ -784,6 +785,9 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
                             density_noise_std, fwd, fwd + L.NR * 3, fwd + L.NR * 4, fwd + L.NR * 5, fwd + L.NR * 8, fwd + L.NR * 9,
                             z_merged, flags, stream);
   if (rc) return rc;
+  if (merged_depths)
+    HIP_TRY(hipMemcpyAsync(merged_depths, z_merged, (size_t)L.NR * L.nm * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (merged_is_new) HIP_TRY(hipMemcpyAsync(merged_is_new, flags, (size_t)L.NR * L.nm, hipMemcpyDeviceToDevice, st));
   // 2. per-ray records
   float* rays = (float*)(ws + L.o_rays);
   for (int c0 = 0; c0 < n_cameras; c0 += RenderKernelParams::MAX_CAMS) {

@@ -634,14 +634,17 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
             return coarse
         return RendererOutput(features=shp(img, 3), depths=shp(dep, 1), masks=shp(msk, 1), prev_stage=coarse)
 
-    def backward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams: dict, grads: dict):
+    def backward_training(self, bundle: ImplicitronRayBundle, implicit_functions, rng_streams: dict, grads: dict,
+                          return_merged: bool = False):
         """Backward of the training-mode forward: what autograd computes in the reference for losses on
         the renderer's outputs (holo_diffusion_model.py:458-489).  ``rng_streams``: the draws of the forward call (all
         streams in use must be given).  ``grads``: gradients of the loss w.r.t. the forward's outputs, any subset of
         ``features (n_cam,n_rays,1,3)``, ``depths``, ``masks (n_cam,n_rays,1,1)`` and ``features_coarse`` / ``depths_coarse``
         / ``masks_coarse`` (the prev_stage outputs).  Returns ``(grad_grid (1,C,R,R,R), {RenderMLP parameter name: grad})``
         with the reference's state_dict names (``_density_net.mlp.<i>.0.weight`` ...).  The importance sampling carries no
-        gradient (PyTorch3D's RayPointRefiner samples under torch.no_grad())."""
+        gradient (PyTorch3D's RayPointRefiner samples under torch.no_grad()).  ``return_merged``: also return the fine
+        pass's depth list ``(n_cam, n_rays, P + Pf)`` and its is-importance-sample flags (the forward kernel's sample
+        placement, held fixed by the backward pass)."""
         a = self._training_setup(bundle, implicit_functions, rng_streams, draw=False)
         h, grid, dev, cams, n_cam, n_rays = a["h"], a["grid"], a["dev"], a["cams"], a["n_cam"], a["n_rays"]
         if not a["two_pass"]:
@@ -661,11 +664,13 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         gi, gd, gm = g("features", 3), g("depths", 1), g("masks", 1)
         gic, gdc, gmc = g("features_coarse", 3), g("depths_coarse", 1), g("masks_coarse", 1)
         grad_grid = torch.empty_like(grid)
+        zm = torch.empty(n_cam, n_rays, a["P"] + a["Pf"], device=dev) if return_merged else None
+        zf = torch.empty(n_cam, n_rays, a["P"] + a["Pf"], device=dev, dtype=torch.uint8) if return_merged else None
         ws = runtime.workspace(self, dev, L.holo_render_rays_backward_workspace_bytes(h, n_cam, n_rays))
         _lib.check(L, L.holo_render_rays_backward(h, runtime.ptr(grid), _camera_array(cams), n_cam, n_rays, runtime.ptr(a["xys"]),
                                                   opt(a["u_c"]), opt(a["u_f"]), opt(a["nz_c"]), opt(a["nz_f"]), a["std"],
                                                   opt(gi), opt(gd), opt(gm), opt(gic), opt(gdc), opt(gmc), runtime.ptr(grad_grid),
-                                                  runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)),
+                                                  opt(zm), opt(zf), runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)),
                    "holo_render_rays_backward")
         pgrads = {}
         for name, prm in a["fn"].render_mlp.named_parameters():
@@ -673,6 +678,8 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
             _lib.check(L, L.holo_renderer_get_grad(h, name.encode(), runtime.ptr(out), out.numel(), runtime.stream_ptr(dev)),
                        "holo_renderer_get_grad")
             pgrads[name] = out
+        if return_merged:
+            return grad_grid, pgrads, zm, zf
         return grad_grid, pgrads
 
     def forward(self, ray_bundle: ImplicitronRayBundle, implicit_functions: List[ImplicitFunctionWrapper],

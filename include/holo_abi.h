@@ -249,6 +249,9 @@ int holo_render_rays(HoloRenderer* r, const float* grid, const HoloCamera* camer
  *   grad_images (n_cameras, 3, n_rays), grad_depths / grad_masks (n_cameras, n_rays), *_coarse the same for the coarse
  *   pass; any of the six may be NULL (= zero)
  *   grad_grid   : (1, C, R, R, R) fp32, overwritten
+ *   merged_depths (n_cameras, n_rays, n_pts_coarse + n_pts_fine) / merged_is_new (same shape, bytes): optional outputs
+ *                 (may be NULL) - the fine pass's depth list of every ray in depth order and a flag per importance sample
+ *                 (the sample placement of the forward kernel, which the backward pass holds fixed)
  * The parameter gradients of the call are fetched with holo_renderer_get_grad (names of holo_renderer_set_param; device
  * destination of `numel` floats).  The call synchronises the stream (the gradients of the folded density net are unfolded
  * to its four Linear layers on the host in float64, like holo_renderer_commit folds them). */
@@ -258,7 +261,8 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
                               const float* noise_fine, float density_noise_std, const float* grad_images,
                               const float* grad_depths, const float* grad_masks, const float* grad_images_coarse,
                               const float* grad_depths_coarse, const float* grad_masks_coarse, float* grad_grid,
-                              void* workspace, size_t workspace_bytes, void* stream);
+                              float* merged_depths, unsigned char* merged_is_new, void* workspace, size_t workspace_bytes,
+                              void* stream);
 int holo_renderer_get_grad(HoloRenderer* r, const char* name, float* out_dev, int64_t numel, void* stream);
 
 /* Stand-alone implicit function.  Replaces HoloVoxelGridImplicitFunction.forward

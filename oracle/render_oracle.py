@@ -344,8 +344,10 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
                 lengths: torch.Tensor, cfg: RenderCfg, prefix: str = "", chunk_rays: int = 4096,
                 with_normals: bool = False, u_coarse: Optional[torch.Tensor] = None, u_fine: Optional[torch.Tensor] = None,
                 noise_coarse: Optional[torch.Tensor] = None, noise_fine: Optional[torch.Tensor] = None,
-                noise_std: float = 0.0) -> Dict[str, torch.Tensor]:
-    """Two-pass render of an ARBITRARY set of rays (origins (n,3), directions (n,3), coarse lengths (n,P)): coarse pass
+                noise_std: float = 0.0, fine_lengths: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """``fine_lengths`` (n, P + Pf): use this merged depth list for the fine pass instead of the refiner's (tests that
+    hold the sample placement of the implementation under test fixed).
+    Two-pass render of an ARBITRARY set of rays (origins (n,3), directions (n,3), coarse lengths (n,P)): coarse pass
     -> refiner -> fine pass (holo_multipass_ea.py:79-125).  Per-ray outputs: rgb (n,3), depth (n,1), mask (n,1), the
     coarse-pass rgb_c / depth_c / mask_c and the sorted fine lengths; with ``with_normals`` also the rendered normals
     of both passes, sum_i w_i n_i (holo_multipass_ea.py:105-109)."""
@@ -362,6 +364,8 @@ def render_rays(grid: torch.Tensor, sd: Dict[str, torch.Tensor], origins: torch.
         diag = {}
         # (the refiner samples under torch.no_grad() in PyTorch3D's RayPointRefiner: the importance samples carry no gradient)
         lf = refine_lengths(l, w.detach(), cfg, diag, u_fine[sl] if u_fine is not None else None).detach()
+        if fine_lengths is not None:
+            lf = fine_lengths[sl]
         dens, col = implicit_function(grid, sd, o, d, lf, cfg, prefix)
         rgb, dep, msk, wf = ea_raymarch(dens, col, lf, cfg, noise_fine[sl] if noise_fine is not None else None, noise_std)
         vals = [("rgb", rgb), ("depth", dep), ("mask", msk), ("rgb_c", rgb_c), ("depth_c", dep_c), ("mask_c", msk_c),
