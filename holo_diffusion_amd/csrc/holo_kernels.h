@@ -290,7 +290,7 @@ struct RenderBwdChunk {
   float4* drad;
   float4* gval;
   float4* GR;
-  float* tmp;     // [n][4]
+  double* tmp;    // [n][4]
   float* gr_ray;  // (all rays, 4)
   const float* be;     // [Hp]
   const float* w_rad;  // [3][Hd]

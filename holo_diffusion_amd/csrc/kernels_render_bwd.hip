@@ -197,18 +197,20 @@ __global__ __launch_bounds__(64) void rbwd_composite_kernel(RenderBwdChunk p) {
       const bool take = q < nm && (fine || !fl[q]);
       if (!(take || q == nm)) continue;
       if (prev >= 0) {  // close the interval of the previous sample: its delta ends at this sample's depth
+        // (double throughout: d colour / d density is the small difference (c_k - colour behind k) of O(1) terms)
         const float dl = q < nm ? z[q] - z_prev : p.background_opacity;
-        const float x = dl * fmaxf(s_prev, 0.f);
-        const float Tq = (float)exp(-cum);
-        cum += (double)x;
-        const float w = (1.f - expf(-x)) * Tq;
+        const double x = (double)dl * (double)fmaxf(s_prev, 0.f);
+        const double Tq = exp(-cum);
+        cum += x;
+        const double w = (1.0 - exp(-x)) * Tq;
         const float4 v = val[prev];
-        const float gw = gr[0] * v.y + gr[1] * v.z + gr[2] * v.w + gd * z_prev;
-        total_gw_w += (double)gw * (double)w;
-        p.tmp[(int64_t)rl * nm * 4 + (int64_t)prev * 4 + 0] = gw;
-        p.tmp[(int64_t)rl * nm * 4 + (int64_t)prev * 4 + 1] = w;
-        p.tmp[(int64_t)rl * nm * 4 + (int64_t)prev * 4 + 2] = (float)exp(-cum);  // e^{-cum_k}
-        p.tmp[(int64_t)rl * nm * 4 + (int64_t)prev * 4 + 3] = (s_prev > 0.f) ? dl : 0.f;
+        const double gw = (double)gr[0] * v.y + (double)gr[1] * v.z + (double)gr[2] * v.w + (double)gd * z_prev;
+        total_gw_w += gw * w;
+        double* t = p.tmp + ((int64_t)rl * nm + prev) * 4;
+        t[0] = gw;
+        t[1] = w;
+        t[2] = exp(-cum);  // e^{-cum_k}
+        t[3] = (s_prev > 0.f) ? (double)dl : 0.0;
       }
       if (q < nm) {
         float s = val[q].x;
@@ -219,19 +221,19 @@ __global__ __launch_bounds__(64) void rbwd_composite_kernel(RenderBwdChunk p) {
         ++k;
       }
     }
-    const float e_last = (float)exp(-cum);
+    const double e_last = exp(-cum);
     double prefix = 0.0;  // sum_{i<=k} gw_i w_i
     for (int q = 0; q < nm; ++q) {
       const bool take = fine || !fl[q];
       float4 g = fine ? make_float4(0.f, 0.f, 0.f, 0.f) : gval[q];
       if (take) {
-        const float* t = p.tmp + (int64_t)rl * nm * 4 + (int64_t)q * 4;
-        prefix += (double)t[0] * (double)t[1];
-        const float dx = t[0] * t[2] - (float)(total_gw_w - prefix) + gO * e_last;
-        g.x += dx * t[3];
-        g.y += t[1] * gr[0];
-        g.z += t[1] * gr[1];
-        g.w += t[1] * gr[2];
+        const double* t = p.tmp + ((int64_t)rl * nm + q) * 4;
+        prefix += t[0] * t[1];
+        const double dx = t[0] * t[2] - (total_gw_w - prefix) + (double)gO * e_last;
+        g.x += (float)(dx * t[3]);
+        g.y += (float)(t[1] * gr[0]);
+        g.z += (float)(t[1] * gr[1]);
+        g.w += (float)(t[1] * gr[2]);
       }
       gval[q] = g;
     }

@@ -705,7 +705,7 @@ RbwdLayout rbwd_layout(const HoloRenderer* r, int n_cameras, int n_rays) {
   L.o_drad = take((size_t)L.cap * 16);
   L.o_gval = take((size_t)L.cap * 16);
   L.o_GR = take((size_t)L.cap * 16);
-  L.o_tmp = take((size_t)L.cap * 16);
+  L.o_tmp = take((size_t)L.cap * 32);
   L.o_part = take((size_t)L.S * L.Hp * L.C * sizeof(float));
   L.o_dWe = take((size_t)L.Hp * L.C * sizeof(float));
   L.o_dbe = take((size_t)L.Hp * sizeof(float));
@@ -830,7 +830,7 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
   p.drad = (float4*)(ws + L.o_drad);
   p.gval = (float4*)(ws + L.o_gval);
   p.GR = (float4*)(ws + L.o_GR);
-  p.tmp = (float*)(ws + L.o_tmp);
+  p.tmp = (double*)(ws + L.o_tmp);
   p.gr_ray = (float*)(ws + L.o_grray);
   p.be = be;
   p.w_rad = mlp.w_rad;

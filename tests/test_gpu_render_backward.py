@@ -76,36 +76,60 @@ def test_render_rays_backward_vs_oracle_autograd(gu, P, Pf, C, R, n_cam, n_rays,
     zm, zf = zm.cpu(), zf.cpu()
     assert zm.shape == (n_cam, n_rays, P + Pf) and int(zf.sum()) == n_cam * n_rays * Pf and (zm.diff(dim=-1) >= 0).all()
 
-    def oracle(fixed):
-        """autograd per camera, summed; fixed: the fine pass uses the kernel's own merged depth list"""
-        wg, wp, dz = torch.zeros_like(grid), None, []
-        for i in range(n_cam):
-            o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
-            og = {keys[k][0]: cot[k][i] for k in keys}
-            g, p, out = ro.render_rays_grad(grid, msd, o, d, l, rcfg, og, u_coarse=rs["u_coarse"][i] if rs else None,
-                                            u_fine=rs["u_fine"][i] if rs else None,
-                                            noise_coarse=rs["noise_coarse"][i] if rs else None,
-                                            noise_fine=rs["noise_fine"][i] if rs else None, noise_std=std,
-                                            fine_lengths=zm[i] if fixed else None)
-            wg += g
-            wp = p if wp is None else {k: wp[k] + p[k] for k in p}
-            dz.append((out["fine_lengths"] - zm[i]).abs())
-        return wg, wp, torch.stack(dz)
+    def oracle(fixed, f64=False):
+        """autograd per camera, summed; fixed: the fine pass uses the kernel's own merged depth list; f64: the oracle's
+        arithmetic in float64 (d colour / d density is a small difference of O(1) terms: the float32 oracle itself sits
+        ~5e-4 from the float64 one on the grid at the large sizes)"""
+        cv = (lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t) if f64 else (lambda t: t)
+        wg, wp, dz = torch.zeros_like(cv(grid)), None, []
+        rays = [ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg) for i in range(n_cam)]  # (float32 on both sides)
+        if f64:
+            torch.set_default_dtype(torch.float64)
+        try:
+            for i in range(n_cam):
+                o, d, l = rays[i]
+                og = {keys[k][0]: cv(cot[k][i]) for k in keys}
+                g, p, out = ro.render_rays_grad(cv(grid), {k: cv(v) for k, v in msd.items()}, cv(o), cv(d), cv(l), rcfg, og,
+                                                u_coarse=cv(rs["u_coarse"][i]) if rs else None,
+                                                u_fine=cv(rs["u_fine"][i]) if rs else None,
+                                                noise_coarse=cv(rs["noise_coarse"][i]) if rs else None,
+                                                noise_fine=cv(rs["noise_fine"][i]) if rs else None, noise_std=std,
+                                                fine_lengths=cv(zm[i]) if fixed else None)
+                wg += g
+                wp = p if wp is None else {k: wp[k] + p[k] for k in p}
+                dz.append((out["fine_lengths"] - zm[i]).abs())
+        finally:
+            torch.set_default_dtype(torch.float32)
+        return wg.float(), {k: v.float() for k, v in wp.items()}, torch.stack(dz).float()
 
-    def worst_of(want_grid, want_p):
-        worst = ("grid", _rel(ggrid.cpu(), want_grid, 1e-6))
+    def worst_of(want_grid, want_p, norm="max"):
+        """worst error over the grid and the parameter tensors, relative to each tensor's scale: max norm or L2"""
+        if norm == "l2":
+            worst = ("grid", float((ggrid.cpu() - want_grid).norm() / want_grid.norm()))
+        else:
+            worst = ("grid", _rel(ggrid.cpu(), want_grid, 1e-6))
         scale = sorted(float(v.abs().max()) for v in want_p.values())[len(want_p) // 2]
         assert set(pg) == set(want_p)
         for k in want_p:
-            e = _rel(pg[k].cpu(), want_p[k], 1e-2 * scale)
+            if norm == "l2":
+                e = float((pg[k].cpu() - want_p[k]).norm() / max(float(want_p[k].norm()), 1e-2 * scale * want_p[k].numel() ** 0.5))
+            else:
+                e = _rel(pg[k].cpu(), want_p[k], 1e-2 * scale)
             if e > worst[1]:
                 worst = (k, e)
         return worst
 
-    # (1) the backward arithmetic, with the sample placement of the forward kernel held fixed on both sides
-    want_grid, want_p, _ = oracle(True)
+    # (1) the backward arithmetic, with the sample placement of the forward kernel held fixed on both sides, against the
+    # float64 oracle.  LeakyReLU / ReLU kinks: a pre-activation within float32 rounding of zero takes the other branch on
+    # one side, which changes ONE hidden unit of ONE sample by its whole slope difference - sparse, O(1e-3) of a tensor's
+    # max per event (measured at 4 x 700 rays, 92 M pre-activations: 10 of 32 768 voxel positions and 3 of 257 rows of
+    # d W3 above 1e-3, the float32 torch oracle against the float64 one shows the same events: 4 positions, 1 row, same
+    # maximum 4.0e-3 / 2.5e-3).  The small cases see no such event and are held to 1e-3 in the max norm; the large ones to
+    # 2e-3 in L2 and 1e-2 in the max norm.
+    want_grid, want_p, _ = oracle(True, f64=True)
     assert float(want_grid.abs().max()) > 1e-3
     worst = worst_of(want_grid, want_p)
+    worst_l2 = worst_of(want_grid, want_p, "l2")
     # (2) the fully independent oracle (its own refiner): the importance samples agree except where the inverse cdf sits on
     # its `denominator < eps` switch (the forward tests' depth tolerance); a moved sample moves one sample's scatter
     free_grid, free_p, dz = oracle(False)
@@ -113,9 +137,11 @@ def test_render_rays_backward_vs_oracle_autograd(gu, P, Pf, C, R, n_cam, n_rays,
     l2 = float((ggrid.cpu() - free_grid).norm() / free_grid.norm())
     worst_free = worst_of(free_grid, free_p)
     print(f"\nrender backward P={P} Pf={Pf} C={C} R={R} rays={n_cam}x{n_rays} [{which}]: worst relative gradient error "
-          f"{worst[1]:.2e} ({worst[0]}) at the kernel's sample placement; independent refiner: {100 * moved:.3f} % of the "
-          f"samples moved by > 1e-3, grid gradient L2 error {l2:.2e}, worst max-norm error {worst_free[1]:.2e} ({worst_free[0]})")
-    assert worst[1] < 1e-3, worst
+          f"{worst[1]:.2e} ({worst[0]}) max norm, {worst_l2[1]:.2e} ({worst_l2[0]}) L2, vs the float64 oracle at the kernel's "
+          f"sample placement; independent float32 oracle: {100 * moved:.3f} % of the samples moved by > 1e-3, grid gradient L2 "
+          f"error {l2:.2e}, worst max-norm error {worst_free[1]:.2e} ({worst_free[0]})")
+    many = n_cam * n_rays * (P + Pf) > 50000
+    assert worst[1] < (1e-2 if many else 1e-3) and worst_l2[1] < (2e-3 if many else 1e-3), (worst, worst_l2)
     assert moved < 5e-3 and l2 < 2e-2 and worst_free[1] < 5e-2, (moved, l2, worst_free)
 
 
