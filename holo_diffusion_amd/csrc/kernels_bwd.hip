@@ -20,6 +20,7 @@
 //   attn_ds_kernel, transpose_kernel   softmax backward rows and the T x T transposition around the batched fp32 MFMA GEMMs
 //   colsum_*                 bias gradients;  time_embed_bwd_kernel, film_bwd_* the (tiny) embedding path
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "holo_common.h"
@@ -131,6 +132,165 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int oc = ct * 32 + row, ic = it * 32 + col;
     if (oc < p.Cout && ic < Cin)
       p.partial[(((int64_t)blockIdx.y * p.Cout + oc) * Cin + ic) * p.ntaps + tap] = v;
+  }
+}
+
+// ---- weight gradient, row-staged form (3x3x3, stride 1, pad 1, OW <= 64) -----------------------------------------------
+// The tile kernel above re-reads gy and x once per (tap, channel-tile pair): 27 x more fabric traffic than the tensors.
+// Here a workgroup owns one (32 co, 32 ci) pair for ALL 27 taps over a slab of output rows (n, od, oh): per output row the
+// gy row [OW][32] and the nine ACTIVATED input rows (kd, kh) [OW + 2][32] sit in LDS (84 KB at OW = 64; a ring of three y
+// rows per kd, so a step along oh brings three new rows, requested under the previous row's MFMAs); wave w accumulates taps
+// w, w + 4, ... (7 x 16 accumulator registers): per voxel pair one A operand (gy) and seven B operands (x at the tap's
+// shift) from LDS, both bank-conflict free (a voxel is one 128-byte row, the pair's two voxels cover the 64 banks).
+constexpr int WR_MAXW = 64;
+struct WgradRowLds {
+  float gy[WR_MAXW * 32];
+  float x[9][(WR_MAXW + 2) * 32];
+};
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(16))) WgradRowLds S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int Cin = p.C0 + p.C1;
+  const int nit = (Cin + 31) / 32;
+  const int it = blockIdx.x % nit, ct = blockIdx.x / nit;
+  const int OW = p.OW, XW = OW + 2;
+  const int SD = p.ups ? (p.ID >> 1) : p.ID, SH = p.ups ? (p.IH >> 1) : p.IH, SW = p.ups ? (p.IW >> 1) : p.IW;
+  // the ci tile lies inside one source of the virtual concat (C0 % 32 == 0)
+  const float* src = p.src0;
+  int Cs = p.C0, cs0 = it * 32;
+  if (cs0 >= p.C0) {
+    src = p.src1;
+    Cs = p.C1;
+    cs0 -= p.C0;
+  }
+  const int64_t nrows = (int64_t)p.N * p.OD * p.OH;
+  const int64_t r_lo = nrows * blockIdx.y / gridDim.y, r_hi = nrows * (blockIdx.y + 1) / gridDim.y;
+  // staging items: (voxel, 4-channel group) as float4.  gy: OW * 8 items; one x row: XW * 8 items
+  constexpr int GYI = (WR_MAXW * 8 + 255) / 256;        // 2
+  constexpr int XI = ((WR_MAXW + 2) * 8 * 3 + 255) / 256;  // 7 (three rows per step)
+  float4 rg[GYI], rx[XI];
+  auto gy_issue = [&](int n, int od, int oh) {
+    const float* row = p.gy + (((int64_t)n * p.OD + od) * p.OH + oh) * (int64_t)OW * p.Cout + ct * 32;
+#pragma unroll
+    for (int i = 0; i < GYI; ++i) {
+      const int id = tid + 256 * i, v = min(id >> 3, OW - 1), g = id & 7;
+      const int c = min(ct * 32 + g * 4, p.Cout - 4) - ct * 32;  // clamped, masked at commit
+      rg[i] = *reinterpret_cast<const float4*>(row + (int64_t)v * p.Cout + c);
+    }
+  };
+  auto gy_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < GYI; ++i) {
+      const int id = tid + 256 * i, v = id >> 3, g = id & 7;
+      if (v < OW) {
+        const bool ok = ct * 32 + g * 4 < p.Cout;
+        *reinterpret_cast<float4*>(S.gy + v * 32 + g * 4) = ok ? rg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  // x rows (kd = 0..2) at input row y of plane od (virtual coordinates z = od + kd - 1), item i of 3 * XW * 8
+  auto x_issue = [&](int n, int od, int y) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int id = min(tid + 256 * i, 3 * XW * 8 - 1);
+      const int kd = id / (XW * 8), rem = id - kd * (XW * 8), v = rem >> 3, g = rem & 7;
+      int z = od + kd - 1, yy = y, xx = v - 1;
+      z = min(max(z, 0), p.ID - 1), yy = min(max(yy, 0), p.IH - 1), xx = min(max(xx, 0), p.IW - 1);
+      if (p.ups) z >>= 1, yy >>= 1, xx >>= 1;
+      const int c = min(cs0 + g * 4, Cs - 4);
+      rx[i] = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + yy) * SW + xx) * Cs + c);
+    }
+  };
+  auto x_commit = [&](int n, int od, int y) {
+    const int ys = ((y % 3) + 3) % 3;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int id = tid + 256 * i;
+      if (id >= 3 * XW * 8) continue;
+      const int kd = id / (XW * 8), rem = id - kd * (XW * 8), v = rem >> 3, g = rem & 7;
+      const int z = od + kd - 1, xx = v - 1;
+      const bool inside = z >= 0 && z < p.ID && y >= 0 && y < p.IH && xx >= 0 && xx < p.IW && it * 32 + g * 4 < Cin;
+      float4 t = rx[i];
+      if (p.coef) {
+        const float4 c01 = *reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + min(it * 32 + g * 4, Cin - 4)) * 2);
+        const float4 c23 = *reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + min(it * 32 + g * 4, Cin - 4)) * 2 + 4);
+        t.x = fmaf(t.x, c01.x, c01.y), t.y = fmaf(t.y, c01.z, c01.w), t.z = fmaf(t.z, c23.x, c23.y), t.w = fmaf(t.w, c23.z, c23.w);
+        if (p.act) t.x = silu_b(t.x), t.y = silu_b(t.y), t.z = silu_b(t.z), t.w = silu_b(t.w);
+      }
+      if (!inside) t = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding AFTER the activation
+      *reinterpret_cast<float4*>(S.x[kd * 3 + ys] + v * 32 + g * 4) = t;
+    }
+  };
+  f32x16 acc[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  int toff[7], tslot_kd[7], tkh[7];  // per tap of this wave: kw, kd, kh
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = min(wave + 4 * j, 26);
+    const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+    toff[j] = kw * 32;
+    tslot_kd[j] = kd * 3;
+    tkh[j] = kh;
+  }
+  const int ntap = wave < 3 ? 7 : 6;
+
+  bool have_plane = false;
+  for (int64_t row = r_lo; row < r_hi; ++row) {
+    const int oh = (int)(row % p.OH);
+    const int od = (int)((row / p.OH) % p.OD);
+    const int n = (int)(row / ((int64_t)p.OH * p.OD));
+    if (!have_plane || oh == 0) {  // first row of the slab or of a plane: all nine rows
+      __syncthreads();
+      for (int y = oh - 1; y <= oh + 1; ++y) {
+        x_issue(n, od, y);
+        x_commit(n, od, y);
+      }
+      gy_issue(n, od, oh);
+      gy_commit();
+      __syncthreads();
+      have_plane = true;
+    }
+    const bool nxt = row + 1 < r_hi && oh + 1 < p.OH;  // the next row continues this plane: request its new data now
+    if (nxt) {
+      x_issue(n, od, oh + 2);
+      gy_issue(n, od, oh + 1);
+    }
+    // ---- MFMAs of this row: voxel pairs (2u, 2u + 1); A = gy[voxel][co li], B = x[voxel + kw][ci li]
+    int slot[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) slot[j] = tslot_kd[j] + ((oh + tkh[j] - 1) % 3 + 3) % 3;
+#pragma unroll 2
+    for (int u = 0; u < OW / 2; ++u) {
+      const int v = 2 * u + lh;
+      const float av = S.gy[v * 32 + li];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        if (j < ntap) {
+          const float bv = S.x[slot[j]][v * 32 + toff[j] + li];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (nxt) {
+      __syncthreads();  // every wave is done with this row's operands
+      x_commit(n, od, oh + 2);
+      gy_commit();
+      __syncthreads();
+    }
+  }
+  // D layout: column = ci li, rows = co (r&3) + 8 (r>>2) + 4 lh
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    if (j >= ntap) continue;
+    const int tap = wave + 4 * j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ic = it * 32 + li;
+      if (oc < p.Cout && ic < Cin) p.partial[(((int64_t)blockIdx.y * p.Cout + oc) * Cin + ic) * p.ntaps + tap] = acc[j][r];
+    }
   }
 }
 
@@ -594,11 +754,30 @@ int weight_tco_ci_launch(const float* in, float* out, int Co, int Ci, int T, voi
   return 0;
 }
 
+// the row-staged kernel serves the stride-1 3x3x3 convolutions of rows up to 64 voxels (HOLO_WGRAD_TILES=1: tile kernel)
+static bool wgrad_rows_ok(const WgradParams& p) {
+#ifndef HOLO_EMU
+  static const char* e = getenv("HOLO_WGRAD_TILES");
+  if (e && atoi(e) > 0) return false;
+#endif
+  const int Cin = p.C0 + p.C1;
+  return p.ksz == 3 && p.stride == 1 && p.pad == 1 && p.OW <= WR_MAXW && (p.OW & 1) == 0 && p.ID == p.OD && p.IH == p.OH &&
+         p.IW == p.OW && (Cin & 3) == 0 && (p.Cout & 3) == 0 && (p.C0 & 3) == 0 && (p.C1 & 3) == 0 && (!p.src1 || (p.C0 & 31) == 0);
+}
 int wgrad_splits(const WgradParams& p, int num_cus) {
   const int Cin = p.C0 + p.C1;
-  const int64_t tiles = (int64_t)((p.Cout + 31) / 32) * ((Cin + 31) / 32) * p.ntaps;
   const int64_t nrows = (int64_t)p.N * p.OD * p.OH;
-  int64_t s = (8LL * (num_cus > 0 ? num_cus : 256) + tiles - 1) / tiles;  // ~8 workgroups per CU in flight over the launch
+  const int ncu = num_cus > 0 ? num_cus : 256;
+  if (wgrad_rows_ok(p)) {  // one workgroup per CU (84 KB of LDS); slabs of at least 8 rows keep the row ring useful
+    const int64_t pairs = (int64_t)((p.Cout + 31) / 32) * ((Cin + 31) / 32);
+    int64_t s = (ncu + pairs - 1) / pairs;
+    if (s > nrows / 8) s = nrows / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+  }
+  const int64_t tiles = (int64_t)((p.Cout + 31) / 32) * ((Cin + 31) / 32) * p.ntaps;
+  int64_t s = (8LL * ncu + tiles - 1) / tiles;  // ~8 workgroups per CU in flight over the launch
   if (s > nrows / 4) s = nrows / 4;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
@@ -615,8 +794,13 @@ int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_c
     return -1;
   }
   const int splits = wgrad_splits(p, num_cus);
-  dim3 grid((unsigned)(((p.Cout + 31) / 32) * ((Cin + 31) / 32) * p.ntaps), (unsigned)splits);
-  HOLO_LAUNCH(conv_wgrad_kernel, grid, dim3(256), stream, p);
+  if (wgrad_rows_ok(p)) {
+    dim3 grid((unsigned)(((p.Cout + 31) / 32) * ((Cin + 31) / 32)), (unsigned)splits);
+    HOLO_LAUNCH(conv_wgrad_rows_kernel, grid, dim3(256), stream, p);
+  } else {
+    dim3 grid((unsigned)(((p.Cout + 31) / 32) * ((Cin + 31) / 32) * p.ntaps), (unsigned)splits);
+    HOLO_LAUNCH(conv_wgrad_kernel, grid, dim3(256), stream, p);
+  }
   const int64_t n = (int64_t)p.Cout * Cin * p.ntaps;
   HOLO_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), stream, p.partial, dw, n, splits, accumulate);
   return 0;
