@@ -142,13 +142,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // rows per kd, so a step along oh brings three new rows, requested under the previous row's MFMAs); wave w accumulates taps
 // w, w + 4, ... (7 x 16 accumulator registers): per voxel pair one A operand (gy) and seven B operands (x at the tap's
 // shift) from LDS, both bank-conflict free (a voxel is one 128-byte row, the pair's two voxels cover the 64 banks).
+// Three shapes: rows up to 64 voxels - 8 waves (4 / 3 taps each), 84 KB: one workgroup per CU, two waves per SIMD;
+// up to 32 and up to 16 - 4 waves (7 / 6 taps), 43 / 23 KB: two workgroups per CU (168 registers would spill).
 constexpr int WR_MAXW = 64;
+template <int MAXW>
 struct WgradRowLds {
-  float gy[WR_MAXW * 32];
-  float x[9][(WR_MAXW + 2) * 32];
+  float gy[MAXW * 32];
+  float x[9][(MAXW + 2) * 32];
 };
-__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
-  __shared__ __attribute__((aligned(16))) WgradRowLds S;
+template <int MAXW, int NW>
+__global__ __launch_bounds__((64 * NW), 2) void conv_wgrad_rows_kernel(WgradParams p) {
+  constexpr int NT = 64 * NW;              // threads
+  constexpr int TPW = (27 + NW - 1) / NW;  // taps per wave
+  __shared__ __attribute__((aligned(16))) WgradRowLds<MAXW> S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int Cin = p.C0 + p.C1;
   const int nit = (Cin + 31) / 32;
@@ -165,55 +171,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
   }
   const int64_t nrows = (int64_t)p.N * p.OD * p.OH;
   const int64_t r_lo = nrows * blockIdx.y / gridDim.y, r_hi = nrows * (blockIdx.y + 1) / gridDim.y;
-  // staging items: (voxel, 4-channel group) as float4.  gy: OW * 8 items; one x row: XW * 8 items
-  constexpr int GYI = (WR_MAXW * 8 + 255) / 256;        // 2
-  constexpr int XI = ((WR_MAXW + 2) * 8 * 3 + 255) / 256;  // 7 (three rows per step)
+  // staging items: (voxel, 4-channel group g) as float4; NT % 8 == 0, so a thread's items all have g = tid & 7 and ONE set
+  // of (a, b) coefficients per sample serves them
+  constexpr int GYI = (MAXW * 8 + NT - 1) / NT;
+  constexpr int XI = ((MAXW + 2) * 8 * 3 + NT - 1) / NT;  // three rows per step
+  const int g = tid & 7;
+  const bool g_in = it * 32 + g * 4 < Cin, g_out = ct * 32 + g * 4 < p.Cout;
+  const int gc_in = min(cs0 + g * 4, Cs - 4), gc_out = min(ct * 32 + g * 4, p.Cout - 4);
   float4 rg[GYI], rx[XI];
+  float4 c01 = make_float4(1.f, 0.f, 1.f, 0.f), c23 = c01;
+  int coef_n = -1;
   auto gy_issue = [&](int n, int od, int oh) {
-    const float* row = p.gy + (((int64_t)n * p.OD + od) * p.OH + oh) * (int64_t)OW * p.Cout + ct * 32;
+    const float* row = p.gy + (((int64_t)n * p.OD + od) * p.OH + oh) * (int64_t)OW * p.Cout + gc_out;
 #pragma unroll
     for (int i = 0; i < GYI; ++i) {
-      const int id = tid + 256 * i, v = min(id >> 3, OW - 1), g = id & 7;
-      const int c = min(ct * 32 + g * 4, p.Cout - 4) - ct * 32;  // clamped, masked at commit
-      rg[i] = *reinterpret_cast<const float4*>(row + (int64_t)v * p.Cout + c);
+      const int v = min((tid + NT * i) >> 3, OW - 1);
+      rg[i] = *reinterpret_cast<const float4*>(row + (int64_t)v * p.Cout);
     }
   };
   auto gy_commit = [&]() {
 #pragma unroll
     for (int i = 0; i < GYI; ++i) {
-      const int id = tid + 256 * i, v = id >> 3, g = id & 7;
-      if (v < OW) {
-        const bool ok = ct * 32 + g * 4 < p.Cout;
-        *reinterpret_cast<float4*>(S.gy + v * 32 + g * 4) = ok ? rg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      const int v = (tid + NT * i) >> 3;
+      if (v < OW) *reinterpret_cast<float4*>(S.gy + v * 32 + g * 4) = g_out ? rg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  // x rows (kd = 0..2) at input row y of plane od (virtual coordinates z = od + kd - 1), item i of 3 * XW * 8
+  // x rows (kd = 0..2) at input row y of plane od (virtual coordinates z = od + kd - 1): item = (kd, voxel)
   auto x_issue = [&](int n, int od, int y) {
+    int yy = min(max(y, 0), p.IH - 1);
+    if (p.ups) yy >>= 1;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int id = min(tid + 256 * i, 3 * XW * 8 - 1);
-      const int kd = id / (XW * 8), rem = id - kd * (XW * 8), v = rem >> 3, g = rem & 7;
-      int z = od + kd - 1, yy = y, xx = v - 1;
-      z = min(max(z, 0), p.ID - 1), yy = min(max(yy, 0), p.IH - 1), xx = min(max(xx, 0), p.IW - 1);
-      if (p.ups) z >>= 1, yy >>= 1, xx >>= 1;
-      const int c = min(cs0 + g * 4, Cs - 4);
-      rx[i] = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + yy) * SW + xx) * Cs + c);
+      const int id = min((tid + NT * i) >> 3, 3 * XW - 1);
+      const int kd = id / XW, v = id - kd * XW;
+      int z = min(max(od + kd - 1, 0), p.ID - 1), xx = min(max(v - 1, 0), p.IW - 1);
+      if (p.ups) z >>= 1, xx >>= 1;
+      rx[i] = *reinterpret_cast<const float4*>(src + ((((int64_t)n * SD + z) * SH + yy) * SW + xx) * Cs + gc_in);
     }
   };
   auto x_commit = [&](int n, int od, int y) {
     const int ys = ((y % 3) + 3) % 3;
+    if (p.coef && n != coef_n) {
+      const float* cf = p.coef + ((int64_t)n * Cin + min(it * 32 + g * 4, Cin - 4)) * 2;
+      c01 = *reinterpret_cast<const float4*>(cf);
+      c23 = *reinterpret_cast<const float4*>(cf + 4);
+      coef_n = n;
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int id = tid + 256 * i;
-      if (id >= 3 * XW * 8) continue;
-      const int kd = id / (XW * 8), rem = id - kd * (XW * 8), v = rem >> 3, g = rem & 7;
+      const int id = (tid + NT * i) >> 3;
+      if (id >= 3 * XW) continue;
+      const int kd = id / XW, v = id - kd * XW;
       const int z = od + kd - 1, xx = v - 1;
-      const bool inside = z >= 0 && z < p.ID && y >= 0 && y < p.IH && xx >= 0 && xx < p.IW && it * 32 + g * 4 < Cin;
+      const bool inside = z >= 0 && z < p.ID && y >= 0 && y < p.IH && xx >= 0 && xx < p.IW && g_in;
       float4 t = rx[i];
       if (p.coef) {
-        const float4 c01 = *reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + min(it * 32 + g * 4, Cin - 4)) * 2);
-        const float4 c23 = *reinterpret_cast<const float4*>(p.coef + ((int64_t)n * Cin + min(it * 32 + g * 4, Cin - 4)) * 2 + 4);
         t.x = fmaf(t.x, c01.x, c01.y), t.y = fmaf(t.y, c01.z, c01.w), t.z = fmaf(t.z, c23.x, c23.y), t.w = fmaf(t.w, c23.z, c23.w);
         if (p.act) t.x = silu_b(t.x), t.y = silu_b(t.y), t.z = silu_b(t.z), t.w = silu_b(t.w);
       }
@@ -221,21 +233,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
       *reinterpret_cast<float4*>(S.x[kd * 3 + ys] + v * 32 + g * 4) = t;
     }
   };
-  f32x16 acc[7];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int j = 0; j < 7; ++j)
+  for (int j = 0; j < TPW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  int toff[7], tslot_kd[7], tkh[7];  // per tap of this wave: kw, kd, kh
+  int toff[TPW], tkd3[TPW], tkh[TPW];  // per tap of this wave: 32 kw, 3 kd, kh
+  int ntap = 0;
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int tap = min(wave + 4 * j, 26);
+  for (int j = 0; j < TPW; ++j) {
+    const int tap = min(wave + NW * j, 26);
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
     toff[j] = kw * 32;
-    tslot_kd[j] = kd * 3;
+    tkd3[j] = kd * 3;
     tkh[j] = kh;
+    if (wave + NW * j < 27) ntap = j + 1;
   }
-  const int ntap = wave < 3 ? 7 : 6;
 
   bool have_plane = false;
   for (int64_t row = r_lo; row < r_hi; ++row) {
@@ -259,17 +272,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
       gy_issue(n, od, oh + 1);
     }
     // ---- MFMAs of this row: voxel pairs (2u, 2u + 1); A = gy[voxel][co li], B = x[voxel + kw][ci li]
-    int slot[7];
+    const float* xb[TPW];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) slot[j] = tslot_kd[j] + ((oh + tkh[j] - 1) % 3 + 3) % 3;
-#pragma unroll 2
+    for (int j = 0; j < TPW; ++j) xb[j] = S.x[tkd3[j] + ((oh + tkh[j] - 1) % 3 + 3) % 3] + toff[j] + lh * 32 + li;
+    const float* ga = S.gy + lh * 32 + li;
+#pragma unroll 4
     for (int u = 0; u < OW / 2; ++u) {
-      const int v = 2 * u + lh;
-      const float av = S.gy[v * 32 + li];
+      const float av = ga[u * 64];
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
+      for (int j = 0; j < TPW; ++j) {
         if (j < ntap) {
-          const float bv = S.x[slot[j]][v * 32 + toff[j] + li];
+          const float bv = xb[j][u * 64];
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
         }
       }
@@ -283,9 +296,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(WgradParams p) {
   }
   // D layout: column = ci li, rows = co (r&3) + 8 (r>>2) + 4 lh
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
+  for (int j = 0; j < TPW; ++j) {
     if (j >= ntap) continue;
-    const int tap = wave + 4 * j;
+    const int tap = wave + NW * j;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int oc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ic = it * 32 + li;
@@ -768,9 +781,9 @@ int wgrad_splits(const WgradParams& p, int num_cus) {
   const int Cin = p.C0 + p.C1;
   const int64_t nrows = (int64_t)p.N * p.OD * p.OH;
   const int ncu = num_cus > 0 ? num_cus : 256;
-  if (wgrad_rows_ok(p)) {  // one workgroup per CU (84 KB of LDS); slabs of at least 8 rows keep the row ring useful
+  if (wgrad_rows_ok(p)) {  // workgroups per CU by LDS / registers (1 or 2); slabs of at least 8 rows keep the row ring useful
     const int64_t pairs = (int64_t)((p.Cout + 31) / 32) * ((Cin + 31) / 32);
-    int64_t s = (ncu + pairs - 1) / pairs;
+    int64_t s = ((p.OW > 32 ? 1 : 2) * (int64_t)ncu + pairs - 1) / pairs;
     if (s > nrows / 8) s = nrows / 8;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
@@ -796,7 +809,13 @@ int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_c
   const int splits = wgrad_splits(p, num_cus);
   if (wgrad_rows_ok(p)) {
     dim3 grid((unsigned)(((p.Cout + 31) / 32) * ((Cin + 31) / 32)), (unsigned)splits);
-    HOLO_LAUNCH(conv_wgrad_rows_kernel, grid, dim3(256), stream, p);
+    if (p.OW > 32) {
+      HOLO_LAUNCH((conv_wgrad_rows_kernel<64, 8>), grid, dim3(512), stream, p);
+    } else if (p.OW > 16) {
+      HOLO_LAUNCH((conv_wgrad_rows_kernel<32, 4>), grid, dim3(256), stream, p);
+    } else {
+      HOLO_LAUNCH((conv_wgrad_rows_kernel<16, 4>), grid, dim3(256), stream, p);
+    }
   } else {
     dim3 grid((unsigned)(((p.Cout + 31) / 32) * ((Cin + 31) / 32) * p.ntaps), (unsigned)splits);
     HOLO_LAUNCH(conv_wgrad_kernel, grid, dim3(256), stream, p);

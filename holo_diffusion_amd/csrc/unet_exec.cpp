@@ -181,6 +181,7 @@ struct HoloUnet {
   float* pstore_wino = nullptr;                        // Winograd-in-depth copies (36 / 2 pseudo-taps)
   std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
   std::map<const float*, const float*> wino2_of;       // fp32 private copy -> (z,y) Winograd copy
+  std::map<std::string, float*> dgrad_wino, dgrad_wino2;  // Winograd copies of the transposed (dgrad) weights
   // holo_unet_set_compute_dtype: 0 exact fp32 MFMA; 1 bf16: activations stored as bf16 in HBM, bf16 products with fp32
   // accumulation in the 3x3x3 convolutions and the long-sequence attention, fp32 GroupNorm statistics; 2 bf16x3 split
   // (fp32 storage, fp32-accurate)
@@ -1503,6 +1504,10 @@ int holo_unet_destroy(HoloUnet* net) {
   if (net->pstore_wino) (void)hipFree(net->pstore_wino);
   for (auto& kv : net->dgrad_w)
     if (kv.second) (void)hipFree(kv.second);
+  for (auto& kv : net->dgrad_wino)
+    if (kv.second) (void)hipFree(kv.second);
+  for (auto& kv : net->dgrad_wino2)
+    if (kv.second) (void)hipFree(kv.second);
   if (net->dgrad_tmp) (void)hipFree(net->dgrad_tmp);
   delete net;
   return 0;
@@ -1789,7 +1794,28 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
     net->dgrad_tmp_floats = (size_t)s.numel;
   }
   if (flip_transpose_weight_launch((const float*)dev_ptr, net->dgrad_tmp, Co, Ci, T, stream)) return HOLO_E_INVALID;
-  return repack_conv_weight_launch(net->dgrad_tmp, dst, Ci, Co, T, pad_cout(Ci), pad_cin(Co), stream) ? HOLO_E_INVALID : 0;
+  if (repack_conv_weight_launch(net->dgrad_tmp, dst, Ci, Co, T, pad_cout(Ci), pad_cin(Co), stream)) return HOLO_E_INVALID;
+  // Winograd copies of the transposed convolution (the dgrad of a wide-level 3x3x3 conv runs on conv_wino2_kernel like
+  // the forward conv: 36 + 48 pseudo-taps, same eligibility as holo_unet_create's except that the transposed conv's output
+  // channels are the forward conv's INPUT channels, up to 768 with the skip concat)
+  static const char* we = getenv("HOLO_CONV_WINO");
+  const bool wino_on = !(we && (we[0] == '0' || we[0] == '1'));
+  if (wino_on && net->compute_mode == 0 && T == 27 && (Ci % 64) == 0 && Ci <= 768 && Co <= 768) {
+    const size_t per_tap = (size_t)pad_cout(Ci) * pad_cin(Co);
+    float*& w1 = net->dgrad_wino[nm];
+    float*& w2 = net->dgrad_wino2[nm];
+    if (!w1 || !w2) {  // a plan sized before these copies existed chose other kernels (and scratch sizes)
+      net->tws_cache.clear();
+      net->tplan_batch = -1;
+    }
+    if (!w1) HIP_TRY(hipMalloc((void**)&w1, 36 * per_tap * sizeof(float)));
+    if (!w2) HIP_TRY(hipMalloc((void**)&w2, 48 * per_tap * sizeof(float)));
+    if (repack_conv_weight_wino_launch(net->dgrad_tmp, w1, Ci, Co, 27, pad_cout(Ci), pad_cin(Co), stream, 1)) return HOLO_E_INVALID;
+    if (repack_conv_weight_wino_launch(net->dgrad_tmp, w2, Ci, Co, 27, pad_cout(Ci), pad_cin(Co), stream, 2)) return HOLO_E_INVALID;
+    net->wino_of[dst] = w1;
+    net->wino2_of[dst] = w2;
+  }
+  return 0;
 }
 
 size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch) {
