@@ -302,8 +302,24 @@ __global__ __launch_bounds__((64 * NW), 2) void conv_wgrad_rows_kernel(WgradPara
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int oc = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, ic = it * 32 + li;
-      if (oc < p.Cout && ic < Cin) p.partial[(((int64_t)blockIdx.y * p.Cout + oc) * Cin + ic) * p.ntaps + tap] = acc[j][r];
+      // tap-major partials [slab][tap][co][ci]: a register's 32 lanes write one 128-byte row (wgrad_reduce_t_kernel
+      // transposes to OIDHW while it sums the slabs)
+      if (oc < p.Cout && ic < Cin) p.partial[(((int64_t)blockIdx.y * p.ntaps + tap) * p.Cout + oc) * Cin + ic] = acc[j][r];
     }
+  }
+}
+
+// dW[co][ci][tap] (+)= sum_s partial[s][tap][co][ci]   (threads walk the partials' layout: coalesced reads)
+__global__ __launch_bounds__(256) void wgrad_reduce_t_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
+                                                            int Cin, int ntaps, int splits, int accumulate) {
+  const int64_t per_tap = (int64_t)Cout * Cin, n = per_tap * ntaps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i / per_tap);
+    const int64_t cc = i - (int64_t)tap * per_tap;  // co * Cin + ci
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += (double)partial[(int64_t)k * n + i];
+    float* d = dw + cc * ntaps + tap;
+    *d = (accumulate ? *d : 0.f) + (float)s;
   }
 }
 
@@ -821,7 +837,11 @@ int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_c
     HOLO_LAUNCH(conv_wgrad_kernel, grid, dim3(256), stream, p);
   }
   const int64_t n = (int64_t)p.Cout * Cin * p.ntaps;
-  HOLO_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), stream, p.partial, dw, n, splits, accumulate);
+  if (wgrad_rows_ok(p)) {
+    HOLO_LAUNCH(wgrad_reduce_t_kernel, dim3(blocks_for(n)), dim3(256), stream, p.partial, dw, p.Cout, Cin, p.ntaps, splits, accumulate);
+  } else {
+    HOLO_LAUNCH(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), stream, p.partial, dw, n, splits, accumulate);
+  }
   return 0;
 }
 
