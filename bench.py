@@ -205,6 +205,30 @@ def side_batched_chains(net, diff, w, device, batches=(2, 4), warm=5, timed=20):
     return res
 
 
+def side_training_step(net, w, device, warm=1, timed=3):
+    """forward + backward of the denoiser at the north-star size through holo_unet_backward (the taped
+    forward re-run, dgrad on the forward's convolution kernels with transposed weights, row-staged wgrad, GroupNorm /
+    attention backward; every parameter gradient + the input gradient).  The optimiser step is the caller's."""
+    x = torch.randn(1, w["feature_size"], *(w["resol"],) * 3, device=device)
+    g = torch.randn_like(x)
+    t = torch.tensor([500], device=device)
+    names = ["out.2.weight"]  # (all gradients are computed; one is fetched)
+    for _ in range(warm):
+        net.backward(x, t, g, params=names)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        net.backward(x, t, g, params=names)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / timed
+    res = {"forward_backward_ms": 1e3 * dt, "calls": timed, "warmup": warm,
+           "tflops_algorithmic": 3 * FLOPS_PER_STEP[w["resol"]] / dt / 1e12,
+           "workload": "north-star denoiser, batch 1: taped forward + input / parameter gradients (3x the forward's multiply-adds)"}
+    net.__dict__.pop("_holo_train_ws", None)
+    torch.cuda.empty_cache()
+    return res
+
+
 def respawn_under_torchrun(n: int) -> None:
     """``python bench.py --gpus N`` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     import socket
@@ -495,7 +519,8 @@ def main():
     # same weights (the UNet's parameters do not depend on the grid size): 3 warm + 5 timed DDPM steps
     side = None
     if world == 1 and args.workload == "north" and args.compute_dtype == "f32" and not args.no_side:
-        side = {"donut128_bf16": side_donut128(usd, device), "batched_chains_f32": side_batched_chains(net, diff, w, device)}
+        side = {"donut128_bf16": side_donut128(usd, device), "batched_chains_f32": side_batched_chains(net, diff, w, device),
+                "training_step_f32": side_training_step(net, w, device)}
 
     # ---------------- the one exchange of the path: all_gather of the rendered frames over RCCL / xGMI.
     # Every rank contributes the frames of its own sample (the timed render call's output); timed separately from the
