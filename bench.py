@@ -545,6 +545,32 @@ def main():
                   "verified": bool(okt.item() == 1.0),
                   "what": f"all_gather of {F} frames x (rgb, depth, mask) @{H}x{W} fp32 per rank (generate.gather_frames)"}
 
+    # ---------------- the training branch's exchange: all-reduce of the denoiser's parameter gradients
+    # (165 M fp32 = 0.66 GB at the north-star size) in 64 MB buckets over RCCL / xGMI (holo_diffusion_amd/ddp.py); synthetic
+    # gradients of the real parameter shapes, timed apart from the denoise and render legs
+    grad_exchange = None
+    if world > 1 and args.workload == "north":
+        from holo_diffusion_amd.ddp import DEFAULT_BUCKET_BYTES, allreduce_gradients, plan_buckets
+        gsd = {k: torch.full(tuple(v.shape), float(rank + 1), device=device) for k, v in usd.items()}
+        nb = sum(v.numel() for v in gsd.values()) * 4
+        allreduce_gradients({k: v.clone() for k, v in list(gsd.items())[:4]})  # warm-up (communicator, rings)
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        allreduce_gradients(gsd)
+        barrier_sync(world)
+        dta = max_over_ranks(time.perf_counter() - t0, world, device)
+        mean = (world + 1) / 2.0
+        okg = torch.tensor([1.0 if all(bool((v == mean).all()) for v in list(gsd.values())[:8]) else 0.0], device=device)
+        dist.all_reduce(okg, op=dist.ReduceOp.MIN)
+        grad_exchange = {"allreduce_ms": 1e3 * dta, "bytes": nb, "buckets": len(plan_buckets(gsd, DEFAULT_BUCKET_BYTES)),
+                         "bucket_bytes": DEFAULT_BUCKET_BYTES, "rccl_world_size": dist.get_world_size(),
+                         "backend": dist.get_backend(), "algbw_GBps": nb / dta / 1e9,
+                         "busbw_GBps": nb * 2 * (world - 1) / world / dta / 1e9, "verified": bool(okg.item() == 1.0),
+                         "what": "average of the north-star denoiser's fp32 parameter gradients over the ranks (pack + bucketed "
+                                 "all_reduce + scale + unpack)"}
+        del gsd
+        torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, usd, msd)
@@ -603,7 +629,7 @@ def main():
                                 "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
                                 "frac_mfma": mlp_flops_per_ray * rays_per_s / world / 1e12 / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
-            "frame_gather": gather,
+            "frame_gather": gather, "grad_exchange": grad_exchange,
             "side_workloads": side,
             "opt_in_modes_not_reported": alt,
         }

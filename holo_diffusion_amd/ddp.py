@@ -1,0 +1,80 @@
+"""Data-parallel gradient exchange of the training branch ("DDP gradient all-reduce over RCCL").
+
+The reference trains under `accelerate` / DistributedDataParallel (experiment.py, trainer/): one process per GPU, every
+rank runs the training branch on its own batch and the parameter gradients are averaged before the optimiser step.  Here
+the gradients come out of the two backward entries as plain dicts (`HoloDiffusionModel.training_backward`), so the
+exchange is explicit: the tensors are packed, in dict order, into flat buckets and every bucket is one
+`all_reduce(SUM)` over the process group (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests),
+issued asynchronously so that packing bucket i+1 overlaps the ring of bucket i, then scaled by 1/world and unpacked.
+
+Bucket size: xGMI is point to point (7 links x ~153 GB/s per GPU) and a ring all-reduce moves 2 (N-1)/N of the bytes over
+every link of the ring, so the exchange is bandwidth bound from a few MB up; 64 MB buckets keep the per-collective launch
+latency (~20 us) three orders of magnitude below the transfer time while the 0.66 GB of fp32 gradients of the north-star
+denoiser still split into ~10 collectives whose packing overlaps the previous ring."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+DEFAULT_BUCKET_BYTES = 64 << 20
+
+
+def plan_buckets(grads: Dict[str, torch.Tensor], bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> List[List[str]]:
+    """Names per bucket, in dict order (identical on every rank: the dicts are built from the same parameter lists); a
+    tensor larger than the bucket gets a bucket of its own."""
+    buckets: List[List[str]] = []
+    cur: List[str] = []
+    cur_bytes = 0
+    for k, v in grads.items():
+        nb = v.numel() * v.element_size()
+        if cur and cur_bytes + nb > bucket_bytes:
+            buckets.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(k)
+        cur_bytes += nb
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def allreduce_gradients(grads: Dict[str, torch.Tensor], group: Optional[dist.ProcessGroup] = None,
+                        bucket_bytes: int = DEFAULT_BUCKET_BYTES, average: bool = True) -> Dict[str, torch.Tensor]:
+    """Sum (or average) every gradient over the ranks of ``group``, in place; returns ``grads``.  All tensors of a call
+    share dtype and device.  A single-process run (no initialised process group, or world size 1) is a no-op."""
+    if not grads or not dist.is_available() or not dist.is_initialized():
+        return grads
+    world = dist.get_world_size(group)
+    if world == 1:
+        return grads
+    first = next(iter(grads.values()))
+    for k, v in grads.items():
+        if v.dtype != first.dtype or v.device != first.device:
+            raise ValueError(f"allreduce_gradients: '{k}' is {v.dtype} on {v.device}, the first gradient {first.dtype} on {first.device}")
+    pending: List[Tuple[List[str], torch.Tensor, "dist.Work"]] = []
+    for names in plan_buckets(grads, bucket_bytes):
+        flat = torch.cat([grads[k].reshape(-1) for k in names])
+        pending.append((names, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
+    scale = 1.0 / world if average else 1.0
+    for names, flat, work in pending:
+        work.wait()
+        if average:
+            flat.mul_(scale)
+        off = 0
+        for k in names:
+            n = grads[k].numel()
+            grads[k].copy_(flat[off:off + n].view_as(grads[k]))
+            off += n
+    return grads
+
+
+def allreduce_training_gradients(out: dict, group: Optional[dist.ProcessGroup] = None,
+                                 bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> dict:
+    """The exchange for the dict ``HoloDiffusionModel.training_backward`` returns: the denoiser's and the RenderMLP's
+    parameter gradients are averaged over the ranks (one bucket sequence over both), the per-rank grid gradients are
+    left alone (every rank trains on its own scene batch)."""
+    merged = {("unet." + k): v for k, v in out["unet"].items()}
+    merged.update({("render_mlp." + k): v for k, v in out["render_mlp"].items()})
+    allreduce_gradients(merged, group=group, bucket_bytes=bucket_bytes, average=True)
+    return out
