@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -276,17 +278,35 @@ __global__ __launch_bounds__((64 * NW), 2) void conv_wgrad_rows_kernel(WgradPara
 #pragma unroll
     for (int j = 0; j < TPW; ++j) xb[j] = S.x[tkd3[j] + ((oh + tkh[j] - 1) % 3 + 3) % 3] + toff[j] + lh * 32 + li;
     const float* ga = S.gy + lh * 32 + li;
-#pragma unroll 4
-    for (int u = 0; u < OW / 2; ++u) {
-      const float av = ga[u * 64];
+    // (two straight-line bodies - TPW or TPW - 1 taps - chosen once per row: a guard per MFMA inside the loop would keep
+    // the compiler from hoisting the next pair's LDS reads above the current pair's MFMAs)
+    auto pairs = [&](auto nt) {
+      constexpr int NTAP = decltype(nt)::value;
+      // software pipelined by hand: the operands of pair u + 1 are requested before the MFMAs of pair u are issued
+      const int np = OW / 2;
+      float av = ga[0], bv[NTAP];
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        if (j < ntap) {
-          const float bv = xb[j][u * 64];
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
-        }
+      for (int j = 0; j < NTAP; ++j) bv[j] = xb[j][0];
+#pragma unroll 2
+      for (int u = 0; u < np; ++u) {
+        const int un = u + 1 < np ? u + 1 : u;
+        const float av_n = ga[un * 64];
+        float bv_n[NTAP];
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) bv_n[j] = xb[j][un * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = av_n;
+#pragma unroll
+        for (int j = 0; j < NTAP; ++j) bv[j] = bv_n[j];
       }
-    }
+    };
+    if (ntap == TPW)
+      pairs(std::integral_constant<int, TPW>());
+    else
+      pairs(std::integral_constant<int, TPW - 1>());
     if (nxt) {
       __syncthreads();  // every wave is done with this row's operands
       x_commit(n, od, oh + 2);

@@ -37,6 +37,7 @@ def _rel(got, want, floor):
 
 
 CASES = [(12, 10, 16, 8, 3, 13, "all")] if EMU else [(12, 10, 16, 8, 3, 13, "all"), (24, 20, 32, 16, 3, 37, "all"),
+                                                     (12, 10, 64, 8, 2, 9, "all"), (12, 10, 16, 8, 33, 5, "all"),
                                                      (64, 64, 32, 32, 2, 300, "all"), (24, 20, 16, 16, 2, 41, "fine_only"),
                                                      (16, 100, 16, 16, 2, 29, "no_noise"), (64, 64, 32, 32, 4, 700, "chunks")]
 
