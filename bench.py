@@ -264,11 +264,21 @@ def dry_run(args) -> None:
         parts = [torch.zeros_like(mine) for _ in range(live)]
         dist.all_gather(parts, mine)
         pids = [int(x.item()) for x in parts]
+        # the two exchanges of the N > 1 run on small tensors: frame all_gather and the gradient all-reduce
+        from holo_diffusion_amd.ddp import allreduce_gradients
+        from holo_diffusion_amd.generate import gather_frames
+        fr = torch.full((2, 5, 4, 4), float(rank), device=dev)
+        allf = gather_frames({rank: fr}, live, tuple(fr.shape), torch.device(dev))
+        g = {"a": torch.full((7, 3), float(rank + 1), device=dev), "b": torch.full((5,), float(rank + 1), device=dev)}
+        allreduce_gradients(g, bucket_bytes=64)
+        exch_ok = bool(torch.equal(allf[rank], fr)) and all(bool((v == (live + 1) / 2.0).all()) for v in g.values())
         dist.barrier()
         dist.destroy_process_group()
+    else:
+        exch_ok = True
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": live, "requested_gpus": args.gpus, "max_over_ranks": float(t.item()),
-                          "pids": pids, "backend": "nccl" if use_gpu else "gloo"}))
+                          "pids": pids, "backend": "nccl" if use_gpu else "gloo", "exchanges_ok": exch_ok}))
 
 
 def main():

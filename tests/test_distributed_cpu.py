@@ -58,6 +58,7 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["requested_gpus"] == 2 and line["max_over_ranks"] == 2.0
+    assert line["exchanges_ok"] is True  # frame all_gather + bucketed gradient all-reduce on small tensors
     assert len(set(line["pids"])) == 2
     # a single-rank run reports 1
     res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dry-run"], capture_output=True, text=True,
