@@ -259,6 +259,10 @@ struct RenderKernelParams {
 
 // ---- backward of the training-mode renderer (kernels_render_bwd.hip) ----
 // per ray record (36 floats): origin 3 | direction 3 | W_dir e(dir) + b_rad 3 | harmonic embedding of the normalised direction 27
+constexpr int RBWD_REC = 36;      // floats per ray record
+constexpr int RBWD_REC_DIR = 3;   // offset of the direction
+constexpr int RBWD_REC_RDIR = 6;  // offset of the radiance direction term
+constexpr int RBWD_REC_EMB = 9;   // offset of the 27 embedding entries
 struct RenderBwdRays {
   RenderKernelParams::Cam cams[RenderKernelParams::MAX_CAMS];
   int n_cams, n_rays;

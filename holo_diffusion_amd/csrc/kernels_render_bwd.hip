@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void rbwd_rays_kernel(RenderBwdRays p) {
     dir[j] = p2 - p1;
     org[j] = p1 - dir[j];
   }
-  float* o = p.rays + (int64_t)(p.ray0 + i) * 36;
+  float* o = p.rays + (int64_t)(p.ray0 + i) * RBWD_REC;
   const float nrm = fmaxf(sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), 1e-12f);  // F.normalize eps
   const float dn[3] = {dir[0] / nrm, dir[1] / nrm, dir[2] / nrm};
   float rd[3] = {p.b_rad[0], p.b_rad[1], p.b_rad[2]};
@@ -56,15 +56,15 @@ __global__ __launch_bounds__(256) void rbwd_rays_kernel(RenderBwdRays p) {
     const int a = j < 24 ? jj >> 2 : j - 24;
     const float arg = dn[a] * (float)(1 << (jj & 3));
     const float e = j < 12 ? sinf(arg) : (j < 24 ? cosf(arg) : dn[a]);
-    o[9 + j] = e;
+    o[RBWD_REC_EMB + j] = e;
 #pragma unroll
     for (int c = 0; c < 3; ++c) rd[c] = fmaf(p.w_dir[c * 27 + j], e, rd[c]);
   }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     o[j] = org[j];
-    o[3 + j] = dir[j];
-    o[6 + j] = rd[j];
+    o[RBWD_REC_DIR + j] = dir[j];
+    o[RBWD_REC_RDIR + j] = rd[j];
   }
 }
 
@@ -97,11 +97,11 @@ __device__ __forceinline__ void tri_setup(float px, float py, float pz, float ha
 }
 __device__ __forceinline__ void point_of(const RenderBwdChunk& p, int64_t pt, float& px, float& py, float& pz) {
   const int64_t ray = p.ray0 + pt / p.nm;
-  const float* rr = p.rays + ray * 36;
+  const float* rr = p.rays + ray * RBWD_REC;
   const float z = p.z_merged[p.ray0 * p.nm + pt];
-  px = rr[0] + z * rr[3];
-  py = rr[1] + z * rr[4];
-  pz = rr[2] + z * rr[5];
+  px = rr[0] + z * rr[RBWD_REC_DIR + 0];
+  py = rr[1] + z * rr[RBWD_REC_DIR + 1];
+  pz = rr[2] + z * rr[RBWD_REC_DIR + 2];
 }
 
 // F[pt][c4..c4+3]: one thread per (point, 4 channels); rows [n, n_pad) are zeroed (K padding of the GEMMs)
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void rbwd_gather_kernel(RenderBwdChunk p) {
 __global__ __launch_bounds__(256) void rbwd_point_fwd_kernel(RenderBwdChunk p) {
   const int64_t pt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pt >= p.n) return;
-  const float* rr = p.rays + (p.ray0 + pt / p.nm) * 36;
-  float r0 = rr[6], r1 = rr[7], r2 = rr[8];
+  const float* rr = p.rays + (p.ray0 + pt / p.nm) * RBWD_REC + RBWD_REC_RDIR;
+  float r0 = rr[0], r1 = rr[1], r2 = rr[2];
   for (int h = 0; h < p.Hd; ++h) {
     const float a = leaky(p.YT[(int64_t)h * p.ld + pt] + p.be[h]);
     p.AT[(int64_t)h * p.ld + pt] = a;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(128) void rbwd_dir_grad_kernel(const float* __restr
   if (i >= 84) return;
   const int j = i / 28, e = i - j * 28;
   double s = 0.0;
-  for (int64_t r = 0; r < n_rays_total; ++r) s += (double)gr_ray[r * 4 + j] * (e < 27 ? (double)rays[r * 36 + 9 + e] : 1.0);
+  for (int64_t r = 0; r < n_rays_total; ++r) s += (double)gr_ray[r * 4 + j] * (e < 27 ? (double)rays[r * RBWD_REC + RBWD_REC_EMB + e] : 1.0);
   out[i] = (float)s;
 }
 

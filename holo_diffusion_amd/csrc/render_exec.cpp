@@ -695,7 +695,7 @@ RbwdLayout rbwd_layout(const HoloRenderer* r, int n_cameras, int n_rays) {
   L.o_fwd = take((size_t)L.NR * 10 * sizeof(float));
   L.o_zm = take((size_t)L.NR * L.nm * sizeof(float));
   L.o_flags = take((size_t)L.NR * L.nm);
-  L.o_rays = take((size_t)L.NR * 36 * sizeof(float));
+  L.o_rays = take((size_t)L.NR * RBWD_REC * sizeof(float));
   L.o_grray = take((size_t)L.NR * 4 * sizeof(float));
   L.o_F = take((size_t)L.cap * L.C * sizeof(float));
   L.o_YT = take((size_t)L.Hp * L.cap * sizeof(float));
