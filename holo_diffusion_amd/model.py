@@ -329,6 +329,38 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             g = self.diffusion._extract(self.diffusion.sqrt_alphas_cumprod, t, g_x.shape) * g_x  # d q_sample / d x_start
         return {"unet": unet_grads, "render_mlp": render_grads, "voxel_features": g, "voxel_grid": g_grid}
 
+    def training_step(self, *, camera: PerspectiveCameras, voxel_features: torch.Tensor, rng_streams: dict, loss_fn) -> Dict[str, Any]:
+        """One optimisation step's worth of gradients for an ARBITRARY torch loss on the rendered outputs - the role of
+        ``preds["objective"].backward()`` in the reference's training loop (holo_diffusion_model.py:458-540, trainer/): the
+        TRAINING forward runs on the HIP path, ``loss_fn(preds)`` is evaluated by torch on the small per-ray tensors
+        (``images_render (n_targets,3,n_rays,1)``, ``depths_render``, ``masks_render`` and the ``*_coarse`` prev-stage
+        counterparts, all leaves that require grad), torch's autograd yields d loss / d outputs, and
+        ``training_backward`` carries them through the renderer and the denoiser.  Returns ``{"loss", "preds", "unet",
+        "render_mlp", "voxel_features", "voxel_grid"}``.  ``rng_streams`` as for ``training_backward`` (all draws given).
+        The reference's own objective (Implicitron ``ViewMetrics`` weighted by ``loss_weights``) is not restated here: any
+        callable on these tensors takes its place."""
+        with torch.no_grad():
+            preds = self.forward(camera=camera, evaluation_mode=EvaluationMode.TRAINING, voxel_features=voxel_features,
+                                 rng_streams=rng_streams)
+        rend = preds["rendered"]
+        leaves = {"images_render": rend.features.permute(0, 3, 1, 2), "depths_render": rend.depths.permute(0, 3, 1, 2),
+                  "masks_render": rend.masks.permute(0, 3, 1, 2)}
+        if rend.prev_stage is not None:
+            leaves.update({"images_render_coarse": rend.prev_stage.features.permute(0, 3, 1, 2),
+                           "depths_render_coarse": rend.prev_stage.depths.permute(0, 3, 1, 2),
+                           "masks_render_coarse": rend.prev_stage.masks.permute(0, 3, 1, 2)})
+        leaves = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+        with torch.enable_grad():
+            loss = loss_fn(dict(leaves))
+            cots = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+        names = {"images_render": "features", "depths_render": "depths", "masks_render": "masks",
+                 "images_render_coarse": "features_coarse", "depths_render_coarse": "depths_coarse",
+                 "masks_render_coarse": "masks_coarse"}
+        grads = {names[k]: g.permute(0, 2, 3, 1).contiguous() for k, g in zip(leaves, cots) if g is not None}
+        out = self.training_backward(camera=camera, voxel_features=voxel_features, rng_streams=rng_streams, grads=grads)
+        out.update({"loss": loss.detach(), "preds": {k: v.detach() for k, v in leaves.items()}})
+        return out
+
     @torch.no_grad()
     def _diffuse_and_denoise(self, voxel_features: torch.Tensor, rng_streams: Optional[dict]) -> torch.Tensor:
         """The diffusion mechanism of the TRAINING branch (holo_diffusion_model.py:386-418), forward only: sample a

@@ -230,3 +230,68 @@ def test_training_backward_chain_vs_oracle_autograd(gu, bootstrap):
                 worst = (group + "." + k, e)
     print(f"\ntraining backward chain (bootstrap={bootstrap}): worst relative gradient error {worst[1]:.2e} ({worst[0]})")
     assert worst[1] < 1e-3, worst
+
+
+@pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
+def test_training_step_with_a_torch_loss_vs_oracle_autograd(gu):
+    """HoloDiffusionModel.training_step: an ordinary torch loss on the rendered outputs (rgb MSE on both passes, mask binary
+    cross-entropy, an L1 depth term - the kind of objective Implicitron's ViewMetrics builds) is differentiated by torch
+    on the per-ray tensors and carried through the HIP backward; loss value and every gradient against the same loss
+    under autograd through the oracle pipeline."""
+    import torch.nn.functional as F
+    from oracle import diffusion_oracle as do
+    from oracle import unet_oracle as uo
+    R, C, P, Pf, n_rays = 8, 16, 16, 16, 29
+    model, ucfg, usd, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.n_train_target_views = 2
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    vf = torch.tanh(torch.from_numpy(np_noise(5, (1, C, R, R, R))))
+    xys = (torch.from_numpy(np_noise(13, (2, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = _streams(2, n_rays, P, Pf, 1200)
+    rs.update({"xys": xys, "timesteps": torch.tensor([420]), "q_noise": torch.from_numpy(np_noise(41, tuple(vf.shape))),
+               "bootstrap": False})
+    tgt_rgb = torch.from_numpy(np_noise(51, (2, 3, n_rays, 1))).mul(0.3).add(0.5).clamp(0, 1)
+    tgt_msk = (torch.from_numpy(np_noise(52, (2, 1, n_rays, 1))) > 0).float()
+    tgt_dep = torch.from_numpy(np_noise(53, (2, 1, n_rays, 1))).abs() + 9.0
+
+    def loss_fn(p, dev="cpu"):
+        m = p["masks_render"].clamp(1e-4, 1 - 1e-4)
+        return (F.mse_loss(p["images_render"], tgt_rgb.to(dev)) + F.mse_loss(p["images_render_coarse"], tgt_rgb.to(dev))
+                + 0.1 * F.binary_cross_entropy(m, tgt_msk.to(dev)) + 0.01 * (p["depths_render"] - tgt_dep.to(dev)).abs().mean())
+
+    dev_rs = {k: (v.to(gu.DEV) if torch.is_tensor(v) else v) for k, v in rs.items()}
+    out = model.training_step(camera=cams.to(gu.DEV), voxel_features=vf.to(gu.DEV), rng_streams=dev_rs,
+                              loss_fn=lambda p: loss_fn(p, gu.DEV))
+    # ---- oracle
+    orc = do.DiffusionOracle(1000)
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    with torch.enable_grad():
+        x0 = vf.clone().requires_grad_(True)
+        pu = {k: v.detach().clone().requires_grad_(True) for k, v in usd.items()}
+        pm = {k: v.detach().clone().requires_grad_(True) for k, v in msd.items()}
+        g = uo.unet_forward.__wrapped__(pu, ucfg, orc.q_sample(x0, rs["timesteps"], rs["q_noise"]), rs["timesteps"]).clamp(-1, 1)
+        rr = []
+        for i in range(2):
+            o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
+            rr.append(ro.render_rays.__wrapped__(g, pm, o, d, l, rcfg, "", u_coarse=rs["u_coarse"][i], u_fine=rs["u_fine"][i],
+                                                 noise_coarse=rs["noise_coarse"][i], noise_fine=rs["noise_fine"][i], noise_std=1.0))
+        st = lambda k, c: torch.stack([r[k].reshape(n_rays, c) for r in rr]).permute(0, 2, 1)[..., None]  # noqa: E731 (2,c,n_rays,1)
+        preds = {"images_render": st("rgb", 3), "depths_render": st("depth", 1), "masks_render": st("mask", 1),
+                 "images_render_coarse": st("rgb_c", 3)}
+        loss = loss_fn(preds)
+        mnames = [k for k in pm if k.startswith("_density_net") or k.startswith("_radiance_net")]
+        gs = torch.autograd.grad(loss, [x0] + [pu[k] for k in pu] + [pm[k] for k in mnames], allow_unused=True)
+    assert abs(float(out["loss"]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    want_u = {k: (v if v is not None else torch.zeros_like(pu[k])) for k, v in zip(pu, gs[1:1 + len(pu)])}
+    want_m = dict(zip(mnames, gs[1 + len(pu):]))
+    worst = ("voxel_features", _rel(out["voxel_features"].cpu(), gs[0], 1e-12))
+    for group, want in (("unet", want_u), ("render_mlp", want_m)):
+        scale = sorted(float(v.abs().max()) for v in want.values())[len(want) // 2]
+        for k in want:
+            e = _rel(out[group][k].cpu(), want[k], 1e-2 * scale)
+            if e > worst[1]:
+                worst = (group + "." + k, e)
+    print(f"\ntraining step (torch loss {float(loss):.5f}): worst relative gradient error {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-3, worst
