@@ -283,6 +283,7 @@ def test_training_step_with_a_torch_loss_vs_oracle_autograd(gu):
         loss = loss_fn(preds)
         mnames = [k for k in pm if k.startswith("_density_net") or k.startswith("_radiance_net")]
         gs = torch.autograd.grad(loss, [x0] + [pu[k] for k in pu] + [pm[k] for k in mnames], allow_unused=True)
+    loss = loss.detach()
     assert abs(float(out["loss"]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
     want_u = {k: (v if v is not None else torch.zeros_like(pu[k])) for k, v in zip(pu, gs[1:1 + len(pu)])}
     want_m = dict(zip(mnames, gs[1 + len(pu):]))
