@@ -28,6 +28,8 @@ static inline float holo_exp2(float x) { return std::exp2(x); }
 static inline float holo_max_xor32(float x) { return std::fmax(x, __shfl_xor(x, 32)); }
 static inline float holo_add_xor32(float x) { return x + __shfl_xor(x, 32); }
 #define HOLO_WAVE_SYNC() emu_wave().bar.wait()
+template <typename T>
+static inline T holo_ld_sys(const T* p) { return *p; }
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
 #define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
@@ -88,6 +90,13 @@ __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
     __builtin_amdgcn_wave_barrier();                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
+// System-scope load for SMALL caller-provided tensors (timesteps, ray lists): a few bytes just copied from pageable host
+// memory can sit behind a stale L2 line of the block's previous owner - measured: 8 wrong timestep reads in 610 calls fed
+// by fresh `tensor.to(device)` copies, 0 in 600 with this load (scripts/attn_first_stress.py); bulk tensors are not affected.
+template <typename T>
+__device__ __forceinline__ T holo_ld_sys(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 #define HOLO_PROBE_CLOCK() wall_clock64()
 // Delays the waves that landed in an odd wave slot of their SIMD (= the second resident workgroup of the CU).
 #define HOLO_PHASE_DELAY(ticks)                                                      \

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const int64_t* __re
   __shared__ float te[256], pre1[1024], h1[1024], gemb[1024], gh[1024];
   const int tid = threadIdx.x;
   for (int n = 0; n < N; ++n) {
-    const float tv = (float)t[n];
+    const float tv = (float)holo_ld_sys(t + n);
     const int half = mc / 2;
     for (int i = tid; i < mc; i += 256) {
       float v = 0.f;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restri
   __shared__ float h1[1024];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
-  const float tv = (float)t[n];
+  const float tv = (float)holo_ld_sys(t + n);  // (the caller's tensor, possibly just copied from the host)
   const int half = mc / 2;
   for (int i = tid; i < mc; i += 256) {
     float v = 0.f;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
                                                         const float* __restrict__ noise, int clip,
                                                         float* __restrict__ sample, float* __restrict__ pred) {
   const int b = blockIdx.y;
-  int64_t tt = timesteps[b];
+  int64_t tt = holo_ld_sys(timesteps + b);
   if (tt < 0) tt = 0;
   if (tt >= T) tt = T - 1;
   const float c1 = tables[tt * 4 + 0];

@@ -875,8 +875,8 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const int ray = min(ray0 + rr, rays_per_cam - 1);
       float xn, yn;
       if (TRAIN) {
-        xn = p.train.xys[((int64_t)cam_i * rays_per_cam + ray) * 2 + 0];
-        yn = p.train.xys[((int64_t)cam_i * rays_per_cam + ray) * 2 + 1];
+        xn = holo_ld_sys(p.train.xys + ((int64_t)cam_i * rays_per_cam + ray) * 2 + 0);  // (small caller tensors: system-scope loads, holo_common.h)
+        yn = holo_ld_sys(p.train.xys + ((int64_t)cam_i * rays_per_cam + ray) * 2 + 1);
       } else {
         const int py = ray / p.W, px = ray - py * p.W;
         const float hx = p.range_x / (float)p.W, hy = p.range_y / (float)p.H;
@@ -937,7 +937,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const float lo = i > 0 ? 0.5f * (zlin(i) + zlin(i - 1)) : zi;
       const float up = i + 1 < nc ? 0.5f * (zlin(i + 1) + zlin(i)) : zi;
       const int ray = min(ray0 + rr, rays_per_cam - 1);
-      const float u = p.train.u_coarse[((int64_t)cam_i * rays_per_cam + ray) * nc + i];
+      const float u = holo_ld_sys(p.train.u_coarse + ((int64_t)cam_i * rays_per_cam + ray) * nc + i);
       return lo + (up - lo) * u;
     };
     auto eval = [&](float z, float& sg, float& cr, float& cg, float& cb) {
@@ -968,7 +968,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const float zn = lane + 1 < nc ? zcoarse_r(rr, min(lane + 1, nc - 1)) : 0.f;
       float sraw = v.x;
       if (TRAIN && p.train.noise_coarse)
-        sraw += p.train.noise_std * p.train.noise_coarse[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nc + ic];
+        sraw += p.train.noise_std * holo_ld_sys(p.train.noise_coarse + ((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nc + ic);
       const float delta = lane + 1 < nc ? zn - zi : p.background_opacity;
       const float x = lane < nc ? delta * fmaxf(sraw, 0.f) : 0.f;
       const double Sx = wave_scan_incl_d((double)x, lane);
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         const int kc = kk < nf ? kk : nf - 1;
         float u = lin_space(0.f, 1.f, ustep, kc, nf);
         if (TRAIN && p.train.u_fine)  // sample_pdf(det = False): u ~ U[0,1) per sample (unsorted; the merge sorts)
-          u = p.train.u_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nf + kc];
+          u = holo_ld_sys(p.train.u_fine + ((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nf + kc);
         int lo = 0, hi = nb;  // ind = #{j < nb : cdf[j] <= u}  (searchsorted right = True)
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         float sraw = vv[e].x;
         if (TRAIN && p.train.noise_fine)  // a fresh draw per sorted point of the fine pass
           sraw += p.train.noise_std *
-                  p.train.noise_fine[((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nm + (q < nm ? q : nm - 1)];
+                  holo_ld_sys(p.train.noise_fine + ((int64_t)cam_i * rays_per_cam + min(ray, rays_per_cam - 1)) * nm + (q < nm ? q : nm - 1));
         const float dl = q + 1 < nm ? zz[e + 1] - zz[e] : p.background_opacity;
         xs[e] = q < nm ? dl * fmaxf(sraw, 0.f) : 0.f;
       }

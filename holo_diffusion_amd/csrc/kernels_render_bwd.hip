@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void rbwd_rays_kernel(RenderBwdRays p) {
   if (i >= p.n_cams * p.n_rays) return;
   const int cam_i = i / p.n_rays;
   const RenderKernelParams::Cam& cam = p.cams[cam_i];
-  const float xn = p.xys[(int64_t)(p.ray0 + i) * 2 + 0], yn = p.xys[(int64_t)(p.ray0 + i) * 2 + 1];
+  const float xn = holo_ld_sys(p.xys + (int64_t)(p.ray0 + i) * 2 + 0), yn = holo_ld_sys(p.xys + (int64_t)(p.ray0 + i) * 2 + 1);
   const float dc0 = (xn - cam.pp[0]) / cam.focal[0], dc1 = (yn - cam.pp[1]) / cam.focal[1], dc2 = 1.0f;
   float org[3], dir[3];
 #pragma unroll
@@ -180,9 +180,9 @@ __global__ __launch_bounds__(64) void rbwd_composite_kernel(RenderBwdChunk p) {
     const float* g_msk = fine ? p.g_mask : p.g_mask_c;
     float gr[3] = {0.f, 0.f, 0.f}, gd = 0.f, gm = 0.f;
     if (g_rgb)
-      for (int j = 0; j < 3; ++j) gr[j] = g_rgb[((int64_t)cam_i * 3 + j) * p.rays_per_cam + rc];
-    if (g_dep) gd = g_dep[ray];
-    if (g_msk) gm = g_msk[ray];
+      for (int j = 0; j < 3; ++j) gr[j] = holo_ld_sys(g_rgb + ((int64_t)cam_i * 3 + j) * p.rays_per_cam + rc);
+    if (g_dep) gd = holo_ld_sys(g_dep + ray);
+    if (g_msk) gm = holo_ld_sys(g_msk + ray);
     const float* noise = fine ? p.noise_fine : p.noise_coarse;
     const int np = fine ? nm : nc;
     const float gO = gm - (gr[0] * p.bg[0] + gr[1] * p.bg[1] + gr[2] * p.bg[2]);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void rbwd_composite_kernel(RenderBwdChunk p) {
       }
       if (q < nm) {
         float s = val[q].x;
-        if (noise) s += p.noise_std * noise[ray * np + k];
+        if (noise) s += p.noise_std * holo_ld_sys(noise + ray * np + k);
         s_prev = s;
         z_prev = z[q];
         prev = q;

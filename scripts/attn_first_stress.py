@@ -1,0 +1,58 @@
+"""Development probe: repeat the first-form bf16 attention case to catch a rare wrong result."""
+import os
+import sys
+
+import torch
+
+os.environ["HOLO_BF16_FLASH_MIN_T"] = "0"
+os.environ["HOLO_NO_FLASH_V2"] = sys.argv[2] if len(sys.argv) > 2 else "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tests.gpu_utils as gu  # noqa: E402
+from oracle import unet_oracle as uo  # noqa: E402
+from oracle.common import np_noise  # noqa: E402
+
+cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=128, num_res_blocks=2, channel_mult=(1, 2),
+                 attention_resolutions=(2,), num_heads=2)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+variant = sys.argv[3] if len(sys.argv) > 3 else "h2d"  # h2d: fresh host->device copies per call; dev: inputs resident; sync: copies + synchronize
+x = torch.from_numpy(np_noise(13, (2, 16, 16, 16, 16)))
+t = torch.tensor([77, 901], dtype=torch.int64)
+bad = 0
+ref = None
+first = None
+for i in range(n):
+    net, sd = gu.make_unet(cfg, seed=7, compute_dtype="bf16")
+    if ref is None:
+        ref = uo.unet_forward(sd, cfg, x, t)
+    # vary what the allocator hands out between iterations
+    junk = torch.full((1 + (i * 7919) % 50_000_000,), float("nan"), device=gu.DEV)
+    with torch.no_grad():
+        if variant == "dev":
+            if i == 0:
+                xd, td = x.to(gu.DEV), t.to(gu.DEV)
+            y = net(xd, td)
+            y2 = net(xd, td)
+        elif variant == "sync":
+            xa, ta = x.to(gu.DEV), t.to(gu.DEV)
+            torch.cuda.synchronize()
+            y = net(xa, ta)
+            xb, tb = x.to(gu.DEV), t.to(gu.DEV)
+            torch.cuda.synchronize()
+            y2 = net(xb, tb)
+        else:
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+            y2 = net(x.to(gu.DEV), t.to(gu.DEV))
+    err = gu.rel_err(y, ref)
+    same = bool(torch.equal(y, y2))
+    if first is None:
+        first = y.clone()
+    rep = bool(torch.equal(y, first))
+    if not (1e-5 < err < 2e-2) or not same or not rep:
+        bad += 1
+        d2 = (y2 - y).abs()
+        print(f"iter {i}: err {err:.3e} same-net repeat equal {same} (max diff {float(d2.max()):.3e}, {int((d2 > 0).sum())} elements, "
+              f"nan {bool(torch.isnan(y2).any())}, err of the repeat {gu.rel_err(y2, ref):.3e}), equal to first iteration {rep}")
+        nz = (d2 > 0).nonzero()
+        print("   first differing indices", nz[:4].tolist(), "last", nz[-2:].tolist())
+    del net, junk
+print(f"{bad} bad of {n}")
