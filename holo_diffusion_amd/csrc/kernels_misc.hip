@@ -309,9 +309,9 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
   int64_t tt = holo_ld_sys(timesteps + b);
   if (tt < 0) tt = 0;
   if (tt >= T) tt = T - 1;
-  const float c1 = tables[tt * 4 + 0];
-  const float c2 = tables[tt * 4 + 1];
-  const float lv = tables[tt * 4 + 2];
+  const float c1 = holo_ld_sys(tables + tt * 4 + 0);  // (a 16 KB table uploaded from the host: see holo_ld_sys)
+  const float c2 = holo_ld_sys(tables + tt * 4 + 1);
+  const float lv = holo_ld_sys(tables + tt * 4 + 2);
   const float sig = tt != 0 ? expf(0.5f * lv) : 0.f;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= per) return;
