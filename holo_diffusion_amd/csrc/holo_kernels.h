@@ -171,6 +171,8 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
                      const float* model_out, const float* noise, int clip, float* sample, float* pred_xstart,
                      void* stream);
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
+// dst = src for a SMALL caller-provided tensor, read with system-scope loads (holo_ld_sys, holo_common.h)
+int copy_sys_launch(const float* src, float* dst, int64_t n, void* stream);
 int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
 
 int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int Cin, int taps, int CoutP, int CinP,

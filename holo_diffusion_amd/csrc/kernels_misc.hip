@@ -335,6 +335,11 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(pred + o) = m;
 }
 
+// copy of a SMALL caller-provided tensor (biases, GroupNorm affine parameters, ...) with system-scope loads (holo_ld_sys)
+__global__ __launch_bounds__(256) void copy_sys_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = holo_ld_sys(src + i);
+}
 __global__ __launch_bounds__(256) void tanh_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = tanhf(x[i]);
@@ -543,6 +548,12 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
   return 0;
 }
 
+int copy_sys_launch(const float* src, float* dst, int64_t n, void* stream) {
+  int64_t blocks = cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  HOLO_LAUNCH(copy_sys_kernel, dim3((unsigned)blocks), dim3(256), stream, src, dst, n);
+  return 0;
+}
 int tanh_launch(const float* x, float* y, int64_t n, void* stream) {
   int64_t blocks = cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;

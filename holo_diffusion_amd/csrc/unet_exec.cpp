@@ -1574,6 +1574,8 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
                                           pad_cin((int)s.shape[1]), stream, 2);
       if (rc) return rc;
     }
+  } else if (s.numel <= 65536) {  // biases, GroupNorm parameters, small Linear layers: see holo_ld_sys
+    if (copy_sys_launch((const float*)dev_ptr, s.priv, s.numel, stream)) return HOLO_E_INVALID;
   } else {
     HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
