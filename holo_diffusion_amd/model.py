@@ -361,12 +361,14 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         out.update({"loss": loss.detach(), "preds": {k: v.detach() for k, v in leaves.items()}})
         return out
 
-    @torch.no_grad()
     def _diffuse_and_denoise(self, voxel_features: torch.Tensor, rng_streams: Optional[dict]) -> torch.Tensor:
-        """The diffusion mechanism of the TRAINING branch (holo_diffusion_model.py:386-418), forward only: sample a
-        timestep, diffuse the clean grid (q_sample), predict it back (pred_xstart of p_mean_variance, clamped) - and, with
-        probability ``bootstrap_prob``, once more on the prediction ("bootstrap").  Random draws may be injected through
-        ``rng_streams``: ``timesteps`` / ``q_noise`` (first round), ``bootstrap`` (bool), ``timesteps2`` / ``q_noise2``."""
+        """The diffusion mechanism of the TRAINING branch (holo_diffusion_model.py:386-418): sample a timestep, diffuse the
+        clean grid (q_sample), predict it back (pred_xstart of p_mean_variance, clamped) - and, with probability
+        ``bootstrap_prob``, once more on the prediction ("bootstrap").  Random draws may be injected through
+        ``rng_streams``: ``timesteps`` / ``q_noise`` (first round), ``bootstrap`` (bool), ``timesteps2`` / ``q_noise2``.
+        With autograd enabled the rounds are differentiable (q_sample and the clamp in torch, the denoiser through its
+        autograd node) - ``loss.backward()`` then reaches the denoiser's parameters and the clean grid as in the reference;
+        otherwise the fused posterior kernel produces pred_xstart."""
         import numpy as np
         rs = rng_streams or {}
         dev = voxel_features.device
@@ -378,6 +380,8 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
             t = torch.as_tensor(t, device=dev, dtype=torch.int64).reshape(x0.shape[0])
             nz = rs.get(n_key)
             x_t = self.diffusion.q_sample(x0, t, noise=nz.to(dev) if nz is not None else None)
+            if torch.is_grad_enabled() and (x_t.requires_grad or any(p.requires_grad for p in self.net_3d.parameters())):
+                return self.net_3d(x_t, t).clamp(-1.0, 1.0)  # pred_xstart of the START_X parameterisation, clip_denoised
             return self.diffusion.p_mean_variance(model=self.net_3d, x=x_t, t=t, clip_denoised=True, model_kwargs={})["pred_xstart"]
 
         out = one_round(voxel_features, "timesteps", "q_noise")

@@ -613,8 +613,27 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         new samples, stratified depths / importance samples, density noise of std ``density_noise_std_train`` on both
         passes.  The random streams are drawn with torch on the device unless injected through ``rng_streams`` (keys
         ``u_coarse (n_cam,n_rays,P)``, ``u_fine (n_cam,n_rays,Pf)``, ``noise_coarse (n_cam,n_rays,P)``,
-        ``noise_fine (n_cam,n_rays,P+Pf)`` - the parity tests inject them).  Forward only: no autograd graph is built."""
+        ``noise_fine (n_cam,n_rays,P+Pf)`` - the parity tests inject them).  With autograd enabled and a grid or RenderMLP
+        parameter that requires grad the outputs hang on an autograd node (``_HoloRenderRaysFn``) whose backward is
+        ``holo_render_rays_backward``: ``loss.backward()`` fills the grid's and the parameters' ``.grad``."""
         a = self._training_setup(bundle, implicit_functions, rng_streams)
+        mlp_params = dict(a["fn"].render_mlp.named_parameters())
+        grid_in = implicit_functions[0].bound_args.get("voxel_grid_features")
+        if torch.is_grad_enabled() and a["two_pass"] and (grid_in.requires_grad or any(p.requires_grad for p in mlp_params.values())):
+            # the draws of this call (injected or made by _training_setup) are what the backward pass must see again
+            streams = {k: a[s] for k, s in (("u_coarse", "u_c"), ("u_fine", "u_f"), ("noise_coarse", "nz_c"), ("noise_fine", "nz_f"))
+                       if a[s] is not None}
+            names = list(mlp_params)
+            outs = _HoloRenderRaysFn.apply(self, bundle, implicit_functions, streams, names, grid_in, *[mlp_params[k] for k in names])
+            n_cam, n_rays = a["n_cam"], a["n_rays"]
+            shp = lambda t, c: t.reshape(n_cam, c, n_rays, 1).permute(0, 2, 3, 1)  # noqa: E731
+            coarse = RendererOutput(features=shp(outs[3], 3), depths=shp(outs[4], 1), masks=shp(outs[5], 1))
+            return RendererOutput(features=shp(outs[0], 3), depths=shp(outs[1], 1), masks=shp(outs[2], 1), prev_stage=coarse)
+        return self._render_rays_raw(a, as_output=True)
+
+    def _render_rays_raw(self, a: dict, as_output: bool):
+        """holo_render_rays on the arguments of ``_training_setup``: the six raw planes (img (n_cam,3,n_rays), dep, msk and the
+        coarse three) or the RendererOutput built from them."""
         h, grid, dev, cams, n_cam, n_rays, two_pass = a["h"], a["grid"], a["dev"], a["cams"], a["n_cam"], a["n_rays"], a["two_pass"]
         u_c, u_f, nz_c, nz_f, std, xys = a["u_c"], a["u_f"], a["nz_c"], a["nz_f"], a["std"], a["xys"]
         L = runtime.lib()
@@ -628,6 +647,8 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
                                          opt(u_f), opt(nz_c), opt(nz_f), std, runtime.ptr(img), runtime.ptr(dep),
                                          runtime.ptr(msk), runtime.ptr(imgc), runtime.ptr(depc), runtime.ptr(mskc),
                                          runtime.ptr(ws), ws.numel(), runtime.stream_ptr(dev)), "holo_render_rays")
+        if not as_output:
+            return img, dep, msk, imgc, depc, mskc
         shp = lambda t, c: t.reshape(n_cam, c, n_rays, 1).permute(0, 2, 3, 1)  # noqa: E731  -> (n_cam, n_rays, 1, c)
         coarse = RendererOutput(features=shp(imgc, 3), depths=shp(depc, 1), masks=shp(mskc, 1))
         if not two_pass:
@@ -736,3 +757,43 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         return RendererOutput(features=img.permute(0, 2, 3, 1), depths=dep.permute(0, 2, 3, 1),
                               masks=msk.permute(0, 2, 3, 1), prev_stage=coarse,
                               normals=nrm.permute(0, 2, 3, 1) if want_normals else None)
+
+
+class _HoloRenderRaysFn(torch.autograd.Function):
+    """Autograd node of the training-mode renderer: forward = holo_render_rays, backward = holo_render_rays_backward with
+    the SAME ray list and random draws.  Inputs that can receive a gradient: the voxel grid and the RenderMLP parameters
+    (``names`` gives their order); outputs: the six raw planes rgb (n_cam,3,n_rays), depth, mask of the fine and the coarse
+    pass."""
+
+    @staticmethod
+    def forward(ctx, renderer, bundle, implicit_functions, streams, names, grid, *params):
+        ctx.renderer, ctx.bundle, ctx.fns, ctx.streams, ctx.names = renderer, bundle, list(implicit_functions), streams, names
+        ctx.grid_needs = grid.requires_grad
+        ctx.save_for_backward(grid.detach())
+        with torch.no_grad():
+            a = renderer._training_setup(bundle, implicit_functions, streams, draw=False)
+            return renderer._render_rays_raw(a, as_output=False)
+
+    @staticmethod
+    def backward(ctx, g_img, g_dep, g_msk, g_imgc, g_depc, g_mskc):
+        (grid,) = ctx.saved_tensors
+        n_cam, n_rays = g_img.shape[0], g_img.shape[2]
+        to4 = lambda t, c: None if t is None else t.reshape(n_cam, c, n_rays, 1).permute(0, 2, 3, 1).contiguous()  # noqa: E731
+        grads = {k: v for k, v in (("features", to4(g_img, 3)), ("depths", to4(g_dep, 1)), ("masks", to4(g_msk, 1)),
+                                   ("features_coarse", to4(g_imgc, 3)), ("depths_coarse", to4(g_depc, 1)),
+                                   ("masks_coarse", to4(g_mskc, 1))) if v is not None}
+        # the grid of the forward call is bound again for the backward kernels (the caller may have unbound it since)
+        saved = [dict(f.bound_args) for f in ctx.fns]
+        for f in ctx.fns:
+            f.bind_args(voxel_grid_features=grid)
+        try:
+            with torch.no_grad():
+                g_grid, pg = ctx.renderer.backward_training(ctx.bundle, ctx.fns, ctx.streams, grads)
+        finally:
+            for f, b in zip(ctx.fns, saved):
+                f.unbind_args()
+                if b:
+                    f.bind_args(**b)
+        wanted = ctx.needs_input_grad[6:]
+        return (None, None, None, None, None, g_grid if ctx.grid_needs else None) + \
+            tuple(pg[k] if need else None for k, need in zip(ctx.names, wanted))

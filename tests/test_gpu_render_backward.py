@@ -296,3 +296,49 @@ def test_training_step_with_a_torch_loss_vs_oracle_autograd(gu):
                 worst = (group + "." + k, e)
     print(f"\ntraining step (torch loss {float(loss):.5f}): worst relative gradient error {worst[1]:.2e} ({worst[0]})")
     assert worst[1] < 1e-3, worst
+
+
+@pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
+def test_training_forward_is_differentiable_like_the_reference(gu):
+    """The reference's training loop calls ``preds = model(**batch)`` and ``preds["objective"].backward()``.  Here
+    ``forward(evaluation_mode=TRAINING)`` under autograd returns tensors hanging on the HIP autograd nodes (denoiser and
+    renderer; q_sample and the clamp in torch), so an ordinary ``loss.backward()`` fills the ``.grad`` of the plugin's
+    parameters - compared with the explicit chain (training_step, itself checked against oracle autograd), bootstrap on."""
+    import torch.nn.functional as F
+    R, C, P, Pf, n_rays = 8, 16, 16, 16, 23
+    model, _, _, _, _ = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.n_train_target_views = 2
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2).to(gu.DEV)
+    vf = torch.tanh(torch.from_numpy(np_noise(5, (1, C, R, R, R)))).to(gu.DEV)
+    rs = _streams(2, n_rays, P, Pf, 1500)
+    rs.update({"xys": (torch.from_numpy(np_noise(14, (2, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous(),
+               "timesteps": torch.tensor([380]), "q_noise": torch.from_numpy(np_noise(61, tuple(vf.shape))), "bootstrap": True,
+               "timesteps2": torch.tensor([90]), "q_noise2": torch.from_numpy(np_noise(62, tuple(vf.shape)))})
+    rs = {k: (v.to(gu.DEV) if torch.is_tensor(v) else v) for k, v in rs.items()}
+    tgt = torch.from_numpy(np_noise(71, (2, 3, n_rays, 1))).mul(0.3).add(0.5).clamp(0, 1).to(gu.DEV)
+
+    def loss_fn(p):
+        return F.mse_loss(p["images_render"], tgt) + 0.2 * p["masks_render"].mean() + 0.01 * p["depths_render"].mean()
+
+    want = model.training_step(camera=cams, voxel_features=vf, rng_streams=rs, loss_fn=loss_fn)
+    model.zero_grad(set_to_none=True)
+    x = vf.clone().requires_grad_(True)
+    preds = model(camera=cams, evaluation_mode=EvaluationMode.TRAINING, voxel_features=x, rng_streams=rs)
+    assert preds["images_render"].requires_grad
+    loss = loss_fn(preds)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want["loss"])) < 1e-6
+    worst = ("voxel_features", _rel(x.grad.cpu(), want["voxel_features"].cpu(), 1e-12))
+    named = dict(model.named_parameters())
+    for group, prefix in (("unet", "net_3d._net."), ("render_mlp", "_implicit_functions.0._fn.render_mlp.")):
+        scale = sorted(float(v.abs().max()) for v in want[group].values())[len(want[group]) // 2]
+        for k, g in want[group].items():
+            got = named[prefix + k].grad
+            assert got is not None, prefix + k
+            e = _rel(got.cpu(), g.cpu(), 1e-2 * scale)
+            if e > worst[1]:
+                worst = (group + "." + k, e)
+    print(f"\nloss.backward() through forward(TRAINING): worst difference to the explicit chain {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-4, worst
