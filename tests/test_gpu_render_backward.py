@@ -323,6 +323,7 @@ def test_training_forward_is_differentiable_like_the_reference(gu):
         return F.mse_loss(p["images_render"], tgt) + 0.2 * p["masks_render"].mean() + 0.01 * p["depths_render"].mean()
 
     want = model.training_step(camera=cams, voxel_features=vf, rng_streams=rs, loss_fn=loss_fn)
+    model.requires_grad_(True)  # (the plugin's parameters are created frozen: inference is the default use)
     model.zero_grad(set_to_none=True)
     x = vf.clone().requires_grad_(True)
     preds = model(camera=cams, evaluation_mode=EvaluationMode.TRAINING, voxel_features=x, rng_streams=rs)
