@@ -156,3 +156,23 @@ def test_camera_host_copy_follows_edits():
     sub = moved[[1, 2]]
     sub.R.mul_(-1.0)
     assert torch.equal(sub.host()[0], -moved.host()[0][[1, 2]])
+
+
+def test_training_entries_validate_their_inputs_and_refuse_the_cpu():
+    """Host logic of the training branch: the backward entry needs the forward's draws (no silent fresh draw),
+    parameters are created frozen (inference is the default use) and un-freeze like any nn.Module, and - like every entry
+    of the package - there is no CPU fallback."""
+    import math
+    model = hda.HoloDiffusionModel(
+        resol=8, feature_size=16, render_image_width=16, render_image_height=16,
+        net_3d_SimpleUnet3D_args=dict(model_channels=32, channel_mult=(1, 2), attention_resolutions=(1, 2)))
+    assert not any(p.requires_grad for p in model.parameters())
+    model.requires_grad_(True)
+    assert all(p.requires_grad for p in model.net_3d.parameters())
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    vf = torch.zeros(1, 16, 8, 8, 8)
+    with pytest.raises(ValueError, match="rng_streams"):
+        model.training_backward(camera=cams, voxel_features=vf, rng_streams={"timesteps": torch.tensor([5])}, grads={})
+    rs = {"timesteps": torch.tensor([5]), "q_noise": torch.zeros_like(vf), "bootstrap": False, "xys": torch.zeros(2, 4, 2)}
+    with pytest.raises(hda._lib.HoloError, match="no CPU fallback"):
+        model.training_backward(camera=cams, voxel_features=vf, rng_streams=rs, grads={})
