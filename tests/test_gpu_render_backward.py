@@ -343,3 +343,73 @@ def test_training_forward_is_differentiable_like_the_reference(gu):
                 worst = (group + "." + k, e)
     print(f"\nloss.backward() through forward(TRAINING): worst difference to the explicit chain {worst[1]:.2e} ({worst[0]})")
     assert worst[1] < 1e-4, worst
+
+
+@pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
+def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu):
+    """End to end: three plain SGD steps of the TRAINING branch (fresh draws per step, injected on both sides) through
+    ``forward`` + ``loss.backward()`` + an in-place parameter update - which the plugin must notice and re-upload (and
+    re-transpose for the next backward) - against the oracle pipeline trained with the same rule by torch autograd: the
+    loss of every step and the parameters after the third."""
+    import torch.nn.functional as F
+    from oracle import diffusion_oracle as do
+    from oracle import unet_oracle as uo
+    R, C, P, Pf, n_rays, lr = 8, 16, 12, 12, 19, 2e-2
+    model, ucfg, usd, _, msd = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.n_train_target_views = 2
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    model.requires_grad_(True)
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    vf = torch.tanh(torch.from_numpy(np_noise(5, (1, C, R, R, R))))
+    orc = do.DiffusionOracle(1000)
+    rcfg = ro.RenderCfg(resol=R, feature_size=C, image_height=16, image_width=16, n_pts_coarse=P, n_pts_fine=Pf)
+    pu = {k: v.detach().clone().requires_grad_(True) for k, v in usd.items()}
+    pm = {k: v.detach().clone().requires_grad_(True) for k, v in msd.items()}
+    mnames = [k for k in pm if k.startswith("_density_net") or k.startswith("_radiance_net")]
+    losses = []
+    for step in range(3):
+        rs = _streams(2, n_rays, P, Pf, 2000 + 10 * step)
+        xys = (torch.from_numpy(np_noise(300 + step, (2, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+        tt = torch.tensor([600 - 200 * step])
+        qn = torch.from_numpy(np_noise(400 + step, tuple(vf.shape)))
+        tgt = torch.from_numpy(np_noise(500 + step, (2, 3, n_rays, 1))).mul(0.3).add(0.5).clamp(0, 1)
+        # ---- HIP: forward (autograd nodes), loss.backward(), in-place SGD update
+        dev_rs = {k: v.to(gu.DEV) for k, v in rs.items()}
+        dev_rs.update({"xys": xys.to(gu.DEV), "timesteps": tt.to(gu.DEV), "q_noise": qn.to(gu.DEV), "bootstrap": False})
+        model.zero_grad(set_to_none=True)
+        preds = model(camera=cams.to(gu.DEV), evaluation_mode=EvaluationMode.TRAINING, voxel_features=vf.to(gu.DEV), rng_streams=dev_rs)
+        loss = F.mse_loss(preds["images_render"], tgt.to(gu.DEV)) + 0.1 * preds["masks_render"].mean()
+        loss.backward()
+        with torch.no_grad():
+            for p_ in model.parameters():
+                if p_.grad is not None:
+                    p_.add_(p_.grad, alpha=-lr)
+        # ---- oracle: the same step under torch autograd
+        with torch.enable_grad():
+            g = uo.unet_forward.__wrapped__(pu, ucfg, orc.q_sample(vf, tt, qn), tt).clamp(-1, 1)
+            rr = []
+            for i in range(2):
+                o, d, l = ro.rays_from_xys(gu.cam_dict(cams, i), xys[i], rcfg)
+                rr.append(ro.render_rays.__wrapped__(g, pm, o, d, l, rcfg, "", u_coarse=rs["u_coarse"][i], u_fine=rs["u_fine"][i],
+                                                     noise_coarse=rs["noise_coarse"][i], noise_fine=rs["noise_fine"][i], noise_std=1.0))
+            st = lambda k, c: torch.stack([r[k].reshape(n_rays, c) for r in rr]).permute(0, 2, 1)[..., None]  # noqa: E731
+            lo = F.mse_loss(st("rgb", 3), tgt) + 0.1 * st("mask", 1).mean()
+            params = [pu[k] for k in pu] + [pm[k] for k in mnames]
+            gs = torch.autograd.grad(lo, params, allow_unused=True)
+        with torch.no_grad():
+            for p_, g_ in zip(params, gs):
+                if g_ is not None:
+                    p_.add_(g_, alpha=-lr)
+        losses.append((float(loss.detach()), float(lo.detach())))
+        assert abs(losses[-1][0] - losses[-1][1]) < 2e-5 * max(1.0, abs(losses[-1][1])), (step, losses)
+    named = dict(model.named_parameters())
+    worst = ("", 0.0)
+    for prefix, ref in (("net_3d._net.", pu), ("_implicit_functions.0._fn.render_mlp.", {k: pm[k] for k in mnames})):
+        for k, v in ref.items():
+            e = _rel(named[prefix + k].detach().cpu(), v.detach(), 1e-6)
+            if e > worst[1]:
+                worst = (prefix + k, e)
+    print(f"\nthree SGD steps: losses (HIP, oracle) {[(round(a, 6), round(b, 6)) for a, b in losses]}; worst parameter difference "
+          f"after the third {worst[1]:.2e} ({worst[0]})")
+    assert worst[1] < 1e-4, worst
