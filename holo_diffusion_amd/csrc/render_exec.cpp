@@ -48,6 +48,11 @@ struct HoloRenderer {
   float* bwd_pack = nullptr;  // WeP [Hp][C] | WeT [C][Hp] | be [Hp]
   bool bwd_pack_valid = false;
   std::map<std::string, std::vector<float>> grads;
+  // ... and their device image: ONE upload per backward; holo_renderer_get_grad copies out of it on the device (a
+  // per-parameter host->device copy of a 3-float bias would be the tiny-copy pattern holo_ld_sys exists for)
+  float* grad_dev = nullptr;
+  size_t grad_dev_floats = 0;
+  std::map<std::string, size_t> grad_off;
 };
 
 static int dir_emb(const HoloRenderCfg& c) { return 3 * (2 * c.dir_emb_dims + 1); }
@@ -101,6 +106,7 @@ int holo_renderer_destroy(HoloRenderer* r) {
   if (!r) return 0;
   if (r->packed) (void)hipFree(r->packed);
   if (r->bwd_pack) (void)hipFree(r->bwd_pack);
+  if (r->grad_dev) (void)hipFree(r->grad_dev);
   delete r;
   return 0;
 }
@@ -985,6 +991,24 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
       dbr[j] = hdir[j * 28 + 27];
     }
   }
+  {  // device image of all parameter gradients
+    size_t total = 0;
+    r->grad_off.clear();
+    for (auto& kv : r->grads) {
+      r->grad_off[kv.first] = total;
+      total += (kv.second.size() + 63) & ~(size_t)63;
+    }
+    if (total > r->grad_dev_floats) {
+      if (r->grad_dev) (void)hipFree(r->grad_dev);
+      r->grad_dev = nullptr;
+      HIP_TRY(hipMalloc((void**)&r->grad_dev, total * sizeof(float)));
+      r->grad_dev_floats = total;
+    }
+    std::vector<float> pack(total, 0.f);
+    for (auto& kv : r->grads) memcpy(pack.data() + r->grad_off[kv.first], kv.second.data(), kv.second.size() * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(r->grad_dev, pack.data(), total * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   return 0;
 }
 
@@ -1002,9 +1026,11 @@ int holo_renderer_get_grad(HoloRenderer* r, const char* name, float* out_dev, in
     set_error("holo_renderer_get_grad: '%s' has %lld elements, not %lld", name, (long long)it->second.size(), (long long)numel);
     return HOLO_E_INVALID;
   }
-  HIP_TRY(hipMemcpyAsync(out_dev, it->second.data(), (size_t)numel * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  return 0;
+  if (!r->grad_dev || !r->grad_off.count(name)) {
+    set_error("holo_renderer_get_grad: no device image of the gradients (run holo_render_rays_backward first)");
+    return HOLO_E_STATE;
+  }
+  return copy_sys_launch(r->grad_dev + r->grad_off[name], out_dev, numel, stream) ? HOLO_E_INVALID : 0;
 }
 
 }  // extern "C"
