@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void flip_transpose_weight_kernel(const float*
     const int t = (int)(i % T);
     const int ci = (int)((i / T) % Ci);
     const int co = (int)(i / ((int64_t)T * Ci));
-    out[((int64_t)ci * Co + co) * T + (T - 1 - t)] = in[i];
+    out[((int64_t)ci * Co + co) * T + (T - 1 - t)] = holo_ld_sys(in + i);  // (caller's tensor: holo_ld_sys)
   }
 }
 
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void weight_tco_ci_kernel(const float* __restr
     const int t = (int)(i % T);
     const int ci = (int)((i / T) % Ci);
     const int co = (int)(i / ((int64_t)T * Ci));
-    out[((int64_t)t * Co + co) * Ci + ci] = in[i];
+    out[((int64_t)t * Co + co) * Ci + ci] = holo_ld_sys(in + i);
   }
 }
 

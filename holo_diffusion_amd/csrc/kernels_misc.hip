@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void repack_conv_weight_kernel(const float* __
     const int tap = (int)(blk / ncc);
     const int co = slice * 16 + lj;
     const int ci = cc * 32 + kq * 8 + half * 4 + e;
-    out[i] = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
+    out[i] = (ci < Cin && co < Cout) ? holo_ld_sys(w + ((int64_t)co * Cin + ci) * taps + tap) : 0.f;  // (caller's tensor: holo_ld_sys)
   }
 }
 
@@ -403,18 +403,18 @@ __global__ __launch_bounds__(256) void repack_conv_weight_wino_kernel(const floa
           const int kx = pt % 3, xy = (pt / 3) & 3, xz = pt / 12;
           double u = 0.0;
           for (int kz = 0; kz < 3; ++kz)
-            for (int ky = 0; ky < 3; ++ky) u += G[xz][kz] * G[xy][ky] * (double)src[kz * 9 + ky * 3 + kx];
+            for (int ky = 0; ky < 3; ++ky) u += G[xz][kz] * G[xy][ky] * (double)holo_ld_sys(src + kz * 9 + ky * 3 + kx);
           v = (float)u;
         } else {  // pt = (xi_z-1)*2 + (xi_y-1): G[xi][1] = +.5 (xi = 1), -.5 (xi = 2)
-          v = ((pt >> 1) == (pt & 1) ? 0.25f : -0.25f) * src[0];
+          v = ((pt >> 1) == (pt & 1) ? 0.25f : -0.25f) * holo_ld_sys(src);
         }
       } else if (src_taps == 27) {
         const int xi = pt / 9, kyx = pt - xi * 9;
-        const double g0 = src[kyx], g1 = src[9 + kyx], g2 = src[18 + kyx];
+        const double g0 = holo_ld_sys(src + kyx), g1 = holo_ld_sys(src + 9 + kyx), g2 = holo_ld_sys(src + 18 + kyx);
         const double u = xi == 0 ? g0 : xi == 1 ? 0.5 * (g0 + g1 + g2) : xi == 2 ? 0.5 * (g0 - g1 + g2) : g2;
         v = (float)u;
       } else {
-        v = pt == 0 ? 0.5f * src[0] : -0.5f * src[0];
+        v = pt == 0 ? 0.5f * holo_ld_sys(src) : -0.5f * holo_ld_sys(src);
       }
     }
     out[i] = v;
@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256) void repack_conv_weight_bf16_kernel(const floa
     const int tap = (int)(blk / ncc);
     const int co = slice * 16 + (lane & 15);
     const int ci = cc * 32 + (lane >> 4) * 8 + e2 * 2;
-    const float v0 = (ci < Cin && co < Cout) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.f;
-    const float v1 = (ci + 1 < Cin && co < Cout) ? w[((int64_t)co * Cin + ci + 1) * taps + tap] : 0.f;
+    const float v0 = (ci < Cin && co < Cout) ? holo_ld_sys(w + ((int64_t)co * Cin + ci) * taps + tap) : 0.f;
+    const float v1 = (ci + 1 < Cin && co < Cout) ? holo_ld_sys(w + ((int64_t)co * Cin + ci + 1) * taps + tap) : 0.f;
     const uint32_t h = pack_bf16x2(v0, v1);
     const float r0 = v0 - __uint_as_float(h << 16), r1 = v1 - __uint_as_float(h & 0xffff0000u);
     const uint32_t m = pack_bf16x2(r0, r1);

@@ -1574,11 +1574,9 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
                                           pad_cin((int)s.shape[1]), stream, 2);
       if (rc) return rc;
     }
-  } else if (s.numel <= 65536) {  // biases, GroupNorm parameters, small Linear layers: see holo_ld_sys
+  } else {  // biases, GroupNorm parameters, Linear layers: a copy kernel with system-scope loads (holo_ld_sys) - like the
+            // weight repack kernels, every ingestion of a caller-provided tensor reads it past the L2
     if (copy_sys_launch((const float*)dev_ptr, s.priv, s.numel, stream)) return HOLO_E_INVALID;
-  } else {
-    HIP_TRY(hipMemcpyAsync(s.priv, dev_ptr, (size_t)s.numel * sizeof(float), hipMemcpyDeviceToDevice,
-                           (hipStream_t)stream));
   }
   s.set = true;
   return 0;
