@@ -92,7 +92,7 @@ __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
   } while (0)
 // System-scope load for SMALL caller-provided tensors (timesteps, ray lists): a few bytes just copied from pageable host
 // memory can sit behind a stale L2 line of the block's previous owner - measured: 8 wrong timestep reads in 610 calls fed
-// by fresh `tensor.to(device)` copies, 0 in 600 with this load (scripts/attn_first_stress.py); bulk tensors are not affected.
+// by fresh `tensor.to(device)` copies, 0 in 600 with this load (scripts/h2d_stress_unet.py); bulk tensors are not affected.
 template <typename T>
 __device__ __forceinline__ T holo_ld_sys(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

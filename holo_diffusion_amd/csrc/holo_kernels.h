@@ -125,8 +125,6 @@ struct AttnParams {
 bool flash_attn_supported(int T, int head_channels);
 int flash_attn_launch(const AttnParams& p, void* stream);
 // bf16-product variant (shared K/V tiles in LDS, v_mfma_f32_16x16x32_bf16), for the opt-in bf16 mode
-bool flash_attn_bf16_supported(int T, int head_channels);
-int flash_attn_bf16_launch(const AttnParams& p, void* stream);
 // Second form of the bf16 attention (bf16 storage mode, long sequences): a pre-pass rewrites qkv once per call as
 // bf16 Q (pre-scaled) / K per head and V TRANSPOSED per head, so that the main kernel stages plain 16-byte rows;
 // 64-key blocks, 64 queries per wave, v_mfma_f32_32x32x16_bf16, exp2-domain softmax; the key range is split across

@@ -356,182 +356,6 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(AttnParams p) {
 
 
 // ---------------------------------------------------------------------------------------------
-// bf16-product variant of the attention for the opt-in bf16 mode and long sequences (T = 32 768 at 128^3): QK^T and
-// PV on v_mfma_f32_16x16x32_bf16 (fp32 accumulate), softmax statistics and the output in fp32.
-//
-// Block = 4 waves x 32 queries = 128 queries of one (sample, head); the block walks the T keys in blocks of 32 that
-// all four waves share through LDS (K as bf16 [key][ch], V TRANSPOSED as bf16 [ch][key]): at this MFMA rate every
-// wave streaming its own K/V from L2, as the fp32 kernel does, would be bound by L2 bandwidth.
-// Same transposed formulation as the fp32 kernel, on 16-wide tiles:
-//   S^T[key][query] = K . Q^T      A = K rows from LDS (lane: key lane&15, channels 8g..8g+7 of the 32-ch k-step),
-//                                  B = Q^T operands kept in registers for the whole loop (pre-scaled by ch^-1/2)
-//   D layout: col = lane&15 = query, row = 4g + r = key  ->  a query's softmax is a max/sum over the lane's own
-//   registers plus two cross-group shuffles (xor 16, 32);
-//   O^T[c][query] += V^T[c][key] . P^T[key][query]:  the B operand of k-group g must hold 8 keys; the lane's P registers
-//   of the two 16-key tiles hold keys {4g..4g+3} and {16+4g..16+4g+3}, so THAT is taken as the k order of the 32-key
-//   step and the A operand reads the same keys of V^T (two 8-byte LDS reads): P never leaves its registers.
-// ---------------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256, 2) void flash_attn_bf16_kernel(AttnParams p) {
-  constexpr int KB = 32;             // keys per block
-  constexpr int KROW = CH / 2 + 4;   // words per K row: CH bf16 + 16 bytes of padding (conflict-free 16-byte reads)
-  constexpr int VROW = KB / 2 + 4;   // words per V^T row: 32 bf16 + 16 bytes of padding
-  constexpr int NKS = CH / 32;       // 32-channel k-steps of QK^T
-  constexpr int NCT = CH / 16;       // 16-channel tiles of O^T
-  __shared__ __attribute__((aligned(16))) uint32_t s_k[KB * KROW];
-  __shared__ __attribute__((aligned(16))) uint32_t s_v[CH * VROW];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int lj = lane & 15;
-  const int g = lane >> 4;
-  const int qtiles = p.T / 128;
-  int b = blockIdx.x;
-  const int qt128 = b % qtiles;
-  b /= qtiles;
-  const int head = b % p.H;
-  const int n = b / p.H;
-  const int C3 = 3 * p.C;
-  const float* base = p.qkv + (int64_t)n * p.T * C3 + head * 3 * CH;  // q at +0, k at +CH, v at +2CH (unet.py:448)
-  const int q0 = qt128 * 128 + wave * 32;
-
-  // Q^T operands (B): query column lj of query tile qt, channels ks*32 + 8g .. +7, scaled, rounded to bf16
-  float4 qf[2][NKS];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const float* qp = base + (int64_t)(q0 + qt * 16 + lj) * C3 + ks * 32 + g * 8;
-      const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
-      uint32_t w[4] = {pack_bf16x2(a.x * p.scale2, a.y * p.scale2), pack_bf16x2(a.z * p.scale2, a.w * p.scale2),
-                       pack_bf16x2(c.x * p.scale2, c.y * p.scale2), pack_bf16x2(c.z * p.scale2, c.w * p.scale2)};
-      float4 o;
-      memcpy(&o, w, 16);
-      qf[qt][ks] = o;
-    }
-
-  f32x4 oacc[NCT][2];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[ct][qt][r] = 0.f;
-  float m_run[2] = {-3.0e38f, -3.0e38f}, l_run[2] = {0.f, 0.f};
-
-  // staging assignment: KB*CH/4 float4 of K and of V per block, 256 threads
-  constexpr int F4 = KB * CH / 4;
-  constexpr int PER = (F4 + 255) / 256;
-  uint16_t* s_v16 = reinterpret_cast<uint16_t*>(s_v);
-
-  for (int kb = 0; kb < p.T; kb += KB) {
-    // ---- stage the key block: all global loads first, then convert + store
-    float4 kreg[PER], vreg[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = min(tid + 256 * j, F4 - 1);
-      const int key = i / (CH / 4), c4 = i - key * (CH / 4);
-      const float* rp = base + (int64_t)(kb + key) * C3 + CH + c4 * 4;
-      kreg[j] = *reinterpret_cast<const float4*>(rp);
-      vreg[j] = *reinterpret_cast<const float4*>(rp + CH);
-    }
-    __syncthreads();  // previous block fully consumed
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = tid + 256 * j;
-      if (i < F4) {
-        const int key = i / (CH / 4), c4 = i - key * (CH / 4);
-        *reinterpret_cast<uint2*>(s_k + key * KROW + c4 * 2) =
-            make_uint2(pack_bf16x2(kreg[j].x, kreg[j].y), pack_bf16x2(kreg[j].z, kreg[j].w));
-        const uint32_t v01 = pack_bf16x2(vreg[j].x, vreg[j].y), v23 = pack_bf16x2(vreg[j].z, vreg[j].w);
-        s_v16[((c4 * 4 + 0) * VROW) * 2 + key] = (uint16_t)(v01 & 0xffffu);
-        s_v16[((c4 * 4 + 1) * VROW) * 2 + key] = (uint16_t)(v01 >> 16);
-        s_v16[((c4 * 4 + 2) * VROW) * 2 + key] = (uint16_t)(v23 & 0xffffu);
-        s_v16[((c4 * 4 + 3) * VROW) * 2 + key] = (uint16_t)(v23 >> 16);
-      }
-    }
-    __syncthreads();
-
-    // ---- S^T tiles: [key tile kt][query tile qt], key = kt*16 + 4g + r, query = lj
-    f32x4 sacc[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[kt][qt][r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const float4 ka = *reinterpret_cast<const float4*>(s_k + (kt * 16 + lj) * KROW + ks * 16 + g * 4);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) sacc[kt][qt] = mfma_bf16_16x16x32(ka, qf[qt][ks], sacc[kt][qt]);
-      }
-
-    // ---- online softmax per query column, P^T operands
-    float4 pf[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = sacc[0][qt][0];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = __expf(m_run[qt] - m_new);
-      float pv[8];
-      float ls = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {  // k order of the PV step: e<4 -> key 4g+e of tile 0, e>=4 -> key 4g+e-4 of tile 1
-        pv[e] = __expf(sacc[e >> 2][qt][e & 3] - m_new);
-        ls += pv[e];
-      }
-      ls += __shfl_xor(ls, 16);
-      ls += __shfl_xor(ls, 32);
-      l_run[qt] = l_run[qt] * alpha + ls;
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[ct][qt][r] *= alpha;
-      uint32_t w[4] = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]), pack_bf16x2(pv[4], pv[5]),
-                       pack_bf16x2(pv[6], pv[7])};
-      float4 o;
-      memcpy(&o, w, 16);
-      pf[qt] = o;
-    }
-
-    // ---- O^T += V^T . P^T : A = V^T rows (channel ct*16 + lj), keys {4g..4g+3, 16+4g..16+4g+3}
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-      const uint32_t* vr = s_v + (ct * 16 + lj) * VROW + 2 * g;
-      const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 8);
-      uint32_t w[4] = {lo.x, lo.y, hi.x, hi.y};
-      float4 va;
-      memcpy(&va, w, 16);
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) oacc[ct][qt] = mfma_bf16_16x16x32(va, pf[qt], oacc[ct][qt]);
-    }
-  }
-
-  // ---- out[q][head*CH + c] = O / l ;  D rows = channels ct*16 + 4g + r, column = query lj: one float4 per tile
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float inv = 1.f / l_run[qt];
-    float* op = p.out + ((int64_t)n * p.T + q0 + qt * 16 + lj) * p.C + head * CH + 4 * g;
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-      *reinterpret_cast<float4*>(op + ct * 16) = make_float4(oacc[ct][qt][0] * inv, oacc[ct][qt][1] * inv,
-                                                             oacc[ct][qt][2] * inv, oacc[ct][qt][3] * inv);
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
 // bf16 attention, second form (bf16 storage mode, T >= 8192).
 //
 // Pre-pass (attn_pack_kernel): qkv fp32 [N][T][3C] -> per (sample, head): Q bf16 [T][CH] scaled by CH^-1/2 * log2(e)
@@ -912,29 +736,6 @@ int flash_attn_launch(const AttnParams& p, void* stream) {
       break;
     default:
       HOLO_LAUNCH(flash_attn_kernel<64>, grid, dim3(256), stream, p);
-      break;
-  }
-  return 0;
-}
-
-bool flash_attn_bf16_supported(int T, int ch) { return (T % 128) == 0 && (ch == 32 || ch == 64 || ch == 128); }
-
-int flash_attn_bf16_launch(const AttnParams& p, void* stream) {
-  const int ch = p.C / p.H;
-  if (!flash_attn_bf16_supported(p.T, ch)) {
-    set_error("flash_attn_bf16: unsupported shape T=%d head channels=%d", p.T, ch);
-    return -1;
-  }
-  dim3 grid((unsigned)((int64_t)p.N * p.H * (p.T / 128)));
-  switch (ch) {
-    case 32:
-      HOLO_LAUNCH(flash_attn_bf16_kernel<32>, grid, dim3(256), stream, p);
-      break;
-    case 64:
-      HOLO_LAUNCH(flash_attn_bf16_kernel<64>, grid, dim3(256), stream, p);
-      break;
-    default:
-      HOLO_LAUNCH(flash_attn_bf16_kernel<128>, grid, dim3(256), stream, p);
       break;
   }
   return 0;

@@ -636,14 +636,14 @@ struct Planner {
       op.attn.H = H;
       const double sc = 1.0 / sqrt(sqrt((double)ch));
       op.attn.scale2 = (float)(sc * sc);
-      // bf16 mode, long sequences: shared-tile bf16 kernel (below ~8k tokens its 128-query tiles under-fill the chip
-      // and the fp32 kernel is as fast); HOLO_BF16_FLASH_MIN_T overrides the threshold (tests)
+      // bf16 mode, sequences of 1 024 tokens and more: the packed-operand bf16 kernel (it splits the key range to fill
+      // the chip, so it also serves the shorter of them; below that the exact-fp32 kernel is as fast).
+      // HOLO_BF16_FLASH_MIN_T lowers the threshold (tests).  (A first, shared-tile form of the bf16 kernel was removed in
+      // round 3: no shape reached it any more, and forced on by the tests it showed a rare dependence on stale memory.)
       const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
-      const int64_t min_t = mt ? atoll(mt) : 8192;
-      op.i0 = (u->compute_mode == 1 && T >= min_t && flash_attn_bf16_supported((int)T, ch)) ? 1 : 0;
-      // the second form splits the key range to fill the chip, so it also serves the shorter sequences
-      if (u->compute_mode == 1 && T >= (min_t < 1024 ? min_t : 1024) && flash_attn_bf16v2_supported((int)T, ch) &&
-          !getenv("HOLO_NO_FLASH_V2")) {
+      const int64_t min_t = mt ? atoll(mt) : 1024;
+      op.i0 = 0;
+      if (u->compute_mode == 1 && T >= min_t && flash_attn_bf16v2_supported((int)T, ch)) {
         // packed bf16 operands (V transposed) in scratch, bf16 attention output
         op.i0 = 2;
         v2_bytes = flash_attn_bf16v2_workspace_bytes(op.attn, u->ctx->num_cus);
@@ -654,7 +654,7 @@ struct Planner {
       }
       if (getenv("HOLO_DEBUG_PLAN"))
         fprintf(stderr, "[plan] attention %s: T=%lld C=%d heads=%d -> %s flash kernel\n", p.c_str(), (long long)T, C, H,
-                op.i0 == 2 ? "bf16 (second form)" : op.i0 ? "bf16" : "fp32");
+                op.i0 == 2 ? "bf16" : "fp32");
       ops.push_back(op);
     } else {
       size_t S = scratch_alloc(s_bytes);
@@ -1340,7 +1340,7 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
       return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
     case OP_FLASH:
       if (op.i0 == 2) return flash_attn_bf16v2_launch(op.attn, op.o1, op.i1, u->ctx->num_cus, stream);
-      return op.i0 ? flash_attn_bf16_launch(op.attn, stream) : flash_attn_launch(op.attn, stream);
+      return flash_attn_launch(op.attn, stream);
     case OP_OUT:
       return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
   }

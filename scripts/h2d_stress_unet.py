@@ -5,7 +5,7 @@ import sys
 import torch
 
 os.environ["HOLO_BF16_FLASH_MIN_T"] = "0"
-os.environ["HOLO_NO_FLASH_V2"] = sys.argv[2] if len(sys.argv) > 2 else "1"
+_ = sys.argv[2] if len(sys.argv) > 2 else None  # (formerly: the removed first-form attention switch)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tests.gpu_utils as gu  # noqa: E402
 from oracle import unet_oracle as uo  # noqa: E402

@@ -285,16 +285,12 @@ def test_bf16_compute_mode_full_size_vs_fp32_path(gu):
         assert ((ym - y32).abs().max() / y32.abs().max()).item() <= tol, mode
 
 
-@pytest.mark.parametrize("form", ["second", "first"])
 @pytest.mark.parametrize("image,mc,mult,attn", [(16, 64, (1, 2, 2), (1, 2)), (16, 128, (1, 2), (2,))])
-def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, form, monkeypatch):
-    """Both bf16 attention kernels forced on at T = 4096 / 512 with head channels 32, 64 and 128 inside the bf16 mode,
-    against the fp32 oracle (rtol 2e-2 of the scale): the second form (packed operands, transposed V, 32x32x16 tiles,
-    key split + recombination: at these sizes the key range IS split 2-8 ways) and the first form (shared fp32->bf16
-    tiles) it replaces wherever it applies."""
+def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
+    """The bf16 attention kernel forced on at T = 4096 / 512 with head channels 32, 64 and 128 inside the bf16 mode,
+    against the fp32 oracle (rtol 2e-2 of the scale): packed operands, transposed V, 32x32x16 tiles, key split +
+    recombination (at these sizes the key range IS split 2-8 ways)."""
     monkeypatch.setenv("HOLO_BF16_FLASH_MIN_T", "0")
-    if form == "first":
-        monkeypatch.setenv("HOLO_NO_FLASH_V2", "1")
     cfg = uo.UNetCfg(image_size=image, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=2,
                      channel_mult=mult, attention_resolutions=attn, num_heads=2)
     net, sd = gu.make_unet(cfg, seed=7, compute_dtype="bf16")
@@ -359,13 +355,12 @@ def test_f32_bf16x3_mode_meets_the_fp32_tolerance(gu, image, mc, mult, attn, bat
         del os.environ["HOLO_KEEP_INTERMEDIATES"]
 
 
-@pytest.mark.parametrize("compute,env", [("f32", {}), ("bf16", {}), ("bf16", {"HOLO_BF16_FLASH_MIN_T": "0", "HOLO_NO_FLASH_V2": "1"}),
-                                         ("bf16", {"HOLO_BF16_FLASH_MIN_T": "0"}), ("f32_bf16x3", {})])
+@pytest.mark.parametrize("compute,env", [("f32", {}), ("bf16", {}), ("bf16", {"HOLO_BF16_FLASH_MIN_T": "0"}), ("f32_bf16x3", {})])
 @pytest.mark.parametrize("image,mc,mult,attn", [(16, 128, (1, 2), (2,)), (16, 64, (1, 2, 2), (1, 2))])
 def test_forward_does_not_depend_on_workspace_contents(gu, compute, env, image, mc, mult, attn, monkeypatch):
     """The caller-owned workspace may hold anything (the caching allocator hands back blocks of earlier work): a forward on
     a workspace filled with 0xFF bytes (NaN as fp32 and as bf16) must give bit-identical, finite output to one on a zeroed
-    workspace, in every arithmetic mode and with each attention kernel forced on."""
+    workspace, in every arithmetic mode and with the bf16 attention kernel forced on."""
     from holo_diffusion_amd import runtime
     for k, v in env.items():
         monkeypatch.setenv(k, v)
