@@ -171,6 +171,25 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
 // dst = src for a SMALL caller-provided tensor, read with system-scope loads (holo_ld_sys, holo_common.h)
 int copy_sys_launch(const float* src, float* dst, int64_t n, void* stream);
+// Host -> device upload of a packed parameter image into a buffer that kernels have been reading (a re-commit after a
+// parameter update): the bytes land in a staging buffer that only copy_sys_kernel ever reads (system-scope loads), which
+// then writes `dst` like any kernel - so no kernel can meet a stale cached line of `dst` (holo_ld_sys).  Synchronises.
+// Returns 0 or the hipError_t.
+inline int upload_via_stage(float** stage, size_t* stage_floats, float* dst, const float* host, size_t n, void* stream) {
+  if (*stage_floats < n) {
+    if (*stage) (void)hipFree(*stage);
+    *stage = nullptr;
+    *stage_floats = 0;
+    hipError_t e = hipMalloc((void**)stage, n * sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    *stage_floats = n;
+  }
+  hipError_t e = hipMemcpyAsync(*stage, host, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (copy_sys_launch(*stage, dst, (int64_t)n, stream)) return -1;
+  e = hipStreamSynchronize((hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
+}
 int clip_launch(const float* x, float* y, float lo, float hi, int64_t n, void* stream);
 
 int repack_conv_weight_bf16_launch(const float* w, uint16_t* out, int Cout, int Cin, int taps, int CoutP, int CinP,

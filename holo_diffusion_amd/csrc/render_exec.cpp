@@ -52,6 +52,8 @@ struct HoloRenderer {
   // per-parameter host->device copy of a 3-float bias would be the tiny-copy pattern holo_ld_sys exists for)
   float* grad_dev = nullptr;
   size_t grad_dev_floats = 0;
+  float* stage = nullptr;  // staging buffer of upload_via_stage (commit / backward re-packs)
+  size_t stage_floats = 0;
   std::map<std::string, size_t> grad_off;
 };
 
@@ -107,6 +109,7 @@ int holo_renderer_destroy(HoloRenderer* r) {
   if (r->packed) (void)hipFree(r->packed);
   if (r->bwd_pack) (void)hipFree(r->bwd_pack);
   if (r->grad_dev) (void)hipFree(r->grad_dev);
+  if (r->stage) (void)hipFree(r->stage);
   delete r;
   return 0;
 }
@@ -226,15 +229,16 @@ int holo_renderer_commit(HoloRenderer* r, void* stream) {
   r->fA1 = A1, r->fc1 = c1, r->fA2 = A2, r->fc2 = c2, r->fWe = We, r->fbe = be;
   r->bwd_pack_valid = false;
   r->grads.clear();
-  HIP_TRY(hipMemcpyAsync(r->packed, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-  if (r->cfg.feature_dim > 0) {
+  if (r->cfg.feature_dim > 0) {  // the feature head's weights and bias follow the folded pack at fnet_off
     const auto &Wf = W("_feature_net.mlp.0.0.weight"), &bf = W("_feature_net.mlp.0.0.bias");
-    HIP_TRY(hipMemcpyAsync(r->packed + r->fnet_off, Wf.data(), Wf.size() * sizeof(float), hipMemcpyHostToDevice,
-                           (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync(r->packed + r->fnet_off + Wf.size(), bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice,
-                           (hipStream_t)stream));
+    pk.resize(r->fnet_off + Wf.size() + bf.size(), 0.f);
+    memcpy(pk.data() + r->fnet_off, Wf.data(), Wf.size() * sizeof(float));
+    memcpy(pk.data() + r->fnet_off + Wf.size(), bf.data(), bf.size() * sizeof(float));
   }
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (upload_via_stage(&r->stage, &r->stage_floats, r->packed, pk.data(), pk.size(), stream)) {
+    set_error("holo_renderer_commit: upload of the packed RenderMLP failed");
+    return HOLO_E_HIP;
+  }
   r->committed = true;
   return 0;
 }
@@ -770,8 +774,10 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
         pk[(size_t)Hp * C + (size_t)j * Hp + i] = (float)r->fWe[(size_t)i * C + j];
       }
     for (int i = 0; i <= Hd; ++i) pk[(size_t)2 * Hp * C + i] = (float)r->fbe[i];
-    HIP_TRY(hipMemcpyAsync(r->bwd_pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (upload_via_stage(&r->stage, &r->stage_floats, r->bwd_pack, pk.data(), pk.size(), stream)) {
+      set_error("holo_render_rays_backward: upload of the folded weights failed");
+      return HOLO_E_HIP;
+    }
     r->bwd_pack_valid = true;
   }
   const float* WeP = r->bwd_pack;

@@ -119,6 +119,8 @@ struct HoloMlpMeanPooler {
   int D = 0, E = 0, dp = 0, emb0 = 0;
   int quad0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float* dev = nullptr;  // a | am | cb | g | g0 | l
+  float* stage = nullptr;  // staging buffer of upload_via_stage
+  size_t stage_floats = 0;
   float l0 = 0.f;
   bool committed = false;
 };
@@ -194,6 +196,7 @@ int holo_mlp_mean_create(HoloCtx* ctx, const HoloMlpMeanCfg* cfg, HoloMlpMeanPoo
 int holo_mlp_mean_destroy(HoloMlpMeanPooler* h) {
   if (!h) return 0;
   if (h->dev) (void)hipFree(h->dev);
+  if (h->stage) (void)hipFree(h->stage);
   delete h;
   return 0;
 }
@@ -288,8 +291,10 @@ int holo_mlp_mean_commit(HoloMlpMeanPooler* h, void* stream) {
     g0[f] = (float)c;
   }
   h->l0 = bl[0];
-  HIP_TRY(hipMemcpyAsync(h->dev, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (upload_via_stage(&h->stage, &h->stage_floats, h->dev, pk.data(), pk.size(), stream)) {
+    set_error("holo_mlp_mean_commit: upload of the folded weights failed");
+    return HOLO_E_HIP;
+  }
   h->committed = true;
   return 0;
 }
