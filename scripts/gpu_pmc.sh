@@ -30,3 +30,5 @@ run_pass grbm GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_ACTIVE
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 ls -la $OUT
+# afterwards, in the development container: python scripts/pmc_to_json.py <tag> profiles/pmc_traffic.json 20
+#   (20 = frames per render launch of the command above) and copy gpurun_out/<tag>/pmc_*.csv to profiles/<round>_pmc_*.csv
