@@ -118,7 +118,9 @@ int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t ds
  * test (holo_diffusion/tests/test_diffusion_utils.py:47-66) and what the training step needs from net_3d
  * (holo_diffusion_model.py:386-418).  fp32 mode.
  *   holo_unet_set_dgrad_weight   per convolution weight (same names / OIDHW tensors as holo_unet_set_param): prepares the
- *                                weight of the transposed convolution; call again whenever the parameter changes
+ *                                weight of the transposed convolution (packed, and for the wide levels its Winograd
+ *                                copies; device buffers are allocated on the first call per weight); call again
+ *                                whenever the parameter changes
  *   holo_unet_backward           runs the forward (every intermediate kept in the workspace) and the backward for
  *                                grad_out = dL/dy (N, Cout, R, R, R); y (optional) receives the forward output, grad_x
  *                                (optional) dL/dx.  Parameter gradients stay in the workspace ...
