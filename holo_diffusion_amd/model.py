@@ -148,7 +148,8 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
     # ---- render (holo_diffusion_model.py:201-540, evaluation branch) ------------------------
     def _weights_epoch(self):
         net = self.net_3d
-        return (getattr(net, "_weights_epoch", 0), getattr(net, "compute_dtype", None), id(net))
+        epoch = net.weights_epoch() if hasattr(net, "weights_epoch") else getattr(net, "_weights_epoch", 0)
+        return (epoch, getattr(net, "compute_dtype", None), id(net))
 
     def invalidate_refined_cache(self) -> None:
         self._refined_cache = None
@@ -387,7 +388,8 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         out = one_round(voxel_features, "timesteps", "q_noise")
         boot = rs.get("bootstrap")
         if boot is None:
-            boot = self.enable_bootstrap and (np.random.uniform() < self.bootstrap_prob)
+            # the reference draws unconditionally and never reads enable_bootstrap here (holo_diffusion_model.py:402)
+            boot = np.random.uniform() < self.bootstrap_prob
         if boot:
             out = one_round(out, "timesteps2", "q_noise2")
         return out

@@ -598,7 +598,9 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
                 raise _lib.HoloError(f"rng_streams['{key}'] must have shape {tuple(shape)}, got {tuple(t.shape)}")
             return t.to(dev, torch.float32).contiguous()
 
-        u_c = stream("u_coarse", (n_cam, n_rays, P), False, bundle.stratified and self.stratified_sampling_coarse_training)
+        # the ray sampler's flag alone jitters the coarse depths; the renderer's flag is the RayPointRefiner's
+        # `random_sampling` (fine pass) only (PyTorch3D MultiPassEmissionAbsorptionRenderer.__post_init__)
+        u_c = stream("u_coarse", (n_cam, n_rays, P), False, bundle.stratified)
         u_f = stream("u_fine", (n_cam, n_rays, Pf), False, two_pass and self.stratified_sampling_coarse_training)
         nz_c = stream("noise_coarse", (n_cam, n_rays, P), True, std > 0.0)
         nz_f = stream("noise_fine", (n_cam, n_rays, P + Pf), True, std > 0.0 and two_pass)
@@ -619,7 +621,12 @@ class HoloMultiPassEmissionAbsorptionRenderer(BaseRenderer, torch.nn.Module):
         a = self._training_setup(bundle, implicit_functions, rng_streams)
         mlp_params = dict(a["fn"].render_mlp.named_parameters())
         grid_in = implicit_functions[0].bound_args.get("voxel_grid_features")
-        if torch.is_grad_enabled() and a["two_pass"] and (grid_in.requires_grad or any(p.requires_grad for p in mlp_params.values())):
+        needs_grad = torch.is_grad_enabled() and (grid_in.requires_grad or any(p.requires_grad for p in mlp_params.values()))
+        if needs_grad and not a["two_pass"]:
+            raise NotImplementedError("the differentiable training-mode renderer is the two-pass one (coarse + fine implicit "
+                                      "function, holo_render_rays_backward); a single-pass render would return outputs "
+                                      "detached from the graph")
+        if needs_grad:
             # the draws of this call (injected or made by _training_setup) are what the backward pass must see again
             streams = {k: a[s] for k, s in (("u_coarse", "u_c"), ("u_fine", "u_f"), ("noise_coarse", "nz_c"), ("noise_fine", "nz_f"))
                        if a[s] is not None}

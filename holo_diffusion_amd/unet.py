@@ -131,8 +131,26 @@ class SimpleUnet3D(Unet3DBase):
         self._mark_dirty()
         return super()._load_from_state_dict(*a, **k)
 
+    def _poll_parameter_versions(self, sd=None):
+        """In-place parameter updates (``opt.step()``, ``p.add_()``) go through none of the hooks above: every tensor's
+        (storage, version counter) is compared with what the library's packed copies were made from; a difference marks
+        the copies dirty and advances ``_weights_epoch``.  Returns the current fingerprint."""
+        if sd is None:
+            sd = dict(self._net.named_parameters())
+        versions = tuple((sd[k].data_ptr(), sd[k]._version) for k in self._param_names)
+        if not self._dirty and versions != self.__dict__.get("_param_versions"):
+            self._mark_dirty()
+        return versions
+
+    def weights_epoch(self) -> int:
+        """Counter that advances whenever the parameters changed by any route (the key of caches of this net's outputs)."""
+        self._poll_parameter_versions()
+        return getattr(self, "_weights_epoch", 0)
+
     def mark_parameters_changed(self) -> None:
-        """Call after modifying parameter tensors in place so the library re-packs its private copies."""
+        """Forces a re-pack of the library's private copies.  Not needed after ordinary in-place updates (``opt.step()``,
+        ``p.add_()``): ``_ensure_handle`` compares every parameter's storage and version counter on each call; this is for
+        writes that bypass the version counter (``p.data`` views, raw pointers)."""
         self._mark_dirty()
 
     # ---- native handle --------------------------------------------------------------------
@@ -165,14 +183,18 @@ class SimpleUnet3D(Unet3DBase):
                 if tuple(shp[:nd.value]) != tuple(shapes.get(k, ())):
                     raise _lib.HoloError(f"parameter '{k}': library shape {tuple(shp[:nd.value])} != {shapes.get(k)}")
             self._handle, self._handle_device, self._handle_size, self._dirty = h, device, size, True
+            # a new native handle holds no transposed (dgrad) weights, whatever address malloc gave it
+            self.__dict__.pop("_dgrad_key", None)
+            self.__dict__["_handle_generation"] = self.__dict__.get("_handle_generation", 0) + 1
         code = {"f32": _lib.HOLO_DTYPE_F32, "bf16": _lib.HOLO_DTYPE_BF16,
                 "f32_bf16x3": _lib.HOLO_DTYPE_F32_BF16X3}.get(self.compute_dtype)
         if code is None:
             raise _lib.HoloError("SimpleUnet3D.compute_dtype must be 'f32', 'bf16' or 'f32_bf16x3' "
                                  f"(got {self.compute_dtype!r})")
         _lib.check(L, L.holo_unet_set_compute_dtype(self._handle, code), "holo_unet_set_compute_dtype")
+        sd = dict(self._net.named_parameters())
+        versions = self._poll_parameter_versions(sd)
         if self._dirty:
-            sd = dict(self._net.named_parameters())
             st = runtime.stream_ptr(device)
             for k in self._param_names:
                 p = sd[k]
@@ -183,6 +205,7 @@ class SimpleUnet3D(Unet3DBase):
                                                    t.dim(), _lib.shape_array(t.shape), st), f"holo_unet_set_param({k})")
             torch.cuda.current_stream(device).synchronize()  # temporaries from .contiguous() must outlive the copies
             self._dirty = False
+            self.__dict__["_param_versions"] = versions
         return self._handle
 
     def __del__(self):
@@ -230,7 +253,8 @@ class SimpleUnet3D(Unet3DBase):
         """Weights of the transposed convolutions (holo_unet_set_dgrad_weight), re-prepared when a parameter changed."""
         h = self._ensure_handle(device)
         key = tuple((k, p.data_ptr(), p._version) for k, p in self._net.named_parameters() if p.dim() >= 3)
-        if self.__dict__.get("_dgrad_key") == (h.value, key):
+        gen = self.__dict__.get("_handle_generation", 0)
+        if self.__dict__.get("_dgrad_key") == (gen, key):
             return
         L = runtime.lib()
         st = runtime.stream_ptr(device)
@@ -241,7 +265,7 @@ class SimpleUnet3D(Unet3DBase):
                 keep.append(t)
                 _lib.check(L, L.holo_unet_set_dgrad_weight(h, k.encode(), runtime.ptr(t), st), f"holo_unet_set_dgrad_weight({k})")
         torch.cuda.current_stream(device).synchronize()
-        self.__dict__["_dgrad_key"] = (h.value, key)
+        self.__dict__["_dgrad_key"] = (gen, key)
 
     @torch.no_grad()
     def backward(self, x: torch.Tensor, timesteps: torch.Tensor, grad_output: torch.Tensor, params=None):

@@ -25,7 +25,13 @@ files on this half cannot be imported (they need PyTorch3D 0.7.4, un-vendored,
     * ``HarmonicEmbedding`` (logspace, append_input)
     * ``EmissionAbsorptionRaymarcher`` (surface_thickness 1, background_opacity 1e10,
       density_relu, blend_output False, bg (1,1,1))
-    * ``RayPointRefiner`` + ``sample_pdf`` (deterministic u = linspace(0,1,n), eps 1e-5)
+    * ``RayPointRefiner`` + ``sample_pdf`` (deterministic u = linspace(0,1,n), eps 1e-5).
+      FIDELITY CAVEAT: PyTorch3D's production refiner calls the compiled ``_C.sample_pdf`` - a sequential fp32 running
+      sum of the normalised weights per ray and a ``bin_weight > eps`` branch for the in-bin interpolation - while this
+      file restates the library's documented equivalent ``sample_pdf_python`` (``torch.cumsum``, ``denom < eps -> 1``).
+      The two agree except on which side of the eps switch an (almost) empty bin falls, i.e. exactly on the "fragile
+      rays" that ``tests/test_gpu_configs.py`` isolates (a raw ``denom`` within 0.3 eps of the switch); the HIP kernel
+      follows ``sample_pdf_python`` too (double running sums rounded to fp32, like torch's CPU cumsum).
     * ``look_at_view_transform`` / ``so3_exp_map``
 """
 from __future__ import annotations

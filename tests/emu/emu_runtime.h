@@ -7,6 +7,7 @@
 // documented gfx950 lane mappings.  This is not a product path: nothing in holo_diffusion_amd/ links it.
 #pragma once
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -107,9 +108,19 @@ extern std::mutex g_atomic_mutex;
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
-static inline void __syncthreads() { emu::t_block->bar.wait(); }
+static inline void emu_serial_abort(const char* what) {
+  fprintf(stderr, "[emu] %s inside a kernel launched in serial mode (emu_serial_kernel list is wrong)\n", what);
+  abort();
+}
+static inline void __syncthreads() {
+  if (!emu::t_block) emu_serial_abort("__syncthreads");
+  emu::t_block->bar.wait();
+}
 
-static inline emu::WaveCtx& emu_wave() { return emu::t_block->waves[emu::t_tid >> 6]; }
+static inline emu::WaveCtx& emu_wave() {
+  if (!emu::t_block) emu_serial_abort("a wave-collective operation");
+  return emu::t_block->waves[emu::t_tid >> 6];
+}
 
 // v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D col = l&31, row = (r&3)+8*(r>>2)+4*(l>>5)
 static inline f32x16 emu_mfma_f32_32x32x2f32(float a, float b, f32x16 c) {
@@ -347,10 +358,85 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 }
 
 namespace emu {
+// Persistent worker pool: a block's lanes are host threads that live across launches (creating 256 threads per block
+// dominated the run time of the barrier-free repack kernels).
+struct Pool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_start, cv_done;
+  std::function<void(int)> job;
+  uint64_t gen = 0;
+  int nactive = 0, remaining = 0;
+  void worker(int i) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_start.wait(lk, [&] { return gen != seen; });
+        seen = gen;
+        if (i >= nactive) continue;
+        f = job;
+      }
+      f(i);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        if (--remaining == 0) cv_done.notify_all();
+      }
+    }
+  }
+  void run(int n, std::function<void(int)> f) {
+    while ((int)th.size() < n) {
+      const int i = (int)th.size();
+      {
+        std::lock_guard<std::mutex> lk(m);  // a new worker must not mistake the CURRENT generation for new work
+      }
+      th.emplace_back([this, i] { worker(i); });
+      th.back().detach();
+    }
+    std::unique_lock<std::mutex> lk(m);
+    job = std::move(f);
+    nactive = n;
+    remaining = n;
+    ++gen;
+    cv_start.notify_all();
+    cv_done.wait(lk, [&] { return remaining == 0; });
+  }
+};
+inline Pool& pool() {
+  static Pool* p = new Pool();  // leaked on purpose: detached workers outlive static destruction
+  return *p;
+}
+
+// Kernels known to be free of barriers and wave-collective operations (weight repacks, element-wise copies): their
+// lanes run one after the other on the calling thread.  A wrong entry aborts loudly (emu_serial_abort).
+static inline bool serial_kernel(const char* name) {
+  static const char* const pre[] = {"repack_", "copy_sys_kernel", "tanh_kernel", "clip_kernel", "ddpm_step_kernel"};
+  for (const char* p : pre)
+    if (strncmp(name, p, strlen(p)) == 0) return true;
+  return false;
+}
+
 template <class K, class... Args>
-void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+void launch(const char* name, K kernel, dim3 grid, dim3 block, Args... args) {
   const int nthreads = (int)(block.x * block.y * block.z);
   const int nwaves = (nthreads + 63) / 64;
+  if (serial_kernel(name)) {
+    t_block = nullptr;
+    blockDim = block;
+    gridDim = grid;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+      for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned bx = 0; bx < grid.x; ++bx) {
+          blockIdx = dim3(bx, by, bz);
+          for (int t = 0; t < nthreads; ++t) {
+            t_tid = t;
+            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            kernel(args...);
+          }
+        }
+    return;
+  }
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
@@ -361,24 +447,24 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
           int n = nthreads - w * 64;
           ctx.waves[w].bar.init(n > 64 ? 64 : n);
         }
-        std::vector<std::thread> th;
-        th.reserve(nthreads);
-        for (int t = 0; t < nthreads; ++t) {
-          th.emplace_back([&, t]() {
-            t_block = &ctx;
-            t_tid = t;
-            threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-            blockIdx = dim3(bx, by, bz);
-            blockDim = block;
-            gridDim = grid;
-            kernel(args...);
-            ctx.waves[t >> 6].bar.drop();
-            ctx.bar.drop();
-          });
-        }
-        for (auto& x : th) x.join();
+        pool().run(nthreads, [&](int t) {
+          t_block = &ctx;
+          t_tid = t;
+          threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+          blockIdx = dim3(bx, by, bz);
+          blockDim = block;
+          gridDim = grid;
+          kernel(args...);
+          ctx.waves[t >> 6].bar.drop();
+          ctx.bar.drop();
+        });
       }
 }
 }  // namespace emu
 
-#define HOLO_LAUNCH(kernel, grid, block, stream, ...) emu::launch(kernel, grid, block, __VA_ARGS__)
+static inline void emu_trace_launch(const char* name, dim3 g, dim3 b) {
+  static const bool on = getenv("HOLO_EMU_TRACE") != nullptr;
+  if (on) fprintf(stderr, "[emu] %s grid (%u,%u,%u) block %u\n", name, g.x, g.y, g.z, b.x * b.y * b.z);
+}
+#define HOLO_LAUNCH(kernel, grid, block, stream, ...) \
+  (emu_trace_launch(#kernel, grid, block), emu::launch(#kernel, kernel, grid, block, __VA_ARGS__))

@@ -132,6 +132,70 @@ def test_north_star_ray_subset_vs_oracle(gu):
         assert int(bad_hip.sum()) <= 3 * int(bad_ctl.sum()) + 0.01 * len(idx)  # same order as the control's own rate
 
 
+def test_north_star_full_frame_vs_oracle(gu):
+    """configs[1], EVERY ray: one whole 400 x 400 frame of the 64^3 x 32 grid against ``ro.render_rays`` on all 160 000
+    rays (about a minute of host time) with the tolerances and the fragile-ray rule of the subset test above: rgb / mask
+    2e-4 on every ray; depth 2e-4 x far on every ray that is not fragile (no importance sample with a raw ``den`` within
+    0.3 eps of sample_pdf's switch), 5e-3 x far on all, 99 % within 2e-4 x far; the coarse pass on every ray."""
+    R, C, H, W = (8, 32, 24, 24) if EMU else (64, 32, 400, 400)
+    model, _, _, rcfg, msd = gu.make_model(R, C, H, W, TINY_UNET if EMU else NORTH_UNET)
+    model.net_3d_enabled = False
+    grid = torch.tanh(torch.from_numpy(np_noise(17, (1, C, R, R, R))))
+    cams = _cams(8)
+    preds = model(camera=cams[3].to(gu.DEV), evaluation_mode=EvaluationMode.EVALUATION, voxel_features=grid.to(gu.DEV))
+    idx = torch.arange(H * W)
+    o, d, l = ro.make_rays(gu.cam_dict(cams, 3), rcfg)
+    ref = ro.render_rays(grid, msd, o, d, l, rcfg)
+    assert ref["rgb"].shape[0] == H * W
+    _check_rays(preds, ref, idx, H, W, coarse=preds["rendered"].prev_stage)
+    margin = 0.3 * rcfg.sample_pdf_eps
+    fragile = (ref["pdf_denom"] - rcfg.sample_pdf_eps).abs().min(dim=1)[0] <= margin
+    e = (preds["depths_render"].reshape(-1).cpu() - ref["depth"].reshape(-1)).abs()
+    bad = e >= 2e-4 * FAR
+    print(f"full frame: {H * W} rays, {int(fragile.sum())} fragile, {int(bad.sum())} outside 2e-4 x far "
+          f"(all of them fragile: {not bool((bad & ~fragile).any())}), max depth error {float(e.max()):.2e}, "
+          f"max rgb error {float((preds['images_render'].reshape(3, -1).t().cpu() - ref['rgb']).abs().max()):.2e}")
+    assert not (bad & ~fragile).any(), int((bad & ~fragile).sum())
+    # the frame is not trivial: opaque and semi-transparent rays both occur
+    m = ref["mask"].reshape(-1)
+    assert float(m.max()) > 0.95 and int(((m > 0.2) & (m < 0.8)).sum()) > 0.001 * H * W
+
+
+@pytest.mark.parametrize("T,max_iter", [(1000, 4), (250, 8)])
+def test_north_star_sampler_chain_vs_oracle(gu, T, max_iter):
+    """configs[1] as a CHAIN: the first ``max_iter`` DDPM steps (``p_sample_loop_progressive``, gaussian_diffusion.py:568-643)
+    of the 64^3 x 32 net with injected noise against ``DiffusionOracle`` driving the pinned UNet oracle - the sizes where
+    conv_wino2_kernel, split-K and the 4^3 weight-streaming level actually run (the recorded reference trajectories and
+    the wide-net chains are 8^3 grids).  Default planner; every step's sample and pred_xstart within 5e-3."""
+    from oracle.common import NORTH_CFG, TINY_CFG
+    cfg = TINY_CFG if EMU else NORTH_CFG
+    net, sd = gu.make_unet(cfg)
+    with np.errstate(divide="ignore"):
+        diff = hda.ImplicitronGaussianDiffusion(num_steps=T)
+    shape = (1, cfg.in_channels, cfg.image_size, cfg.image_size, cfg.image_size)
+    ns_dev = lambda t, shp, device=None: torch.from_numpy(np_noise(77 * 100003 + t, tuple(shp))).to(gu.DEV)  # noqa: E731
+    ns_cpu = lambda t, shp, device=None: torch.from_numpy(np_noise(77 * 100003 + t, tuple(shp)))  # noqa: E731
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        steps = [{k: v.cpu() for k, v in s.items() if k in ("sample", "pred_xstart")}
+                 for s in diff.p_sample_loop_progressive(net, shape, clip_denoised=True, noise_sampler=ns_dev, max_iter=max_iter)]
+        ref = list(do.DiffusionOracle(T).p_sample_loop_progressive(lambda x, t: uo.unet_forward(sd, cfg, x, t), shape,
+                                                                   ns_cpu, True, max_iter))
+    assert len(steps) == len(ref) == max_iter
+    worst = 0.0
+    for i, (s, r) in enumerate(zip(steps, ref)):
+        for k in ("sample", "pred_xstart"):
+            e = gu.rel_err(s[k], r[k])
+            worst = max(worst, e)
+            assert e < 5e-3, (k, i, e)
+    print(f"north-star chain T={T}, {max_iter} steps: worst relative error {worst:.2e}")
+    if not EMU:  # the planner's own choice put the wide levels on the (z,y) Winograd kernel
+        ops = net.time_ops(1, 1, gu.DEV)
+        kinds = {o_["kernel"] for o_ in ops if o_["op"] == "conv"}
+        assert any(k.startswith("conv_wino2") for k in kinds), kinds
+        assert any(o_["op"] == "conv" and o_["nsplit"] > 1 for o_ in ops)
+
+
 def test_config0_plumbing_frame_vs_oracle(gu):
     """configs[0] (unet_with_no_diffusion.yaml: diffusion disabled, the path is tanh(net_3d(vf, 0)) + render): 32^3 x 16
     grid, model_channels 64, one camera at 128x128, n_pts_per_ray_fine_evaluation = 16 (configs/...yaml:155-156): the

@@ -367,6 +367,7 @@ def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu):
     pu = {k: v.detach().clone().requires_grad_(True) for k, v in usd.items()}
     pm = {k: v.detach().clone().requires_grad_(True) for k, v in msd.items()}
     mnames = [k for k in pm if k.startswith("_density_net") or k.startswith("_radiance_net")]
+    pu_prev = {k: v.detach().clone() for k, v in pu.items()}  # the denoiser ONE update behind: what a stale forward would use
     losses = []
     for step in range(3):
         rs = _streams(2, n_rays, P, Pf, 2000 + 10 * step)
@@ -398,11 +399,24 @@ def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu):
             params = [pu[k] for k in pu] + [pm[k] for k in mnames]
             gs = torch.autograd.grad(lo, params, allow_unused=True)
         with torch.no_grad():
+            pu_prev = {k: v.detach().clone() for k, v in pu.items()}
             for p_, g_ in zip(params, gs):
                 if g_ is not None:
                     p_.add_(g_, alpha=-lr)
         losses.append((float(loss.detach()), float(lo.detach())))
         assert abs(losses[-1][0] - losses[-1][1]) < 2e-5 * max(1.0, abs(losses[-1][1])), (step, losses)
+        # the loss alone cannot tell a stale forward from a fresh one (one update moves it by 0.1 of the tolerance above -
+        # the round-3 advisor's point); the denoiser's output can: 0.8 % per update at this learning rate
+        with torch.no_grad():
+            x_t = orc.q_sample(vf, tt, qn)
+            y_new = uo.unet_forward.__wrapped__(pu, ucfg, x_t, tt)
+            y_old = uo.unet_forward.__wrapped__(pu_prev, ucfg, x_t, tt)
+            y_hip = model.net_3d(x_t.to(gu.DEV), tt.to(gu.DEV)).cpu()
+        scale = float(y_new.abs().max())
+        assert float((y_new - y_old).abs().max()) > 5e-3 * scale, "the update is too small for this check to notice stale weights"
+        assert float((y_hip - y_new).abs().max()) < 5e-4 * scale, ("forward after the in-place update", step,
+                                                                 float((y_hip - y_new).abs().max()) / scale,
+                                                                 float((y_hip - y_old).abs().max()) / scale)
     named = dict(model.named_parameters())
     worst = ("", 0.0)
     for prefix, ref in (("net_3d._net.", pu), ("_implicit_functions.0._fn.render_mlp.", {k: pm[k] for k in mnames})):

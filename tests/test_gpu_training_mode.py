@@ -47,7 +47,8 @@ def _oracle_training_render(grid, msd, cams, xys, rs, rcfg, noise_std, gu):
     return {k: torch.stack([o[k] for o in outs]) for k in ("rgb", "depth", "mask", "rgb_c", "depth_c", "mask_c")}
 
 
-@pytest.mark.parametrize("P,Pf,C,which", [(24, 20, 16, "all"), (64, 64, 32, "all"), (24, 20, 32, "noise_only"), (16, 100, 16, "strat_only")])
+@pytest.mark.parametrize("P,Pf,C,which", [(24, 20, 16, "all"), (64, 64, 32, "all"), (24, 20, 32, "noise_only"), (16, 100, 16, "strat_only"),
+                                          (24, 20, 16, "coarse_strat_only")])
 def test_training_mode_render_vs_oracle(gu, P, Pf, C, which):
     """holo_render_rays through the renderer plugin's TRAINING branch: explicit NDC ray lists per camera (ragged 4-ray
     tiles), P stratified coarse depths, Pf stratified importance samples (unsorted draws: the kernel sorts them), density
@@ -69,6 +70,11 @@ def test_training_mode_render_vs_oracle(gu, P, Pf, C, which):
     if which == "strat_only":
         model.renderer.density_noise_std_train = std = 0.0
         rs = {k: v for k, v in rs.items() if k.startswith("u_")}
+    if which == "coarse_strat_only":
+        # the ray sampler's flag alone jitters the coarse depths; the renderer's flag only makes the RayPointRefiner's
+        # importance samples random (PyTorch3D MultiPassEmissionAbsorptionRenderer: random_sampling of the refiner)
+        model.renderer.stratified_sampling_coarse_training = False
+        rs = {k: v for k, v in rs.items() if k != "u_fine"}
     for fn in model._implicit_functions:
         fn.bind_args(voxel_grid_features=grid.to(gu.DEV))
     bundle = model.raysampler(cams.to(gu.DEV), EvaluationMode.TRAINING, xys=xys.to(gu.DEV))

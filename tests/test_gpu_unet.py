@@ -181,6 +181,54 @@ def test_forward_is_deterministic_and_param_rebind(gu):
     torch.testing.assert_close(c, a + 1.0, rtol=1e-5, atol=1e-5)
 
 
+def test_in_place_parameter_update_is_noticed_without_a_hint(gu):
+    """An optimiser step / ``p.add_()`` goes through none of the module hooks: the plugin compares every parameter's
+    (storage, version counter) on each call and re-uploads (round-3 advisor finding: the forward kept the old weights
+    while the transposed dgrad weights were refreshed)."""
+    net, sd = gu.make_unet(TINY_CFG)
+    x = seeded_input(TINY_CFG, 1).to(gu.DEV)
+    t = torch.tensor([10], device=gu.DEV)
+    a = net(x, t)
+    e0 = net.weights_epoch()
+    with torch.no_grad():
+        dict(net.named_parameters())["_net.out.2.bias"].add_(1.0)  # no mark_parameters_changed()
+    assert net.weights_epoch() == e0 + 1
+    b = net(x, t)
+    torch.testing.assert_close(b, a + 1.0, rtol=1e-5, atol=1e-5)
+    # a convolution weight: forward AND backward must both see the new values (oracle on the updated state dict)
+    name = "input_blocks.1.0.in_layers.2.weight"
+    with torch.no_grad():
+        dict(net.named_parameters())["_net." + name].mul_(1.5)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["out.2.bias"] += 1.0
+    sd2[name] *= 1.5
+    xr = seeded_input(TINY_CFG, 1).requires_grad_(True)
+    with torch.enable_grad():
+        yr = uo.unet_forward.__wrapped__(sd2, TINY_CFG, xr, torch.tensor([10]))
+        w = torch.from_numpy(np.random.RandomState(3).randn(*yr.shape).astype(np.float32))
+        gxr, = torch.autograd.grad((yr * w).sum(), xr)
+    y, gx, _ = net.backward(x, t, w.to(gu.DEV), params=[])
+    assert gu.rel_err(y, yr.detach()) < TOL
+    assert gu.rel_err(gx, gxr) < 2e-3
+    assert gu.rel_err(net(x, t), yr.detach()) < TOL
+
+
+def test_backward_after_a_grid_size_switch(gu):
+    """A forward at another grid size recreates the native handle; the transposed (dgrad) weights of the new handle must
+    be prepared again even if malloc hands out the old address (round-3 advisor finding)."""
+    net, sd = gu.make_unet(TINY_CFG)
+    R = TINY_CFG.image_size
+    t = torch.tensor([10], device=gu.DEV)
+    x = seeded_input(TINY_CFG, 1).to(gu.DEV)
+    g = torch.ones_like(x)
+    _, gx_a, _ = net.backward(x, t, g, params=[])
+    big = torch.zeros(1, TINY_CFG.in_channels, 2 * R, 2 * R, 2 * R, device=gu.DEV)
+    net(big, t)  # switches the plan (and the handle) to the larger grid
+    net.backward(big, t, torch.ones_like(big), params=[])
+    _, gx_b, _ = net.backward(x, t, g, params=[])  # and back
+    assert torch.equal(gx_a, gx_b)
+
+
 def test_wrong_shape_and_unset_errors(gu):
     net, _ = gu.make_unet(TINY_CFG)
     for bad in ((1, 16, 8, 8, 8), (1, 32, 7, 7, 7), (1, 32, 8, 8, 4)):  # channels; not a multiple of 2^(levels-1); not cubic
