@@ -397,7 +397,7 @@ def main():
     if rank == 0:
         all_ops = net.time_ops(1, args.conv_iters, device)
         ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
-        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_bf16t_kernel")
+        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_bf16t_kernel", "conv_wino3_kernel")
         variants = {}
         for o in ops:
             key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"], 4 if o["cout"] >= 64 else 2) \
@@ -426,6 +426,10 @@ def main():
             label = f"{kname}<{'true' if sk else 'false'}> at {od}^3 output"
             what = ("3x3x3 conv3d, LDS voxel-halo implicit GEMM in Winograd F(2x2,3x3) form over (depth, height): 48 "
                     "pseudo-taps per 2x2 outputs instead of 108")
+        elif kname == "conv_wino3_kernel":
+            label = f"{kname}<{'true' if sk else 'false'}> at {od}^3 output"
+            what = ("3x3x3 conv3d, LDS voxel-halo implicit GEMM in Winograd F(2x2x2,3x3x3) form over all three axes: 64 "
+                    "pseudo-taps per 2x2x2 outputs instead of 216; one persistent 512-register wave per SIMD")
         elif kname == "conv_bf16t_kernel":
             label = f"{kname}<{2 if nwn == 4 else 1}, {'true' if sk else 'false'}, true> at {od}^3 output"
             what = ("3x3x3 conv3d on bf16 activations, 8x8x8 output tiles, LDS voxel-halo implicit GEMM, "
@@ -452,7 +456,7 @@ def main():
                 "effective_tflops": ach, "effective_frac": ach / peak,
                 "note": ("achieved/frac count the multiply-adds ISSUED to the matrix pipe (executed flops / average launch "
                          "time, hipEvents on the launch stream); effective_* count the ALGORITHMIC flops of the convolution "
-                         "(27 taps, what the reference computes) - the Winograd F(2x2,3x3) kernel issues 4/9 of them, so "
+                         "(27 taps, what the reference computes) - the Winograd kernels issue 8/27 (F(2x2x2)) or 4/9 (F(2x2)) of them, so "
                          "effective_frac may pass 1 while frac cannot"),
                 "traffic": traffic, "launches_per_forward": dom["n"], "avg_launch_ms": dom["ms"] / dom["n"],
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["n"] / 1e9,

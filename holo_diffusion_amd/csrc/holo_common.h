@@ -33,6 +33,11 @@ static inline T holo_ld_sys(const T* p) { return *p; }
 #define HOLO_PROBE_CLOCK() 0ull
 #define HOLO_PROBE_HWID(hw, xcc) ((hw) = 0u, (xcc) = 0u)
 #define HOLO_PHASE_DELAY(ticks) ((void)(ticks))
+#define HOLO_UNIFORM(x) (x)
+#define HOLO_PIN_ACC(x) ((void)0)
+#define HOLO_MFMA16_ACC(acc, a, b) ((acc) = emu_mfma_f32_16x16x4f32((a), (b), (acc)))
+#define HOLO_MFMA16_ACC_FIRST(acc, a, b) ((acc) = emu_mfma_f32_16x16x4f32((a), (b), (acc)))
+#define HOLO_MFMA_DRAIN() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -97,6 +102,22 @@ template <typename T>
 __device__ __forceinline__ T holo_ld_sys(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// A wave-uniform value the compiler cannot prove uniform (e.g. threadIdx.x >> 6): v_readfirstlane moves it to an SGPR,
+// so that addresses built from it use scalar bases.
+#define HOLO_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// Forces a value (an MFMA accumulator) to sit in AGPRs at this point of the program.
+#define HOLO_PIN_ACC(x) asm volatile("" : "+a"(x))
+// v_mfma_f32_16x16x4_f32 with the accumulator TIED to an AGPR tuple (dst = src C).  For kernels whose accumulators fill
+// the whole accumulation half of the register file (256 registers, one wave per SIMD): through the builtin the register
+// allocator renames accumulators between MFMAs and, with no spare AGPR, parks a dozen sets in arch VGPRs (copies at every
+// loop edge, scratch spills); tied operands leave it nothing to shuffle.  hipcc pads no hazards inside an asm statement
+// (cdna_hip_programming.md 5.7 item 2): _FIRST opens with `s_nop 1` for A / B operands a VALU instruction has just
+// written (use it for the first MFMA after the vector arithmetic that produced the operands); the accumulate chain itself
+// needs no states; HOLO_MFMA_DRAIN() before anything but an MFMA reads the accumulators (8-pass MFMA: 12 states).
+#define HOLO_MFMA16_ACC(acc, a, b) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define HOLO_MFMA16_ACC_FIRST(acc, a, b) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+#define HOLO_MFMA_DRAIN() asm volatile("s_nop 15" ::: "memory")
 #define HOLO_PROBE_CLOCK() wall_clock64()
 // Delays the waves that landed in an odd wave slot of their SIMD (= the second resident workgroup of the CU).
 #define HOLO_PHASE_DELAY(ticks)                                                      \

@@ -72,7 +72,11 @@ struct ConvParams {
   // (xi_z*4 + xi_y)*3 + kx; the fused skip as 4 pseudo-taps (xi_z,xi_y in {1,2}^2: +-w/4)
   const float* w_wino2;
   const float* skip_w_wino2;
-  int wino;               // set by conv_plan: 0 direct, 1 Winograd in depth, 2 Winograd in depth and height
+  int wino;               // set by conv_plan: 0 direct, 1 Winograd in depth, 2 Winograd in depth and height, 3 all three axes
+  // F(2x2x2, 3x3x3) form (conv_wino3_kernel, kernels_conv3.hip): the 64 pseudo-taps in the wave's consumption order
+  // (repack_conv_weight_wino3_launch); the fused skip as 8 signed copies of the 1x1x1 weight
+  const float* w_wino3;
+  const float* skip_w_wino3;
   // bf16 wide-tile kernel (conv_bf16t_kernel, 8x8x8 output tiles, v_mfma_f32_32x32x16_bf16): plane 3 of the bf16
   // weight buffer, packed [ksz^3][CinP/16][CoutP/32][lane 64][8 bf16] = one 1 KB block of B operands per
   // (tap, 16-channel chunk, 32-Cout slice); lane's 8 values are channels 8*(lane>>5) .. +7 of output channel lane&31
@@ -85,6 +89,12 @@ struct ConvParams {
   int res_bf16;           // residual
   int out_bf16;           // out
 };
+
+// kernels_conv3.hip
+int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps);
+int repack_conv_weight_wino3_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
+                                    void* stream);
+int conv_wino3_launch(const ConvParams& p, void* stream);
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
 size_t conv_plan(ConvParams& p, int num_cus);

@@ -2664,6 +2664,39 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     p.wino = (p.tz == 2 && p.w_wino && p.bf16 == 0 && p.Cout >= 64 && (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino)) ? 1 : 0;
     if (p.wino && p.w_wino2 && (!p.skip_w || p.skip_w_wino2)) p.wino = 2;  // both depth and height in Winograd form
     if (p.tz == 2 && p.w_wino2 && p.bf16 == 0 && p.Cout == 32 && !p.skip_w) p.wino = 2;  // 32-channel (z,y) form, two wave rows
+    // F(2x2x2, 3x3x3) form (kernels_conv3.hip): ONE persistent 4-wave workgroup per CU walks (tile, 64-Cout block, split)
+    // items, so the chip is full from num_cus items on (the (z,y) form needs 2 workgroups per CU); split-K only up to that.
+    // HOLO_CONV_WINO3=0 disables it, HOLO_CONV_WINO3_MIN_ITEMS=<n> moves the threshold (default num_cus / 2)
+    {
+      const char* e3 = getenv("HOLO_CONV_WINO3");
+      const char* m3 = getenv("HOLO_CONV_WINO3_MIN_ITEMS");
+      const int64_t t3 = (M / 128) * (p.Cout / 64);
+      const int64_t min_items = m3 ? atoi(m3) : num_cus / 2;
+      if (!(e3 && e3[0] == '0') && p.tz == 2 && p.w_wino3 && p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && p.Cout >= 64 &&
+          (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino3) && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.OD % 2) == 0) {
+        int ns3 = 1;
+        if (t3 < num_cus) {
+          ns3 = (int)cdiv(num_cus, t3);
+          if (ns3 > ncc) ns3 = ncc;
+        }
+        const int cps3 = (int)cdiv(ncc, ns3);
+        ns3 = (int)cdiv(ncc, cps3);
+        if (t3 * ns3 >= min_items) {
+          p.wino = 3;
+          p.nsplit = ns3;
+          p.chunks_per_split = cps3;
+          p.skip_chunks_per_split = (int)cdiv(nsk, ns3);
+          const int64_t items = t3 * ns3;
+          // every workgroup gets the same number of items when the list allows it (the last round is then full)
+          const int64_t rounds = cdiv(items, num_cus);
+          p.grid_x = (int)cdiv(items, rounds);
+          if (getenv("HOLO_DEBUG_PLAN"))
+            fprintf(stderr, "[plan] conv %d->%d @%d^3: F(2x2x2) Winograd kernel, %lld items on %d workgroups, split-K %d%s\n", Cin,
+                    p.Cout, p.OD, (long long)items, p.grid_x, ns3, p.skip_w ? ", fused skip" : "");
+          return ns3 > 1 ? (size_t)ns3 * M * p.Cout * sizeof(float) : 0;
+        }
+      }
+    }
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   if (tiles < target) {
@@ -2705,6 +2738,8 @@ double conv_flops(const ConvParams& p) {
 double conv_exec_flops(const ConvParams& p) {
   if (!p.wino) return conv_flops(p);
   const double M = (double)p.N * p.OD * p.OH * p.OW;
+  if (p.wino == 3)  // 64 pseudo-taps per 2 x 2 x 2 outputs; the fused skip is accumulated directly (1 per output)
+    return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 8.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
   if (p.wino == 2)  // 48 pseudo-taps per 2 x 2 outputs, the fused skip 4 pseudo-taps per 4 outputs
     return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 12.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
   return 2.0 * M * p.Cout * ((double)(p.C0 + p.C1) * 18.0 + (p.skip_w ? p.skip_C0 + p.skip_C1 : 0));
@@ -2747,6 +2782,8 @@ int conv_launch(const ConvParams& p, void* stream) {
         }
       }
 #undef HOLO_BF16T
+    } else if (p.wino == 3) {
+      if (conv_wino3_launch(p, stream)) return -1;
     } else if (p.wino == 2) {
       if (!wide) {
         HOLO_LAUNCH((conv_wino2_kernel<false, 2>), hgrid, block, stream, p);

@@ -73,6 +73,7 @@ struct ParamSlot {
   uint16_t* priv_bf = nullptr;  // conv weights: bf16 (RNE) copy packed for v_mfma_f32_16x16x32_bf16
   float* priv_wino = nullptr;   // conv weights of the wide top levels: Winograd-in-depth pseudo-taps (conv_wino_kernel)
   float* priv_wino2 = nullptr;  // ... and the (z,y) Winograd pseudo-taps (conv_wino2_kernel)
+  float* priv_wino3 = nullptr;  // ... and the F(2x2x2, 3x3x3) pseudo-taps (conv_wino3_kernel)
   bool set;
 };
 
@@ -181,6 +182,7 @@ struct HoloUnet {
   float* pstore_wino = nullptr;                        // Winograd-in-depth copies (36 / 2 pseudo-taps)
   std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
   std::map<const float*, const float*> wino2_of;       // fp32 private copy -> (z,y) Winograd copy
+  std::map<const float*, const float*> wino3_of;       // fp32 private copy -> F(2x2x2, 3x3x3) Winograd copy
   std::map<std::string, float*> dgrad_wino, dgrad_wino2;  // Winograd copies of the transposed (dgrad) weights
   // holo_unet_set_compute_dtype: 0 exact fp32 MFMA; 1 bf16: activations stored as bf16 in HBM, bf16 products with fp32
   // accumulation in the 3x3x3 convolutions and the long-sequence attention, fp32 GroupNorm statistics; 2 bf16x3 split
@@ -506,6 +508,8 @@ struct Planner {
       p.w_wino = it == u->wino_of.end() ? nullptr : it->second;
       auto it2 = u->wino2_of.find(w);
       p.w_wino2 = it2 == u->wino2_of.end() ? nullptr : it2->second;
+      auto it3 = u->wino3_of.find(w);
+      p.w_wino3 = it3 == u->wino3_of.end() ? nullptr : it3->second;
     }
     p.coef = has_coef ? ptr<float>(coef_off) : nullptr;
     p.act = act;
@@ -529,6 +533,8 @@ struct Planner {
         p.skip_w_wino = it == u->wino_of.end() ? nullptr : it->second;
         auto it2 = u->wino2_of.find(skip_w);
         p.skip_w_wino2 = it2 == u->wino2_of.end() ? nullptr : it2->second;
+        auto it3 = u->wino3_of.find(skip_w);
+        p.skip_w_wino3 = it3 == u->wino3_of.end() ? nullptr : it3->second;
       }
       p.skip_CinP = pad_cin(p.skip_C0 + p.skip_C1);
       p.skip_bias = skip_bias;
@@ -1456,9 +1462,18 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
     };
     const bool enable2 = enable && !(we && we[0] == '1');  // HOLO_CONV_WINO=1: depth only; default: both forms prepared
     auto wino2_numel = [&](const ParamSlot& s) -> int64_t { return enable2 ? wino_numel(s) / (s.kind == P_CONV3 ? 36 : 2) * (s.kind == P_CONV3 ? 48 : 4) : 0; };
+    // F(2x2x2, 3x3x3) copies (conv_wino3_kernel, 64 pseudo-taps / 8 signed skip copies): the levels whose workgroup list
+    // can fill the chip - up to 128 output channels (64^3 .. 16^3 in the released nets); HOLO_CONV_WINO3=0: none
+    const char* w3e = getenv("HOLO_CONV_WINO3");
+    const bool enable3 = enable2 && !(w3e && w3e[0] == '0');
+    auto wino3_numel = [&](const ParamSlot& s) -> int64_t {
+      if (!enable3 || wino_numel(s) == 0 || s.shape[0] % 64 || s.shape[0] > 128 || s.shape[1] > 384) return 0;
+      return conv_wino3_weight_floats(pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]), s.kind == P_CONV3 ? 27 : 1);
+    };
     int64_t tw = 0;
     if (enable)
-      for (auto& s : u->params) tw += ((wino_numel(s) + 63) & ~(int64_t)63) + ((wino2_numel(s) + 63) & ~(int64_t)63);
+      for (auto& s : u->params)
+        tw += ((wino_numel(s) + 63) & ~(int64_t)63) + ((wino2_numel(s) + 63) & ~(int64_t)63) + ((wino3_numel(s) + 63) & ~(int64_t)63);
     if (tw > 0) {
       if (hipMalloc((void**)&u->pstore_wino, (size_t)tw * sizeof(float)) != hipSuccess) {
         set_error("holo_unet_create: hipMalloc of %lld Winograd weights failed", (long long)tw);
@@ -1479,6 +1494,12 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
           s.priv_wino2 = cw;
           u->wino2_of[s.priv] = cw;
           cw += (nw2 + 63) & ~(int64_t)63;
+        }
+        const int64_t nw3 = wino3_numel(s);
+        if (nw3) {
+          s.priv_wino3 = cw;
+          u->wino3_of[s.priv] = cw;
+          cw += (nw3 + 63) & ~(int64_t)63;
         }
       }
     }
@@ -1572,6 +1593,12 @@ int holo_unet_set_param(HoloUnet* net, const char* name, const void* dev_ptr, in
       rc = repack_conv_weight_wino_launch((const float*)dev_ptr, s.priv_wino2, (int)s.shape[0], (int)s.shape[1],
                                           s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]),
                                           pad_cin((int)s.shape[1]), stream, 2);
+      if (rc) return rc;
+    }
+    if (s.priv_wino3) {
+      rc = repack_conv_weight_wino3_launch((const float*)dev_ptr, s.priv_wino3, (int)s.shape[0], (int)s.shape[1],
+                                           s.kind == P_CONV3 ? 27 : 1, pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]),
+                                           stream);
       if (rc) return rc;
     }
   } else {  // biases, GroupNorm parameters, Linear layers: a copy kernel with system-scope loads (holo_ld_sys) - like the
@@ -1734,7 +1761,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.bf16t ? 5 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
+        t.kernel = c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

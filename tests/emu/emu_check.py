@@ -232,6 +232,8 @@ if __name__ == "__main__":
         allok &= check_unet()
     if "unet_wide" in what:
         allok &= check_unet_wide()
+    if "unet_wide16" in what:  # 16^3 top level: 8 spatial tiles per conv, several items per workgroup
+        allok &= check_unet_wide(image=16)
     if "unet_wide_bf16" in what:
         allok &= check_unet_wide(bf16=True)
     if "unet_wide_split" in what:

@@ -322,7 +322,8 @@ struct hipDeviceProp_t {
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
-  p->multiProcessorCount = 4;  // small "chip" so that split-K paths are exercised on tiny problems
+  const char* e = getenv("HOLO_EMU_CUS");
+  p->multiProcessorCount = e ? atoi(e) : 4;  // small "chip" so that split-K paths are exercised on tiny problems
   return hipSuccess;
 }
 static inline hipError_t hipMalloc(void** p, size_t n) {

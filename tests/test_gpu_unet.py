@@ -108,16 +108,22 @@ def test_mid_size_unet_vs_oracle_blockwise(gu, image, mc, mult, attn, batch):
         del os.environ["HOLO_KEEP_INTERMEDIATES"]
 
 
-@pytest.mark.parametrize("wino_kernel,wino_env", [("conv_wino2_kernel", "2"), ("conv_wino_kernel", "1")])
+@pytest.mark.parametrize("wino_kernel,wino_env", [("conv_wino3_kernel", "2"), ("conv_wino2_kernel", "2"), ("conv_wino_kernel", "1")])
 @pytest.mark.parametrize("image,mc,mult,attn,batch", [(16, 64, (1, 2), (), 1), (8, 64, (1, 2, 2), (2,), 2),
                                                        (16, 32, (1, 1), (), 1)])  # 32-channel convs: two-wave-row variant
 def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kernel, wino_env, monkeypatch):
-    """conv_wino2_kernel / conv_wino_kernel (the Winograd F(2,3) forms of the 128-voxel halo kernel over (depth, height)
-    / depth only; the former is what the 64^3 level of the north-star net runs on) forced onto small grids: plain,
+    """conv_wino3_kernel / conv_wino2_kernel / conv_wino_kernel (the Winograd F(2,3) forms over all three axes - what the
+    64^3 and 32^3 levels of the north-star net run on -, over (depth, height), over depth only) forced onto small grids: plain,
     fused-skip, upsample-on-load, virtual-concat and split-K launches, every block output against the pinned oracle at
     the SAME per-op tolerance as the direct kernel."""
     monkeypatch.setenv("HOLO_CONV_FORCE_TZ2", "1")
     monkeypatch.setenv("HOLO_CONV_WINO", wino_env)  # 2 (default): both forms prepared, (z,y) preferred; 1: depth only
+    if wino_kernel == "conv_wino3_kernel":
+        monkeypatch.setenv("HOLO_CONV_WINO3_MIN_ITEMS", "1")  # the three-axis form on work lists far below one per CU
+        if mc == 32:
+            pytest.skip("the three-axis form needs 64-channel output blocks")
+    else:
+        monkeypatch.setenv("HOLO_CONV_WINO3", "0")
     if mc == 32 and wino_env == "1":
         pytest.skip("the depth-only form has no 32-channel variant")
     monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
@@ -141,6 +147,7 @@ def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kerne
     # and the direct kernel on the same net agrees with it to rounding
     monkeypatch.setenv("HOLO_CONV_FORCE_TZ2", "0")
     monkeypatch.setenv("HOLO_CONV_WINO", "0")
+    monkeypatch.setenv("HOLO_CONV_WINO3", "0")
     net2, _ = gu.make_unet(cfg, seed=77)
     with torch.no_grad():
         y2 = net2(x.to(gu.DEV), t.to(gu.DEV))
