@@ -38,6 +38,8 @@ static inline T holo_ld_sys(const T* p) { return *p; }
 #define HOLO_MFMA16_ACC(acc, a, b) ((acc) = emu_mfma_f32_16x16x4f32((a), (b), (acc)))
 #define HOLO_MFMA16_ACC_FIRST(acc, a, b) ((acc) = emu_mfma_f32_16x16x4f32((a), (b), (acc)))
 #define HOLO_MFMA_DRAIN() ((void)0)
+#define HOLO_SINK8(a, b, c, d, e, f, g, h) ((void)0)
+#define HOLO_PIN_V2(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -118,6 +120,11 @@ __device__ __forceinline__ T holo_ld_sys(const T* p) {
 #define HOLO_MFMA16_ACC_FIRST(acc, a, b) \
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
 #define HOLO_MFMA_DRAIN() asm volatile("s_nop 15" ::: "memory")
+// pins the computation of a register pair at this point of the program (an empty asm volatile that "modifies" it: asm
+// volatile statements keep their order, so the value is formed before the next asm MFMA)
+#define HOLO_PIN_V2(x) asm volatile("" : "+v"(x))
+// keeps eight values (and the loads behind them) alive without using them (development probes)
+#define HOLO_SINK8(a, b, c, d, e, f, g, h) asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h))
 #define HOLO_PROBE_CLOCK() wall_clock64()
 // Delays the waves that landed in an odd wave slot of their SIMD (= the second resident workgroup of the CU).
 #define HOLO_PHASE_DELAY(ticks)                                                      \

@@ -2673,7 +2673,9 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       const int64_t t3 = (M / 128) * (p.Cout / 64);
       const int64_t min_items = m3 ? atoi(m3) : num_cus / 2;
       if (!(e3 && e3[0] == '0') && p.tz == 2 && p.w_wino3 && p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && p.Cout >= 64 &&
-          (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino3) && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.OD % 2) == 0) {
+          (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino3) && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.OD % 2) == 0 &&
+          (!p.coef || p.act) &&  // (its staging applies the affine and SiLU together)
+          (int64_t)p.N * src_vox * cmax * 4 < ((int64_t)1 << 32)) {  // (buffer addressing of a whole source tensor)
         int ns3 = 1;
         if (t3 < num_cus) {
           ns3 = (int)cdiv(num_cus, t3);

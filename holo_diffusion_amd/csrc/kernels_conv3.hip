@@ -35,8 +35,24 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
+
+// Development probes (tools/conv_ab builds extra copies of this file with -DW3_PROBE=<bits> -DW3_ENTRY=<name>): 1 no halo
+// requests / commits inside the stage loop, 2 no weight requests, 4 no patch reads / input transforms, 8 no MFMAs, 16 weight
+// requests into registers nobody waits for, 32 halo requests but no commits, 64 commits without the activation.
+#ifndef W3_PROBE
+#define W3_PROBE 0
+#endif
+#ifndef W3_WDIST
+#define W3_WDIST 3  // weight requests run this many 16-MFMA groups ahead (2: measured ~190 cycles of wait per group)
+#endif
+#ifndef W3_ENTRY
+#define W3_ENTRY conv_wino3_launch
+#endif
 
 namespace holo {
 
@@ -53,16 +69,46 @@ constexpr int W3_WSKIP = 4 * W3_WSUB;          // floats per (skip chunk, slice)
 
 __device__ __forceinline__ float w3_silu(float v) { return v * holo_rcp(1.0f + __expf(-v)); }
 
-#ifdef HOLO_EMU
-struct w3v4 {
-  float x, y, z, w;
+// 16 bytes as two register pairs: arithmetic on the pairs is v_pk_add_f32 / v_pk_fma_f32 (one instruction per two values:
+// with ONE wave per SIMD every instruction costs an issue slot of ~4-5 cycles, whatever it does)
+struct w3q {
+  f32x2 lo, hi;
 };
-static inline w3v4 operator+(w3v4 a, w3v4 b) { return w3v4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
-static inline w3v4 operator-(w3v4 a, w3v4 b) { return w3v4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+__device__ __forceinline__ w3q w3_ld(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return w3q{f32x2{v.x, v.y}, f32x2{v.z, v.w}};
+}
+// Buffer addressing (scalar resource + 32-bit vector offset + 32-bit scalar offset): a request then needs NO vector
+// instruction for its address - a vector instruction between two MFMAs costs ~15 cycles (tools/mfma_shadow_probe.cpp).
+// The whole tensor must lie within 4 GB of its base (conv_plan checks).
+#ifdef HOLO_EMU
+struct w3_rsrc {
+  const char* base;
+};
+static inline w3_rsrc w3_make_rsrc(const void* p) { return w3_rsrc{reinterpret_cast<const char*>(p)}; }
+static inline w3q w3_bld(const w3_rsrc& r, unsigned voff, unsigned soff) {
+  return w3_ld(reinterpret_cast<const float*>(r.base + (size_t)voff + (size_t)soff));
+}
 #else
-typedef float w3v4 __attribute__((ext_vector_type(4)));  // arithmetic on it compiles to v_pk_add_f32 pairs
+typedef __amdgpu_buffer_rsrc_t w3_rsrc;
+typedef unsigned w3u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w3_rsrc w3_make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ w3q w3_bld(w3_rsrc r, unsigned voff, unsigned soff) {
+  const w3u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return w3q{f32x2{__uint_as_float(v.x), __uint_as_float(v.y)}, f32x2{__uint_as_float(v.z), __uint_as_float(v.w)}};
+}
 #endif
-__device__ __forceinline__ w3v4 w3_ld(const float* p) { return *reinterpret_cast<const w3v4*>(p); }
+__device__ __forceinline__ w3q w3_add(const w3q& a, const w3q& b) { return w3q{pk_add(a.lo, b.lo), pk_add(a.hi, b.hi)}; }
+__device__ __forceinline__ w3q w3_sub(const w3q& a, const w3q& b) { return w3q{pk_sub(a.lo, b.lo), pk_sub(a.hi, b.hi)}; }
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the 16 MFMA slots of a group as straight-line code with
+// compile-time slot numbers (a `#pragma unroll` loop over them inside the two unrolled group loops is refused by the unroller)
+template <class F, int... K>
+__device__ __forceinline__ void w3_static_for(F&& f, std::integer_sequence<int, K...>) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
 
 // One persistent workgroup per CU.  Work list: item = ((split * ny + cout block) * ntiles + tile), dealt round robin.
 // XF: the input passes through the per-(sample, channel) affine (GroupNorm folded with FiLM) and, with p.act, SiLU.
@@ -110,145 +156,166 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
     I.sk_end = min(I.sk_begin + p.skip_chunks_per_split, nsk);
   };
 
-  // ---- producer side: item = ((y,x) column, channel quad); a thread holds the column's four planes
+  // ---- producer side: item = ((y,x) column, channel quad); a thread holds the column's four planes.  A stage's four items
+  //      are requested in two halves (two items = 8 x 16 bytes in flight) and committed piece by piece (commit_piece).
   const int q = tid & 7;
-  w3v4 hreg[2][4];  // two items in flight: a stage's four items are requested in two halves
-  unsigned h_cvalid = 0;  // bit i: column of item i lies inside the volume (y,x)
-  unsigned h_zvalid = 0;  // bit pl: plane pl lies inside the volume (z)
+  w3q hrA[4], hrB[4];  // items 0, 2 / items 1, 3 (two separate arrays: never indexed by anything but literals)
+  unsigned h_off[4];       // byte offset of item i's column and channel quad inside a source plane (clamped)
+  unsigned h_cvalid = 0;   // bit i: column of item i lies inside the volume (y,x)
+  unsigned h_zvalid = 0;   // bit pl: plane pl lies inside the volume (z)
+  unsigned h_zoff[4];      // byte offset of source plane pl of the chunk's sample (clamped; wave-uniform: scalar registers)
+  const w3_rsrc rsrc0 = w3_make_rsrc(p.src0), rsrc1 = w3_make_rsrc(p.src1 ? p.src1 : p.src0);
+  bool h_second = false;   // the chunk's source
   bool h_chvalid = false;
-  int h_c = 0, h_n = 0;
-  float h_a[4] = {1.f, 1.f, 1.f, 1.f}, h_b[4] = {0.f, 0.f, 0.f, 0.f};  // the chunk's affine coefficients (XF)
-  auto halo_issue = [&](const Item& I, int cc, int hpart) {
+  float4 h_c01 = make_float4(1.f, 0.f, 1.f, 0.f), h_c23 = h_c01;  // the chunk's affine (XF): (a,b) of the thread's 4 channels
+  // Addresses, masks and coefficients of a stage's halo (no requests yet).  Scalar work (source, planes) and the requests of
+  // the coefficients first; the vector part is the four column offsets.
+  auto halo_setup = [&](const Item& I, int cc) {
     int c = cc * W3_BK + q * 4;
-    h_c = c;
-    h_n = I.n;
     h_chvalid = c < Cin;
     if (!h_chvalid) c = 0;  // clamped, masked at commit
     // virtual concat: C0 is a multiple of the chunk size when there is a second source, so a chunk has ONE source (scalar)
     const bool second = p.src1 != nullptr && cc * W3_BK >= p.C0;
-    const float* src = second ? p.src1 : p.src0;
     const int Cs = second ? p.C1 : p.C0;
     const int cs = second ? c - p.C0 : c;
-    if (XF && hpart == 0) {
+    if (XF) {
       const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)I.n * Cin + c) * 2);
-      const float4 c01 = cf[0], c23 = cf[1];  // (a,b) interleaved per channel
-      h_a[0] = c01.x, h_b[0] = c01.y, h_a[1] = c01.z, h_b[1] = c01.w, h_a[2] = c23.x, h_b[2] = c23.y, h_a[3] = c23.z, h_b[3] = c23.w;
+      h_c01 = cf[0], h_c23 = cf[1];  // (a,b) interleaved per channel; first used by the commit ~8 groups later
     }
-    const char* sbase = reinterpret_cast<const char*>(src + (int64_t)I.n * SD * SH * SW * Cs);
-    const unsigned cbytes = (unsigned)Cs * 4u, cofs = (unsigned)cs * 4u;
-    unsigned zsrc[4];
+    const unsigned cbytes = (unsigned)Cs * 4u;
+    h_second = second;
     h_zvalid = 0;
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
       int z = I.tz0 + pl - 1;
       h_zvalid |= (z >= 0 && z < p.ID ? 1u : 0u) << pl;
-      z = min(max(z, 0), p.ID - 1);
-      if (p.ups) z >>= 1;
-      zsrc[pl] = (unsigned)(z * SH * SW);
+      z = min(max(z, 0), p.ID - 1) >> p.ups;
+      h_zoff[pl] = (unsigned)((I.n * SD + z) * SH * SW) * cbytes;
     }
-    if (hpart == 0) h_cvalid = 0;
+    h_cvalid = 0;
 #pragma unroll
-    for (int i = 2 * hpart; i < 2 * hpart + 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int col = min((tid >> 3) + 32 * i, W3_PLANE - 1);
       const int hy = col / W3_HX, hx = col - hy * W3_HX;
       int y = I.ty0 + hy - 1, x = I.tx0 + hx - 1;
       const bool ok = y >= 0 && y < p.IH && x >= 0 && x < p.IW;
-      y = min(max(y, 0), p.IH - 1);
-      x = min(max(x, 0), p.IW - 1);
-      if (p.ups) {
-        y >>= 1;
-        x >>= 1;
-      }
+      y = min(max(y, 0), p.IH - 1) >> p.ups;
+      x = min(max(x, 0), p.IW - 1) >> p.ups;
       h_cvalid |= (ok ? 1u : 0u) << i;
-      const unsigned yx = (unsigned)(y * SW + x);
-      // unconditional loads from clamped addresses, masked at commit; uniform base + 32-bit byte offsets
-#pragma unroll
-      for (int pl = 0; pl < 4; ++pl) hreg[i & 1][pl] = w3_ld(reinterpret_cast<const float*>(sbase + ((zsrc[pl] + yx) * cbytes + cofs)));
+      h_off[i] = (unsigned)(y * SW + x) * cbytes + (unsigned)cs * 4u;
     }
   };
-  // activation, zero padding (AFTER the activation), input transform along z, one item -> four 16-byte LDS writes.
-  // Branch free: the lanes of item 3 beyond column 99 hold (and write) a copy of column 99's values.
-  auto halo_commit = [&](int i, float* buf) {
-    const int col = min((tid >> 3) + 32 * i, W3_PLANE - 1);
-    const bool act = p.act != 0;
-    float v[4][4];
+  // one 16-byte request: item i, plane pl (unconditional, from a clamped address; masked at commit): scalar base + 32-bit
+  // vector offset, no address arithmetic at the request
+  auto halo_load = [&](int i, int pl) {
+    const w3q v = h_second ? w3_bld(rsrc1, h_off[i], h_zoff[pl]) : w3_bld(rsrc0, h_off[i], h_zoff[pl]);
+    if (i & 1)
+      hrB[pl] = v;
+    else
+      hrA[pl] = v;
+  };
+  // Commit of item i: affine + SiLU + zero padding (AFTER the activation) of its 16 values in place - sixteen independent
+  // chains, so the in-order wave always has something to issue -, then the input transform along z (xi0 = d0 - d2,
+  // xi1 = d1 + d2, xi2 = d2 - d1, xi3 = d1 - d3) and four 16-byte LDS writes.  Branch free: the lanes of item 3 beyond
+  // column 99 hold (and write) a copy of column 99's values.
+  auto commit_item_on = [&](w3q(&H)[4], int i, float* buf) {
+    // stage by stage over the eight register pairs, each stage pinned behind the previous one: a dependent instruction is
+    // then always eight instructions away from its producer (the in-order wave has no other wave to fill a latency with)
+    f32x2* V[8] = {&H[0].lo, &H[0].hi, &H[1].lo, &H[1].hi, &H[2].lo, &H[2].hi, &H[3].lo, &H[3].hi};
+    if (XF && !(W3_PROBE & 64)) {
+      f32x2 e[8];
+      const f32x2 ca[2] = {f32x2{h_c01.x, h_c01.z}, f32x2{h_c23.x, h_c23.z}}, cb[2] = {f32x2{h_c01.y, h_c01.w}, f32x2{h_c23.y, h_c23.w}};
 #pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-      const w3v4 h = hreg[i & 1][pl];
-      v[pl][0] = h.x, v[pl][1] = h.y, v[pl][2] = h.z, v[pl][3] = h.w;
-      const bool keep = h_chvalid && ((h_cvalid >> i) & 1u) && ((h_zvalid >> pl) & 1u);
+      for (int j = 0; j < 8; ++j) *V[j] = pk_fma(*V[j], ca[j & 1], cb[j & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float t = v[pl][e];
-        if (XF) {
-          t = fmaf(t, h_a[e], h_b[e]);
-          const float sl = w3_silu(t);
-          t = act ? sl : t;
-        }
-        v[pl][e] = keep ? t : 0.f;
-      }
+      for (int j = 0; j < 8; ++j) e[j] = pk_mul(*V[j], f32x2{-1.4426950408889634f, -1.4426950408889634f});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = f32x2{holo_exp2(e[j].x), holo_exp2(e[j].y)};  // exp(-t), v_exp_f32
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = pk_add(e[j], f32x2{1.f, 1.f});
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = f32x2{holo_rcp(e[j].x), holo_rcp(e[j].y)};  // v_rcp_f32 (1 ulp)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *V[j] = pk_mul(*V[j], e[j]);  // SiLU = t / (1 + exp(-t))  (XF implies p.act: conv_plan)
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // B^T d along z: xi0 = d0 - d2, xi1 = d1 + d2, xi2 = d2 - d1, xi3 = d1 - d3
+    const float kc = (h_chvalid && ((h_cvalid >> i) & 1u)) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float keep = ((h_zvalid >> (j >> 1)) & 1u) ? kc : 0.f;  // zero padding AFTER the activation
+      *V[j] = pk_mul(*V[j], f32x2{keep, keep});
+    }
+    const int col = min((tid >> 3) + 32 * i, W3_PLANE - 1);
     float* dst = buf + col * W3_RS + q * 4;
-    *reinterpret_cast<float4*>(dst + 0 * W3_PLANE * W3_RS) =
-        make_float4(v[0][0] - v[2][0], v[0][1] - v[2][1], v[0][2] - v[2][2], v[0][3] - v[2][3]);
-    *reinterpret_cast<float4*>(dst + 1 * W3_PLANE * W3_RS) =
-        make_float4(v[1][0] + v[2][0], v[1][1] + v[2][1], v[1][2] + v[2][2], v[1][3] + v[2][3]);
-    *reinterpret_cast<float4*>(dst + 2 * W3_PLANE * W3_RS) =
-        make_float4(v[2][0] - v[1][0], v[2][1] - v[1][1], v[2][2] - v[1][2], v[2][3] - v[1][3]);
-    *reinterpret_cast<float4*>(dst + 3 * W3_PLANE * W3_RS) =
-        make_float4(v[1][0] - v[3][0], v[1][1] - v[3][1], v[1][2] - v[3][2], v[1][3] - v[3][3]);
+    const w3q o0 = w3_sub(H[0], H[2]), o1 = w3_add(H[1], H[2]), o2 = w3_sub(H[2], H[1]), o3 = w3_sub(H[1], H[3]);
+    *reinterpret_cast<float4*>(dst + 0 * W3_PLANE * W3_RS) = make_float4(o0.lo.x, o0.lo.y, o0.hi.x, o0.hi.y);
+    *reinterpret_cast<float4*>(dst + 1 * W3_PLANE * W3_RS) = make_float4(o1.lo.x, o1.lo.y, o1.hi.x, o1.hi.y);
+    *reinterpret_cast<float4*>(dst + 2 * W3_PLANE * W3_RS) = make_float4(o2.lo.x, o2.lo.y, o2.hi.x, o2.hi.y);
+    *reinterpret_cast<float4*>(dst + 3 * W3_PLANE * W3_RS) = make_float4(o3.lo.x, o3.lo.y, o3.hi.x, o3.hi.y);
+  };
+  auto commit_item = [&](int i, float* buf) {
+    if (i & 1)
+      commit_item_on(hrB, i, buf);
+    else
+      commit_item_on(hrA, i, buf);
   };
 
   // ---- consumer side
   f32x4 acc[64];  // [xi_z][xi_y][xi_x]; register r of a lane: y tile r, x tile kq, output channel lj
   // MFMA row lj = (y tile lj & 3, x tile lj >> 2); the lane's k group kq holds channels 4 kq + 16 half .. +3
   const int a_off = ((2 * (lj & 3)) * W3_HX + 2 * (lj >> 2)) * W3_RS + kq * 4;
-  w3v4 P[4][4];  // the lane's 4 x 4 (halo row, halo column) patch of one (xi_z, half); x-transformed in place
-  auto load_patch = [&](const float* buf, int xz, int half) {
-    const float* base = buf + a_off + (xz * W3_PLANE) * W3_RS + half * 16;
+  w3q P[4][4];  // the lane's 4 x 4 (halo row, halo column) patch of one step = (xi_z, half); x-transformed in place
+  w3q Y[2][4];  // A operands of a group (one xi_y, four xi_x): group g reads Y[g & 1] while Y[(g + 1) & 1] is being formed
+  auto load_patch_row = [&](const float* buf, int step, int a) {
+    const float* base = buf + a_off + ((step >> 1) * W3_PLANE + a * W3_HX) * W3_RS + (step & 1) * 16;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) P[a][b] = w3_ld(base + (a * W3_HX + b) * W3_RS);
+    for (int b = 0; b < 4; ++b) P[a][b] = w3_ld(base + b * W3_RS);
   };
-  auto xform_rows = [&]() {  // B^T along x, in place: 32 v_pk_add_f32
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const w3v4 t0 = P[a][0] - P[a][2], t1 = P[a][1] + P[a][2], t2 = P[a][2] - P[a][1], t3 = P[a][1] - P[a][3];
-      P[a][0] = t0, P[a][1] = t1, P[a][2] = t2, P[a][3] = t3;
+  // B^T along x of row a, in place, in two halves: (xi_x 0, 3) then (xi_x 1, 2); 4 v_pk_add_f32 each
+  auto xform_row_half = [&](int a, int h) {
+    if (h == 0) {
+      const w3q t0 = w3_sub(P[a][0], P[a][2]), t3 = w3_sub(P[a][1], P[a][3]);
+      P[a][0] = t0, P[a][3] = t3;
+    } else {
+      const w3q t1 = w3_add(P[a][1], P[a][2]), t2 = w3_sub(P[a][2], P[a][1]);
+      P[a][1] = t1, P[a][2] = t2;
     }
   };
-  auto yform = [&](w3v4 (&Y)[4], int xy) {  // B^T along y for one xi_y: 8 v_pk_add_f32
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-      Y[b] = xy == 0 ? P[0][b] - P[2][b] : xy == 1 ? P[1][b] + P[2][b] : xy == 2 ? P[2][b] - P[1][b] : P[1][b] - P[3][b];
+  // B^T along y for (xi_y, column b): 2 v_pk_add_f32
+  auto yform1 = [&](int xy, int b) {
+    return xy == 0 ? w3_sub(P[0][b], P[2][b]) : xy == 1 ? w3_add(P[1][b], P[2][b]) : xy == 2 ? w3_sub(P[2][b], P[1][b]) : w3_sub(P[1][b], P[3][b]);
   };
-  // the four accumulators of a group advance together, k-step by k-step: consecutive MFMAs are independent.  The
-  // accumulators are TIED to their AGPR tuples (HOLO_MFMA16_ACC, holo_common.h): 64 sets fill the accumulation file.
-  auto mfma16 = [&](f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const w3v4 (&A)[4], const w3v4 (&B)[4]) {
-    HOLO_MFMA16_ACC_FIRST(c0, A[0].x, B[0].x);
-    HOLO_MFMA16_ACC(c1, A[1].x, B[1].x);
-    HOLO_MFMA16_ACC(c2, A[2].x, B[2].x);
-    HOLO_MFMA16_ACC(c3, A[3].x, B[3].x);
-    HOLO_MFMA16_ACC(c0, A[0].y, B[0].y);
-    HOLO_MFMA16_ACC(c1, A[1].y, B[1].y);
-    HOLO_MFMA16_ACC(c2, A[2].y, B[2].y);
-    HOLO_MFMA16_ACC(c3, A[3].y, B[3].y);
-    HOLO_MFMA16_ACC(c0, A[0].z, B[0].z);
-    HOLO_MFMA16_ACC(c1, A[1].z, B[1].z);
-    HOLO_MFMA16_ACC(c2, A[2].z, B[2].z);
-    HOLO_MFMA16_ACC(c3, A[3].z, B[3].z);
-    HOLO_MFMA16_ACC(c0, A[0].w, B[0].w);
-    HOLO_MFMA16_ACC(c1, A[1].w, B[1].w);
-    HOLO_MFMA16_ACC(c2, A[2].w, B[2].w);
-    HOLO_MFMA16_ACC(c3, A[3].w, B[3].w);
+  w3q Bdummy[4] = {};  // (W3_PROBE & 16)
+  w3q Bw[4][4];  // ring of weight groups: group g lives in slot g & 3 and is requested W3_WDIST groups ahead
+  // MFMA k of a group: k-step e = k >> 2 (the component of the 16-byte operands), pseudo-tap t = k & 3.  The accumulators are
+  // TIED to their AGPR tuples (HOLO_MFMA16_ACC, holo_common.h): 64 sets fill the accumulation file.
+  auto mfma1 = [&](f32x4& c, const w3q& A, const w3q& B, int e, bool first) {
+#if W3_PROBE & 8
+    HOLO_SINK8(A.lo.x, A.lo.y, A.hi.x, A.hi.y, B.lo.x, B.lo.y, B.hi.x, B.hi.y);
+    return;
+#endif
+    const float a = e == 0 ? A.lo.x : e == 1 ? A.lo.y : e == 2 ? A.hi.x : A.hi.y;
+    const float b = e == 0 ? B.lo.x : e == 1 ? B.lo.y : e == 2 ? B.hi.x : B.hi.y;
+    if (first)
+      HOLO_MFMA16_ACC_FIRST(c, a, b);
+    else
+      HOLO_MFMA16_ACC(c, a, b);
   };
-  w3v4 Bw[4][4];  // ring of weight groups: group g lives in slot g & 3 and is requested two groups (32 MFMAs) ahead (three
-                  // groups are live at a time; four names because a chunk's 32 groups must map onto whole ring turns)
-  auto load_w = [&](int slot, const float* wp) {
+
+  // a whole group at once (the fused skip): the four accumulators advance together, k-step by k-step
+  auto mfma16 = [&](f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, const w3q (&A)[4], const w3q (&B)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) Bw[slot][t] = w3_ld(wp + t * 256);
+    for (int e = 0; e < 4; ++e) {
+      mfma1(c0, A[0], B[0], e, e == 0);
+      mfma1(c1, A[1], B[1], e, false);
+      mfma1(c2, A[2], B[2], e, false);
+      mfma1(c3, A[3], B[3], e, false);
+    }
   };
 
   unsigned long long* dbg = p.dbg ? p.dbg + (int64_t)blockIdx.x * 8 : nullptr;
@@ -259,24 +326,46 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
   Item cur, nxt;
   decode(it, cur);
   // weights of (item, chunk): this wave's 16-Cout slice
-  auto w_of = [&](const Item& I, int cc) {
-    return p.w_wino3 + ((int64_t)cc * wnsl + (I.n0 >> 4) + wn) * W3_WCHUNK + lane * 4;
-  };
+  // (wave-uniform: the lane's 16 bytes are added at the request as a 32-bit vector offset to a scalar base)
+  auto w_of = [&](const Item& I, int cc) { return (unsigned)((cc * wnsl + (I.n0 >> 4) + wn) * W3_WCHUNK) * 4u; };  // byte offset
+  const w3_rsrc rsrcw = w3_make_rsrc(p.w_wino3);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto w_ld = [&](unsigned ubase, int ofs_floats) { return w3_bld(rsrcw, lane16, ubase + (unsigned)ofs_floats * 4u); };
 
-  // ---- prologue: the first stage's halo, exposed once per workgroup
+  // ---- prologue, exposed once per workgroup: the first stage's halo, its first weights, its first patch
   int stage = 0;  // parity = LDS buffer of the current stage
   int cc = cur.cc_begin;
 #pragma unroll
-  for (int g = 0; g < 2; ++g) load_w(g, w_of(cur, cc) + g * W3_WSUB);
+  for (int g = 0; g < W3_WDIST; ++g)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Bw[g][t] = w_ld(w_of(cur, cc), g * W3_WSUB + t * 256);
+  halo_setup(cur, cc);
 #pragma unroll
   for (int hp = 0; hp < 2; ++hp) {
-    halo_issue(cur, cc, hp);
-    halo_commit(2 * hp, s_halo);
-    halo_commit(2 * hp + 1, s_halo);
+#pragma unroll
+    for (int i = 2 * hp; i < 2 * hp + 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 4; ++pl) halo_load(i, pl);
+#pragma unroll
+    for (int i = 2 * hp; i < 2 * hp + 2; ++i) commit_item(i, s_halo);
   }
   __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a) load_patch_row(s_halo, 0, a);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    xform_row_half(a, 0);
+    xform_row_half(a, 1);
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) Y[0][b] = yform1(0, b);
   if (dbg && tid == 0) dbg[1] = HOLO_PROBE_CLOCK();
 
+#ifdef W3_TIMELINE
+  // (development) shader-clock sums of wave 0: [0] the 16 MFMAs of a group with the requests between them, [1] clumps that only
+  // form A operands, [2] clumps with the x transform, [3] commit clumps, [4] the setup clump, [5] barrier, [6] number of stages
+  unsigned long long tl[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   for (;;) {
     // ---------------- one item
 #pragma unroll
@@ -301,43 +390,98 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       }
       const float* buf = s_halo + (stage & 1) * W3_HALO;
       float* obuf = s_halo + ((stage + 1) & 1) * W3_HALO;
-      const float* wp = w_of(cur, cc);
-      const float* wnext = w_of(nxt, ncc_);
-      // fused skip chunk riding on this stage (chunk j of the skip rides on main chunk j; leftovers on the last)
-      load_patch(buf, 0, 0);
-      halo_issue(nxt, ncc_, 0);
-      xform_rows();
+      const unsigned wp = w_of(cur, cc), wnext = w_of(nxt, ncc_);
+#ifdef W3_TIMELINE
+      const unsigned long long t_stage = HOLO_PROBE_CLOCK();
+#endif
+      // ---- 32 groups of 16 MFMAs; group g = (step st = (xi_z, half), xi_y).  With ONE wave per SIMD nothing hides behind
+      //      another wave, and what the wave can issue in the shadow of its own exact-fp32 MFMA is measured
+      //      (tools/mfma_shadow_probe.cpp, cycles per MFMA with K fillers behind each): scalar instructions and s_nop are free
+      //      up to 3; ds_read_b128 up to 2 (LDS bandwidth beyond); one global_load_dwordx4 per FOUR MFMAs (1 KB per wave
+      //      instruction against 64 B/clk of L1); a VECTOR instruction is never hidden - the fp32 MFMA runs on the vector
+      //      lanes - and the first one after an MFMA costs ~15 cycles, every further one ~4-5 (v_pk_* the same: two values).
+      //      Hence: requests ride BETWEEN the MFMAs of a group, vector work sits in ONE clump per group behind its last MFMA:
+      //        MFMA k = 0, 4, 8, 12          one of the four weight requests of group g + 2
+      //        xi_y == 3, k = 0..7           the next step's patch, two 16-byte LDS reads each
+      //        groups 1 / 16, eight k's      the halo requests of items 0,1 / 2,3 of the next stage
+      //        behind MFMA 15                A operands of group g + 1 (8 v_pk_add); after xi_y == 3 the x transform of the new
+      //                                      patch first (32 v_pk_add); after group 0 the next stage's halo addresses; after
+      //                                      groups 8 / 12 / 20 / 24 the commit of halo item 0 / 1 / 2 / 3 (~2 500 cycles after
+      //                                      its requests)
+      //      Group 28 opens with THE barrier of the stage: the last patch of this stage's buffer was read in group 27 and the
+      //      last item of the next stage's buffer was written behind group 24, so from here on the other buffer is complete
+      //      (group 31 reads the next stage's first patch from it) and this one is free for the next stage's producer.
+      auto group = [&](auto gc) {  // straight-line code: accumulator sets, ring slots, slot work are compile-time choices
+        constexpr int g = decltype(gc)::value, st = g >> 2, xy = g & 3;
+#ifdef W3_TIMELINE
+        const unsigned long long tA0 = clock64();
+#endif
+        if (g == 28) __syncthreads();
+#ifdef W3_TIMELINE
+        const unsigned long long tA = clock64();
+        if (g == 28) tl[5] += tA - tA0;
+#endif
+        auto slot = [&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          mfma1(acc[(st >> 1) * 16 + xy * 4 + (k & 3)], Y[g & 1][k & 3], Bw[g & 3][k & 3], k >> 2, k == 0);
+          if ((k & 3) == 0 && !(W3_PROBE & 2)) {
+            const unsigned wsrc = g + W3_WDIST < 32 ? wp : wnext;
+            constexpr int wofs = (g + W3_WDIST < 32 ? g + W3_WDIST : g + W3_WDIST - 32) * W3_WSUB + (k >> 2) * 256;
+            if (W3_PROBE & 16)
+              Bdummy[k >> 2] = w_ld(wsrc, wofs);
+            else
+              Bw[(g + W3_WDIST) & 3][k >> 2] = w_ld(wsrc, wofs);
+          }
+          if (xy == 3 && k < 8 && !(W3_PROBE & 4)) {
+            // the next step's patch: of this buffer, or (last step) the next stage's first patch from the other buffer
+            const float* pb = st < 7 ? buf : obuf;
+            constexpr int nstep = st < 7 ? st + 1 : 0;
+            const float* base = pb + a_off + ((nstep >> 1) * W3_PLANE + (k >> 1) * W3_HX) * W3_RS + (nstep & 1) * 16;
+            P[k >> 1][(2 * k) & 3] = w3_ld(base + ((2 * k) & 3) * W3_RS);
+            P[k >> 1][(2 * k + 1) & 3] = w3_ld(base + ((2 * k + 1) & 3) * W3_RS);
+          }
+          if ((g == 1 || g == 16) && !(W3_PROBE & 1)) {
+            constexpr int hl = k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : k == 6 ? 4 : k == 7 ? 5 : k == 9 ? 6 : k == 10 ? 7 : -1;
+            if (hl >= 0) halo_load((g == 16 ? 2 : 0) + ((hl < 0 ? 0 : hl) >> 2), (hl < 0 ? 0 : hl) & 3);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // requests stay behind THEIR MFMA
+        };
+        w3_static_for(slot, std::make_integer_sequence<int, 16>{});
+#ifdef W3_TIMELINE
+        const unsigned long long tB = clock64();
+        tl[0] += tB - tA;
+#endif
+        // ---- the group's vector clump
+        if (!(W3_PROBE & 4)) {
+          if (xy == 3) {
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {  // fully unrolled: accumulator sets and ring slots are compile-time choices
-        const int xz = st >> 1;
-#pragma unroll
-        for (int xy = 0; xy < 4; ++xy) {
-          const int g = st * 4 + xy;
-          w3v4 Y[4];
-          yform(Y, xy);
-          if (xy == 3 && st < 7) load_patch(buf, (st + 1) >> 1, (st + 1) & 1);  // P is dead: the next patch flies under 16 MFMAs
-          if (g + 2 < 32)
-            load_w((g + 2) & 3, wp + (g + 2) * W3_WSUB);
-          else
-            load_w((g + 2) & 3, wnext + (g + 2 - 32) * W3_WSUB);
-          __builtin_amdgcn_sched_barrier(0);  // requests stay AHEAD of the MFMAs that hide them
-          mfma16(acc[xz * 16 + xy * 4 + 0], acc[xz * 16 + xy * 4 + 1], acc[xz * 16 + xy * 4 + 2], acc[xz * 16 + xy * 4 + 3], Y, Bw[g & 3]);
-          __builtin_amdgcn_sched_barrier(0);
-          // the next stage's halo in two halves: items 0,1 (requested at the start of the stage) are committed in steps
-          // 2,3, then items 2,3 are requested and committed in steps 5,6 (~130 MFMAs after their request)
-          if (xy == 0) {
-            if (st == 2) halo_commit(0, obuf);
-            if (st == 3) {
-              halo_commit(1, obuf);
-              halo_issue(nxt, ncc_, 1);
+            for (int a = 0; a < 4; ++a) {
+              xform_row_half(a, 0);
+              xform_row_half(a, 1);
             }
-            if (st == 5) halo_commit(2, obuf);
-            if (st == 6) halo_commit(3, obuf);
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) Y[(g + 1) & 1][b] = yform1((xy + 1) & 3, b);
+        }
+        if (!(W3_PROBE & 1)) {
+          if (g == 0) halo_setup(nxt, ncc_);
+          if (!(W3_PROBE & 32)) {
+            if (g == 8) commit_item(0, obuf);
+            if (g == 12) commit_item(1, obuf);
+            if (g == 20) commit_item(2, obuf);
+            if (g == 24) commit_item(3, obuf);
           }
         }
-        if (st < 7) xform_rows();
-      }
-      __syncthreads();  // this stage's buffer is free, the next stage's is complete
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef W3_TIMELINE
+        tl[g == 0 ? 4 : (g == 8 || g == 12 || g == 20 || g == 24) ? 3 : xy == 3 ? 2 : 1] += clock64() - tB;
+        if (g == 0) tl[6] += 1;
+#endif
+      };
+      w3_static_for(group, std::make_integer_sequence<int, 32>{});
+#ifdef W3_TIMELINE
+      if (dbg && tid == 0) dbg[6] += HOLO_PROBE_CLOCK() - t_stage;  // the stage's own work (barrier wait included)
+#endif
     }
     // ---------------- fused 1x1x1 skip connection: raw block input at the lane's own voxels -> pseudo-taps {0,3}^3
     if (SKIP) {
@@ -346,8 +490,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       // group sg = (skip chunk, half, dz): four voxels (dy,dx) of the lane's patch = one 16-MFMA group; operands of group
       // sg + 1 are requested before the MFMAs of group sg (two buffers; dz = sg & 1 keeps the accumulator choice static)
       const int nsg = (cur.sk_end - cur.sk_begin) * 4;
-      w3v4 SA[2][4], SB[2][4];
-      auto skip_load = [&](int sg, w3v4 (&A)[4], w3v4 (&B)[4]) {
+      w3q SA[2][4], SB[2][4];
+      auto skip_load = [&](int sg, w3q (&A)[4], w3q (&B)[4]) {
         const int sc = cur.sk_begin + (sg >> 2), half = (sg >> 1) & 1, dz = sg & 1;
         const float* swp = p.skip_w_wino3 + ((int64_t)sc * wnsl + (cur.n0 >> 4) + wn) * W3_WSKIP + lane * 4;
         int c = sc * W3_BK + half * 16 + kq * 4;
@@ -377,93 +521,114 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
     }
     if (dbg && tid == 0) dbg[2] = HOLO_PROBE_CLOCK();
     HOLO_MFMA_DRAIN();  // the last MFMAs' results, before vector instructions read the accumulators
+#if W3_PROBE & 16
+    HOLO_SINK8(Bdummy[0].lo, Bdummy[0].hi, Bdummy[1].lo, Bdummy[1].hi, Bdummy[2].lo, Bdummy[2].hi, Bdummy[3].lo, Bdummy[3].hi);
+#endif
+#if W3_PROBE & 32
+    HOLO_SINK8(hrA[0].lo, hrA[1].lo, hrA[2].lo, hrA[3].lo, hrB[0].lo, hrB[1].lo, hrB[2].lo, hrB[3].lo);
+#endif
 
-    // ---------------- output transform (lane-local: x, y, z) + epilogue.  D row 4 kq + r = (y tile r, x tile kq)
+    // ---------------- output transform (lane-local: x, y, z) + epilogue.  D row 4 kq + r = (y tile r, x tile kq).
+    //                  Two register indices r at a time (v_pk_add_f32); the residual is requested before anything else.
     {
       const int co = cur.n0 + wn * 16 + lj;
       const int coc = co < p.Cout ? co : p.Cout - 1;
       const bool direct = p.nsplit == 1;
+      const bool has_res = direct && p.residual != nullptr;
       float bv = (direct && p.bias) ? p.bias[coc] : 0.f;
       if (direct && p.skip_bias) bv += p.skip_bias[coc];
-      const int64_t tbase = ((((int64_t)cur.n * p.OD + cur.tz0) * p.OH + cur.ty0) * p.OW + cur.tx0 + 2 * kq) * p.Cout;
+      const int64_t tbase = ((((int64_t)cur.n * p.OD + cur.tz0) * p.OH + cur.ty0) * p.OW + cur.tx0 + 2 * kq) * p.Cout + coc;
       const int64_t zstride = (int64_t)p.OH * p.OW * p.Cout;
       const int ystride = p.OW * p.Cout;
-      float ssum = 0.f, ssq = 0.f;
       float* obase = direct ? p.out : p.partial + (int64_t)cur.split * M * p.Cout;
+      // voxel (dz, 2 r + dy, dx) of the lane's x tile
+      auto vofs = [&](int r, int dz, int dy, int dx) { return tbase + dz * zstride + (int64_t)(2 * r + dy) * ystride + dx * p.Cout; };
+      // one register index r (= y tile) at a time: 64 accumulator reads, x and y transforms on (xi_z, xi_z + 1) register
+      // pairs (v_pk_add_f32), the z transform on their halves; the residual of r + 1 is requested before r is transformed
+      float res[2][2][2][2];
+      auto load_res = [&](int r) {
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) res[r & 1][dz][dy][dx] = has_res ? p.residual[vofs(r, dz, dy, dx)] : 0.f;
+      };
+      load_res(0);
+      float ssum = 0.f, ssq = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float res[2][2][2];
-        const int64_t vo = tbase + (int64_t)(2 * r) * ystride + coc;
-        if (direct && p.residual) {
+        if (r < 3) load_res(r + 1);
+        f32x2 oz[2][2][2];  // [xi_z pair][dy][dx]
 #pragma unroll
-          for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-              for (int dx = 0; dx < 2; ++dx) res[dz][dy][dx] = p.residual[vo + dz * zstride + dy * ystride + dx * p.Cout];
-        }
-        float oz[4][2][2];  // [xi_z][dy][dx]
-#pragma unroll
-        for (int xz = 0; xz < 4; ++xz) {
-          float oy[4][2];  // [xi_y][dx]
+        for (int zp = 0; zp < 2; ++zp) {
+          f32x2 oy[4][2];  // [xi_y][dx]
 #pragma unroll
           for (int xy = 0; xy < 4; ++xy) {
-            const float m0 = acc[xz * 16 + xy * 4 + 0][r], m1 = acc[xz * 16 + xy * 4 + 1][r], m2 = acc[xz * 16 + xy * 4 + 2][r],
-                        m3 = acc[xz * 16 + xy * 4 + 3][r];
-            oy[xy][0] = (m0 + m1) + m2;
-            oy[xy][1] = (m1 - m2) - m3;
+            const int s0 = (2 * zp) * 16 + xy * 4, s1 = s0 + 16;
+            const f32x2 m0 = f32x2{acc[s0 + 0][r], acc[s1 + 0][r]}, m1 = f32x2{acc[s0 + 1][r], acc[s1 + 1][r]},
+                        m2 = f32x2{acc[s0 + 2][r], acc[s1 + 2][r]}, m3 = f32x2{acc[s0 + 3][r], acc[s1 + 3][r]};
+            oy[xy][0] = pk_add(pk_add(m0, m1), m2);
+            oy[xy][1] = pk_sub(pk_sub(m1, m2), m3);
           }
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
-            oz[xz][0][dx] = (oy[0][dx] + oy[1][dx]) + oy[2][dx];
-            oz[xz][1][dx] = (oy[1][dx] - oy[2][dx]) - oy[3][dx];
+            oz[zp][0][dx] = pk_add(pk_add(oy[0][dx], oy[1][dx]), oy[2][dx]);
+            oz[zp][1][dx] = pk_sub(pk_sub(oy[1][dx], oy[2][dx]), oy[3][dx]);
           }
         }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx) {
-            float o0 = (oz[0][dy][dx] + oz[1][dy][dx]) + oz[2][dy][dx];
-            float o1 = (oz[1][dy][dx] - oz[2][dy][dx]) - oz[3][dy][dx];
+            const f32x2 za = oz[0][dy][dx], zb = oz[1][dy][dx];  // (xi_z 0, 1), (xi_z 2, 3)
+            float o0 = (za.x + za.y) + zb.x;
+            float o1 = (za.y - zb.x) - zb.y;
             if (direct) {
-              if (p.residual) {
-                o0 += res[0][dy][dx];
-                o1 += res[1][dy][dx];
-              }
-              o0 += bv;
-              o1 += bv;
+              o0 = (o0 + res[r & 1][0][dy][dx]) + bv;
+              o1 = (o1 + res[r & 1][1][dy][dx]) + bv;
               ssum += o0 + o1;
-              ssq += o0 * o0 + o1 * o1;
+              ssq = fmaf(o0, o0, fmaf(o1, o1, ssq));
             }
             if (co < p.Cout) {
-              obase[vo + dy * ystride + dx * p.Cout] = o0;
-              obase[vo + zstride + dy * ystride + dx * p.Cout] = o1;
+              obase[vofs(r, 0, dy, dx)] = o0;
+              obase[vofs(r, 1, dy, dx)] = o1;
             }
           }
       }
       // GroupNorm statistics of the tensor just produced: one slab per tile (conv_stats_slabs)
       if (p.stats && direct) {
-        ssum += __shfl_xor(ssum, 16);
-        ssq += __shfl_xor(ssq, 16);
-        ssum += __shfl_xor(ssum, 32);
-        ssq += __shfl_xor(ssq, 32);
+        float s1 = ssum, s2 = ssq;
+        s1 += __shfl_xor(s1, 16);
+        s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
         if (kq == 0 && co < p.Cout) {
           const int tiles_per_sample = ntx * nty * ntz;
           const int slab = (it % ntiles) % tiles_per_sample;
           double* d = p.stats + (((int64_t)cur.n * tiles_per_sample + slab) * p.Cout + co) * 2;
-          d[0] = (double)ssum;
-          d[1] = (double)ssq;
+          d[0] = (double)s1;
+          d[1] = (double)s2;
         }
       }
     }
     if (dbg && tid == 0) {
-      dbg[3] = HOLO_PROBE_CLOCK();
+      const unsigned long long t_now = HOLO_PROBE_CLOCK();
+      dbg[5] += t_now - dbg[2];  // skip-drain + output transform + stores
+      dbg[3] = t_now;
       dbg[7] += 1;
     }
     it += (int)gridDim.x;
     if (it >= nitems) break;
     cur = nxt;
   }
+#ifdef W3_TIMELINE
+  if (p.dbg && tid == 0) {
+    unsigned long long* d = p.dbg + ((int64_t)gridDim.x + blockIdx.x) * 8;  // second half of the probe buffer
+#pragma unroll
+    for (int i = 0; i < 7; ++i) d[i] = tl[i];
+  }
+#endif
 }
 
 // OIDHW [Cout][Cin][27] -> the 64 pseudo-taps U = (G x G x G) g (float64, rounded once) in the wave's consumption order
@@ -511,6 +676,7 @@ __global__ __launch_bounds__(256) void repack_conv_weight_wino3_kernel(const flo
 
 }  // namespace
 
+#if W3_PROBE == 0 && !defined(W3_TIMELINE)
 int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps) {
   return (int64_t)(CinP >> 5) * (CoutP >> 4) * (src_taps == 27 ? W3_WCHUNK : W3_WSKIP);
 }
@@ -525,9 +691,12 @@ int repack_conv_weight_wino3_launch(const float* w, float* out, int Cout, int Ci
   return 0;
 }
 
+#endif  // the library copy
+
 // p.wino == 3 (conv_plan): p.grid_x persistent workgroups
-int conv_wino3_launch(const ConvParams& p, void* stream) {
-  if (!p.w_wino3 || (p.skip_w && !p.skip_w_wino3) || (p.OD & 1) || (p.OH & 7) || (p.OW & 7) || (p.Cout & 63)) {
+int W3_ENTRY(const ConvParams& p, void* stream) {
+  if (!p.w_wino3 || (p.skip_w && !p.skip_w_wino3) || (p.OD & 1) || (p.OH & 7) || (p.OW & 7) || (p.Cout & 63) ||
+      (p.coef && !p.act)) {
     set_error("conv_wino3_launch: unsupported shape / weights not prepared");
     return -1;
   }

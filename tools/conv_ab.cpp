@@ -1,8 +1,7 @@
 // conv_ab — A/B timing of the stride-1 3x3x3 convolution kernels on one shape list (development probe, not part of the
 // library): conv_wino2_kernel (two workgroups per CU, (z,y) Winograd) against conv_wino3_kernel (one persistent 512-register
 // wave per SIMD, F(2x2x2,3x3x3)), random data, planner-chosen split-K.
-// Build: hipcc -O2 --offload-arch=gfx950 tools/conv_ab.cpp holo_diffusion_amd/csrc/kernels_conv.o \
-//              holo_diffusion_amd/csrc/kernels_conv3.o holo_diffusion_amd/csrc/kernels_misc.o -o tools/conv_ab
+// Build: bash tools/build_conv_ab.sh
 // Usage: conv_ab [iters=20]
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
@@ -19,6 +18,17 @@ void set_error(const char* fmt, ...) {
   va_end(a);
   printf("\n");
 }
+}  // namespace holo
+namespace holo {  // probe copies of kernels_conv3.hip (see its W3_PROBE)
+int conv_wino3_launch_p1(const ConvParams& p, void* stream);
+int conv_wino3_launch_p2(const ConvParams& p, void* stream);
+int conv_wino3_launch_p4(const ConvParams& p, void* stream);
+int conv_wino3_launch_p7(const ConvParams& p, void* stream);
+int conv_wino3_launch_p8(const ConvParams& p, void* stream);
+int conv_wino3_launch_p16(const ConvParams& p, void* stream);
+int conv_wino3_launch_p32(const ConvParams& p, void* stream);
+int conv_wino3_launch_p64(const ConvParams& p, void* stream);
+int conv_wino3_launch_tl(const ConvParams& p, void* stream);
 }  // namespace holo
 using namespace holo;
 #define CK(x)                                                               \
@@ -45,6 +55,7 @@ struct Shape {
 };
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
   const Shape shapes[] = {
       {64, 64, 0, 64, 1, 0, 0, 0, "64^3 64->64 GN+SiLU (ResBlock conv1)"},
@@ -96,7 +107,7 @@ int main(int argc, char** argv) {
       p.residual = dev_random(V * Cout, 1.f);
       p.bias = dev_random(Cout, 1.f);
       double* st;
-      CK(hipMalloc(&st, (size_t)(V / 64) * Cout * 2 * 8));
+      CK(hipMalloc(&st, (size_t)std::max<int64_t>(V / 64, 256) * Cout * 2 * 8));
       p.stats = st;
     }
     if (s.skip) {
@@ -151,9 +162,50 @@ int main(int argc, char** argv) {
           tot += d[i * 8 + 3] - d[i * 8];
           items += d[i * 8 + 7];
         }
-        printf("          timeline: span %.1f us; per workgroup: prologue %.2f us, busy %.1f us, %.1f items -> %.2f us per item\n",
-               (t1 - t0) * 0.01, pro / q.grid_x * 0.01, tot / q.grid_x * 0.01, items / q.grid_x, (tot - pro) / items * 0.01);
+        double bar = 0, epi = 0, work = 0;
+        for (int i = 0; i < q.grid_x; ++i) bar += d[i * 8 + 4], epi += d[i * 8 + 5], work += d[i * 8 + 6];
+        printf("          timeline: span %.1f us; per workgroup: prologue %.2f us, busy %.1f us, %.1f items -> %.2f us per item "
+               "(stage work %.2f + barrier wait %.2f + skip/epilogue %.2f)\n",
+               (t1 - t0) * 0.01, pro / q.grid_x * 0.01, tot / q.grid_x * 0.01, items / q.grid_x, (tot - pro) / items * 0.01,
+               work / items * 0.01, bar / items * 0.01, epi / items * 0.01);
+        {  // shader-clock sums of wave 0 of every workgroup (the W3_TIMELINE copy of the kernel)
+          CK(hipFree(dbg));
+          CK(hipMalloc(&dbg, (size_t)q.grid_x * 128));
+          CK(hipMemset(dbg, 0, (size_t)q.grid_x * 128));
+          q.dbg = dbg;
+          conv_wino3_launch_tl(q, nullptr);
+          CK(hipDeviceSynchronize());
+          std::vector<unsigned long long> t((size_t)q.grid_x * 16);
+          CK(hipMemcpy(t.data(), dbg, t.size() * 8, hipMemcpyDeviceToHost));
+          double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+          for (int i = 0; i < q.grid_x; ++i)
+            for (int j = 0; j < 7; ++j) sum[j] += t[((size_t)q.grid_x + i) * 8 + j];
+          const double ns = sum[6];
+          printf("          shader cycles per stage (wave 0): 32 x 16 MFMAs + requests %.0f | A-operand clumps (20) %.0f | x-transform clumps (8) "
+                 "%.0f | commit clumps (4) %.0f | setup clump %.0f | barrier %.0f\n",
+                 sum[0] / ns, sum[1] / ns, sum[2] / ns, sum[3] / ns, sum[4] / ns, sum[5] / ns);
+        }
         CK(hipFree(dbg));
+        q.dbg = nullptr;
+        // probe copies of the kernel: what the stage loop costs without one of its parts
+        struct { const char* what; int (*fn)(const ConvParams&, void*); } probes[] = {
+            {"no halo requests/commits in the loop", conv_wino3_launch_p1}, {"no weight requests", conv_wino3_launch_p2},
+            {"no patch reads / input transforms", conv_wino3_launch_p4}, {"MFMAs only (none of the three)", conv_wino3_launch_p7},
+            {"everything but the MFMAs", conv_wino3_launch_p8},
+            {"weight requests nobody waits for", conv_wino3_launch_p16},
+            {"halo requests but no commits", conv_wino3_launch_p32},
+            {"commits without the activation", conv_wino3_launch_p64}};
+        for (auto& pr : probes) {
+          for (int i = 0; i < 2; ++i) pr.fn(q, nullptr);
+          CK(hipDeviceSynchronize());
+          CK(hipEventRecord(e0, nullptr));
+          for (int i = 0; i < iters; ++i) pr.fn(q, nullptr);
+          CK(hipEventRecord(e1, nullptr));
+          CK(hipEventSynchronize(e1));
+          float pms;
+          CK(hipEventElapsedTime(&pms, e0, e1));
+          printf("          probe %-40s %8.1f us\n", pr.what, pms / iters * 1e3);
+        }
       }
       if (q.partial) CK(hipFree(q.partial));
     }
