@@ -2675,7 +2675,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       if (!(e3 && e3[0] == '0') && p.tz == 2 && p.w_wino3 && p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && p.Cout >= 64 &&
           (p.Cout % 64) == 0 && (!p.skip_w || p.skip_w_wino3) && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.OD % 2) == 0 &&
           (!p.coef || p.act) &&  // (its staging applies the affine and SiLU together)
-          (int64_t)p.N * src_vox * cmax * 4 < ((int64_t)1 << 32)) {  // (buffer addressing of a whole source tensor)
+          (int64_t)p.N * src_vox * (cmax > skmax ? cmax : skmax) * 4 < ((int64_t)1 << 32) &&  // (buffer addressing of whole tensors)
+          (!p.skip_w || ((p.skip_C0 % 16) == 0 && (p.skip_C1 % 4) == 0))) {
         int ns3 = 1;
         if (t3 < num_cus) {
           ns3 = (int)cdiv(num_cus, t3);

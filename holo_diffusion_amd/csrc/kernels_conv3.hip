@@ -483,40 +483,68 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       if (dbg && tid == 0) dbg[6] += HOLO_PROBE_CLOCK() - t_stage;  // the stage's own work (barrier wait included)
 #endif
     }
-    // ---------------- fused 1x1x1 skip connection: raw block input at the lane's own voxels -> pseudo-taps {0,3}^3
+    // ---------------- fused 1x1x1 skip connection: raw block input at the lane's own voxels -> pseudo-taps {0,3}^3.
+    //   group sg = (skip chunk, half, dz): the four voxels (dy,dx) of the lane's 2 x 2 x 2 patch = one 16-MFMA group with
+    //   accumulators (3dz, 3dy, 3dx).  Its operands come straight from global memory (no halo, no LDS, no barrier), THREE
+    //   groups ahead, into the registers of the patch (A) and of the weight ring (B) - what the last stage left there for the
+    //   next item is simply requested again afterwards, under the epilogue.  Buffer addressing: no vector instruction per
+    //   request (the skip tensors lie within 4 GB: conv_plan).
     if (SKIP) {
-      const int yt = lj & 3, xt = lj >> 2;
-      const int64_t vbase = (((int64_t)cur.n * p.OD + cur.tz0) * p.OH + cur.ty0 + 2 * yt) * p.OW + cur.tx0 + 2 * xt;
-      // group sg = (skip chunk, half, dz): four voxels (dy,dx) of the lane's patch = one 16-MFMA group; operands of group
-      // sg + 1 are requested before the MFMAs of group sg (two buffers; dz = sg & 1 keeps the accumulator choice static)
       const int nsg = (cur.sk_end - cur.sk_begin) * 4;
-      w3q SA[2][4], SB[2][4];
-      auto skip_load = [&](int sg, w3q (&A)[4], w3q (&B)[4]) {
-        const int sc = cur.sk_begin + (sg >> 2), half = (sg >> 1) & 1, dz = sg & 1;
-        const float* swp = p.skip_w_wino3 + ((int64_t)sc * wnsl + (cur.n0 >> 4) + wn) * W3_WSKIP + lane * 4;
-        int c = sc * W3_BK + half * 16 + kq * 4;
-        if (c >= SCin) c = 0;  // (the packed weights of padding channels are zero)
-        const bool second = c >= p.skip_C0;
-        const float* sp = second ? p.skip_src1 : p.skip_src0;
-        const int Cs = second ? p.skip_C1 : p.skip_C0;
-        const int cs = second ? c - p.skip_C0 : c;
+      if (nsg > 0) {
+        const w3_rsrc rs0 = w3_make_rsrc(p.skip_src0), rs1 = w3_make_rsrc(p.skip_src1 ? p.skip_src1 : p.skip_src0);
+        const w3_rsrc rsw = w3_make_rsrc(p.skip_w_wino3);
+        const int yt = lj & 3, xt = lj >> 2;
+        // voxel (dy, dx) of the lane's patch relative to the tile's first voxel, in voxels
+        unsigned vrel[4];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int64_t v = vbase + ((int64_t)dz * p.OH + (d >> 1)) * p.OW + (d & 1);
-          A[d] = w3_ld(sp + v * Cs + cs);
-          B[d] = w3_ld(swp + ((half * 2 + dz) * 4 + d) * 256);
+        for (int d = 0; d < 4; ++d) vrel[d] = (unsigned)((2 * yt + (d >> 1)) * p.OW + 2 * xt + (d & 1));
+        const unsigned vtile = (unsigned)(((cur.n * p.OD + cur.tz0) * p.OH + cur.ty0) * p.OW + cur.tx0);
+        const unsigned zvox = (unsigned)(p.OH * p.OW);
+        const unsigned wbase = (unsigned)((cur.n0 >> 4) + wn) * (unsigned)W3_WSKIP * 4u;
+        auto skip_load = [&](int sg, int slot) {
+          const int sc = cur.sk_begin + (sg >> 2), half = (sg >> 1) & 1, dz = sg & 1;
+          const int c0 = sc * W3_BK + half * 16;        // first channel of the 16-channel half (wave-uniform)
+          const bool pad = c0 >= SCin;  // a half of padding channels: its packed weights are zero, read channel 0 instead
+          const bool second = !pad && c0 >= p.skip_C0;  // (skip_C0 is a multiple of 16 when there are two sources: conv_plan)
+          const unsigned Cs = (unsigned)(second ? p.skip_C1 : p.skip_C0);
+          const unsigned cs = pad ? 0u : (unsigned)(second ? c0 - p.skip_C0 : c0);
+          const unsigned soff = ((vtile + (unsigned)dz * zvox) * Cs + cs) * 4u;
+          const unsigned wsoff = (unsigned)sc * (unsigned)wnsl * (unsigned)W3_WSKIP * 4u + wbase + (unsigned)((half * 2 + dz) * 4) * 1024u;
+          // (channels beyond the skip's last one: the packed weights there are zero, the activations any finite value)
+          const unsigned koff = (unsigned)min(kq * 4, max((int)Cs - (int)cs - 4, 0)) * 4u;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned voff = vrel[d] * Cs * 4u + koff;
+            P[slot][d] = second ? w3_bld(rs1, voff, soff) : w3_bld(rs0, voff, soff);
+            Bw[slot][d] = w3_bld(rsw, lane16, wsoff + (unsigned)d * 1024u);
+          }
+        };
+#pragma unroll
+        for (int g0 = 0; g0 < 3; ++g0)
+          if (g0 < nsg) skip_load(g0, g0);
+        for (int sg = 0; sg < nsg; sg += 4) {  // four groups per turn: ring slots and accumulator choices stay static
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (sg + j + 3 < nsg) skip_load(sg + j + 3, (j + 3) & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j & 1)
+              mfma16(acc[48], acc[51], acc[60], acc[63], P[j], Bw[j]);
+            else
+              mfma16(acc[0], acc[3], acc[12], acc[15], P[j], Bw[j]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-      };
-      if (nsg > 0) skip_load(0, SA[0], SB[0]);
-      for (int sg = 0; sg < nsg; sg += 2) {
-        skip_load(sg + 1, SA[1], SB[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(acc[0], acc[3], acc[12], acc[15], SA[0], SB[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sg + 2 < nsg) skip_load(sg + 2, SA[0], SB[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma16(acc[48], acc[51], acc[60], acc[63], SA[1], SB[1]);
-        __builtin_amdgcn_sched_barrier(0);
+        // what the skip overwrote: the next stage's first weights and first patch (its A operands are formed after the
+        // epilogue, under which these requests complete)
+        const float* nbuf = s_halo + (stage & 1) * W3_HALO;
+        const unsigned wn0 = w_of(nxt, nxt.cc_begin);
+#pragma unroll
+        for (int g0 = 0; g0 < W3_WDIST; ++g0)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) Bw[g0][t] = w_ld(wn0, g0 * W3_WSUB + t * 256);
+#pragma unroll
+        for (int a4 = 0; a4 < 4; ++a4) load_patch_row(nbuf, 0, a4);
       }
     }
     if (dbg && tid == 0) dbg[2] = HOLO_PROBE_CLOCK();
@@ -620,6 +648,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
     }
     it += (int)gridDim.x;
     if (it >= nitems) break;
+    if (SKIP && cur.sk_end > cur.sk_begin) {  // the patch requested again behind the skip section: its x and y transforms
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        xform_row_half(a4, 0);
+        xform_row_half(a4, 1);
+      }
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) Y[0][b4] = yform1(0, b4);
+    }
     cur = nxt;
   }
 #ifdef W3_TIMELINE
