@@ -134,28 +134,49 @@ def test_north_star_ray_subset_vs_oracle(gu):
 
 def test_north_star_full_frame_vs_oracle(gu):
     """configs[1], EVERY ray: one whole 400 x 400 frame of the 64^3 x 32 grid against ``ro.render_rays`` on all 160 000
-    rays (about a minute of host time) with the tolerances and the fragile-ray rule of the subset test above: rgb / mask
-    2e-4 on every ray; depth 2e-4 x far on every ray that is not fragile (no importance sample with a raw ``den`` within
-    0.3 eps of sample_pdf's switch), 5e-3 x far on all, 99 % within 2e-4 x far; the coarse pass on every ray."""
+    rays (about a minute of host time).  Every NON-FRAGILE ray: rgb / mask within 2e-4, depth within 2e-4 x far, both
+    passes.  A ray is fragile when the reference algorithm itself is discontinuous at it within float32 rounding:
+      (a) an importance sample with a raw ``den`` within 0.3 eps of sample_pdf's ``den < eps -> 1`` switch (see
+          test_north_star_ray_subset_vs_oracle), or
+      (b) a raw density of the LAST sample (the far bound, whose interval is the raymarcher's background_opacity = 1e10)
+          within 1e-4 of zero: density_relu * 1e10 makes the ray fully opaque or leaves it as it was on the SIGN of that
+          value - seen on 1 of 160 000 rays of this frame (oracle mask 1.0 / depth 11.6, kernel 0.553 / 5.3).
+    Fragile rays must be few (<= 0.1 %) and stay within 5e-3 unless of kind (b)."""
     R, C, H, W = (8, 32, 24, 24) if EMU else (64, 32, 400, 400)
     model, _, _, rcfg, msd = gu.make_model(R, C, H, W, TINY_UNET if EMU else NORTH_UNET)
     model.net_3d_enabled = False
     grid = torch.tanh(torch.from_numpy(np_noise(17, (1, C, R, R, R))))
     cams = _cams(8)
     preds = model(camera=cams[3].to(gu.DEV), evaluation_mode=EvaluationMode.EVALUATION, voxel_features=grid.to(gu.DEV))
-    idx = torch.arange(H * W)
     o, d, l = ro.make_rays(gu.cam_dict(cams, 3), rcfg)
     ref = ro.render_rays(grid, msd, o, d, l, rcfg)
     assert ref["rgb"].shape[0] == H * W
-    _check_rays(preds, ref, idx, H, W, coarse=preds["rendered"].prev_stage)
     margin = 0.3 * rcfg.sample_pdf_eps
-    fragile = (ref["pdf_denom"] - rcfg.sample_pdf_eps).abs().min(dim=1)[0] <= margin
-    e = (preds["depths_render"].reshape(-1).cpu() - ref["depth"].reshape(-1)).abs()
-    bad = e >= 2e-4 * FAR
-    print(f"full frame: {H * W} rays, {int(fragile.sum())} fragile, {int(bad.sum())} outside 2e-4 x far "
-          f"(all of them fragile: {not bool((bad & ~fragile).any())}), max depth error {float(e.max()):.2e}, "
-          f"max rgb error {float((preds['images_render'].reshape(3, -1).t().cpu() - ref['rgb']).abs().max()):.2e}")
-    assert not (bad & ~fragile).any(), int((bad & ~fragile).sum())
+    frag_pdf = (ref["pdf_denom"] - rcfg.sample_pdf_eps).abs().min(dim=1)[0] <= margin
+    dens_last, _ = ro.implicit_function(grid, msd, o, d, l[:, -1:], rcfg)
+    frag_far = dens_last.reshape(-1).abs() <= 1e-4
+    fragile = frag_pdf | frag_far
+    flat = lambda t, c: t.reshape(c, H * W).t().cpu()  # noqa: E731  (1,c,H,W) -> (rays,c)
+    coarse = preds["rendered"].prev_stage
+    cflat = lambda t: t.permute(0, 3, 1, 2).reshape(t.shape[3], H * W).t().cpu()  # noqa: E731
+    errs = {
+        "rgb": ((flat(preds["images_render"], 3) - ref["rgb"]).abs().max(dim=1)[0], 2e-4),
+        "mask": ((flat(preds["masks_render"], 1) - ref["mask"]).abs().reshape(-1), 2e-4),
+        "depth": ((flat(preds["depths_render"], 1) - ref["depth"]).abs().reshape(-1), 2e-4 * FAR),
+        "rgb_c": ((cflat(coarse.features) - ref["rgb_c"]).abs().max(dim=1)[0], 2e-4),
+        "mask_c": ((cflat(coarse.masks) - ref["mask_c"]).abs().reshape(-1), 2e-4),
+        "depth_c": ((cflat(coarse.depths) - ref["depth_c"]).abs().reshape(-1), 2e-4 * FAR),
+    }
+    summary = []
+    for k, (e, tol) in errs.items():
+        bad = e >= tol
+        summary.append(f"{k} {int(bad.sum())} outside (max {float(e.max()):.2e}, max non-fragile {float(e[~fragile].max()):.2e})")
+        assert not (bad & ~fragile).any(), (k, int((bad & ~fragile).sum()), float(e[~fragile].max()))
+        loose = 5e-3 * (FAR if "depth" in k else 1.0)
+        assert not ((e >= loose) & ~frag_far).any(), (k, "a ray away from the far-sample sign switch misses the loose bound")
+    print(f"full frame: {H * W} rays, fragile {int(frag_pdf.sum())} (sample_pdf switch) + {int(frag_far.sum())} (far-sample sign); "
+          + "; ".join(summary))
+    assert int(fragile.sum()) <= 0.001 * H * W + 2
     # the frame is not trivial: opaque and semi-transparent rays both occur
     m = ref["mask"].reshape(-1)
     assert float(m.max()) > 0.95 and int(((m > 0.2) & (m < 0.8)).sum()) > 0.001 * H * W
