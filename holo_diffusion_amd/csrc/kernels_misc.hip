@@ -7,6 +7,8 @@
 //   time_embed timestep_embedding + time_embed MLP (nn.py:109-127, unet.py:645-650)
 //   rows_linear all ResBlock emb_layers Linear(SiLU(emb)) at once (unet.py:199-205,245)
 //   ddpm_step  clamp + posterior mean + noise (gaussian_diffusion.py:314-343,237-240,499-506)
+#include <stdlib.h>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -243,12 +245,25 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(256) void time_embed_kernel(const int64_t* __restrict__ t, int mc, int ted,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ w2, const float* __restrict__ b2,
-                                                         float* __restrict__ emb, float* __restrict__ emb_silu) {
+                                                         float* __restrict__ emb, float* __restrict__ emb_silu,
+                                                         int load_kind) {
   __shared__ float te[256];
   __shared__ float h1[1024];
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
-  const float tv = (float)holo_ld_sys(t + n);  // (the caller's tensor, possibly just copied from the host)
+  // the caller's tensor, possibly just copied from the host: system-scope load (holo_ld_sys).  load_kind != 0 is a
+  // DEVELOPMENT knob (HOLO_DEBUG_TIMESTEP_LOAD, scripts/h2d_stress_kinds.py) that reads it the two ways a compiler would:
+  // 1 = wave-uniform address (s_load_dwordx2, through the scalar cache), 2 = per-lane address (global_load_dwordx2)
+  float tv;
+  if (load_kind == 1) {
+    tv = (float)t[n];
+  } else if (load_kind == 2) {
+    const int64_t* tp = t + n;
+    HOLO_LAUNDER(tp);  // the address in vector registers
+    tv = (float)*tp;
+  } else {
+    tv = (float)holo_ld_sys(t + n);
+  }
   const int half = mc / 2;
   for (int i = tid; i < mc; i += 256) {
     float v = 0.f;
@@ -524,7 +539,9 @@ int time_embed_launch(const int64_t* t, int N, int mc, int ted, const float* w1,
     set_error("time_embed: model_channels=%d too large", mc);
     return -1;
   }
-  HOLO_LAUNCH(time_embed_kernel, dim3((unsigned)N), dim3(256), stream, t, mc, ted, w1, b1, w2, b2, emb, emb_silu);
+  const char* lk = getenv("HOLO_DEBUG_TIMESTEP_LOAD");  // development knob, see the kernel
+  HOLO_LAUNCH(time_embed_kernel, dim3((unsigned)N), dim3(256), stream, t, mc, ted, w1, b1, w2, b2, emb, emb_silu,
+              lk ? atoi(lk) : 0);
   return 0;
 }
 

@@ -540,10 +540,10 @@ struct Planner {
       p.skip_bias = skip_bias;
     }
     size_t sb = conv_plan(p, u->ctx->num_cus);
+    size_t so = 0;
     if (sb) {
-      size_t so = scratch_alloc(sb);
+      so = scratch_alloc(sb);
       p.partial = ptr<float>(so);
-      scratch_free(so, sb);  // stream order protects it until the reduce kernel has run
     }
     // GroupNorm statistics of the output: from the conv / split-K-reduce epilogue when the launch can
     // produce them, else by a separate pass over the output
@@ -552,6 +552,12 @@ struct Planner {
       alloc_stats(*stats_of, slabs);
       p.stats = ptr<double>(stats_of->stats_off);
     }
+    // The split-K scratch is released only AFTER the statistics buffer has its place: the reduce kernel of this very
+    // launch writes the statistics while other workgroups of it still read partial sums, so the two must not share memory.
+    // (Released before, first fit could hand the scratch's own first bytes to the statistics: sample 0 of a split launch then
+    // came out wrong in ~25 % of the runs of the bf16 mode at 32^3 - scripts/bf16_batch_check.py, found in round 4.)
+    // Stream order protects the scratch against every LATER launch.
+    if (sb) scratch_free(so, sb);
     ops.push_back(op);
     if (stats_of && slabs == 0) emit_stats(*stats_of);
   }
@@ -1463,11 +1469,11 @@ int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
     const bool enable2 = enable && !(we && we[0] == '1');  // HOLO_CONV_WINO=1: depth only; default: both forms prepared
     auto wino2_numel = [&](const ParamSlot& s) -> int64_t { return enable2 ? wino_numel(s) / (s.kind == P_CONV3 ? 36 : 2) * (s.kind == P_CONV3 ? 48 : 4) : 0; };
     // F(2x2x2, 3x3x3) copies (conv_wino3_kernel, 64 pseudo-taps / 8 signed skip copies): the levels whose workgroup list
-    // can fill the chip - up to 128 output channels (64^3 .. 16^3 in the released nets); HOLO_CONV_WINO3=0: none
+    // can fill the chip - up to 256 output channels (64^3 .. 8^3 in the released nets); HOLO_CONV_WINO3=0: none
     const char* w3e = getenv("HOLO_CONV_WINO3");
     const bool enable3 = enable2 && !(w3e && w3e[0] == '0');
     auto wino3_numel = [&](const ParamSlot& s) -> int64_t {
-      if (!enable3 || wino_numel(s) == 0 || s.shape[0] % 64 || s.shape[0] > 128 || s.shape[1] > 384) return 0;
+      if (!enable3 || wino_numel(s) == 0 || s.shape[0] % 64 || s.shape[0] > 256 || s.shape[1] > 768) return 0;
       return conv_wino3_weight_floats(pad_cout((int)s.shape[0]), pad_cin((int)s.shape[1]), s.kind == P_CONV3 ? 27 : 1);
     };
     int64_t tw = 0;
