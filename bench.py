@@ -351,11 +351,19 @@ def main():
         t0 = time.perf_counter()
         for k in range(Wm, Wm + K):
             img = one_step(img, k)
+        torch.cuda.synchronize()
+        dt_own = time.perf_counter() - t0  # this rank's own K steps (before it waits for the others)
         barrier_sync(world)
         dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, device)
     assert torch.isfinite(img).all()
     steps_per_s = world * K / dt
+    per_rank_steps_per_s = [K / dt_own]
+    if world > 1:  # every rank's own rate, gathered for the line rank 0 prints
+        tr = torch.tensor([K / dt_own], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(tr) for _ in range(world)]
+        dist.all_gather(allr, tr)
+        per_rank_steps_per_s = [float(a.item()) for a in allr]
 
     # ---------------- render leg: frames of one grid per GPU (UNet-at-t=0 refinement hoisted, cached)
     import holo_diffusion_amd as hda
@@ -644,6 +652,8 @@ def main():
                                 "frac_mfma": mlp_flops_per_ray * rays_per_s / world / 1e12 / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
             "frame_gather": gather, "grad_exchange": grad_exchange,
+            "rccl_world_size": (gather or {}).get("rccl_world_size", 1), "gather_ms": (gather or {}).get("gather_ms"),
+            "per_rank_steps_per_s": per_rank_steps_per_s,
             "side_workloads": side,
             "opt_in_modes_not_reported": alt,
         }

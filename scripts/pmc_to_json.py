@@ -47,6 +47,13 @@ for (k, grid), (n, f_kib) in fetch.items():
         if mw.group(3) == "2":
             continue  # the 32-channel two-wave-row variant: its grid is not distinguishable from the 64-channel one here
         label = f"conv_wino{mw.group(1)}_kernel<{mw.group(2)}> at {od}^3 output"
+    elif "conv_wino3_kernel" in k:
+        m3 = re.search(r"conv_wino3_kernel<(true|false), (true|false)>", k)
+        if grid != 256 * 256:  # launches below one item per CU (under-filled levels) are not the reported ones
+            continue
+        # (all levels launch 256 persistent workgroups: the average is over the variant's launches of the profiled command,
+        #  dominated by the 64^3 level - 9 of 17 for <false, true>)
+        label = f"conv_wino3_kernel<{m3.group(1)}, {m3.group(2)}> (256 persistent workgroups, all levels)"
     elif "render2_kernel" in k or "render_kernel" in k:
         mr = re.search(r"(render2?_kernel)<([^>]*)>", k)
         label = f"{mr.group(1)}<{mr.group(2)}>"

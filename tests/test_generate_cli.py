@@ -65,3 +65,47 @@ def test_generate_cli_world2_gloo_equals_single_process(tmp_path):
     a0 = torch.load(str(tmp_path / "two" / "sample_00000_frames.pt"))["images_render"]
     a1 = torch.load(str(tmp_path / "two" / "sample_00001_frames.pt"))["images_render"]
     assert not torch.equal(a0, a1)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("HOLO_TEST_EMU_SLOW") != "1" or not os.path.isfile(os.path.join(REPO, "tests", "emu", "libholo_emu.so")),
+                    reason="opt-in (HOLO_TEST_EMU_SLOW=1 + `make -C holo_diffusion_amd/csrc emu`): ~15 minutes of host emulation")
+def test_generate_cli_world2_gloo_on_the_emulated_kernels(tmp_path):
+    """The same entry with the REAL model on the host emulation of the kernels (tests/support/generate_cli_emu.py): a
+    2-step DDPM schedule on an 8^3 x 16 grid, 2 samples sharded over 2 ranks, frames gathered over gloo - equal, bit for bit,
+    to the single-process run of the same samples (per-sample seeds seed + i), and different between samples."""
+    from holo_diffusion_amd import checkpoint as ck
+    import holo_diffusion_amd as hda
+    from tests.test_checkpoint_loading import _expconfig, _reference_like_state
+    d = tmp_path / "exp"
+    d.mkdir()
+    cfg = _expconfig(resol=8, feat=16, mc=32)
+    margs = cfg["model_factory_ImplicitronModelFactory_args"]["model_HoloDiffusionModel_args"]
+    margs["diffusion_args"]["num_steps"] = 20  # (the shortest schedule whose scaled linear betas stay <= 1)
+    with open(d / "expconfig.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    kw, _ = ck.model_args_from_expconfig(ck.read_expconfig(str(d))[0])
+    torch.save(_reference_like_state(hda.HoloDiffusionModel(**kw), 11), str(d / "model_epoch_00000001.pth"))
+    script = os.path.join(REPO, "tests", "support", "generate_cli_emu.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    args = ["num_samples=2", "n_eval_cameras=2", "render_size=[8,8]", "seed=5"]
+    port = 29700 + os.getpid() % 1500
+
+    def run(cmd):
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
+        assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+        return res.stdout
+
+    out2 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), script, f"exp_dir={d}", f"output_directory={tmp_path / 'two'}"] + args)
+    assert "on 2 rank(s), backend gloo" in out2
+    out1 = run([sys.executable, script, f"exp_dir={d}", f"output_directory={tmp_path / 'one'}"] + args)
+    assert "on 1 rank(s)" in out1
+    frames = []
+    for i in range(2):
+        a = torch.load(str(tmp_path / "two" / f"sample_{i:05d}_frames.pt"))
+        b = torch.load(str(tmp_path / "one" / f"sample_{i:05d}_frames.pt"))
+        for k in ("images_render", "depths_render", "masks_render"):
+            assert torch.equal(a[k], b[k]), (i, k)
+        frames.append(a["images_render"])
+    assert not torch.equal(frames[0], frames[1])
