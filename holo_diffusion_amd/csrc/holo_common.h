@@ -97,9 +97,10 @@ __device__ __forceinline__ float holo_rcp_exact(float x) { return 1.0f / x; }
     __builtin_amdgcn_wave_barrier();                       \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
-// System-scope load for SMALL caller-provided tensors (timesteps, ray lists): a few bytes just copied from pageable host
-// memory can sit behind a stale L2 line of the block's previous owner - measured: 8 wrong timestep reads in 610 calls fed
-// by fresh `tensor.to(device)` copies, 0 in 600 with this load (scripts/h2d_stress_unet.py); bulk tensors are not affected.
+// System-scope load for SMALL caller-provided tensors (timesteps, ray lists, random streams, cotangents).  Introduced in
+// round 3 against a suspected stale L2 line behind fresh pageable host->device copies; round 4 traced those runs to a
+// workspace race in the planner instead (tests/test_gpu_unet.py::test_repeated_forwards_are_bit_identical) and
+// could not provoke a stale read with ANY kind of load (tools/h2d_stale_probe.cpp).  Kept: a handful of loads per call.
 template <typename T>
 __device__ __forceinline__ T holo_ld_sys(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -183,7 +183,7 @@ struct HoloUnet {
   std::map<const float*, const float*> wino_of;        // fp32 private copy -> Winograd copy
   std::map<const float*, const float*> wino2_of;       // fp32 private copy -> (z,y) Winograd copy
   std::map<const float*, const float*> wino3_of;       // fp32 private copy -> F(2x2x2, 3x3x3) Winograd copy
-  std::map<std::string, float*> dgrad_wino, dgrad_wino2;  // Winograd copies of the transposed (dgrad) weights
+  std::map<std::string, float*> dgrad_wino, dgrad_wino2, dgrad_wino3;  // Winograd copies of the transposed (dgrad) weights
   // holo_unet_set_compute_dtype: 0 exact fp32 MFMA; 1 bf16: activations stored as bf16 in HBM, bf16 products with fp32
   // accumulation in the 3x3x3 convolutions and the long-sequence attention, fp32 GroupNorm statistics; 2 bf16x3 split
   // (fp32 storage, fp32-accurate)
@@ -1533,6 +1533,8 @@ int holo_unet_destroy(HoloUnet* net) {
     if (kv.second) (void)hipFree(kv.second);
   for (auto& kv : net->dgrad_wino)
     if (kv.second) (void)hipFree(kv.second);
+  for (auto& kv : net->dgrad_wino3)
+    if (kv.second) (void)hipFree(kv.second);
   for (auto& kv : net->dgrad_wino2)
     if (kv.second) (void)hipFree(kv.second);
   if (net->dgrad_tmp) (void)hipFree(net->dgrad_tmp);
@@ -1847,6 +1849,18 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
     if (repack_conv_weight_wino_launch(net->dgrad_tmp, w2, Ci, Co, 27, pad_cout(Ci), pad_cin(Co), stream, 2)) return HOLO_E_INVALID;
     net->wino_of[dst] = w1;
     net->wino2_of[dst] = w2;
+    // ... and on conv_wino3_kernel where the forward convolutions do (transposed: output channels = the forward's inputs)
+    static const char* w3e = getenv("HOLO_CONV_WINO3");
+    if (!(w3e && w3e[0] == '0') && Ci <= 256 && Co <= 768) {
+      float*& w3 = net->dgrad_wino3[nm];
+      if (!w3) {
+        net->tws_cache.clear();
+        net->tplan_batch = -1;
+        HIP_TRY(hipMalloc((void**)&w3, (size_t)conv_wino3_weight_floats(pad_cout(Ci), pad_cin(Co), 27) * sizeof(float)));
+      }
+      if (repack_conv_weight_wino3_launch(net->dgrad_tmp, w3, Ci, Co, 27, pad_cout(Ci), pad_cin(Co), stream)) return HOLO_E_INVALID;
+      net->wino3_of[dst] = w3;
+    }
   }
   return 0;
 }
