@@ -155,6 +155,33 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
     I.sk_begin = min(I.split * p.skip_chunks_per_split, nsk);
     I.sk_end = min(I.sk_begin + p.skip_chunks_per_split, nsk);
   };
+  // The workgroup's next item = this one + gridDim.x: added digit by digit in the mixed radix (x tile, y tile, z tile,
+  // sample, cout block, split) - a handful of scalar adds and selects per item instead of five integer divisions (a uniform
+  // division is ~25 instructions, several of them on the vector pipe the MFMAs run on).
+  Item stride;  // gridDim.x in the same digits (tx0, ty0, tz0, n0 scaled like an item's)
+  decode((int)(gridDim.x % (unsigned)nitems), stride);  // (a grid >= the work list never advances)
+  auto advance = [&](const Item& a, Item& I) {
+    int tx = a.tx0 + stride.tx0, c = tx >= p.OW ? 1 : 0;
+    I.tx0 = tx - (c ? p.OW : 0);
+    int ty = a.ty0 + stride.ty0 + 8 * c;
+    c = ty >= p.OH ? 1 : 0;
+    I.ty0 = ty - (c ? p.OH : 0);
+    int tz = a.tz0 + stride.tz0 + 2 * c;
+    c = tz >= p.OD ? 1 : 0;
+    I.tz0 = tz - (c ? p.OD : 0);
+    int n = a.n + stride.n + c;
+    c = n >= p.N ? 1 : 0;
+    I.n = n - (c ? p.N : 0);
+    int nb = a.n0 + stride.n0 + 64 * c;
+    c = nb >= 64 * ny ? 1 : 0;
+    I.n0 = nb - (c ? 64 * ny : 0);
+    I.split = a.split + stride.split + c;  // (callers advance only while the item number stays below nitems)
+    I.cc_begin = I.split * p.chunks_per_split;
+    I.cc_end = min(I.cc_begin + p.chunks_per_split, ncc);
+    const int nsk = SKIP ? (SCin + W3_BK - 1) / W3_BK : 0;
+    I.sk_begin = min(I.split * p.skip_chunks_per_split, nsk);
+    I.sk_end = min(I.sk_begin + p.skip_chunks_per_split, nsk);
+  };
 
   // ---- producer side: item = ((y,x) column, channel quad); a thread holds the column's four planes.  A stage's four items
   //      are requested in two halves (two items = 8 x 16 bytes in flight) and committed piece by piece (commit_piece).
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       if (last_chunk) {
         const int nit = it + (int)gridDim.x;
         if (nit < nitems) {
-          decode(nit, nxt);
+          advance(cur, nxt);
           ncc_ = nxt.cc_begin;
         } else {
           ncc_ = cc;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
         s2 += __shfl_xor(s2, 32);
         if (kq == 0 && co < p.Cout) {
           const int tiles_per_sample = ntx * nty * ntz;
-          const int slab = (it % ntiles) % tiles_per_sample;
+          const int slab = ((cur.tz0 >> 1) * nty + (cur.ty0 >> 3)) * ntx + (cur.tx0 >> 3);
           double* d = p.stats + (((int64_t)cur.n * tiles_per_sample + slab) * p.Cout + co) * 2;
           d[0] = (double)s1;
           d[1] = (double)s2;

@@ -141,13 +141,18 @@ def test_north_star_full_frame_vs_oracle(gu):
       (b) a raw density of the LAST sample (the far bound, whose interval is the raymarcher's background_opacity = 1e10)
           within 1e-4 of zero: density_relu * 1e10 makes the ray fully opaque or leaves it as it was on the SIGN of that
           value - seen on 1 of 160 000 rays of this frame (oracle mask 1.0 / depth 11.6, kernel 0.553 / 5.3).
-      (c) any other ray outside the tolerance must be one the ORACLE itself moves by a comparable amount when the grid is
-          perturbed by 1e-6 (the control experiment of the subset test, run on exactly those rays).
-    Fragile rays must be few (<= 0.1 %) and stay within 5e-3 unless of kind (b).  At most TWO rays of the frame may stay
-    unexplained, within the loose 5e-3 bound: one such ray exists (pixel 81 331: an importance sample in a bin of raw
-    ``den`` = 1.6e-5, amplification 6e4) on which the ORACLE ITSELF gives depth 5.9304 on the 256-thread GPU host and
-    5.9165 in the 8-thread development container (float64: 5.9154; kernel: 5.9353) - torch's CPU reductions round
-    differently with the thread count, and this ray turns that into 1e-2 x depth; a 1e-6 grid perturbation happens not to."""
+      (c) any other ray outside the tolerance must be one the ORACLE itself moves by a comparable amount (>= a quarter of
+          the kernel's distance) under a perturbation of float32-rounding size, run on exactly those rays: the grid
+          + 1e-6 noise (the control of the subset test), or the inverse-CDF abscissae u +- 2e-6.  The latter is the
+          rounding of the cdf itself - a running sum of 64 float32 terms near 1, reproducible to ~2e-6 between two correct
+          evaluations - and it is what these rays amplify: an importance sample in a bin of raw ``den`` ~ 1.5e-5 (just
+          ABOVE the eps switch, so not of kind (a)) moves by 2e-6 / den = 13 % of the bin.  Seen on 2 ... 14 rays of the
+          frame depending on the host that runs the oracle (torch's CPU reductions round differently with the thread
+          count): on pixel 81 331 the ORACLE ITSELF gives depth 5.9304 on the 256-thread GPU host, 5.9165 in the 8-thread
+          development container, 5.9154 in float64 (kernel: 5.9353); every such ray moves by 2e-3 ... 1.5e-2 under
+          u +- 2e-6, ordinary rays by 1e-5 ... 5e-5.
+    Fragile rays must be few (<= 0.1 %) and stay within 5e-3 x far unless of kind (b).  At most TWO rays of the frame may
+    stay unexplained, within the same loose bound."""
     R, C, H, W = (8, 32, 24, 24) if EMU else (64, 32, 400, 400)
     model, _, _, rcfg, msd = gu.make_model(R, C, H, W, TINY_UNET if EMU else NORTH_UNET)
     model.net_3d_enabled = False
@@ -181,11 +186,13 @@ def test_north_star_full_frame_vs_oracle(gu):
         idx = torch.nonzero(unexplained).flatten()
         assert len(idx) <= 0.001 * H * W + 2, len(idx)
         pert = grid + 1e-6 * torch.from_numpy(np_noise(8, tuple(grid.shape)))
-        ref2 = ro.render_rays(pert, msd, o[idx], d[idx], l[idx], rcfg)
-        moved = {"rgb": (ref2["rgb"] - ref["rgb"][idx]).abs().max(dim=1)[0], "mask": (ref2["mask"] - ref["mask"][idx]).abs().reshape(-1),
-                 "depth": (ref2["depth"] - ref["depth"][idx]).abs().reshape(-1),
-                 "rgb_c": (ref2["rgb_c"] - ref["rgb_c"][idx]).abs().max(dim=1)[0], "mask_c": (ref2["mask_c"] - ref["mask_c"][idx]).abs().reshape(-1),
-                 "depth_c": (ref2["depth_c"] - ref["depth_c"][idx]).abs().reshape(-1)}
+        u0 = torch.linspace(0.0, 1.0, ref["pdf_denom"].shape[1])[None].expand(len(idx), -1)
+        controls = [ro.render_rays(pert, msd, o[idx], d[idx], l[idx], rcfg)]
+        controls += [ro.render_rays(grid, msd, o[idx], d[idx], l[idx], rcfg, u_fine=(u0 + du).clamp(0.0, 1.0)) for du in (2e-6, -2e-6)]
+        moved = {}
+        for k in errs:
+            per = [(c[k] - ref[k][idx]).abs() for c in controls]
+            moved[k] = torch.stack([(m.max(dim=1)[0] if m.dim() > 1 and m.shape[1] > 1 else m.reshape(-1)) for m in per]).max(dim=0)[0]
         for j, pix in enumerate(idx.tolist()):
             sens = any(float(moved[k][j]) >= 0.25 * float(errs[k][0][pix]) for k in errs if float(errs[k][0][pix]) >= errs[k][1])
             print(f"  ray {pix}: " + ", ".join(f"{k} kernel-vs-oracle {float(errs[k][0][pix]):.2e} / oracle-vs-perturbed-oracle {float(moved[k][j]):.2e}"
