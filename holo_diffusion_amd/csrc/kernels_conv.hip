@@ -2231,15 +2231,16 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   bool av[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int64_t m = m0 + r0 + 32 * j;
-    av[j] = m < M;
-    if (!av[j]) m = 0;
-    int ow = (int)(m % p.OW);
-    int64_t t = m / p.OW;
-    int oh = (int)(t % p.OH);
-    t /= p.OH;
-    int od = (int)(t % p.OD);
-    an[j] = (int)(t / p.OD);
+    const int64_t m64 = m0 + r0 + 32 * j;
+    av[j] = m64 < M;
+    // (32-bit: M < 2^31, conv_small_launch; a 64-bit division is ~150 instructions and this kernel is all fixed cost)
+    const unsigned m = av[j] ? (unsigned)m64 : 0u;
+    int ow = (int)(m % (unsigned)p.OW);
+    unsigned t = m / (unsigned)p.OW;
+    int oh = (int)(t % (unsigned)p.OH);
+    t /= (unsigned)p.OH;
+    int od = (int)(t % (unsigned)p.OD);
+    an[j] = (int)(t / (unsigned)p.OD);
     az[j] = od * p.stride - p.pad;
     ay[j] = oh * p.stride - p.pad;
     ax[j] = ow * p.stride - p.pad;
@@ -2250,9 +2251,10 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 
   float4 ra[SGH][2], rc01[SGH][2], rc23[SGH][2];
   unsigned amask[SGH];
-  auto load_a = [&](int i, int kc) {
-    const int tap = kc / ncc;
-    const int cc = kc - tap * ncc;
+  int g_tap[SG], g_cc[SG];  // (tap, channel chunk) of the group's chunks (wave-uniform; one division per group, not per chunk)
+  auto load_a = [&](int i, int slot) {
+    const int tap = g_tap[slot];
+    const int cc = g_cc[slot];
     int kd = 0, kh = 0, kw = 0;
     if (p.ksz == 3) {
       kd = tap / 9;
@@ -2333,28 +2335,42 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 
   for (int g = kc_begin; g < kc_end; g += SG) {
     if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
-    // 1. the (small, L2-resident) activation rows of the whole group: two short round trips
+    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget);
+    // 2. every weight of the group is requested at once, right BEHIND the requests of the last activation batch and before
+    //    that batch is waited for: memory returns a wave's loads in order, so the activations are not held behind 28+ MB
+    //    of weights, the wait for them overlaps the weights' round trip (a 1x1x1 convolution is then ONE round trip plus
+    //    its MFMAs), and the chunk loop below starts on chunk 0 as soon as ITS weights are back while the rest streams.
+    {
+      int tap = p.ksz == 1 ? 0 : g / ncc, cc = g - tap * ncc;
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        g_tap[i] = tap, g_cc[i] = cc;
+        if (g + i + 1 < kc_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
+          ++cc;
+          if (cc == ncc) cc = 0, ++tap;
+        }
+      }
+    }
+    float4 bw[SG][2];
+    auto load_w = [&]() {
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const int tap = g_tap[i];
+        const int cc = g_cc[i];
+        const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
+        bw[i][0] = *reinterpret_cast<const float4*>(wp);
+        if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
+      }
+    };
 #pragma unroll
     for (int h = 0; h < SG; h += SGH) {
       if (g + h < kc_end) {  // uniform
 #pragma unroll
-        for (int i = 0; i < SGH; ++i) load_a(i, min(g + h + i, kc_end - 1));
+        for (int i = 0; i < SGH; ++i) load_a(i, h + i);
+        if (h + SGH >= SG || g + h + SGH >= kc_end) load_w();  // (uniform) the group's last batch
 #pragma unroll
         for (int i = 0; i < SGH; ++i) store_a(i, h + i);
       }
-    }
-    // 2. every weight of the group is requested at once, AFTER the activations: memory returns a wave's loads in
-    //    order, so the chunk loop below can start on chunk 0 as soon as ITS weights are back while the rest of the
-    //    group is still streaming (requested first, they would hold the activation loads behind 28+ MB of weights)
-    float4 bw[SG][2];
-#pragma unroll
-    for (int i = 0; i < SG; ++i) {
-      const int kc = min(g + i, kc_end - 1);
-      const int tap = kc / ncc;
-      const int cc = kc - tap * ncc;
-      const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
-      bw[i][0] = *reinterpret_cast<const float4*>(wp);
-      if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
     }
     __syncthreads();
 #pragma unroll
@@ -2456,6 +2472,42 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   }
 }
 
+// s = b + sum over the splits of partial[k][i .. i+3], in the fixed order both reduce kernels share
+__device__ __forceinline__ float4 splitk_sum4(const float* __restrict__ partial, int nsplit, int64_t MC, int64_t i, float4 b) {
+  float4 s = b;
+  int k = 0;
+  for (; k + 16 <= nsplit; k += 16) {  // deep splits (row-tile kernel): sixteen independent loads in flight
+    float4 t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(k + u) * MC + i);
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      s.x += (t[u].x + t[u + 1].x) + (t[u + 2].x + t[u + 3].x);
+      s.y += (t[u].y + t[u + 1].y) + (t[u + 2].y + t[u + 3].y);
+      s.z += (t[u].z + t[u + 1].z) + (t[u + 2].z + t[u + 3].z);
+      s.w += (t[u].w + t[u + 1].w) + (t[u + 2].w + t[u + 3].w);
+    }
+  }
+  for (; k + 4 <= nsplit; k += 4) {  // four independent loads in flight per thread
+    const float4 t0 = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
+    const float4 t1 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 1) * MC + i);
+    const float4 t2 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 2) * MC + i);
+    const float4 t3 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 3) * MC + i);
+    s.x += (t0.x + t1.x) + (t2.x + t3.x);
+    s.y += (t0.y + t1.y) + (t2.y + t3.y);
+    s.z += (t0.z + t1.z) + (t2.z + t3.z);
+    s.w += (t0.w + t1.w) + (t2.w + t3.w);
+  }
+  for (; k < nsplit; ++k) {
+    const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
+    s.x += t.x;
+    s.y += t.y;
+    s.z += t.z;
+    s.w += t.w;
+  }
+  return s;
+}
+
 // out = sum_s partial[s] + bias + residual, fused with the GroupNorm statistics of `out`.
 // Thread layout of gn_stats_kernel: cq = Cout/4 threads across channels (float4), rows = 256/cq voxels per
 // pass, one workgroup per voxel slab of one sample; grid = (B, N) with B, vox_per_block from
@@ -2492,37 +2544,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     for (int64_t v = vbeg + vr; v < vend; v += rows) {
       const int64_t i = ((int64_t)n * V + v) * Cout + c_base + c4 * 4;
-      float4 s = b;
-      int k = 0;
-      for (; k + 16 <= nsplit; k += 16) {  // deep splits (row-tile kernel): sixteen independent loads in flight
-        float4 t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float4*>(partial + (int64_t)(k + u) * MC + i);
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) {
-          s.x += (t[u].x + t[u + 1].x) + (t[u + 2].x + t[u + 3].x);
-          s.y += (t[u].y + t[u + 1].y) + (t[u + 2].y + t[u + 3].y);
-          s.z += (t[u].z + t[u + 1].z) + (t[u + 2].z + t[u + 3].z);
-          s.w += (t[u].w + t[u + 1].w) + (t[u + 2].w + t[u + 3].w);
-        }
-      }
-      for (; k + 4 <= nsplit; k += 4) {  // four independent loads in flight per thread
-        const float4 t0 = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
-        const float4 t1 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 1) * MC + i);
-        const float4 t2 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 2) * MC + i);
-        const float4 t3 = *reinterpret_cast<const float4*>(partial + (int64_t)(k + 3) * MC + i);
-        s.x += (t0.x + t1.x) + (t2.x + t3.x);
-        s.y += (t0.y + t1.y) + (t2.y + t3.y);
-        s.z += (t0.z + t1.z) + (t2.z + t3.z);
-        s.w += (t0.w + t1.w) + (t2.w + t3.w);
-      }
-      for (; k < nsplit; ++k) {
-        const float4 t = *reinterpret_cast<const float4*>(partial + (int64_t)k * MC + i);
-        s.x += t.x;
-        s.y += t.y;
-        s.z += t.z;
-        s.w += t.w;
-      }
+      float4 s = splitk_sum4(partial, nsplit, MC, i, b);
       if (residual) {
         const float4 r = ld_act4(residual, i, res_bf16);
         s.x += r.x;
@@ -2558,6 +2580,114 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int e = 0; e < 4; ++e) {
       dst[e * 2 + 0] = s[e];
       dst[e * 2 + 1] = s[4 + e];
+    }
+  }
+}
+
+// Small outputs (V <= 512 voxels per sample: the 8^3 and 4^3 levels) - one workgroup per (GroupNorm group, sample) sums the
+// split-K partials of ITS group's channels over all voxels, adds bias / residual and writes the output.  It then holds the
+// whole group: the statistics go out as ONE slab per sample (for every later consumer of the tensor), and when the planner
+// attached the first consumer's affine / FiLM rows (fin_coef) the (a, b) coefficients are finished here, in the arithmetic
+// of gn_finalize_kernel - that launch disappears.  q4 = channels of a group / 4 (a power of two) threads across the group's
+// channels, 256 / q4 voxels per pass.  grid = (groups, N).
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ partial, int nsplit, int64_t MC,
+                                                                  int Cout, int V, const float* __restrict__ bias,
+                                                                  const float* __restrict__ bias2,
+                                                                  const float* __restrict__ residual, float* __restrict__ out,
+                                                                  double* __restrict__ stats, int res_bf16, int out_bf16,
+                                                                  int groups, float eps, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  const float* __restrict__ film, int film_stride,
+                                                                  int film_cout, float* __restrict__ coef,
+                                                                  float* __restrict__ moments) {
+  __shared__ double red[256 * 8];
+  __shared__ double tot[2];
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int cpg = Cout / groups;
+  const int q4 = cpg >> 2;
+  const int rows = 256 / q4;
+  const int quarter = tid % q4, vr = tid / q4;
+  const int c = g * cpg + quarter * 4;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) b = *reinterpret_cast<const float4*>(bias + c);
+  if (bias2) {
+    const float4 b2 = *reinterpret_cast<const float4*>(bias2 + c);
+    b.x += b2.x;
+    b.y += b2.y;
+    b.z += b2.z;
+    b.w += b2.w;
+  }
+  double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
+  for (int v = vr; v < V; v += rows) {
+    const int64_t i = ((int64_t)n * V + v) * Cout + c;
+    float4 s = splitk_sum4(partial, nsplit, MC, i, b);
+    if (residual) {
+      const float4 r = ld_act4(residual, i, res_bf16);
+      s.x += r.x;
+      s.y += r.y;
+      s.z += r.z;
+      s.w += r.w;
+    }
+    st_act4(out, i, s, out_bf16);
+    ds[0] += s.x, ds[1] += s.y, ds[2] += s.z, ds[3] += s.w;
+    dq[0] += (double)s.x * s.x, dq[1] += (double)s.y * s.y, dq[2] += (double)s.z * s.z, dq[3] += (double)s.w * s.w;
+  }
+  if (!stats) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[tid * 8 + e] = ds[e];
+    red[tid * 8 + 4 + e] = dq[e];
+  }
+  __syncthreads();
+  // tree over the voxel rows: threads tid and tid + o hold the same channels while o is a multiple of q4
+  for (int o = 128; o >= q4; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[tid * 8 + e] += red[(tid + o) * 8 + e];
+    }
+    __syncthreads();
+  }
+  if (tid < q4) {  // per-channel sums of the sample: the tensor's (single) statistics slab
+    double* dst = stats + ((int64_t)n * Cout + g * cpg + tid * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dst[e * 2 + 0] = red[tid * 8 + e];
+      dst[e * 2 + 1] = red[tid * 8 + 4 + e];
+    }
+  }
+  if (!coef) return;
+  if (tid == 0) {
+    double s = 0.0, sq = 0.0;
+    for (int t = 0; t < q4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s += red[t * 8 + e];
+        sq += red[t * 8 + 4 + e];
+      }
+    tot[0] = s;
+    tot[1] = sq;
+  }
+  __syncthreads();
+  if (tid < cpg) {  // (gn_finalize_kernel's arithmetic)
+    const int cc = g * cpg + tid;
+    const double cnt = (double)cpg * (double)V;
+    const double mean = tot[0] / cnt;
+    double var = tot[1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    double a = rstd * (double)gamma[cc];
+    double bb = (double)beta[cc] - mean * a;
+    if (film) {
+      const double sc = 1.0 + (double)film[(int64_t)n * film_stride + cc];
+      const double sh = (double)film[(int64_t)n * film_stride + film_cout + cc];
+      a *= sc;
+      bb = bb * sc + sh;
+    }
+    coef[((int64_t)n * Cout + cc) * 2 + 0] = (float)a;
+    coef[((int64_t)n * Cout + cc) * 2 + 1] = (float)bb;
+    if (moments) {
+      moments[((int64_t)n * Cout + cc) * 2 + 0] = (float)mean;
+      moments[((int64_t)n * Cout + cc) * 2 + 1] = (float)rstd;
     }
   }
 }
@@ -2717,8 +2847,19 @@ size_t conv_plan(ConvParams& p, int num_cus) {
 
 // Number of GroupNorm-statistics slabs per sample the launch of `p` writes into p.stats (0 = this launch cannot
 // produce them: un-split gather kernel; use gn_stats_launch on the output instead).
+bool conv_reduce_groupwise(const ConvParams& p) {
+  static const bool enabled = [] {
+    const char* e = getenv("HOLO_REDUCE_GROUPWISE");
+    return !(e && e[0] == '0');
+  }();
+  const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+  const int q4 = p.Cout / 128;  // float4s per voxel of one of the 32 GroupNorm groups
+  return enabled && p.nsplit > 1 && V <= 512 && p.Cout % 128 == 0 && q4 <= 64 && (q4 & (q4 - 1)) == 0;
+}
+
 int conv_stats_slabs(const ConvParams& p) {
   const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+  if (conv_reduce_groupwise(p)) return 1;
   if (p.nsplit > 1) {
     int B, vpb;
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
@@ -2841,6 +2982,10 @@ int conv_launch(const ConvParams& p, void* stream) {
 #undef HOLO_HALO
     }
   } else if (p.mode == 2) {
+    if (M >= ((int64_t)1 << 31)) {
+      set_error("conv_launch: the row-tile kernel indexes output voxels in 32 bits (M = %lld)", (long long)M);
+      return -1;
+    }
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);
     if (p.bf16 == 1 && p.w_bf) {  // bf16 compute mode
       HOLO_LAUNCH(conv_small_kernel<true>, sgrid, block, stream, p);
@@ -2855,6 +3000,12 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.nsplit > 1) {
     const int64_t MC = M * p.Cout;
     const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+    if (p.stats && conv_reduce_groupwise(p)) {  // one workgroup per (GroupNorm group, sample); optionally the finalize too
+      HOLO_LAUNCH(splitk_reduce_group_kernel, dim3(32u, (unsigned)p.N), dim3(256), stream, (const float*)p.partial, p.nsplit,
+                  MC, p.Cout, (int)V, p.bias, p.skip_bias, p.residual, p.out, p.stats, p.res_bf16, p.out_bf16, 32, 1e-5f,
+                  p.fin_gamma, p.fin_beta, p.fin_film, p.fin_film_stride, p.fin_film_cout, p.fin_coef, p.fin_moments);
+      return 0;
+    }
     int B, vpb;
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N, (unsigned)cdiv(p.Cout, 1024)), dim3(256), stream,

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       //      Hence: requests ride BETWEEN the MFMAs of a group, vector work sits in ONE clump per group behind its last MFMA:
       //        MFMA k = 0, 4, 8, 12          one of the four weight requests of group g + 2
       //        xi_y == 3, k = 0..7           the next step's patch, two 16-byte LDS reads each
-      //        groups 1 / 16, eight k's      the halo requests of items 0,1 / 2,3 of the next stage
+      //        groups 1-4 / 16-19, k = 2, 10 the halo requests of items 0,1 / 2,3 of the next stage (five 16-byte requests
+      //                                      per 16 MFMAs with the weights: the L1 takes one per four MFMAs for free)
       //        behind MFMA 15                A operands of group g + 1 (8 v_pk_add); after xi_y == 3 the x transform of the new
       //                                      patch first (32 v_pk_add); after group 0 the next stage's halo addresses; after
       //                                      groups 8 / 12 / 20 / 24 the commit of halo item 0 / 1 / 2 / 3 (~2 500 cycles after
@@ -467,9 +468,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
             P[k >> 1][(2 * k) & 3] = w3_ld(base + ((2 * k) & 3) * W3_RS);
             P[k >> 1][(2 * k + 1) & 3] = w3_ld(base + ((2 * k + 1) & 3) * W3_RS);
           }
-          if ((g == 1 || g == 16) && !(W3_PROBE & 1)) {
-            constexpr int hl = k == 1 ? 0 : k == 2 ? 1 : k == 3 ? 2 : k == 5 ? 3 : k == 6 ? 4 : k == 7 ? 5 : k == 9 ? 6 : k == 10 ? 7 : -1;
-            if (hl >= 0) halo_load((g == 16 ? 2 : 0) + ((hl < 0 ? 0 : hl) >> 2), (hl < 0 ? 0 : hl) & 3);
+          if (((g >= 1 && g <= 4) || (g >= 16 && g <= 19)) && (k == 2 || k == 10) && !(W3_PROBE & 1)) {
+            constexpr int hl = (g >= 16 ? g - 16 : g >= 1 ? g - 1 : 0) * 2 + (k == 10 ? 1 : 0);  // 0..7: (item of the pair, plane)
+            halo_load((g >= 16 ? 2 : 0) + (hl >> 2), hl & 3);
           }
           __builtin_amdgcn_sched_barrier(0);  // requests stay behind THEIR MFMA
         };
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
     //                  Two register indices r at a time (v_pk_add_f32); the residual is requested before anything else.
     {
       const int co = cur.n0 + wn * 16 + lj;
-      const int coc = co < p.Cout ? co : p.Cout - 1;
+      const int coc = co;  // (Cout is a multiple of 64: conv_wino3_launch)
       const bool direct = p.nsplit == 1;
       const bool has_res = direct && p.residual != nullptr;
       float bv = (direct && p.bias) ? p.bias[coc] : 0.f;
@@ -645,10 +646,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
               ssum += o0 + o1;
               ssq = fmaf(o0, o0, fmaf(o1, o1, ssq));
             }
-            if (co < p.Cout) {
-              obase[vofs(r, 0, dy, dx)] = o0;
-              obase[vofs(r, 1, dy, dx)] = o1;
-            }
+            obase[vofs(r, 0, dy, dx)] = o0;
+            obase[vofs(r, 1, dy, dx)] = o1;
           }
       }
       // GroupNorm statistics of the tensor just produced: one slab per tile (conv_stats_slabs)
@@ -658,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
         s2 += __shfl_xor(s2, 16);
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
-        if (kq == 0 && co < p.Cout) {
+        if (kq == 0) {
           const int tiles_per_sample = ntx * nty * ntz;
           const int slab = ((cur.tz0 >> 1) * nty + (cur.ty0 >> 3)) * ntx + (cur.tx0 >> 3);
           double* d = p.stats + (((int64_t)cur.n * tiles_per_sample + slab) * p.Cout + co) * 2;

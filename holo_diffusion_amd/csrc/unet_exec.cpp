@@ -129,6 +129,7 @@ struct Act {  // channels-last activation [N][R][R][R][C]
   int stats_B = 0;
   int C = 0, R = 0;
   int refs = 0;
+  int reduce_op = -1;  // index of the producing conv op when its split-K reduce can finish a GroupNorm (conv_reduce_groupwise)
 };
 
 struct Tape {  // one layer of the training forward (what its backward needs)
@@ -447,6 +448,21 @@ struct Planner {
                        int film_cout) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     size_t coef = small_alloc((size_t)N * Cin * 2 * sizeof(float));
+    // The first single-source GroupNorm over a tensor whose producer is a group-wise split-K reduce is finished BY that
+    // reduce (ConvParams::fin_coef): no launch here.  (The coefficient buffers are never reused inside a forward, and the FiLM
+    // rows are written at its start, so computing them at the producer is safe.)  Not in the training forward, whose tape
+    // records the finalize's moments.
+    if (!x1 && !tape && x0.reduce_op >= 0 && ops[x0.reduce_op].kind == OP_CONV && !ops[x0.reduce_op].conv.fin_coef &&
+        ops[x0.reduce_op].conv.stats == ptr<double>(x0.stats_off)) {
+      ConvParams& c = ops[x0.reduce_op].conv;
+      c.fin_gamma = gamma;
+      c.fin_beta = beta;
+      c.fin_film = film;
+      c.fin_film_stride = u->emb_rows;
+      c.fin_film_cout = film_cout;
+      c.fin_coef = ptr<float>(coef);
+      return coef;
+    }
     Op op;
     op.kind = OP_FINAL;
     if (tape) {
@@ -551,6 +567,7 @@ struct Planner {
     if (slabs > 0) {
       alloc_stats(*stats_of, slabs);
       p.stats = ptr<double>(stats_of->stats_off);
+      stats_of->reduce_op = conv_reduce_groupwise(p) ? (int)ops.size() : -1;  // (this op's index: pushed below)
     }
     // The split-K scratch is released only AFTER the statistics buffer has its place: the reduce kernel of this very
     // launch writes the statistics while other workgroups of it still read partial sums, so the two must not share memory.

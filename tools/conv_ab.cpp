@@ -2,7 +2,8 @@
 // library): conv_wino2_kernel (two workgroups per CU, (z,y) Winograd) against conv_wino3_kernel (one persistent 512-register
 // wave per SIMD, F(2x2x2,3x3x3)), random data, planner-chosen split-K.
 // Build: bash tools/build_conv_ab.sh
-// Usage: conv_ab [iters=20]
+// Usage: conv_ab [iters=20] [nshapes]   CONV_AB_COLD=1: also time every launch behind a 768 MB write (input and weights
+//        evicted from the L2s and the memory-side cache: what a layer sees in the middle of a forward pass)
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -54,9 +55,18 @@ struct Shape {
   const char* what;
 };
 
+__global__ void flush_kernel(float4* buf, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) buf[i] = make_float4(v, v, v, v);
+}
+
 int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
   const int iters = argc > 1 ? atoi(argv[1]) : 20;
+  const int nshapes = argc > 2 ? atoi(argv[2]) : 100;
+  const bool cold = getenv("CONV_AB_COLD") != nullptr;
+  float4* flushbuf = nullptr;
+  const size_t flush_n = (size_t)768 << 20 >> 4;
+  if (cold) CK(hipMalloc(&flushbuf, flush_n * 16));
   const Shape shapes[] = {
       {64, 64, 0, 64, 1, 0, 0, 0, "64^3 64->64 GN+SiLU (ResBlock conv1)"},
       {64, 64, 0, 64, 1, 1, 0, 0, "64^3 64->64 GN+SiLU + residual/bias/stats (ResBlock conv2)"},
@@ -72,7 +82,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
+  int shape_no = 0;
   for (const Shape& s : shapes) {
+    if (shape_no++ >= nshapes) break;
     const int R = s.R, Cin = s.C0 + s.C1, Cout = s.Cout;
     const int64_t V = (int64_t)R * R * R;
     const int SR = s.ups ? R / 2 : R;
@@ -144,6 +156,20 @@ int main(int argc, char** argv) {
       const double fl = conv_flops(q), fx = conv_exec_flops(q);
       printf("   wino%d: %8.1f us  nsplit %d grid %d | algorithmic %6.1f TF/s, issued %6.1f TF/s = %.3f of the fp32 pipe\n", form,
              ms * 1e3, q.nsplit, q.grid_x, fl / ms * 1e-9, fx / ms * 1e-9, fx / ms * 1e-9 / 157.3);
+      if (cold) {
+        float tot = 0.f;
+        for (int i = 0; i < iters; ++i) {
+          flush_kernel<<<2048, 256>>>(flushbuf, flush_n, (float)i);
+          CK(hipEventRecord(e0, nullptr));
+          conv_launch(q, nullptr);
+          CK(hipEventRecord(e1, nullptr));
+          CK(hipEventSynchronize(e1));
+          float t;
+          CK(hipEventElapsedTime(&t, e0, e1));
+          tot += t;
+        }
+        printf("          cold (behind a 768 MB write): %8.1f us\n", tot / iters * 1e3);
+      }
       if (form == 3) {  // per-workgroup timeline of one launch
         unsigned long long* dbg;
         CK(hipMalloc(&dbg, (size_t)q.grid_x * 64));
@@ -173,6 +199,7 @@ int main(int argc, char** argv) {
           CK(hipMalloc(&dbg, (size_t)q.grid_x * 128));
           CK(hipMemset(dbg, 0, (size_t)q.grid_x * 128));
           q.dbg = dbg;
+          if (cold) flush_kernel<<<2048, 256>>>(flushbuf, flush_n, 3.f);
           conv_wino3_launch_tl(q, nullptr);
           CK(hipDeviceSynchronize());
           std::vector<unsigned long long> t((size_t)q.grid_x * 16);
