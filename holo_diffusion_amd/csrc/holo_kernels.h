@@ -54,16 +54,6 @@ struct ConvParams {
   const float* skip_bias;
   double* stats;          // optional: GroupNorm partial sums of `out`, [N][conv_stats_slabs(p)][Cout][2]
   float* partial;         // [nsplit][M][Cout] scratch when nsplit > 1
-  // Split launches of a SMALL output (conv_reduce_groupwise: the 8^3 / 4^3 levels) are reduced by one workgroup per
-  // (GroupNorm group, sample), which then holds the whole group and can finish the GroupNorm this tensor feeds: with
-  // fin_coef set (by the planner: the consumer's affine, optional FiLM rows) it writes the (a, b) coefficients the
-  // gn_finalize launch would have written; `stats` then has ONE slab per sample.
-  const float* fin_gamma;
-  const float* fin_beta;
-  const float* fin_film;
-  int fin_film_stride, fin_film_cout;
-  float* fin_coef;
-  float* fin_moments;
   int nsplit;             // split-K factor over (tap, cin-chunk) chunks
   int chunks_per_split;
   int skip_chunks_per_split;  // halo kernel with a fused skip: skip chunks are dealt evenly to the same splits
@@ -110,8 +100,6 @@ int conv_wino3_launch(const ConvParams& p, void* stream);
 size_t conv_plan(ConvParams& p, int num_cus);
 int conv_launch(const ConvParams& p, void* stream);
 int conv_stats_slabs(const ConvParams& p);
-// split launch whose reduce runs one workgroup per (GroupNorm group, sample): see ConvParams::fin_coef
-bool conv_reduce_groupwise(const ConvParams& p);
 double conv_flops(const ConvParams& p);       // algorithmic (the reference's multiply-adds x 2)
 double conv_exec_flops(const ConvParams& p);  // issued to the matrix pipe (differs for the Winograd-in-depth kernel)
 

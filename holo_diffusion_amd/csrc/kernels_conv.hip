@@ -2333,24 +2333,29 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, 16-Cout slice) block
   const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;  // 1 KB contiguous per wave instruction
 
+  // (tap, chunk) of the SG chunks that start at chunk g0
+  auto group_chunks = [&](int g0) {
+    int tap = p.ksz == 1 ? 0 : g0 / ncc, cc = g0 - tap * ncc;
+#pragma unroll
+    for (int i = 0; i < SG; ++i) {
+      g_tap[i] = tap, g_cc[i] = cc;
+      if (g0 + i + 1 < kc_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
+        ++cc;
+        if (cc == ncc) cc = 0, ++tap;
+      }
+    }
+  };
+  group_chunks(kc_begin);
+#pragma unroll
+  for (int i = 0; i < SGH; ++i) load_a(i, i);  // the first group's first batch
   for (int g = kc_begin; g < kc_end; g += SG) {
     if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
-    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget);
+    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget).  The
+    //    FIRST batch of a group is already on its way: it was requested before the previous group's MFMAs (below).
     // 2. every weight of the group is requested at once, right BEHIND the requests of the last activation batch and before
     //    that batch is waited for: memory returns a wave's loads in order, so the activations are not held behind 28+ MB
     //    of weights, the wait for them overlaps the weights' round trip (a 1x1x1 convolution is then ONE round trip plus
     //    its MFMAs), and the chunk loop below starts on chunk 0 as soon as ITS weights are back while the rest streams.
-    {
-      int tap = p.ksz == 1 ? 0 : g / ncc, cc = g - tap * ncc;
-#pragma unroll
-      for (int i = 0; i < SG; ++i) {
-        g_tap[i] = tap, g_cc[i] = cc;
-        if (g + i + 1 < kc_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
-          ++cc;
-          if (cc == ncc) cc = 0, ++tap;
-        }
-      }
-    }
     float4 bw[SG][2];
     auto load_w = [&]() {
 #pragma unroll
@@ -2365,12 +2370,19 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 #pragma unroll
     for (int h = 0; h < SG; h += SGH) {
       if (g + h < kc_end) {  // uniform
+        if (h > 0) {
 #pragma unroll
-        for (int i = 0; i < SGH; ++i) load_a(i, h + i);
+          for (int i = 0; i < SGH; ++i) load_a(i, h + i);
+        }
         if (h + SGH >= SG || g + h + SGH >= kc_end) load_w();  // (uniform) the group's last batch
 #pragma unroll
         for (int i = 0; i < SGH; ++i) store_a(i, h + i);
       }
+    }
+    if (g + SG < kc_end) {  // the next group's first batch: lands under this group's MFMAs
+      group_chunks(g + SG);
+#pragma unroll
+      for (int i = 0; i < SGH; ++i) load_a(i, i);
     }
     __syncthreads();
 #pragma unroll
@@ -2584,114 +2596,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// Small outputs (V <= 512 voxels per sample: the 8^3 and 4^3 levels) - one workgroup per (GroupNorm group, sample) sums the
-// split-K partials of ITS group's channels over all voxels, adds bias / residual and writes the output.  It then holds the
-// whole group: the statistics go out as ONE slab per sample (for every later consumer of the tensor), and when the planner
-// attached the first consumer's affine / FiLM rows (fin_coef) the (a, b) coefficients are finished here, in the arithmetic
-// of gn_finalize_kernel - that launch disappears.  q4 = channels of a group / 4 (a power of two) threads across the group's
-// channels, 256 / q4 voxels per pass.  grid = (groups, N).
-__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const float* __restrict__ partial, int nsplit, int64_t MC,
-                                                                  int Cout, int V, const float* __restrict__ bias,
-                                                                  const float* __restrict__ bias2,
-                                                                  const float* __restrict__ residual, float* __restrict__ out,
-                                                                  double* __restrict__ stats, int res_bf16, int out_bf16,
-                                                                  int groups, float eps, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta,
-                                                                  const float* __restrict__ film, int film_stride,
-                                                                  int film_cout, float* __restrict__ coef,
-                                                                  float* __restrict__ moments) {
-  __shared__ double red[256 * 8];
-  __shared__ double tot[2];
-  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  const int cpg = Cout / groups;
-  const int q4 = cpg >> 2;
-  const int rows = 256 / q4;
-  const int quarter = tid % q4, vr = tid / q4;
-  const int c = g * cpg + quarter * 4;
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (bias) b = *reinterpret_cast<const float4*>(bias + c);
-  if (bias2) {
-    const float4 b2 = *reinterpret_cast<const float4*>(bias2 + c);
-    b.x += b2.x;
-    b.y += b2.y;
-    b.z += b2.z;
-    b.w += b2.w;
-  }
-  double ds[4] = {0, 0, 0, 0}, dq[4] = {0, 0, 0, 0};
-  for (int v = vr; v < V; v += rows) {
-    const int64_t i = ((int64_t)n * V + v) * Cout + c;
-    float4 s = splitk_sum4(partial, nsplit, MC, i, b);
-    if (residual) {
-      const float4 r = ld_act4(residual, i, res_bf16);
-      s.x += r.x;
-      s.y += r.y;
-      s.z += r.z;
-      s.w += r.w;
-    }
-    st_act4(out, i, s, out_bf16);
-    ds[0] += s.x, ds[1] += s.y, ds[2] += s.z, ds[3] += s.w;
-    dq[0] += (double)s.x * s.x, dq[1] += (double)s.y * s.y, dq[2] += (double)s.z * s.z, dq[3] += (double)s.w * s.w;
-  }
-  if (!stats) return;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    red[tid * 8 + e] = ds[e];
-    red[tid * 8 + 4 + e] = dq[e];
-  }
-  __syncthreads();
-  // tree over the voxel rows: threads tid and tid + o hold the same channels while o is a multiple of q4
-  for (int o = 128; o >= q4; o >>= 1) {
-    if (tid < o) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) red[tid * 8 + e] += red[(tid + o) * 8 + e];
-    }
-    __syncthreads();
-  }
-  if (tid < q4) {  // per-channel sums of the sample: the tensor's (single) statistics slab
-    double* dst = stats + ((int64_t)n * Cout + g * cpg + tid * 4) * 2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      dst[e * 2 + 0] = red[tid * 8 + e];
-      dst[e * 2 + 1] = red[tid * 8 + 4 + e];
-    }
-  }
-  if (!coef) return;
-  if (tid == 0) {
-    double s = 0.0, sq = 0.0;
-    for (int t = 0; t < q4; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s += red[t * 8 + e];
-        sq += red[t * 8 + 4 + e];
-      }
-    tot[0] = s;
-    tot[1] = sq;
-  }
-  __syncthreads();
-  if (tid < cpg) {  // (gn_finalize_kernel's arithmetic)
-    const int cc = g * cpg + tid;
-    const double cnt = (double)cpg * (double)V;
-    const double mean = tot[0] / cnt;
-    double var = tot[1] / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    double a = rstd * (double)gamma[cc];
-    double bb = (double)beta[cc] - mean * a;
-    if (film) {
-      const double sc = 1.0 + (double)film[(int64_t)n * film_stride + cc];
-      const double sh = (double)film[(int64_t)n * film_stride + film_cout + cc];
-      a *= sc;
-      bb = bb * sc + sh;
-    }
-    coef[((int64_t)n * Cout + cc) * 2 + 0] = (float)a;
-    coef[((int64_t)n * Cout + cc) * 2 + 1] = (float)bb;
-    if (moments) {
-      moments[((int64_t)n * Cout + cc) * 2 + 0] = (float)mean;
-      moments[((int64_t)n * Cout + cc) * 2 + 1] = (float)rstd;
-    }
-  }
-}
-
 }  // namespace
 
 size_t conv_plan(ConvParams& p, int num_cus) {
@@ -2847,19 +2751,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
 
 // Number of GroupNorm-statistics slabs per sample the launch of `p` writes into p.stats (0 = this launch cannot
 // produce them: un-split gather kernel; use gn_stats_launch on the output instead).
-bool conv_reduce_groupwise(const ConvParams& p) {
-  static const bool enabled = [] {
-    const char* e = getenv("HOLO_REDUCE_GROUPWISE");
-    return !(e && e[0] == '0');
-  }();
-  const int64_t V = (int64_t)p.OD * p.OH * p.OW;
-  const int q4 = p.Cout / 128;  // float4s per voxel of one of the 32 GroupNorm groups
-  return enabled && p.nsplit > 1 && V <= 512 && p.Cout % 128 == 0 && q4 <= 64 && (q4 & (q4 - 1)) == 0;
-}
-
 int conv_stats_slabs(const ConvParams& p) {
   const int64_t V = (int64_t)p.OD * p.OH * p.OW;
-  if (conv_reduce_groupwise(p)) return 1;
   if (p.nsplit > 1) {
     int B, vpb;
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
@@ -3000,12 +2893,6 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.nsplit > 1) {
     const int64_t MC = M * p.Cout;
     const int64_t V = (int64_t)p.OD * p.OH * p.OW;
-    if (p.stats && conv_reduce_groupwise(p)) {  // one workgroup per (GroupNorm group, sample); optionally the finalize too
-      HOLO_LAUNCH(splitk_reduce_group_kernel, dim3(32u, (unsigned)p.N), dim3(256), stream, (const float*)p.partial, p.nsplit,
-                  MC, p.Cout, (int)V, p.bias, p.skip_bias, p.residual, p.out, p.stats, p.res_bf16, p.out_bf16, 32, 1e-5f,
-                  p.fin_gamma, p.fin_beta, p.fin_film, p.fin_film_stride, p.fin_film_cout, p.fin_coef, p.fin_moments);
-      return 0;
-    }
     int B, vpb;
     gn_stats_geometry(p.Cout < 1024 ? p.Cout : 1024, V, &B, &vpb);
     HOLO_LAUNCH(splitk_reduce_kernel, dim3((unsigned)B, (unsigned)p.N, (unsigned)cdiv(p.Cout, 1024)), dim3(256), stream,

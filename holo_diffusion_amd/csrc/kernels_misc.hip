@@ -155,6 +155,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  unsigned long long b;
+  memcpy(&b, &v, 8);
+  const float lo = __shfl_xor(__uint_as_float((uint32_t)(b & 0xffffffffull)), mask);
+  const float hi = __shfl_xor(__uint_as_float((uint32_t)(b >> 32)), mask);
+  b = (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+
 // coef[n][c] = (a, b) with GN(x)*(1+scale)+shift = a*x + b.  grid = (groups, N), block = 256
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part0, int C0, int B0,
                                                           const double* __restrict__ part1, int C1, int B1, int64_t V,
@@ -163,10 +174,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ film, int film_stride,
                                                           int film_cout, float* __restrict__ coef,
                                                           float* __restrict__ moments) {
-  __shared__ double rs[256], rq[256];
+  __shared__ double rs[4], rq[4];
   const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
   const int Cin = C0 + C1;
   const int cpg = Cin / groups;
+  // the channel's affine / FiLM rows are requested FIRST: they come back under the reduction instead of after it (this
+  // kernel is nothing but dependent round trips: ~66 launches per forward)
+  float pg = 0.f, pb = 0.f, psc = 0.f, psh = 0.f;
+  if (tid < cpg) {
+    const int c = g * cpg + tid;
+    pg = gamma[c];
+    pb = beta[c];
+    if (film) {
+      psc = film[(int64_t)n * film_stride + c];
+      psh = film[(int64_t)n * film_stride + film_cout + c];
+    }
+  }
   // Every (slab, channel-of-the-group) pair is one 16-byte (sum, sumsq) record; consecutive channels of a slab are
   // contiguous, so the threads walk the pairs with the channel index fastest (coalesced runs of cpg records) and keep
   // eight independent loads in flight.  The summation order depends on nothing but the launch geometry: deterministic.
@@ -205,28 +228,29 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
       }
     }
   }
-  rs[tid] = s;
-  rq[tid] = sq;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
-      rs[tid] += rs[tid + o];
-      rq[tid] += rq[tid + o];
-    }
-    __syncthreads();
+  // fixed-order butterfly inside each wave (no barrier), then the four wave totals in wave order: one barrier in all
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s += shfl_xor_f64(s, o);
+    sq += shfl_xor_f64(sq, o);
   }
+  if ((tid & 63) == 0) {
+    rs[tid >> 6] = s;
+    rq[tid >> 6] = sq;
+  }
+  __syncthreads();
   if (tid < cpg) {
     const int c = g * cpg + tid;
     const double cnt = (double)cpg * (double)V;
-    const double mean = rs[0] / cnt;
-    double var = rq[0] / cnt - mean * mean;
+    const double mean = (((rs[0] + rs[1]) + rs[2]) + rs[3]) / cnt;
+    double var = (((rq[0] + rq[1]) + rq[2]) + rq[3]) / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
-    double a = rstd * (double)gamma[c];
-    double b = (double)beta[c] - mean * a;
+    double a = rstd * (double)pg;
+    double b = (double)pb - mean * a;
     if (film) {
-      const double sc = 1.0 + (double)film[(int64_t)n * film_stride + c];
-      const double sh = (double)film[(int64_t)n * film_stride + film_cout + c];
+      const double sc = 1.0 + (double)psc;
+      const double sh = (double)psh;
       a *= sc;
       b = b * sc + sh;
     }

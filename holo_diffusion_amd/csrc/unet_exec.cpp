@@ -129,7 +129,6 @@ struct Act {  // channels-last activation [N][R][R][R][C]
   int stats_B = 0;
   int C = 0, R = 0;
   int refs = 0;
-  int reduce_op = -1;  // index of the producing conv op when its split-K reduce can finish a GroupNorm (conv_reduce_groupwise)
 };
 
 struct Tape {  // one layer of the training forward (what its backward needs)
@@ -448,21 +447,6 @@ struct Planner {
                        int film_cout) {
     const int Cin = x0.C + (x1 ? x1->C : 0);
     size_t coef = small_alloc((size_t)N * Cin * 2 * sizeof(float));
-    // The first single-source GroupNorm over a tensor whose producer is a group-wise split-K reduce is finished BY that
-    // reduce (ConvParams::fin_coef): no launch here.  (The coefficient buffers are never reused inside a forward, and the FiLM
-    // rows are written at its start, so computing them at the producer is safe.)  Not in the training forward, whose tape
-    // records the finalize's moments.
-    if (!x1 && !tape && x0.reduce_op >= 0 && ops[x0.reduce_op].kind == OP_CONV && !ops[x0.reduce_op].conv.fin_coef &&
-        ops[x0.reduce_op].conv.stats == ptr<double>(x0.stats_off)) {
-      ConvParams& c = ops[x0.reduce_op].conv;
-      c.fin_gamma = gamma;
-      c.fin_beta = beta;
-      c.fin_film = film;
-      c.fin_film_stride = u->emb_rows;
-      c.fin_film_cout = film_cout;
-      c.fin_coef = ptr<float>(coef);
-      return coef;
-    }
     Op op;
     op.kind = OP_FINAL;
     if (tape) {
@@ -567,7 +551,6 @@ struct Planner {
     if (slabs > 0) {
       alloc_stats(*stats_of, slabs);
       p.stats = ptr<double>(stats_of->stats_off);
-      stats_of->reduce_op = conv_reduce_groupwise(p) ? (int)ops.size() : -1;  // (this op's index: pushed below)
     }
     // The split-K scratch is released only AFTER the statistics buffer has its place: the reduce kernel of this very
     // launch writes the statistics while other workgroups of it still read partial sums, so the two must not share memory.
@@ -909,6 +892,17 @@ struct Planner {
       ops.push_back(op);
     }
     release(y);
+    if (getenv("HOLO_PLAN_DEBUG")) {  // development: what the plan launches
+      int n_fin = 0, n_conv = 0, n_split = 0;
+      for (const Op& o : ops) {
+        n_fin += o.kind == OP_FINAL;
+        if (o.kind != OP_CONV) continue;
+        ++n_conv;
+        n_split += o.conv.nsplit > 1;
+      }
+      fprintf(stderr, "[plan] batch %d: %zu ops | %d convs, %d of them split-K (+ a reduce launch) | %d gn_finalize launches\n", N, ops.size(),
+              n_conv, n_split, n_fin);
+    }
   }
   size_t total_bytes() const { return arena_base + arena.peak; }
   bool regions_ok() const { return stats_top <= stats_cap && small_top <= small_cap; }
