@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
 HOLO_DTYPE_F32_BF16X3 = 2
-ABI_VERSION = 3  # include/holo_abi.h HOLO_ABI_VERSION
+ABI_VERSION = 4  # include/holo_abi.h HOLO_ABI_VERSION
 
 
 class HoloError(RuntimeError):
@@ -123,6 +123,11 @@ SIGNATURES = {
     "holo_view_pool_workspace_bytes": (C.c_size_t, [C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
     "holo_view_pool": (C.c_int, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int,
                                  C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_view_pool_backward_workspace_bytes": (C.c_size_t, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature),
+                                                             C.c_int, C.c_int]),
+    "holo_view_pool_backward": (C.c_int, [_vp, C.POINTER(HoloViewPoolCfg), C.POINTER(HoloViewFeature), C.c_int,
+                                          C.POINTER(HoloCamera), C.c_int, _vp, _vp, _vp, C.POINTER(_vp), _vp, _vp, _vp,
+                                          C.c_size_t, _vp]),
     "holo_mlp_mean_create": (C.c_int, [_vp, C.POINTER(HoloMlpMeanCfg), C.POINTER(_vp)]),
     "holo_mlp_mean_destroy": (C.c_int, [_vp]),
     "holo_mlp_mean_set_param": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int, _i64p, _vp]),

@@ -387,6 +387,19 @@ struct ViewPoolParams {
   float* out;         // (1, F, R, R, R)
 };
 int view_pool_launch(const ViewPoolParams& p, void* stream);
+// backward of view_pool_kernel (kernels_viewpool_bwd.hip): fwd as for the forward launch (feature maps channels-last in the
+// workspace, transposed mapper weight), gout = d loss / d voxel_features (1, F, R, R, R)
+struct ViewPoolBwdParams {
+  ViewPoolParams fwd;
+  const float* gout;
+  float* gfeat[ViewPoolParams::MAX_FEATS];  // zeroed (n_views, H, W, Cp) gradient maps, or null per key
+  int want_feats;
+  float* partial;  // [n_wgs][A * F + F]
+  float* dW;       // (F, A) or null
+  float* dbias;    // (F) or null
+};
+int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream);
+int nhwc_pad_to_nchw_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 // MLPMeanFeatureAggregator path (kernels_viewpool.hip): the folded aggregator + mapper (viewpool_exec.cpp); vp carries the
 // views, the feature maps (quad0 = first quad in the kernel's padded channel order), R, F, proj_eps and the output
 struct MlpMeanParams {

@@ -35,10 +35,15 @@ size_t holo_view_pool_workspace_bytes(const HoloViewPoolCfg* cfg, const HoloView
   return b + 256;
 }
 
-int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
-                   const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
-                   float* voxel_features, void* workspace, size_t workspace_bytes, void* stream) {
-  if (!ctx || !cfg || !feats || !cameras || !mapper_weight || !voxel_features || !workspace) {
+}  // extern "C"
+
+// everything of holo_view_pool up to the launch: argument checks, channels-last copies of the feature maps and the transposed
+// mapper weight at the start of the workspace (ws is advanced behind them), cameras
+static int setup_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
+                           const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
+                           void* workspace, size_t workspace_bytes, size_t workspace_need, void* stream, ViewPoolParams& p,
+                           char*& ws) {
+  if (!ctx || !cfg || !feats || !cameras || !mapper_weight || !workspace) {
     set_error("holo_view_pool: null argument");
     return HOLO_E_INVALID;
   }
@@ -47,13 +52,12 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
     set_error("holo_view_pool: 1..%d source views, 1..%d feature maps", ViewPoolParams::MAX_VIEWS, ViewPoolParams::MAX_FEATS);
     return HOLO_E_UNSUPPORTED;
   }
-  if (workspace_bytes < holo_view_pool_workspace_bytes(cfg, feats, n_feats, n_views)) {
+  if (workspace_bytes < workspace_need) {
     set_error("holo_view_pool: workspace too small");
     return HOLO_E_WORKSPACE;
   }
-  ViewPoolParams p;
   memset(&p, 0, sizeof p);
-  char* ws = (char*)workspace;
+  ws = (char*)workspace;
   int quad = 0, outc = 0;
   for (int k = 0; k < n_feats; ++k) {
     const HoloViewFeature& f = feats[k];
@@ -84,6 +88,7 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
   p.F = cfg->feature_size;
   if (transpose_small_launch(mapper_weight, (float*)ws, p.F, p.A, stream)) return HOLO_E_INVALID;  // (F, A) -> (A, F)
   p.wt = (const float*)ws;
+  ws += align256((size_t)p.A * p.F * sizeof(float));
   p.bias = mapper_bias;
   p.n_views = n_views;
   for (int v = 0; v < n_views; ++v) {
@@ -103,8 +108,90 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
   p.gamma = cfg->weight_by_ray_angle_gamma;
   p.min_weight = cfg->min_ray_angle_weight;
   p.proj_eps = cfg->projection_eps;
+  return 0;
+}
+
+extern "C" {
+
+int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
+                   const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
+                   float* voxel_features, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!voxel_features) {
+    set_error("holo_view_pool: null argument");
+    return HOLO_E_INVALID;
+  }
+  ViewPoolParams p;
+  char* ws;
+  const int rc = setup_view_pool(ctx, cfg, feats, n_feats, cameras, n_views, mapper_weight, mapper_bias, workspace,
+                                 workspace_bytes, cfg && feats ? holo_view_pool_workspace_bytes(cfg, feats, n_feats, n_views) : 0,
+                                 stream, p, ws);
+  if (rc) return rc;
   p.out = voxel_features;
   return view_pool_launch(p, stream) ? HOLO_E_INVALID : 0;
+}
+
+// ---- backward (kernels_viewpool_bwd.hip).  Workspace: the forward's part, then the zeroed channels-last gradient maps,
+//      then the per-workgroup partials of d weight / d bias.
+static int view_pool_bwd_wgs(HoloCtx* ctx, int resol) {
+  const int64_t groups = ((int64_t)resol * resol * resol + 15) / 16;
+  int64_t n = 2 * (int64_t)ctx->num_cus;
+  return (int)(groups < n ? groups : n);
+}
+
+size_t holo_view_pool_backward_workspace_bytes(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats,
+                                               int n_feats, int n_views) {
+  if (!ctx || !cfg || !feats || n_feats < 1 || n_views < 1) return 0;
+  size_t b = holo_view_pool_workspace_bytes(cfg, feats, n_feats, n_views);
+  int sumC = 0;
+  for (int k = 0; k < n_feats; ++k) {
+    const size_t Cp = (size_t)((feats[k].channels + 3) / 4 * 4);
+    b += align256((size_t)n_views * feats[k].height * feats[k].width * Cp * sizeof(float));
+    sumC += feats[k].channels;
+  }
+  b += align256((size_t)view_pool_bwd_wgs(ctx, cfg->resol) * ((size_t)2 * sumC * cfg->feature_size + cfg->feature_size) * sizeof(float));
+  return b + 256;
+}
+
+int holo_view_pool_backward(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
+                            const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
+                            const float* grad_voxel_features, float* const* grad_feats, float* grad_mapper_weight,
+                            float* grad_mapper_bias, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grad_voxel_features) {
+    set_error("holo_view_pool_backward: null argument");
+    return HOLO_E_INVALID;
+  }
+  ViewPoolBwdParams b;
+  memset(&b, 0, sizeof b);
+  char* ws;
+  int rc = setup_view_pool(ctx, cfg, feats, n_feats, cameras, n_views, mapper_weight, mapper_bias, workspace, workspace_bytes,
+                           ctx && cfg && feats ? holo_view_pool_backward_workspace_bytes(ctx, cfg, feats, n_feats, n_views) : 0, stream,
+                           b.fwd, ws);
+  if (rc) return rc;
+  b.gout = grad_voxel_features;
+  for (int k = 0; k < n_feats; ++k) {
+    const ViewPoolParams::Feat& f = b.fwd.feat[k];
+    const size_t bytes = (size_t)n_views * f.H * f.W * f.Cp * sizeof(float);
+    if (grad_feats && grad_feats[k]) {
+      b.gfeat[k] = (float*)ws;
+      b.want_feats = 1;
+      if (hipMemsetAsync(ws, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+        set_error("holo_view_pool_backward: hipMemsetAsync failed");
+        return HOLO_E_HIP;
+      }
+    }
+    ws += align256(bytes);
+  }
+  const int n_wgs = view_pool_bwd_wgs(ctx, cfg->resol);
+  b.partial = (float*)ws;
+  b.dW = grad_mapper_weight;
+  b.dbias = grad_mapper_bias;
+  if (view_pool_bwd_launch(b, n_wgs, stream)) return HOLO_E_UNSUPPORTED;
+  for (int k = 0; k < n_feats; ++k)
+    if (b.gfeat[k]) {
+      const ViewPoolParams::Feat& f = b.fwd.feat[k];
+      if (nhwc_pad_to_nchw_launch(b.gfeat[k], grad_feats[k], n_views, f.C, f.Cp, (int64_t)f.H * f.W, stream)) return HOLO_E_INVALID;
+    }
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -412,6 +412,22 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         return self.view_pooler.pool_to_voxel_features(image_features, source_cameras, pm.weight, pm.bias, self.resol,
                                                        self.volume_extent)
 
+    def pool_views_backward(self, image_features: Dict[str, torch.Tensor], source_cameras,
+                            grad_voxel_features: torch.Tensor, want_feature_grads: bool = True) -> Dict[str, Any]:
+        """The encoder side of ``loss.backward()`` (holo_diffusion_model.py:340-373 under autograd): the gradient of the
+        pooled grid - ``training_backward(...)["voxel_features"]`` when the grid came from ``pool_views_to_voxel_features`` -
+        through tanh, ``pooled_feature_mapper`` and the view pooling.  Returns ``{"image_features": {key: grad},
+        "pooled_feature_mapper": {"weight": grad, "bias": grad}}``; the feature-map gradients are what autograd hands the
+        image feature extractor (which is outside this path)."""
+        assert self.view_pooler_enabled and self.view_pooler is not None, "view_pooler must be enabled"
+        pm = self.pooled_feature_mapper
+        if isinstance(pm.weight, torch.nn.parameter.UninitializedParameter):
+            raise RuntimeError("pool_views_backward: pooled_feature_mapper is not materialised (run the forward first)")
+        gf, gw, gb = self.view_pooler.pool_to_voxel_features_backward(
+            image_features, source_cameras, pm.weight, pm.bias, self.resol, self.volume_extent, grad_voxel_features,
+            want_feature_grads=want_feature_grads)
+        return {"image_features": gf, "pooled_feature_mapper": {"weight": gw, "bias": gb}}
+
     def render_views(self, voxel_features: torch.Tensor, cameras: PerspectiveCameras) -> Dict[str, torch.Tensor]:
         """Batched turntable render: all cameras of a fly-around in ONE holo_render call (BASELINE config 4).
         Equivalent to calling forward() once per camera with the same voxel_features."""

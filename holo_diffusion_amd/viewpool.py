@@ -209,6 +209,67 @@ class ViewPooler(Configurable, torch.nn.Module):
         return out
 
     @torch.no_grad()
+    def pool_to_voxel_features_backward(self, feats: Dict[str, torch.Tensor], camera, mapper_weight: torch.Tensor,
+                                        mapper_bias: Optional[torch.Tensor], resol: int, volume_extent: float,
+                                        grad_voxel_features: torch.Tensor, want_feature_grads: bool = True):
+        """Backward of ``pool_to_voxel_features`` (``holo_view_pool_backward``): the gradient of the clean grid
+        (``training_backward(...)["voxel_features"]``) -> ``({key: grad of feats[key]}, grad mapper weight, grad mapper
+        bias)`` - what autograd leaves behind holo_diffusion_model.py:358-373 for the image feature extractor and on
+        ``pooled_feature_mapper``.  AngleWeightedReductionFeatureAggregator (the released configuration) only."""
+        agg = self.feature_aggregator
+        if isinstance(agg, MLPMeanFeatureAggregator):
+            raise NotImplementedError("view pooling backward: MLPMeanFeatureAggregator has no backward on this path yet")
+        if agg.exclude_target_view or agg.exclude_target_view_mask_features:
+            raise _lib.HoloError("view pooling: exclude_target_view(_mask_features) must be False "
+                                 "(HoloDiffusionModel sets both, holo_diffusion_model.py:114-116)")
+        from .render import _camera_array
+        keys = list(feats)
+        t0 = feats[keys[0]]
+        runtime.require_device(t0, "ViewPooler.pool_to_voxel_features_backward")
+        dev, n_src = t0.device, int(t0.shape[0])
+        arr = (_lib.HoloViewFeature * len(keys))()
+        held, grads = [], {}
+        gptr = (C.c_void_p * len(keys))()
+        for i, k in enumerate(keys):
+            t = feats[k]
+            if t.dim() != 4 or t.shape[0] != n_src or t.device != dev:
+                raise _lib.HoloError(f"feature map '{k}' must be (n_src={n_src}, C, H, W) on {dev}, got {tuple(t.shape)}")
+            t = t.detach().contiguous().float()
+            held.append(t)
+            arr[i].feats = t.data_ptr()
+            arr[i].channels, arr[i].height, arr[i].width = int(t.shape[1]), int(t.shape[2]), int(t.shape[3])
+            if want_feature_grads:
+                grads[k] = torch.empty_like(t)
+                gptr[i] = grads[k].data_ptr()
+            else:
+                gptr[i] = None
+        cams = _camera_array(camera)
+        if len(cams) != n_src:
+            raise _lib.HoloError(f"{len(cams)} cameras for {n_src} source views")
+        F = int(mapper_weight.shape[0])
+        A = self.get_aggregated_feature_dim({k: feats[k] for k in keys})
+        if tuple(mapper_weight.shape) != (F, A):
+            raise _lib.HoloError(f"pooled_feature_mapper.weight must be ({F}, {A}), got {tuple(mapper_weight.shape)}")
+        g = grad_voxel_features.detach().contiguous().float()
+        if tuple(g.shape) != (1, F, resol, resol, resol) or g.device != dev:
+            raise _lib.HoloError(f"grad_voxel_features must be (1, {F}, {resol}, {resol}, {resol}) on {dev}, got {tuple(g.shape)}")
+        cfg = _lib.HoloViewPoolCfg(int(resol), float(volume_extent), F, float(agg.weight_by_ray_angle_gamma),
+                                   float(agg.min_ray_angle_weight), 1e-2)
+        L = runtime.lib()
+        ctx = runtime.ctx(dev)
+        nbytes = L.holo_view_pool_backward_workspace_bytes(ctx, C.byref(cfg), arr, len(keys), n_src)
+        ws = runtime.workspace(self, dev, nbytes)
+        w = mapper_weight.detach().contiguous().float()
+        b = mapper_bias.detach().contiguous().float() if mapper_bias is not None else None
+        gw = torch.empty_like(w)
+        gb = torch.empty(F, device=dev)
+        _lib.check(L, L.holo_view_pool_backward(ctx, C.byref(cfg), arr, len(keys), cams, n_src, runtime.ptr(w),
+                                                runtime.ptr(b) if b is not None else C.c_void_p(None), runtime.ptr(g), gptr,
+                                                runtime.ptr(gw), runtime.ptr(gb), runtime.ptr(ws), ws.numel(),
+                                                runtime.stream_ptr(dev)), "holo_view_pool_backward")
+        return grads, gw, (gb if mapper_bias is not None else None)
+
+    @torch.no_grad()
     def _pool_mlp_mean(self, feats: Dict[str, torch.Tensor], camera, mapper_weight, mapper_bias, resol: int,
                        volume_extent: float) -> torch.Tensor:
         from .render import _camera_array

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 3
+#define HOLO_ABI_VERSION 4
 
 enum {
   HOLO_OK = 0,
@@ -323,6 +323,23 @@ size_t holo_view_pool_workspace_bytes(const HoloViewPoolCfg* cfg, const HoloView
 int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
                    const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
                    float* voxel_features, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of holo_view_pool for a gradient on its output: what autograd computes in the reference behind
+ * `tanh(pooled_feature_mapper(view_pooler(...)))` (holo_diffusion_model.py:358-373) when the encoder side is trained -
+ * the chain continues from HoloDiffusionModel.training_backward's gradient of the clean grid.  Same inputs as the forward
+ * (nothing of it is kept: the aggregation is recomputed), plus
+ *   grad_voxel_features : (1, feature_size, R, R, R)
+ * Outputs (each may be NULL):
+ *   grad_feats[k]       : (n_views, channels_k, height_k, width_k) NCHW - the gradient of entry k of the extractor's dict
+ *                         (bilinear scatter by atomic adds, like grid_sample's backward: summation order not fixed)
+ *   grad_mapper_weight  : (feature_size, 2 * sum channels);  grad_mapper_bias : (feature_size)   (fixed summation order)
+ * feature_size <= 32 (every released configuration).  The angular weights depend on the cameras only: no gradient. */
+size_t holo_view_pool_backward_workspace_bytes(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats,
+                                               int n_feats, int n_views);
+int holo_view_pool_backward(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeature* feats, int n_feats,
+                            const HoloCamera* cameras, int n_views, const float* mapper_weight, const float* mapper_bias,
+                            const float* grad_voxel_features, float* const* grad_feats, float* grad_mapper_weight,
+                            float* grad_mapper_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same entry with the reference's own LEARNT aggregator, MLPMeanFeatureAggregator (holo_diffusion/custom_modules.py:
  * 162-293 + _get_point_to_source_camera_ray_dirs :296-334; selected by configs/hydrant.yaml:184 and

@@ -99,6 +99,50 @@ def test_view_pool_kernel_vs_oracle(R, n_src, radius, gamma):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,n_src,radius,gamma", [(8, 3, 10.0, 1.0), (16, 5, 6.0, 2.0), (8, 9, 3.0, 1.0)])
+def test_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius, gamma):
+    """holo_view_pool_backward against torch autograd through the oracle's forward (the reference trains this branch with
+    autograd, holo_diffusion_model.py:340-373): gradients of the three feature maps, of pooled_feature_mapper.weight and
+    .bias for a random cotangent on the grid.  Same geometries as the forward test (cameras inside the volume: taps with
+    zero weight, |z| clamp).  STD = sqrt(clamp(var, 1e-4)): a channel whose variance sits within rounding of the clamp
+    takes the other branch on one side - the maps here keep var far from 1e-4 except for voxels that project outside
+    every view (all samples zero, var = 0: clamped, zero gradient, on both sides)."""
+    import tests.gpu_utils as gu
+    F = 16
+    feats, A = _synthetic_views(n_src, 50 + R)
+    cams_d = _cams(n_src, radius=radius)
+    w = synth_state_dict({"w": (F, A), "b": (F,)}, 9)
+    w["b"] = 0.1 * torch.from_numpy(np_noise(4, (F,)))
+    g = torch.from_numpy(np_noise(123, (1, F, R, R, R)))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    mw, mb = w["w"].clone().requires_grad_(True), w["b"].clone().requires_grad_(True)
+    out = vo.voxel_features_from_views(leaves, cams_d, mw, mb, R, 8.0, gamma=gamma)
+    out.backward(g)
+    model = hda.HoloDiffusionModel(resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False,
+                                   diffusion_enabled=False, render_image_width=8, render_image_height=8,
+                                   view_pooler_args=dict(feature_aggregator_AngleWeightedReductionFeatureAggregator_args=dict(
+                                       weight_by_ray_angle_gamma=gamma)))
+    model.load_state_dict({"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}, strict=False)
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    dev_feats = {k: v.to(gu.DEV) for k, v in feats.items()}
+    model.pool_views_to_voxel_features(dev_feats, cams.to(gu.DEV))
+    got = model.pool_views_backward(dev_feats, cams.to(gu.DEV), g.to(gu.DEV))
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert rel(got["pooled_feature_mapper"]["weight"], mw.grad) < 1e-3, rel(got["pooled_feature_mapper"]["weight"], mw.grad)
+    assert rel(got["pooled_feature_mapper"]["bias"], mb.grad) < 1e-3
+    for k in feats:
+        assert got["image_features"][k].shape == feats[k].shape
+        assert float(leaves[k].grad.abs().max()) > 0
+        assert rel(got["image_features"][k], leaves[k].grad) < 1e-3, (k, rel(got["image_features"][k], leaves[k].grad))
+    # the mapper-only form (no feature-map gradients requested) gives the same parameter gradients
+    got2 = model.pool_views_backward(dev_feats, cams.to(gu.DEV), g.to(gu.DEV), want_feature_grads=False)
+    assert got2["image_features"] == {} and torch.equal(got2["pooled_feature_mapper"]["weight"], got["pooled_feature_mapper"]["weight"])
+
+
+@pytest.mark.gpu
 def test_model_forward_from_source_views():
     """HoloDiffusionModel.forward with source-view features (the reconstruction entry, holo_diffusion_model.py:327-374):
     camera batch = [target, sources...]; the pooled grid goes through tanh(net_3d(., 0)) and the renderer like a
