@@ -135,6 +135,10 @@ SIGNATURES = {
     "holo_mlp_mean_workspace_bytes": (C.c_size_t, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
     "holo_mlp_mean_pool": (C.c_int, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.POINTER(HoloCamera), C.c_int, _vp, _vp,
                                      C.c_size_t, _vp]),
+    "holo_mlp_mean_backward_workspace_bytes": (C.c_size_t, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.c_int]),
+    "holo_mlp_mean_backward": (C.c_int, [_vp, C.POINTER(HoloViewFeature), C.c_int, C.POINTER(HoloCamera), C.c_int, _vp,
+                                         C.POINTER(_vp), _vp, C.c_size_t, _vp]),
+    "holo_mlp_mean_get_grad": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
     "holo_event_timer_create": (C.c_int, [C.POINTER(_vp)]),
     "holo_event_timer_start": (C.c_int, [_vp, _vp]),
     "holo_event_timer_stop": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),

@@ -416,6 +416,19 @@ struct MlpMeanParams {
   int n_harmonic;
 };
 int mlp_mean_pool_launch(const MlpMeanParams& p, int num_cus, void* stream);
+// backward of the MLPMeanFeatureAggregator path (kernels_viewpool_bwd.hip): the row buffers live in the workspace,
+// rows = view * P + voxel; NRp / Pp = row counts padded for the split-K products (the padding rows are zero)
+struct MlpMeanBwdParams {
+  MlpMeanParams fwd;
+  const float* gout;  // (1, F, R, R, R)
+  int FW;             // width of a DUL row: F values of du, dlogit at column F, zero padding to a multiple of 4
+  int64_t NRp, Pp;
+  float *X, *MEAN, *CM, *PRE, *H, *U, *DUL, *DULT, *DPRET, *DC, *DCT, *DX, *DCA;
+  float* gfeat[ViewPoolParams::MAX_FEATS];
+};
+int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream);
+int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream);
+int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream);
 int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
 // ---------------------------------------------------------------------------------------------

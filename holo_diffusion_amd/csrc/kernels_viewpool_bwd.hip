@@ -258,6 +258,270 @@ __global__ __launch_bounds__(256) void nhwc_pad_to_nchw_kernel(const float* __re
   }
 }
 
+
+// =====================================================================================================================
+// MLPMeanFeatureAggregator (custom_modules.py:162-293), backward.  The forward kernel (mlp_mean_pool_kernel) works on the
+// FOLDED parameters A = W1 Ws, Am = W1 Wm, b' = W1 (bs + bm) + b1, G = M Wl, g0 = M bl + mapper bias, l = Wl[0], l0 = bl[0]
+// (viewpool_exec.cpp); so does the backward, and the host un-folds the gradients in float64.  Per voxel p, views v (weights 1):
+//   x_v = [bilinear samples | harmonic(ray direction)],  mean = sum_v x_v / max(V, 1e-2)
+//   pre_v = A x_v + Am mean + b',  h_v = LeakyReLU_0.2(pre_v),  logit_v = l.h_v + l0,  a = softmax_v(logit)
+//   out = tanh(sum_v a_v G h_v + g0)
+// Backward of g on out:  dz = g (1 - out^2);  du_v = a_v dz;  da_v = dz . (G h_v);  dlogit_v = a_v (da_v - sum_u a_u da_u)
+//   dh_v = G^T du_v + dlogit_v l;  dpre_v = dh_v lrelu'(pre_v);  dc = sum_v dpre_v
+//   dx_v = A^T dpre_v + Am^T dc / max(V, 1e-2)   -> feature columns scattered through the bilinear taps
+//   dG = sum du_v h_v^T, dl = sum dlogit_v h_v, dl0 = sum dlogit_v, dg0 = sum dz, dA = sum dpre_v x_v^T, dAm = sum dc mean^T,
+//   db' = sum dc
+// A training-side path built from plain pieces rather than one fused kernel: every per-(voxel, view) row vector lives in the
+// workspace (rows = view * P + voxel; ~3 GB at 64^3 with four views - 1 % of the HBM), the matrix products run on
+// gemm_kernel (fp32 MFMA; the reductions over all rows as split-K batches with the transposed operand written explicitly by
+// the producing kernel), the kernels below are the element-wise and per-voxel steps between them.
+// =====================================================================================================================
+struct VoxelProj {
+  float ndcx, ndcy, d[3];
+};
+__device__ __forceinline__ VoxelProj project_voxel(const ViewPoolParams& vp, int vi, int64_t p) {
+  const int R = vp.R;
+  const float step = 2.0f / (float)(R - 1);
+  auto lin = [&](int i) { return (i < R / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(R - 1 - i)) * vp.half_extent; };
+  const int x = (int)(p % R), y = (int)((p / R) % R), z = (int)(p / ((int64_t)R * R));
+  const float px = lin(x), py = lin(y), pz = lin(z);
+  const ViewPoolParams::Cam& c = vp.cams[vi];
+  const float cx = px * c.Rm[0] + py * c.Rm[3] + pz * c.Rm[6] + c.T[0];
+  const float cy = px * c.Rm[1] + py * c.Rm[4] + pz * c.Rm[7] + c.T[1];
+  float cz = px * c.Rm[2] + py * c.Rm[5] + pz * c.Rm[8] + c.T[2];
+  if (fabsf(cz) < vp.proj_eps) cz = cz < 0.f ? -vp.proj_eps : vp.proj_eps;
+  VoxelProj o;
+  o.ndcx = c.focal[0] * cx / cz + c.pp[0];
+  o.ndcy = c.focal[1] * cy / cz + c.pp[1];
+  float dx = px - c.centre[0], dy = py - c.centre[1], dz = pz - c.centre[2];
+  const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+  o.d[0] = dx / nrm, o.d[1] = dy / nrm, o.d[2] = dz / nrm;
+  return o;
+}
+
+// X[row][dp]: the padded input rows of the forward kernel (feature maps at their quads, the embedding at emb0, zeros else)
+__global__ __launch_bounds__(256) void mm_gather_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const ViewPoolParams& vp = m.vp;
+  const int dq = m.dp >> 2;
+  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const int64_t total = (int64_t)vp.n_views * P * dq;
+  const int nh = m.n_harmonic;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % dq);
+    const int64_t row = i / dq;
+    const int vi = (int)(row / P);
+    const int64_t p = row - (int64_t)vi * P;
+    const VoxelProj pr = project_voxel(vp, vi, p);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool done = false;
+    for (int k = 0; k < vp.n_feats && !done; ++k) {
+      const ViewPoolParams::Feat& f = vp.feat[k];
+      if (q >= f.quad0 && q < f.quad0 + f.Cp / 4) {
+        const Tap t = tap_of(f, pr.ndcx, pr.ndcy);
+        float s[4];
+        sample4(f.data + ((int64_t)vi * f.H * f.W) * f.Cp + (q - f.quad0) * 4, t, s);
+        o = make_float4(s[0], s[1], s[2], s[3]);
+        done = true;
+      }
+    }
+    if (!done && q * 4 >= m.emb0) {
+      float e[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = q * 4 + c - m.emb0;  // [sin(2^f d_a) | cos(2^f d_a) | d], index a * n + f
+        float val = 0.f;
+        if (j < 3 * nh) {
+          val = sinf(pr.d[j / nh] * (float)(1 << (j % nh)));
+        } else if (j < 6 * nh) {
+          const int jj = j - 3 * nh;
+          val = cosf(pr.d[jj / nh] * (float)(1 << (jj % nh)));
+        } else if (j < 6 * nh + 3) {
+          val = pr.d[j - 6 * nh];
+        }
+        e[c] = val;
+      }
+      o = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    *reinterpret_cast<float4*>(b.X + row * m.dp + q * 4) = o;
+  }
+}
+
+// MEAN[p][dp] = sum_v X[v, p] / max(V, 1e-2)
+__global__ __launch_bounds__(256) void mm_mean_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const int dq = m.dp >> 2, V = m.vp.n_views;
+  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const float inv = 1.f / fmaxf((float)V, 1e-2f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * dq; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % dq);
+    const int64_t p = i / dq;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < V; ++v) {
+      const float4 t = *reinterpret_cast<const float4*>(b.X + ((int64_t)v * P + p) * m.dp + q * 4);
+      s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+    }
+    *reinterpret_cast<float4*>(b.MEAN + p * m.dp + q * 4) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+// PRE[row] += CM[p] + b';  H = LeakyReLU_0.2(PRE)
+__global__ __launch_bounds__(256) void mm_hidden_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const int64_t total = (int64_t)m.vp.n_views * P * 32;  // 128 / 4 quads per row
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 31);
+    const int64_t row = i >> 5, p = row % P;
+    float4 v = *reinterpret_cast<const float4*>(b.PRE + row * 128 + q * 4);
+    const float4 c = *reinterpret_cast<const float4*>(b.CM + p * 128 + q * 4);
+    const float4 cb = *reinterpret_cast<const float4*>(m.cb + q * 4);
+    v.x += c.x + cb.x, v.y += c.y + cb.y, v.z += c.z + cb.z, v.w += c.w + cb.w;
+    *reinterpret_cast<float4*>(b.PRE + row * 128 + q * 4) = v;
+    *reinterpret_cast<float4*>(b.H + row * 128 + q * 4) =
+        make_float4(v.x > 0.f ? v.x : 0.2f * v.x, v.y > 0.f ? v.y : 0.2f * v.y, v.z > 0.f ? v.z : 0.2f * v.z, v.w > 0.f ? v.w : 0.2f * v.w);
+  }
+}
+
+// one wave per voxel: logits, softmax over the views, out, dz, du_v (columns 0..F-1 of DUL), dlogit_v (column F)
+__global__ __launch_bounds__(256) void mm_head_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const ViewPoolParams& vp = m.vp;
+  const int lane = threadIdx.x & 63, F = vp.F, V = vp.n_views, FW = b.FW;
+  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const float l_lo = m.l[lane], l_hi = m.l[lane + 64];
+  for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (int64_t)gridDim.x * 4) {
+    float logit[ViewPoolParams::MAX_VIEWS], a[ViewPoolParams::MAX_VIEWS], u[ViewPoolParams::MAX_VIEWS];
+    float mx = -3.0e38f;
+    for (int v = 0; v < V; ++v) {
+      const float* h = b.H + ((int64_t)v * P + p) * 128;
+      float part = h[lane] * l_lo + h[lane + 64] * l_hi;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+      logit[v] = part + m.l0;
+      mx = fmaxf(mx, logit[v]);
+      u[v] = lane < F ? b.U[((int64_t)v * P + p) * FW + lane] : 0.f;
+    }
+    float den = 0.f;
+    for (int v = 0; v < V; ++v) {
+      a[v] = expf(logit[v] - mx);
+      den += a[v];
+    }
+    float z = lane < F ? m.g0[lane] : 0.f;
+    for (int v = 0; v < V; ++v) {
+      a[v] /= den;
+      z = fmaf(a[v], u[v], z);
+    }
+    const float out = tanhf(z);
+    const float dz = lane < F ? b.gout[(int64_t)lane * P + p] * (1.f - out * out) : 0.f;
+    float s = 0.f, da[ViewPoolParams::MAX_VIEWS];
+    for (int v = 0; v < V; ++v) {
+      float part = dz * u[v];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+      da[v] = part;
+      s = fmaf(a[v], part, s);
+    }
+    for (int v = 0; v < V; ++v) {
+      const int64_t row = (int64_t)v * P + p;
+      const float val = lane < F ? a[v] * dz : (lane == F ? a[v] * (da[v] - s) : 0.f);
+      if (lane < FW) {
+        b.DUL[row * FW + lane] = val;
+        b.DULT[(int64_t)lane * b.NRp + row] = val;
+      }
+    }
+  }
+}
+
+// DPRE = (DH + dlogit l) lrelu'(PRE), in place of PRE and transposed into DPRET
+__global__ __launch_bounds__(256) void mm_dpre_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const int64_t total = (int64_t)m.vp.n_views * P * 128;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i & 127);
+    const int64_t row = i >> 7;
+    const float dh = b.H[i] + b.DUL[row * b.FW + m.vp.F] * m.l[k];
+    const float d = b.PRE[i] > 0.f ? dh : 0.2f * dh;
+    b.PRE[i] = d;
+    b.DPRET[(int64_t)k * b.NRp + row] = d;
+  }
+}
+
+// DC[p] = sum_v DPRE[v, p], and its transpose
+__global__ __launch_bounds__(256) void mm_dc_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const int V = m.vp.n_views;
+  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * 128; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i & 127);
+    const int64_t p = i >> 7;
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += b.PRE[((int64_t)v * P + p) * 128 + k];
+    b.DC[i] = s;
+    b.DCT[(int64_t)k * b.Pp + p] = s;
+  }
+}
+
+// d x_v = DX[row] + DCA[p] / max(V, 1e-2): the feature columns through the bilinear taps into the channels-last gradient maps
+__global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
+  const MlpMeanParams& m = b.fwd;
+  const ViewPoolParams& vp = m.vp;
+  const int fq = m.emb0 >> 2;  // feature quads come first in the padded order
+  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const int64_t total = (int64_t)vp.n_views * P * fq;
+  const float inv = 1.f / fmaxf((float)vp.n_views, 1e-2f);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % fq);
+    const int64_t row = i / fq;
+    const int vi = (int)(row / P);
+    const int64_t p = row - (int64_t)vi * P;
+    int k = 0;
+    while (k + 1 < vp.n_feats && q >= vp.feat[k + 1].quad0) ++k;
+    const ViewPoolParams::Feat& f = vp.feat[k];
+    float* gmap = b.gfeat[k];
+    if (!gmap) continue;
+    const float4 dx = *reinterpret_cast<const float4*>(b.DX + row * m.dp + q * 4);
+    const float4 dc = *reinterpret_cast<const float4*>(b.DCA + p * m.dp + q * 4);
+    const float g4[4] = {dx.x + dc.x * inv, dx.y + dc.y * inv, dx.z + dc.z * inv, dx.w + dc.w * inv};
+    const VoxelProj pr = project_voxel(vp, vi, p);
+    const Tap t = tap_of(f, pr.ndcx, pr.ndcy);
+    const int cq = q - f.quad0;
+    float* base = gmap + ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (cq * 4 + e < f.C && g4[e] != 0.f) {
+        if (t.w00 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o00, t.w00 * g4[e]);
+        if (t.w01 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o01, t.w01 * g4[e]);
+        if (t.w10 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o10, t.w10 * g4[e]);
+        if (t.w11 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o11, t.w11 * g4[e]);
+      }
+    }
+  }
+}
+
+// column sums of a (rows, cols <= 256) matrix: block b sums its row range -> partial[b][cols]
+__global__ __launch_bounds__(256) void mm_colsum_kernel(const float* __restrict__ src, int64_t rows, int cols, int ld,
+                                                        float* __restrict__ partial) {
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  if ((int)threadIdx.x < cols) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += src[r * ld + threadIdx.x];
+    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = s;
+  }
+}
+
+// out[i] = sum_s partial[s][i], s in order
+__global__ __launch_bounds__(256) void mm_sum_partials_kernel(const float* __restrict__ partial, int S, int64_t n,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += partial[(int64_t)k * n + i];
+  out[i] = s;
+}
+
 }  // namespace
 
 int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
@@ -277,6 +541,47 @@ int nhwc_pad_to_nchw_launch(const float* in, float* out, int n, int C, int Cp, i
   int64_t blocks = (total + 255) / 256;
   if (blocks > 65535) blocks = 65535;
   HOLO_LAUNCH(nhwc_pad_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), stream, in, out, C, Cp, HW, total);
+  return 0;
+}
+
+static unsigned mm_blocks(int64_t total) {
+  int64_t bl = (total + 255) / 256;
+  return (unsigned)(bl < 1 ? 1 : (bl > 65535 ? 65535 : bl));
+}
+int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream) {
+  const int64_t P = (int64_t)b.fwd.vp.R * b.fwd.vp.R * b.fwd.vp.R, NR = P * b.fwd.vp.n_views;
+  switch (step) {
+    case 0:
+      HOLO_LAUNCH(mm_gather_kernel, dim3(mm_blocks(NR * (b.fwd.dp / 4))), dim3(256), stream, b);
+      HOLO_LAUNCH(mm_mean_kernel, dim3(mm_blocks(P * (b.fwd.dp / 4))), dim3(256), stream, b);
+      return 0;
+    case 1:
+      HOLO_LAUNCH(mm_hidden_kernel, dim3(mm_blocks(NR * 32)), dim3(256), stream, b);
+      return 0;
+    case 2:
+      HOLO_LAUNCH(mm_head_kernel, dim3(mm_blocks(P * 64)), dim3(256), stream, b);
+      return 0;
+    case 3:
+      HOLO_LAUNCH(mm_dpre_kernel, dim3(mm_blocks(NR * 128)), dim3(256), stream, b);
+      HOLO_LAUNCH(mm_dc_kernel, dim3(mm_blocks(P * 128)), dim3(256), stream, b);
+      return 0;
+    case 4:
+      HOLO_LAUNCH(mm_scatter_kernel, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);
+      return 0;
+  }
+  return -1;
+}
+int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream) {
+  if (cols > 256) {
+    set_error("mm_colsum: at most 256 columns");
+    return -1;
+  }
+  HOLO_LAUNCH(mm_colsum_kernel, dim3((unsigned)n_blocks), dim3(256), stream, src, rows, cols, ld, partial);
+  HOLO_LAUNCH(mm_sum_partials_kernel, dim3(1), dim3(256), stream, (const float*)partial, n_blocks, (int64_t)cols, out);
+  return 0;
+}
+int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream) {
+  HOLO_LAUNCH(mm_sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream, partial, S, n, out);
   return 0;
 }
 

@@ -210,7 +210,11 @@ struct HoloMlpMeanPooler {
   size_t stage_floats = 0;
   float l0 = 0.f;
   bool committed = false;
+  std::map<std::string, std::vector<float>> grads;  // holo_mlp_mean_backward: by reference parameter name
 };
+
+static int mlp_mean_fill(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras, int n_views,
+                         void* stream, MlpMeanParams& p, char*& ws);
 
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
@@ -416,8 +420,19 @@ int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n
     return HOLO_E_WORKSPACE;
   }
   MlpMeanParams p;
-  memset(&p, 0, sizeof p);
   char* ws = (char*)workspace;
+  const int rc = mlp_mean_fill(h, feats, n_feats, cameras, n_views, stream, p, ws);
+  if (rc) return rc;
+  p.vp.out = voxel_features;
+  return mlp_mean_pool_launch(p, h->ctx->num_cus, stream) ? HOLO_E_INVALID : 0;
+}
+
+}  // extern "C"
+
+// the forward's launch parameters: channels-last copies of the maps at ws (advanced), cameras, folded weights
+static int mlp_mean_fill(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras, int n_views,
+                         void* stream, MlpMeanParams& p, char*& ws) {
+  memset(&p, 0, sizeof p);
   for (int k = 0; k < n_feats; ++k) {
     const HoloViewFeature& f = feats[k];
     if (!f.feats || f.channels != h->cfg.channels[k] || f.height < 1 || f.width < 1) {
@@ -452,7 +467,6 @@ int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n
   p.vp.half_extent = 0.5f * (float)(h->cfg.resol - 1) * (h->cfg.volume_extent / (float)h->cfg.resol);
   p.vp.proj_eps = h->cfg.projection_eps;
   p.vp.F = h->cfg.feature_size;
-  p.vp.out = voxel_features;
   const int nh = h->cfg.n_hidden, F = h->cfg.feature_size;
   p.a = h->dev;
   p.am = p.a + (size_t)nh * h->dp;
@@ -464,7 +478,259 @@ int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n
   p.dp = h->dp;
   p.emb0 = h->emb0;
   p.n_harmonic = h->cfg.n_harmonic_functions_ray;
-  return mlp_mean_pool_launch(p, h->ctx->num_cus, stream) ? HOLO_E_INVALID : 0;
+  return 0;
+}
+
+// ---- backward (kernels_viewpool_bwd.hip: the MLPMean section).  Workspace layout, shared by the size query and the run.
+struct MmBwdLayout {
+  int64_t P, NR, NRp, Pp;
+  int S, S2, FW, dp;
+  size_t maps, gmaps, X, MEAN, CM, PRE, H, U, DUL, DULT, DPRET, DC, DCT, DX, DCA, part, fold, total;
+};
+static MmBwdLayout mm_bwd_layout(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views) {
+  MmBwdLayout L;
+  memset(&L, 0, sizeof L);
+  const int R = h->cfg.resol, F = h->cfg.feature_size;
+  L.P = (int64_t)R * R * R;
+  L.NR = L.P * n_views;
+  L.dp = h->dp;
+  L.FW = (F + 1 + 3) / 4 * 4;
+  auto splits = [](int64_t rows, int64_t& padded) {
+    int64_t S = rows / 1024;
+    S = S < 1 ? 1 : (S > 128 ? 128 : S);
+    const int64_t kc = ((rows + S - 1) / S + 31) / 32 * 32;
+    padded = S * kc;
+    return (int)S;
+  };
+  L.S = splits(L.NR, L.NRp);
+  L.S2 = splits(L.P, L.Pp);
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    const size_t o = off;
+    off += align256(floats * sizeof(float));
+    return o;
+  };
+  size_t mapf = 0;
+  for (int k = 0; k < n_feats; ++k)
+    mapf += align256((size_t)n_views * feats[k].height * feats[k].width * ((feats[k].channels + 3) / 4 * 4) * sizeof(float)) / sizeof(float);
+  L.maps = take(mapf);
+  L.gmaps = take(mapf);
+  L.X = take((size_t)L.NRp * L.dp);
+  L.MEAN = take((size_t)L.Pp * L.dp);
+  L.CM = take((size_t)L.P * 128);
+  L.PRE = take((size_t)L.NR * 128);
+  L.H = take((size_t)L.NRp * 128);
+  L.U = take((size_t)L.NR * L.FW);
+  L.DUL = take((size_t)L.NR * L.FW);
+  L.DULT = take((size_t)L.FW * L.NRp);
+  L.DPRET = take((size_t)128 * L.NRp);
+  L.DC = take((size_t)L.P * 128);
+  L.DCT = take((size_t)128 * L.Pp);
+  L.DX = take((size_t)L.NR * L.dp);
+  L.DCA = take((size_t)L.P * L.dp);
+  const size_t pa = (size_t)L.S * 128 * L.dp, pam = (size_t)L.S2 * 128 * L.dp, pg = (size_t)L.S * L.FW * 128;
+  const size_t pcol = (size_t)256 * 256;
+  L.part = take(pa > pam ? (pa > pg ? (pa > pcol ? pa : pcol) : (pg > pcol ? pg : pcol)) : (pam > pg ? (pam > pcol ? pam : pcol) : (pg > pcol ? pg : pcol)));
+  L.fold = take((size_t)2 * 128 * L.dp + 128 + (size_t)L.FW * 128 + L.FW);  // dA | dAm | dcb | dGext | dg0 dl0
+  L.total = off + 256;
+  return L;
+}
+
+static int mm_gemm(const float* A, int lda, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N, int K, int nb,
+                   int64_t sa, int64_t sb, int64_t sc, void* stream) {
+  GemmParams g;
+  memset(&g, 0, sizeof g);
+  g.A = A, g.B = B, g.C = C;
+  g.M = M, g.Nn = N, g.K = K;
+  g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+  g.nb0 = nb, g.nb1 = 1;
+  g.sa0 = sa, g.sb0 = sb, g.sc0 = sc;
+  g.b_kmajor = b_kmajor;
+  g.alpha = 1.f;
+  return gemm_launch(g, stream);
+}
+
+extern "C" {
+
+size_t holo_mlp_mean_backward_workspace_bytes(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views) {
+  if (!h || !feats || n_feats < 1 || n_views < 1) return 0;
+  return mm_bwd_layout(h, feats, n_feats, n_views).total;
+}
+
+int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras, int n_views,
+                           const float* grad_voxel_features, float* const* grad_feats, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (!h || !feats || !cameras || !grad_voxel_features || !workspace) {
+    set_error("holo_mlp_mean_backward: null argument");
+    return HOLO_E_INVALID;
+  }
+  if (!h->committed) {
+    set_error("holo_mlp_mean_backward: call holo_mlp_mean_commit after setting the parameters");
+    return HOLO_E_STATE;
+  }
+  if (n_feats != h->cfg.n_feats || n_views < 1 || n_views > ViewPoolParams::MAX_VIEWS || (h->cfg.feature_size & 3)) {
+    set_error("holo_mlp_mean_backward: %d feature maps (created for %d), 1..%d source views, feature_size a multiple of 4", n_feats,
+              h->cfg.n_feats, ViewPoolParams::MAX_VIEWS);
+    return HOLO_E_INVALID;
+  }
+  const MmBwdLayout L = mm_bwd_layout(h, feats, n_feats, n_views);
+  if (workspace_bytes < L.total) {
+    set_error("holo_mlp_mean_backward: workspace too small");
+    return HOLO_E_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  // zero everything behind the forward's maps: the gradient maps, the padding rows of the split-K operands
+  HIP_TRY(hipMemsetAsync(base + L.gmaps, 0, L.total - 256 - L.gmaps, st));
+  MlpMeanBwdParams b;
+  memset(&b, 0, sizeof b);
+  char* ws = base + L.maps;
+  int rc = mlp_mean_fill(h, feats, n_feats, cameras, n_views, stream, b.fwd, ws);
+  if (rc) return rc;
+  const int F = h->cfg.feature_size, dp = L.dp, FW = L.FW;
+  b.gout = grad_voxel_features;
+  b.FW = FW;
+  b.NRp = L.NRp;
+  b.Pp = L.Pp;
+  auto fp = [&](size_t off) { return (float*)(base + off); };
+  b.X = fp(L.X), b.MEAN = fp(L.MEAN), b.CM = fp(L.CM), b.PRE = fp(L.PRE), b.H = fp(L.H), b.U = fp(L.U), b.DUL = fp(L.DUL);
+  b.DULT = fp(L.DULT), b.DPRET = fp(L.DPRET), b.DC = fp(L.DC), b.DCT = fp(L.DCT), b.DX = fp(L.DX), b.DCA = fp(L.DCA);
+  {
+    char* g = base + L.gmaps;
+    for (int k = 0; k < n_feats; ++k) {
+      const ViewPoolParams::Feat& f = b.fwd.vp.feat[k];
+      if (grad_feats && grad_feats[k]) b.gfeat[k] = (float*)g;
+      g += align256((size_t)n_views * f.H * f.W * f.Cp * sizeof(float));
+    }
+  }
+  float* part = fp(L.part);
+  float* fold = fp(L.fold);
+  float *dA = fold, *dAm = dA + (size_t)128 * dp, *dcb = dAm + (size_t)128 * dp, *dG = dcb + 128, *dgl = dG + (size_t)FW * 128;
+  const int NR = (int)L.NR, P = (int)L.P;
+  const int Kc = (int)(L.NRp / L.S), Kc2 = (int)(L.Pp / L.S2);
+#define MM_TRY(x)                      \
+  do {                                 \
+    if (x) return HOLO_E_INVALID;      \
+  } while (0)
+  // forward recomputation
+  MM_TRY(mm_bwd_step_launch(b, 0, stream));                                                                    // X, MEAN
+  MM_TRY(mm_gemm(b.MEAN, dp, b.fwd.am, dp, 0, b.CM, 128, P, 128, dp, 1, 0, 0, 0, stream));                     // CM = MEAN Am^T
+  MM_TRY(mm_gemm(b.X, dp, b.fwd.a, dp, 0, b.PRE, 128, NR, 128, dp, 1, 0, 0, 0, stream));                       // PRE = X A^T
+  MM_TRY(mm_bwd_step_launch(b, 1, stream));                                                                    // + CM + b', H
+  MM_TRY(mm_gemm(b.H, 128, b.fwd.g, 128, 0, b.U, FW, NR, F, 128, 1, 0, 0, 0, stream));                         // U = H G^T
+  MM_TRY(mm_bwd_step_launch(b, 2, stream));                                                                    // DUL, DULT
+  // dG (rows 0..F-1) and dl (row F) = DULT H, split over the rows
+  MM_TRY(mm_gemm(b.DULT, (int)L.NRp, b.H, 128, 1, part, 128, FW, 128, Kc, L.S, Kc, (int64_t)Kc * 128, (int64_t)FW * 128, stream));
+  MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)FW * 128, dG, stream));
+  MM_TRY(mm_colsum_launch(b.DUL, L.NR, FW, FW, part, 256, dgl, stream));                                       // dg0 | dl0
+  MM_TRY(mm_gemm(b.DUL, FW, b.fwd.g, 128, 1, b.H, 128, NR, 128, F, 1, 0, 0, 0, stream));                       // DH = DU G  (into H)
+  MM_TRY(mm_bwd_step_launch(b, 3, stream));                                                                    // DPRE (in PRE), DPRET, DC, DCT
+  MM_TRY(mm_gemm(b.DPRET, (int)L.NRp, b.X, dp, 1, part, dp, 128, dp, Kc, L.S, Kc, (int64_t)Kc * dp, (int64_t)128 * dp, stream));
+  MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)128 * dp, dA, stream));
+  MM_TRY(mm_gemm(b.DCT, (int)L.Pp, b.MEAN, dp, 1, part, dp, 128, dp, Kc2, L.S2, Kc2, (int64_t)Kc2 * dp, (int64_t)128 * dp, stream));
+  MM_TRY(mm_sum_partials_launch(part, L.S2, (int64_t)128 * dp, dAm, stream));
+  MM_TRY(mm_colsum_launch(b.DC, L.P, 128, 128, part, 256, dcb, stream));
+  bool want = false;
+  for (int k = 0; k < n_feats; ++k) want |= b.gfeat[k] != nullptr;
+  if (want) {
+    MM_TRY(mm_gemm(b.PRE, 128, b.fwd.a, dp, 1, b.DX, dp, NR, dp, 128, 1, 0, 0, 0, stream));                    // DX = DPRE A
+    MM_TRY(mm_gemm(b.DC, 128, b.fwd.am, dp, 1, b.DCA, dp, P, dp, 128, 1, 0, 0, 0, stream));                    // DCA = DC Am
+    MM_TRY(mm_bwd_step_launch(b, 4, stream));
+    for (int k = 0; k < n_feats; ++k)
+      if (b.gfeat[k]) {
+        const ViewPoolParams::Feat& f = b.fwd.vp.feat[k];
+        MM_TRY(nhwc_pad_to_nchw_launch(b.gfeat[k], grad_feats[k], n_views, f.C, f.Cp, (int64_t)f.H * f.W, stream));
+      }
+  }
+#undef MM_TRY
+  // ---- the folded gradients come to the host and are un-folded in float64 (the chain rule of holo_mlp_mean_commit's fold)
+  const size_t nfold = (size_t)2 * 128 * dp + 128 + (size_t)FW * 128 + FW;
+  std::vector<float> hf(nfold);
+  HIP_TRY(hipMemcpyAsync(hf.data(), fold, nfold * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int nh = 128, D = h->D, dout = h->cfg.dim_out;
+  const float *hA = hf.data(), *hAm = hA + (size_t)128 * dp, *hcb = hAm + (size_t)128 * dp, *hG = hcb + 128, *hgl = hG + (size_t)FW * 128;
+  auto W = [&](const char* n) -> const std::vector<float>& { return h->host[n]; };
+  const auto &Ws = W("_first_sampled.weight"), &bs = W("_first_sampled.bias"), &Wm = W("_first_mean.weight"),
+             &bm = W("_first_mean.bias"), &W1 = W("_mlp.mlp.0.0.weight"), &Wl = W("_last.weight"), &bl = W("_last.bias"),
+             &M = W("pooled_feature_mapper.weight");
+  std::vector<int> col(D);
+  {
+    int c = 0;
+    for (int k = 0; k < h->cfg.n_feats; ++k)
+      for (int j = 0; j < h->cfg.channels[k]; ++j) col[c++] = h->quad0[k] * 4 + j;
+    for (int j = 0; j < h->E; ++j) col[c++] = h->emb0 + j;
+  }
+  std::vector<double> gW1((size_t)nh * nh, 0.0), gWs((size_t)nh * D, 0.0), gWm((size_t)nh * D, 0.0), gbsm(nh, 0.0), gb1(nh, 0.0);
+  for (int i = 0; i < nh; ++i) {  // A = W1 Ws, Am = W1 Wm, b' = W1 (bs + bm) + b1
+    gb1[i] = hcb[i];
+    for (int k = 0; k < nh; ++k) {
+      double acc = (double)hcb[i] * ((double)bs[k] + (double)bm[k]);
+      const double w = W1[(size_t)i * nh + k];
+      for (int j = 0; j < D; ++j) {
+        const double da = hA[(size_t)i * dp + col[j]], dam = hAm[(size_t)i * dp + col[j]];
+        acc += da * Ws[(size_t)k * D + j] + dam * Wm[(size_t)k * D + j];
+        gWs[(size_t)k * D + j] += w * da;
+        gWm[(size_t)k * D + j] += w * dam;
+      }
+      gW1[(size_t)i * nh + k] = acc;
+      gbsm[k] += w * hcb[i];
+    }
+  }
+  std::vector<double> gM((size_t)F * dout, 0.0), gWl((size_t)dout * nh, 0.0), gbl(dout, 0.0), gmb(F, 0.0);
+  for (int f = 0; f < F; ++f) {  // G = M Wl, g0 = M bl + mapper bias
+    gmb[f] = hgl[f];
+    for (int o = 0; o < dout; ++o) {
+      double acc = (double)hgl[f] * bl[o];
+      const double w = M[(size_t)f * dout + o];
+      for (int k = 0; k < nh; ++k) {
+        const double dg = hG[(size_t)f * 128 + k];
+        acc += dg * Wl[(size_t)o * nh + k];
+        gWl[(size_t)o * nh + k] += w * dg;
+      }
+      gM[(size_t)f * dout + o] = acc;
+      gbl[o] += w * hgl[f];
+    }
+  }
+  for (int k = 0; k < nh; ++k) gWl[k] += hG[(size_t)F * 128 + k];  // l = Wl[0]
+  gbl[0] += hgl[F];                                                  // l0 = bl[0]
+  auto put = [&](const char* name, const std::vector<double>& v) {
+    std::vector<float>& o = h->grads[name];
+    o.resize(v.size());
+    for (size_t i = 0; i < v.size(); ++i) o[i] = (float)v[i];
+  };
+  put("_first_sampled.weight", gWs);
+  put("_first_sampled.bias", gbsm);
+  put("_first_mean.weight", gWm);
+  put("_first_mean.bias", gbsm);
+  put("_mlp.mlp.0.0.weight", gW1);
+  put("_mlp.mlp.0.0.bias", gb1);
+  put("_last.weight", gWl);
+  put("_last.bias", gbl);
+  put("pooled_feature_mapper.weight", gM);
+  put("pooled_feature_mapper.bias", gmb);
+  return 0;
+}
+
+int holo_mlp_mean_get_grad(HoloMlpMeanPooler* h, const char* name, float* out_dev, int64_t numel, void* stream) {
+  if (!h || !name || !out_dev) {
+    set_error("holo_mlp_mean_get_grad: null argument");
+    return HOLO_E_INVALID;
+  }
+  auto it = h->grads.find(name);
+  if (it == h->grads.end()) {
+    set_error("holo_mlp_mean_get_grad: no gradient for '%s' (run holo_mlp_mean_backward first)", name);
+    return HOLO_E_STATE;
+  }
+  if ((int64_t)it->second.size() != numel) {
+    set_error("holo_mlp_mean_get_grad: '%s' has %lld elements, not %lld", name, (long long)it->second.size(), (long long)numel);
+    return HOLO_E_INVALID;
+  }
+  if (upload_via_stage(&h->stage, &h->stage_floats, out_dev, it->second.data(), it->second.size(), stream)) {
+    set_error("holo_mlp_mean_get_grad: upload failed");
+    return HOLO_E_HIP;
+  }
+  return 0;
 }
 
 }  // extern "C"

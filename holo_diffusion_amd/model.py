@@ -417,8 +417,9 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         """The encoder side of ``loss.backward()`` (holo_diffusion_model.py:340-373 under autograd): the gradient of the
         pooled grid - ``training_backward(...)["voxel_features"]`` when the grid came from ``pool_views_to_voxel_features`` -
         through tanh, ``pooled_feature_mapper`` and the view pooling.  Returns ``{"image_features": {key: grad},
-        "pooled_feature_mapper": {"weight": grad, "bias": grad}}``; the feature-map gradients are what autograd hands the
-        image feature extractor (which is outside this path)."""
+        "pooled_feature_mapper": {"weight": grad, "bias": grad}}`` (+ ``"feature_aggregator": {name: grad}`` for the learnt
+        MLPMeanFeatureAggregator); the feature-map gradients are what autograd hands the image feature extractor (which is
+        outside this path)."""
         assert self.view_pooler_enabled and self.view_pooler is not None, "view_pooler must be enabled"
         pm = self.pooled_feature_mapper
         if isinstance(pm.weight, torch.nn.parameter.UninitializedParameter):
@@ -426,7 +427,11 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         gf, gw, gb = self.view_pooler.pool_to_voxel_features_backward(
             image_features, source_cameras, pm.weight, pm.bias, self.resol, self.volume_extent, grad_voxel_features,
             want_feature_grads=want_feature_grads)
-        return {"image_features": gf, "pooled_feature_mapper": {"weight": gw, "bias": gb}}
+        out = {"image_features": gf, "pooled_feature_mapper": {"weight": gw, "bias": gb}}
+        agg_grads = getattr(self.view_pooler.feature_aggregator, "native_grads", None)
+        if agg_grads is not None:  # MLPMeanFeatureAggregator: its own parameters, by reference name
+            out["feature_aggregator"] = dict(agg_grads)
+        return out
 
     def render_views(self, voxel_features: torch.Tensor, cameras: PerspectiveCameras) -> Dict[str, torch.Tensor]:
         """Batched turntable render: all cameras of a fly-around in ONE holo_render call (BASELINE config 4).

@@ -218,7 +218,8 @@ class ViewPooler(Configurable, torch.nn.Module):
         ``pooled_feature_mapper``.  AngleWeightedReductionFeatureAggregator (the released configuration) only."""
         agg = self.feature_aggregator
         if isinstance(agg, MLPMeanFeatureAggregator):
-            raise NotImplementedError("view pooling backward: MLPMeanFeatureAggregator has no backward on this path yet")
+            return self._pool_mlp_mean_backward(feats, camera, mapper_weight, mapper_bias, resol, volume_extent,
+                                                grad_voxel_features, want_feature_grads)
         if agg.exclude_target_view or agg.exclude_target_view_mask_features:
             raise _lib.HoloError("view pooling: exclude_target_view(_mask_features) must be False "
                                  "(HoloDiffusionModel sets both, holo_diffusion_model.py:114-116)")
@@ -269,9 +270,9 @@ class ViewPooler(Configurable, torch.nn.Module):
                                                 runtime.stream_ptr(dev)), "holo_view_pool_backward")
         return grads, gw, (gb if mapper_bias is not None else None)
 
-    @torch.no_grad()
-    def _pool_mlp_mean(self, feats: Dict[str, torch.Tensor], camera, mapper_weight, mapper_bias, resol: int,
-                       volume_extent: float) -> torch.Tensor:
+    def _mlp_mean_native(self, feats: Dict[str, torch.Tensor], camera, mapper_weight, mapper_bias, resol: int,
+                         volume_extent: float):
+        """The native pooler of the MLPMean aggregator with the current parameters committed, and the call's arrays."""
         from .render import _camera_array
         agg: MLPMeanFeatureAggregator = self.feature_aggregator
         keys = list(feats)
@@ -323,6 +324,47 @@ class ViewPooler(Configurable, torch.nn.Module):
                            f"holo_mlp_mean_set_param({k})")
             _lib.check(L, L.holo_mlp_mean_commit(h, st), "holo_mlp_mean_commit")
             agg._native[2] = versions
+        return h, arr, held, cams, n_src, dev, F, keys, params
+
+    @torch.no_grad()
+    def _pool_mlp_mean_backward(self, feats, camera, mapper_weight, mapper_bias, resol, volume_extent, grad_voxel_features,
+                                want_feature_grads):
+        """``holo_mlp_mean_backward``: as ``pool_to_voxel_features_backward``; the aggregator's own parameter gradients are
+        left in ``self.feature_aggregator.native_grads`` (reference names ``_first_sampled.weight`` ...)."""
+        h, arr, held, cams, n_src, dev, F, keys, params = self._mlp_mean_native(feats, camera, mapper_weight, mapper_bias, resol,
+                                                                              volume_extent)
+        g = grad_voxel_features.detach().contiguous().float()
+        if tuple(g.shape) != (1, F, resol, resol, resol) or g.device != dev:
+            raise _lib.HoloError(f"grad_voxel_features must be (1, {F}, {resol}, {resol}, {resol}) on {dev}, got {tuple(g.shape)}")
+        grads = {}
+        gptr = (C.c_void_p * len(keys))()
+        for i, k in enumerate(keys):
+            if want_feature_grads:
+                grads[k] = torch.empty_like(held[i])
+                gptr[i] = grads[k].data_ptr()
+            else:
+                gptr[i] = None
+        L = runtime.lib()
+        ws = runtime.workspace(self, dev, L.holo_mlp_mean_backward_workspace_bytes(h, arr, len(keys), n_src))
+        st = runtime.stream_ptr(dev)
+        _lib.check(L, L.holo_mlp_mean_backward(h, arr, len(keys), cams, n_src, runtime.ptr(g), gptr, runtime.ptr(ws), ws.numel(),
+                                               st), "holo_mlp_mean_backward")
+        pg = {}
+        for k, p in params.items():
+            t = torch.empty(p.shape, device=dev, dtype=torch.float32)
+            _lib.check(L, L.holo_mlp_mean_get_grad(h, k.encode(), runtime.ptr(t), t.numel(), st), f"holo_mlp_mean_get_grad({k})")
+            pg[k] = t
+        gw = pg.pop("pooled_feature_mapper.weight")
+        gb = pg.pop("pooled_feature_mapper.bias")
+        self.feature_aggregator.__dict__["native_grads"] = pg
+        return grads, gw, (gb if mapper_bias is not None else None)
+
+    @torch.no_grad()
+    def _pool_mlp_mean(self, feats: Dict[str, torch.Tensor], camera, mapper_weight, mapper_bias, resol: int,
+                       volume_extent: float) -> torch.Tensor:
+        h, arr, held, cams, n_src, dev, F, keys, _ = self._mlp_mean_native(feats, camera, mapper_weight, mapper_bias, resol,
+                                                                         volume_extent)
+        L = runtime.lib()
         ws = runtime.workspace(self, dev, L.holo_mlp_mean_workspace_bytes(h, arr, len(keys), n_src))
         out = torch.empty(1, F, resol, resol, resol, device=dev)
         _lib.check(L, L.holo_mlp_mean_pool(h, arr, len(keys), cams, n_src, runtime.ptr(out), runtime.ptr(ws), ws.numel(),

@@ -372,6 +372,17 @@ size_t holo_mlp_mean_workspace_bytes(const HoloMlpMeanPooler* h, const HoloViewF
 int holo_mlp_mean_pool(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras,
                        int n_views, float* voxel_features, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of holo_mlp_mean_pool for a gradient on its output (ABI 4): the gradients autograd leaves on the aggregator's
+ * parameters (custom_modules.py:179-196), on pooled_feature_mapper and on the source-view feature maps.  Nothing of the
+ * forward is kept: the per-(voxel, view) rows are recomputed into the workspace (about 3 GB at 64^3 with four views).
+ *   grad_voxel_features : (1, feature_size, R, R, R);   grad_feats[k] : (n_views, channels_k, height_k, width_k) or NULL
+ * The parameter gradients are fetched by reference name with holo_mlp_mean_get_grad (the names of holo_mlp_mean_set_param). */
+size_t holo_mlp_mean_backward_workspace_bytes(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views);
+int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, const HoloCamera* cameras, int n_views,
+                           const float* grad_voxel_features, float* const* grad_feats, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int holo_mlp_mean_get_grad(HoloMlpMeanPooler* h, const char* name, float* out_dev, int64_t numel, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement helpers (bench.py): time `iters` back-to-back launches of the dominant kernels with
  * hipEvents recorded on `stream` (torch.cuda.Event only sees torch's current stream).

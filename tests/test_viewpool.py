@@ -251,6 +251,55 @@ def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_har
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,n_src,radius,F,dim_out,n_harm", [(8, 3, 10.0, 16, 24, 3), (16, 5, 6.0, 32, 128, 3), (8, 9, 3.0, 16, 128, 2)])
+def test_mlp_mean_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius, F, dim_out, n_harm):
+    """holo_mlp_mean_backward against torch autograd through the oracle (whose aggregator is bit-equal to the reference
+    class): gradients of every aggregator parameter, of pooled_feature_mapper and of the three source-view feature maps for a
+    random cotangent on the grid; the geometries of the forward test.  LeakyReLU kink: a hidden pre-activation within float32
+    rounding of zero takes the other slope on one side - one unit of one (voxel, view) row, far below the tolerance."""
+    import tests.gpu_utils as gu
+    feats, _ = _synthetic_views(n_src, 150 + R)
+    D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
+    cams_d = _cams(n_src, radius=radius)
+    shapes = vo.mlp_mean_param_shapes(D, 128, dim_out)
+    sd = synth_state_dict(shapes, 21)
+    for k in shapes:
+        if k.endswith("bias"):
+            sd[k] = 0.1 * torch.from_numpy(np_noise(len(k), shapes[k]))
+    w = synth_state_dict({"w": (F, dim_out), "b": (F,)}, 9)
+    w["b"] = 0.1 * torch.from_numpy(np_noise(4, (F,)))
+    g = torch.from_numpy(np_noise(321, (1, F, R, R, R)))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    mw, mb = w["w"].clone().requires_grad_(True), w["b"].clone().requires_grad_(True)
+    vo.voxel_features_from_views_mlp_mean(leaves, cams_d, psd, mw, mb, R, 8.0, n_harmonic=n_harm).backward(g)
+    model = hda.HoloDiffusionModel(
+        resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False, diffusion_enabled=False,
+        render_image_width=8, render_image_height=8,
+        view_pooler_args=dict(feature_aggregator_class_type="MLPMeanFeatureAggregator",
+                              feature_aggregator_MLPMeanFeatureAggregator_args=dict(dim_out=dim_out, n_harmonic_functions_ray=n_harm)))
+    full = {"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}
+    full.update({"view_pooler.feature_aggregator." + k: v for k, v in sd.items()})
+    model.load_state_dict(full, strict=False)
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    dev_feats = {k: v.to(gu.DEV) for k, v in feats.items()}
+    model.pool_views_to_voxel_features(dev_feats, cams.to(gu.DEV))
+    got = model.pool_views_backward(dev_feats, cams.to(gu.DEV), g.to(gu.DEV))
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert rel(got["pooled_feature_mapper"]["weight"], mw.grad) < 1e-3, rel(got["pooled_feature_mapper"]["weight"], mw.grad)
+    assert rel(got["pooled_feature_mapper"]["bias"], mb.grad) < 1e-3
+    assert set(got["feature_aggregator"]) == set(shapes)
+    for k in shapes:
+        assert float(psd[k].grad.abs().max()) > 0
+        assert rel(got["feature_aggregator"][k], psd[k].grad) < 1e-3, (k, rel(got["feature_aggregator"][k], psd[k].grad))
+    for k in feats:
+        assert rel(got["image_features"][k], leaves[k].grad) < 1e-3, (k, rel(got["image_features"][k], leaves[k].grad))
+
+
+@pytest.mark.gpu
 def test_reconstruction_flyaround_from_a_dataset_sequence(tmp_path):
     """render_flyaround(dataset, sequence_name, model, sample_mode=False) - the reconstruction mode of
     visualize_reconstruction.py:60-162 / flyaround.py:153-171,219-253: source frames drawn with the reference's seeded
