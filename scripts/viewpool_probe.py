@@ -46,3 +46,43 @@ maps = sum(v.numel() for v in feats.values()) * 4
 print(f"view pooling: {n_src} views -> {R}^3 x {F}: {ms:.3f} ms per call (incl. the host wrapper); aggregated features {A}; "
       f"logical gather {logical / 1e9:.2f} GB -> {logical / ms / 1e6:.0f} GB/s; feature maps {maps / 1e6:.1f} MB (cache resident); "
       f"output {vox * F * 4 / 1e6:.1f} MB; finite {bool(torch.isfinite(out).all())}")
+
+# ---- backward of the same call (holo_view_pool_backward), and of the learnt aggregator's path (holo_mlp_mean_backward)
+gout = torch.randn(1, F, R, R, R, device=dev)
+for _ in range(2):
+    gr = model.pool_views_backward(dfeats, cams, gout)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    gr = model.pool_views_backward(dfeats, cams, gout)
+e1.record()
+torch.cuda.synchronize()
+print(f"view pooling backward (AngleWeightedReduction): {e0.elapsed_time(e1) / 5:.3f} ms per call; "
+      f"finite {all(bool(torch.isfinite(v).all()) for v in gr['image_features'].values())}")
+m2 = hda.HoloDiffusionModel(resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False, diffusion_enabled=False,
+                            render_image_width=8, render_image_height=8,
+                            view_pooler_args=dict(feature_aggregator_class_type="MLPMeanFeatureAggregator"))
+m2.load_state_dict({"pooled_feature_mapper.weight": 0.1 * torch.randn(F, 128, generator=g),
+                    "pooled_feature_mapper.bias": torch.zeros(F)}, strict=False)
+m2.to(dev)
+n2 = min(n_src, 4)
+f2 = {k: v[:n2] for k, v in dfeats.items()}
+c2 = cams[list(range(n2))]
+for _ in range(2):
+    out2 = m2.pool_views_to_voxel_features(f2, c2)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(5):
+    out2 = m2.pool_views_to_voxel_features(f2, c2)
+e1.record()
+torch.cuda.synchronize()
+fwd_ms = e0.elapsed_time(e1) / 5
+m2.pool_views_backward(f2, c2, gout)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(3):
+    gr2 = m2.pool_views_backward(f2, c2, gout)
+e1.record()
+torch.cuda.synchronize()
+print(f"MLPMean aggregator, {n2} views: forward {fwd_ms:.3f} ms, backward {e0.elapsed_time(e1) / 3:.3f} ms per call "
+      f"(row buffers + gemm_kernel; workspace {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB peak allocated)")
