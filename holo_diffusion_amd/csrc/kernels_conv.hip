@@ -2217,7 +2217,11 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   const int Cin = p.C0 + p.C1;
   const int ncc = (Cin + BK - 1) / BK;
   const int ntaps = p.ksz * p.ksz * p.ksz;
-  const int nchunks = ntaps * ncc;
+  // a ResBlock's 1x1x1 skip_connection rides along as extra K chunks BEHIND the (tap, chunk) list (the deepest levels, where
+  // it used to be a launch + a reduce of its own): raw block input at the output voxel, no GroupNorm / SiLU, its own weights
+  const int SCin = p.skip_w ? p.skip_C0 + p.skip_C1 : 0;
+  const int nmain = ntaps * ncc;
+  const int nchunks = nmain + (SCin + BK - 1) / BK;
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int64_t m0 = (int64_t)blockIdx.x * SM_ROWS;
   const int n0 = blockIdx.y * 64;
@@ -2255,6 +2259,26 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   auto load_a = [&](int i, int slot) {
     const int tap = g_tap[slot];
     const int cc = g_cc[slot];
+    if (tap < 0) {  // (uniform) chunk cc of the fused skip: the block input at the row's own voxel
+      int c = cc * BK + q * 4;
+      const bool cvalid = c < SCin;
+      if (!cvalid) c = 0;
+      const float* src = p.skip_src0;
+      int Cs = p.skip_C0, cs = c;
+      if (c >= p.skip_C0) {
+        src = p.skip_src1;
+        Cs = p.skip_C1;
+        cs = c - p.skip_C0;
+      }
+      amask[i] = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int z = az[j] + p.pad, y = ay[j] + p.pad, x = ax[j] + p.pad;  // (stride 1: conv_plan)
+        ra[i][j] = ld_act4(src, ((((int64_t)an[j] * p.OD + z) * p.OH + y) * p.OW + x) * Cs + cs, p.in_bf16);
+        amask[i] |= (av[j] && cvalid ? 1u : 0u) << j;
+      }
+      return;
+    }
     int kd = 0, kh = 0, kw = 0;
     if (p.ksz == 3) {
       kd = tap / 9;
@@ -2298,7 +2322,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float4 v = ra[i][j];
-      if (p.coef) {
+      if (p.coef && g_tap[slot] >= 0) {
         v.x = v.x * rc01[i][j].x + rc01[i][j].y;
         v.y = v.y * rc01[i][j].z + rc01[i][j].w;
         v.z = v.z * rc23[i][j].x + rc23[i][j].y;
@@ -2332,16 +2356,25 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
   constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, 16-Cout slice) block
   const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;  // 1 KB contiguous per wave instruction
+  const float* skw_lane = (BF ? reinterpret_cast<const float*>(p.skip_w_bf) : p.skip_w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;
 
   // (tap, chunk) of the SG chunks that start at chunk g0
   auto group_chunks = [&](int g0) {
-    int tap = p.ksz == 1 ? 0 : g0 / ncc, cc = g0 - tap * ncc;
+    int tap, cc;
+    if (g0 >= nmain) {
+      tap = -1, cc = g0 - nmain;
+    } else {
+      tap = p.ksz == 1 ? 0 : g0 / ncc, cc = g0 - tap * ncc;
+    }
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
       g_tap[i] = tap, g_cc[i] = cc;
       if (g0 + i + 1 < kc_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
         ++cc;
-        if (cc == ncc) cc = 0, ++tap;
+        if (tap >= 0 && cc == ncc) {
+          cc = 0;
+          tap = tap + 1 < ntaps ? tap + 1 : -1;  // behind the last tap: the skip's chunks
+        }
       }
     }
   };
@@ -2362,7 +2395,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       for (int i = 0; i < SG; ++i) {
         const int tap = g_tap[i];
         const int cc = g_cc[i];
-        const float* wp = w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
+        const float* wp = tap < 0 ? skw_lane + (int64_t)cc * wnsl * WBLK : w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
         bw[i][0] = *reinterpret_cast<const float4*>(wp);
         if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
       }
@@ -2423,7 +2456,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   // ---- epilogue: col = lane&15 (Cout), row = 4*(lane>>4) + r inside each 16-voxel tile
   const int co = n0 + wave * 16 + lj;
   const int coc = co < p.Cout ? co : p.Cout - 1;
-  const float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  float bv = (p.nsplit == 1 && p.bias) ? p.bias[coc] : 0.f;
+  if (p.nsplit == 1 && p.skip_w && p.skip_bias) bv += p.skip_bias[coc];
   float ssum = 0.f, ssq = 0.f;
   int64_t mo[4][4];  // clamped row offsets (masked at the store): residual loads are issued as ONE batch
   bool mv[4][4];
@@ -2621,11 +2655,13 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
     const int64_t tgt = 2 * (int64_t)num_cus;
     nsplit = t2 < tgt ? (int)cdiv(tgt, t2) : 1;
-    int max_split = nchunks / SG;  // a split below one full staging group only adds a reduce launch
+    // (a fused 1x1x1 skip: its chunks follow the (tap, chunk) list; stride 1 and no upsampling there: conv_launch)
+    const int nall = nchunks + (p.skip_w ? (int)cdiv(p.skip_C0 + p.skip_C1, BK) : 0);
+    int max_split = nall / SG;  // a split below one full staging group only adds a reduce launch
     if (max_split < 1) max_split = 1;
     if (nsplit > max_split) nsplit = max_split;
-    int cps = (int)cdiv(nchunks, nsplit);
-    nsplit = (int)cdiv(nchunks, cps);
+    int cps = (int)cdiv(nall, nsplit);
+    nsplit = (int)cdiv(nall, cps);
     p.nsplit = nsplit;
     p.chunks_per_split = cps;
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
@@ -2877,6 +2913,10 @@ int conv_launch(const ConvParams& p, void* stream) {
   } else if (p.mode == 2) {
     if (M >= ((int64_t)1 << 31)) {
       set_error("conv_launch: the row-tile kernel indexes output voxels in 32 bits (M = %lld)", (long long)M);
+      return -1;
+    }
+    if (p.skip_w && (p.stride != 1 || p.ups || p.ID != p.OD || (p.bf16 == 1 && p.w_bf && !p.skip_w_bf))) {
+      set_error("conv_launch: the row-tile kernel fuses a skip connection at stride 1 without upsampling only");
       return -1;
     }
     dim3 sgrid((unsigned)cdiv(M, SM_ROWS), (unsigned)cdiv(p.Cout, 64), (unsigned)p.nsplit);

@@ -579,7 +579,10 @@ struct Planner {
     const bool has_skip = b.cin != b.cout;
     // the 1x1x1 skip conv rides inside the second 3x3x3 conv (halo kernel) wherever that kernel applies
     // (the bf16x3 kernel has no fused-skip variant: its skip connection runs as a separate fp32 1x1x1 conv)
-    const bool fuse_skip = has_skip && (R % 8) == 0 && b.cout >= 64 && u->compute_mode != 2 && !getenv("HOLO_NO_SKIP_FUSION");
+    // (below 8^3 the convolution runs on the row-tile kernel, which takes the skip's channels as extra K chunks: exact-fp32
+    //  mode; four launches + four reduces less at the 4^3 level of the north-star net)
+    const bool fuse_skip = has_skip && ((R % 8) == 0 || (u->compute_mode == 0 && R < 8)) && b.cout >= 64 && u->compute_mode != 2 &&
+                           !getenv("HOLO_NO_SKIP_FUSION");
     if (has_skip && !fuse_skip) {
       s = new_act(b.cout, R);
       emit_conv(x0, x1, R, 0, R, 1, 1, P(u, p + ".skip_connection.weight"), P(u, p + ".skip_connection.bias"), 0,
