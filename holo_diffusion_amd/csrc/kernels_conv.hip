@@ -2259,41 +2259,27 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   auto load_a = [&](int i, int slot) {
     const int tap = g_tap[slot];
     const int cc = g_cc[slot];
-    if (tap < 0) {  // (uniform) chunk cc of the fused skip: the block input at the row's own voxel
-      int c = cc * BK + q * 4;
-      const bool cvalid = c < SCin;
-      if (!cvalid) c = 0;
-      const float* src = p.skip_src0;
-      int Cs = p.skip_C0, cs = c;
-      if (c >= p.skip_C0) {
-        src = p.skip_src1;
-        Cs = p.skip_C1;
-        cs = c - p.skip_C0;
-      }
-      amask[i] = 0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int z = az[j] + p.pad, y = ay[j] + p.pad, x = ax[j] + p.pad;  // (stride 1: conv_plan)
-        ra[i][j] = ld_act4(src, ((((int64_t)an[j] * p.OD + z) * p.OH + y) * p.OW + x) * Cs + cs, p.in_bf16);
-        amask[i] |= (av[j] && cvalid ? 1u : 0u) << j;
-      }
-      return;
-    }
+    // (uniform) tap < 0: chunk cc of the fused skip = the CENTRE tap on the block input (same resolution: conv_launch), its
+    // own channel count and sources, no GroupNorm / SiLU
+    const bool sk = tap < 0;
     int kd = 0, kh = 0, kw = 0;
-    if (p.ksz == 3) {
+    if (sk) {
+      kd = kh = kw = p.pad;
+    } else if (p.ksz == 3) {
       kd = tap / 9;
       kh = (tap - kd * 9) / 3;
       kw = tap - kd * 9 - kh * 3;
     }
     int c = cc * BK + q * 4;
-    const bool cvalid = c < Cin;
+    const bool cvalid = c < (sk ? SCin : Cin);
     if (!cvalid) c = 0;
-    const float* src = p.src0;
-    int Cs = p.C0, cs = c;
-    if (c >= p.C0) {
-      src = p.src1;
-      Cs = p.C1;
-      cs = c - p.C0;
+    const int C0s = sk ? p.skip_C0 : p.C0;
+    const float* src = sk ? p.skip_src0 : p.src0;
+    int Cs = C0s, cs = c;
+    if (c >= C0s) {
+      src = sk ? p.skip_src1 : p.src1;
+      Cs = sk ? p.skip_C1 : p.C1;
+      cs = c - C0s;
     }
     amask[i] = 0;
 #pragma unroll
@@ -2311,7 +2297,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       // unconditional load from a clamped address, masked afterwards (see the halo kernel)
       ra[i][j] = ld_act4(src, ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs, p.in_bf16);
       amask[i] |= (ok ? 1u : 0u) << j;
-      if (p.coef) {
+      if (p.coef && !sk) {
         const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
         rc01[i][j] = cf[0];
         rc23[i][j] = cf[1];
@@ -2356,7 +2342,8 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
   constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, 16-Cout slice) block
   const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;  // 1 KB contiguous per wave instruction
-  const float* skw_lane = (BF ? reinterpret_cast<const float*>(p.skip_w_bf) : p.skip_w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;
+  // (the skip's packed weights through the same per-lane pointer: a wave-uniform distance, no second address in registers)
+  const int64_t skw_delta = p.skip_w ? (BF ? reinterpret_cast<const float*>(p.skip_w_bf) - reinterpret_cast<const float*>(p.w_bf) : p.skip_w - p.w) : 0;
 
   // (tap, chunk) of the SG chunks that start at chunk g0
   auto group_chunks = [&](int g0) {
@@ -2378,13 +2365,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       }
     }
   };
-  group_chunks(kc_begin);
-#pragma unroll
-  for (int i = 0; i < SGH; ++i) load_a(i, i);  // the first group's first batch
   for (int g = kc_begin; g < kc_end; g += SG) {
     if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
-    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget).  The
-    //    FIRST batch of a group is already on its way: it was requested before the previous group's MFMAs (below).
+    group_chunks(g);
+    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget).
+    //    (Requesting the next group's first batch under this group's MFMAs was tried: 96 more live registers, spills as soon
+    //    as anything else is added, and no measurable gain - the second resident workgroup already fills the gap.)
     // 2. every weight of the group is requested at once, right BEHIND the requests of the last activation batch and before
     //    that batch is waited for: memory returns a wave's loads in order, so the activations are not held behind 28+ MB
     //    of weights, the wait for them overlaps the weights' round trip (a 1x1x1 convolution is then ONE round trip plus
@@ -2395,7 +2381,7 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       for (int i = 0; i < SG; ++i) {
         const int tap = g_tap[i];
         const int cc = g_cc[i];
-        const float* wp = tap < 0 ? skw_lane + (int64_t)cc * wnsl * WBLK : w_lane + (int64_t)(tap * wncc + cc) * wnsl * WBLK;
+        const float* wp = w_lane + (tap < 0 ? skw_delta + (int64_t)cc * wnsl * WBLK : (int64_t)(tap * wncc + cc) * wnsl * WBLK);
         bw[i][0] = *reinterpret_cast<const float4*>(wp);
         if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
       }
@@ -2403,19 +2389,12 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 #pragma unroll
     for (int h = 0; h < SG; h += SGH) {
       if (g + h < kc_end) {  // uniform
-        if (h > 0) {
 #pragma unroll
-          for (int i = 0; i < SGH; ++i) load_a(i, h + i);
-        }
+        for (int i = 0; i < SGH; ++i) load_a(i, h + i);
         if (h + SGH >= SG || g + h + SGH >= kc_end) load_w();  // (uniform) the group's last batch
 #pragma unroll
         for (int i = 0; i < SGH; ++i) store_a(i, h + i);
       }
-    }
-    if (g + SG < kc_end) {  // the next group's first batch: lands under this group's MFMAs
-      group_chunks(g + SG);
-#pragma unroll
-      for (int i = 0; i < SGH; ++i) load_a(i, i);
     }
     __syncthreads();
 #pragma unroll
@@ -2650,7 +2629,11 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1
                : 0;
-  if (p.mode == 0 && p.Cout >= 64) {  // 1x1x1, strided and deepest-level convs: row-tile kernel
+  static const int64_t small_max_m = [] {  // development knob: rows above which mode 0 keeps the per-tap gather kernel
+    const char* e = getenv("HOLO_CONV_SMALL_MAX_M");
+    return e ? (int64_t)atoll(e) : ((int64_t)1 << 40);
+  }();
+  if (p.mode == 0 && p.Cout >= 64 && (M <= small_max_m || p.ksz == 1)) {  // 1x1x1, strided and deepest-level convs: row-tile kernel
     p.mode = 2;
     const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
     const int64_t tgt = 2 * (int64_t)num_cus;
