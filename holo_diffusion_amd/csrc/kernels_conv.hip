@@ -2259,27 +2259,21 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   auto load_a = [&](int i, int slot) {
     const int tap = g_tap[slot];
     const int cc = g_cc[slot];
-    // (uniform) tap < 0: chunk cc of the fused skip = the CENTRE tap on the block input (same resolution: conv_launch), its
-    // own channel count and sources, no GroupNorm / SiLU
-    const bool sk = tap < 0;
     int kd = 0, kh = 0, kw = 0;
-    if (sk) {
-      kd = kh = kw = p.pad;
-    } else if (p.ksz == 3) {
+    if (p.ksz == 3) {
       kd = tap / 9;
       kh = (tap - kd * 9) / 3;
       kw = tap - kd * 9 - kh * 3;
     }
     int c = cc * BK + q * 4;
-    const bool cvalid = c < (sk ? SCin : Cin);
+    const bool cvalid = c < Cin;
     if (!cvalid) c = 0;
-    const int C0s = sk ? p.skip_C0 : p.C0;
-    const float* src = sk ? p.skip_src0 : p.src0;
-    int Cs = C0s, cs = c;
-    if (c >= C0s) {
-      src = sk ? p.skip_src1 : p.src1;
-      Cs = sk ? p.skip_C1 : p.C1;
-      cs = c - C0s;
+    const float* src = p.src0;
+    int Cs = p.C0, cs = c;
+    if (c >= p.C0) {
+      src = p.src1;
+      Cs = p.C1;
+      cs = c - p.C0;
     }
     amask[i] = 0;
 #pragma unroll
@@ -2297,18 +2291,18 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       // unconditional load from a clamped address, masked afterwards (see the halo kernel)
       ra[i][j] = ld_act4(src, ((((int64_t)an[j] * SD + z) * SH + y) * SW + x) * Cs + cs, p.in_bf16);
       amask[i] |= (ok ? 1u : 0u) << j;
-      if (p.coef && !sk) {
+      if (p.coef) {
         const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)an[j] * Cin + c) * 2);
         rc01[i][j] = cf[0];
         rc23[i][j] = cf[1];
       }
     }
   };
-  auto store_a = [&](int i, int slot) {
+  auto store_a = [&](int i, int slot, bool plain = false) {  // plain: a chunk of the fused skip (no GroupNorm / SiLU)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float4 v = ra[i][j];
-      if (p.coef && g_tap[slot] >= 0) {
+      if (p.coef && !plain) {
         v.x = v.x * rc01[i][j].x + rc01[i][j].y;
         v.y = v.y * rc01[i][j].z + rc01[i][j].w;
         v.z = v.z * rc23[i][j].x + rc23[i][j].y;
@@ -2342,64 +2336,27 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
   const int wncc = p.CinP / BK, wnsl = p.CoutP >> 4;
   constexpr int WBLK = BF ? 256 : 512;  // words per (tap, chunk, 16-Cout slice) block
   const float* w_lane = (BF ? reinterpret_cast<const float*>(p.w_bf) : p.w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;  // 1 KB contiguous per wave instruction
-  // (the skip's packed weights through the same per-lane pointer: a wave-uniform distance, no second address in registers)
-  const int64_t skw_delta = p.skip_w ? (BF ? reinterpret_cast<const float*>(p.skip_w_bf) - reinterpret_cast<const float*>(p.w_bf) : p.skip_w - p.w) : 0;
 
+  // The main (tap, chunk) list and the skip's chunks behind it are walked by two loops over the same staging tile: the main
+  // loop is exactly the kernel without a skip (a variant with both kinds in one load path lost 1.5 - 3 us on EVERY launch).
+  const int kc_main_end = kc_end < nmain ? kc_end : nmain;
   // (tap, chunk) of the SG chunks that start at chunk g0
   auto group_chunks = [&](int g0) {
-    int tap, cc;
-    if (g0 >= nmain) {
-      tap = -1, cc = g0 - nmain;
-    } else {
-      tap = p.ksz == 1 ? 0 : g0 / ncc, cc = g0 - tap * ncc;
-    }
+    int tap = p.ksz == 1 ? 0 : g0 / ncc, cc = g0 - tap * ncc;
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
       g_tap[i] = tap, g_cc[i] = cc;
-      if (g0 + i + 1 < kc_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
+      if (g0 + i + 1 < kc_main_end) {  // (chunks beyond the split's last one repeat it: loaded, never used)
         ++cc;
-        if (tap >= 0 && cc == ncc) {
-          cc = 0;
-          tap = tap + 1 < ntaps ? tap + 1 : -1;  // behind the last tap: the skip's chunks
-        }
+        if (cc == ncc) cc = 0, ++tap;
       }
     }
   };
-  for (int g = kc_begin; g < kc_end; g += SG) {
-    if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
-    group_chunks(g);
-    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget).
-    //    (Requesting the next group's first batch under this group's MFMAs was tried: 96 more live registers, spills as soon
-    //    as anything else is added, and no measurable gain - the second resident workgroup already fills the gap.)
-    // 2. every weight of the group is requested at once, right BEHIND the requests of the last activation batch and before
-    //    that batch is waited for: memory returns a wave's loads in order, so the activations are not held behind 28+ MB
-    //    of weights, the wait for them overlaps the weights' round trip (a 1x1x1 convolution is then ONE round trip plus
-    //    its MFMAs), and the chunk loop below starts on chunk 0 as soon as ITS weights are back while the rest streams.
-    float4 bw[SG][2];
-    auto load_w = [&]() {
-#pragma unroll
-      for (int i = 0; i < SG; ++i) {
-        const int tap = g_tap[i];
-        const int cc = g_cc[i];
-        const float* wp = w_lane + (tap < 0 ? skw_delta + (int64_t)cc * wnsl * WBLK : (int64_t)(tap * wncc + cc) * wnsl * WBLK);
-        bw[i][0] = *reinterpret_cast<const float4*>(wp);
-        if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
-      }
-    };
-#pragma unroll
-    for (int h = 0; h < SG; h += SGH) {
-      if (g + h < kc_end) {  // uniform
-#pragma unroll
-        for (int i = 0; i < SGH; ++i) load_a(i, h + i);
-        if (h + SGH >= SG || g + h + SGH >= kc_end) load_w();  // (uniform) the group's last batch
-#pragma unroll
-        for (int i = 0; i < SGH; ++i) store_a(i, h + i);
-      }
-    }
-    __syncthreads();
+  // the MFMAs of one staged group: chunks [g, min(g + SG, kend))
+  auto mfma_group = [&](int g, int kend, const float4 (&bw)[SG][2]) {
 #pragma unroll
     for (int i = 0; i < SG; ++i) {
-      if (g + i < kc_end) {  // uniform
+      if (g + i < kend) {  // uniform
         const float* ab = s_a + i * (SM_ROWS * RW) + lj * RW + kq * (BF ? 4 : 8);
         float4 a0[4], a1[4];
 #pragma unroll
@@ -2429,6 +2386,87 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t].w, bw[i][1].w, acc[t], 0, 0, 0);
       }
+    }
+  };
+  for (int g = kc_begin; g < kc_main_end; g += SG) {
+    if (g != kc_begin) __syncthreads();  // previous group's activation tile fully consumed
+    group_chunks(g);
+    // 1. the (small, L2-resident) activation rows of the whole group, in batches of SGH chunks (register budget).
+    //    (Requesting the next group's first batch under this group's MFMAs was tried: 96 more live registers, no gain - the
+    //    second resident workgroup already fills the gap.)
+    // 2. every weight of the group is requested at once, right BEHIND the requests of the last activation batch and before
+    //    that batch is waited for: memory returns a wave's loads in order, so the activations are not held behind 28+ MB
+    //    of weights, the wait for them overlaps the weights' round trip (a 1x1x1 convolution is then ONE round trip plus
+    //    its MFMAs), and the chunk loop below starts on chunk 0 as soon as ITS weights are back while the rest streams.
+    float4 bw[SG][2];
+    auto load_w = [&]() {
+#pragma unroll
+      for (int i = 0; i < SG; ++i) {
+        const float* wp = w_lane + (int64_t)(g_tap[i] * wncc + g_cc[i]) * wnsl * WBLK;
+        bw[i][0] = *reinterpret_cast<const float4*>(wp);
+        if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
+      }
+    };
+#pragma unroll
+    for (int h = 0; h < SG; h += SGH) {
+      if (g + h < kc_main_end) {  // uniform
+#pragma unroll
+        for (int i = 0; i < SGH; ++i) load_a(i, h + i);
+        if (h + SGH >= SG || g + h + SGH >= kc_main_end) load_w();  // (uniform) the group's last batch
+#pragma unroll
+        for (int i = 0; i < SGH; ++i) store_a(i, h + i);
+      }
+    }
+    __syncthreads();
+    mfma_group(g, kc_main_end, bw);
+  }
+  // ---- the fused skip's chunks (p.skip_w; launches without one never enter): raw block input at the row's OWN voxel (stride 1,
+  //      same resolution: conv_launch), zero for rows / channels beyond the ends, its own packed weights
+  if (kc_end > nmain) {
+    const float* skw_lane = (BF ? reinterpret_cast<const float*>(p.skip_w_bf) : p.skip_w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;
+    const int sk_lo = (kc_begin > nmain ? kc_begin : nmain) - nmain, sk_hi = kc_end - nmain;  // skip chunks [sk_lo, sk_hi)
+    for (int g = sk_lo; g < sk_hi; g += SG) {
+      if (g != sk_lo || kc_begin < nmain) __syncthreads();
+      float4 bw[SG][2];
+#pragma unroll
+      for (int h = 0; h < SG; h += SGH) {
+        if (g + h < sk_hi) {  // uniform
+#pragma unroll
+          for (int i = 0; i < SGH; ++i) {
+            const int sc = g + h + i < sk_hi ? g + h + i : sk_hi - 1;
+            int c = sc * BK + q * 4;
+            const bool cvalid = c < SCin;
+            if (!cvalid) c = 0;
+            const float* src = p.skip_src0;
+            int Cs = p.skip_C0, cs = c;
+            if (c >= p.skip_C0) {
+              src = p.skip_src1;
+              Cs = p.skip_C1;
+              cs = c - p.skip_C0;
+            }
+            amask[i] = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int z = az[j] + p.pad, y = ay[j] + p.pad, x = ax[j] + p.pad;
+              ra[i][j] = ld_act4(src, ((((int64_t)an[j] * p.OD + z) * p.OH + y) * p.OW + x) * Cs + cs, p.in_bf16);
+              amask[i] |= (av[j] && cvalid ? 1u : 0u) << j;
+            }
+          }
+          if (h + SGH >= SG || g + h + SGH >= sk_hi) {
+#pragma unroll
+            for (int i = 0; i < SG; ++i) {
+              const int sc = g + i < sk_hi ? g + i : sk_hi - 1;
+              const float* wp = skw_lane + (int64_t)sc * wnsl * WBLK;
+              bw[i][0] = *reinterpret_cast<const float4*>(wp);
+              if (!BF) bw[i][1] = *reinterpret_cast<const float4*>(wp + 256);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < SGH; ++i) store_a(i, h + i, true);
+        }
+      }
+      __syncthreads();
+      mfma_group(g, sk_hi, bw);
     }
   }
 
@@ -2629,11 +2667,9 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1
                : 0;
-  static const int64_t small_max_m = [] {  // development knob: rows above which mode 0 keeps the per-tap gather kernel
-    const char* e = getenv("HOLO_CONV_SMALL_MAX_M");
-    return e ? (int64_t)atoll(e) : ((int64_t)1 << 40);
-  }();
-  if (p.mode == 0 && p.Cout >= 64 && (M <= small_max_m || p.ksz == 1)) {  // 1x1x1, strided and deepest-level convs: row-tile kernel
+  // 1x1x1, strided and deepest-level convs: row-tile kernel (also for the 32^3 stride-2 convolution with its 32 768 rows: the
+  // per-tap gather kernel takes 118 us there, this one 95)
+  if (p.mode == 0 && p.Cout >= 64) {
     p.mode = 2;
     const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
     const int64_t tgt = 2 * (int64_t)num_cus;
