@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counter passes (separate from tracing, as the pool requires): bash scripts/gpu_pmc.sh tag
+# PMC counter passes (separate from tracing, as the pool requires): bash scripts/gpu_pmc.sh tag [traffic]   (traffic: only FETCH_SIZE / WRITE_SIZE)
 TAG=${1:-pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,7 +14,12 @@ run_pass () {
 import csv, sys, collections
 agg = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r["Kernel_Name"][:110], r.get("Grid_Size", r.get("Grid_Size_X", "")), r["Counter_Name"])
+    grid = r.get("Grid_Size", r.get("Grid_Size_X", ""))
+    # conv_wino3_kernel launches 256 persistent workgroups on EVERY level: its 64^3 launches (the reported ones) are told from
+    # the rest by the traffic itself (>= 24 MiB on the raw counter; the 32^3 level moves a quarter of that at most)
+    if "conv_wino3_kernel" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE") and float(r["Counter_Value"]) >= 24576:
+        grid += "@64"
+    k = (r["Kernel_Name"][:110], grid, r["Counter_Name"])
     a = agg.setdefault(k, [0, 0.0])
     a[0] += 1; a[1] += float(r["Counter_Value"])
 with open(sys.argv[2], "w") as f:
@@ -25,8 +30,10 @@ with open(sys.argv[2], "w") as f:
 PY
   done
 }
+if [ "$2" != "traffic" ]; then
 run_pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run_pass grbm GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
+fi
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 ls -la $OUT

@@ -18,13 +18,15 @@ out = sys.argv[2] if len(sys.argv) > 2 else "profiles/pmc_traffic.json"
 def load(fn):
     d = {}
     for r in csv.DictReader(open(fn)):
-        d[(r["kernel"], int(r["grid"]))] = (int(r["dispatches"]), float(r["avg"]))
+        g = r["grid"]
+        d[(r["kernel"], g if "@" in g else int(g))] = (int(r["dispatches"]), float(r["avg"]))
     return d
 
 
 fetch = load(f"gpurun_out/{tag}/pmc_fetch.csv")
 write = load(f"gpurun_out/{tag}/pmc_write.csv")
 res = {}
+big = {}  # conv_wino3_kernel at 64^3: SKIP -> [(dispatches, fetch KiB, write KiB)] over its XF variants
 for (k, grid), (n, f_kib) in fetch.items():
     w_kib = write.get((k, grid), (0, 0.0))[1]
     frames = None
@@ -49,6 +51,9 @@ for (k, grid), (n, f_kib) in fetch.items():
         label = f"conv_wino{mw.group(1)}_kernel<{mw.group(2)}> at {od}^3 output"
     elif "conv_wino3_kernel" in k:
         m3 = re.search(r"conv_wino3_kernel<(true|false), (true|false)>", k)
+        if grid == "65536@64":  # the 64^3 launches (scripts/gpu_pmc.sh tells them by their traffic): bench.py's label, per SKIP
+            big.setdefault(m3.group(1), []).append((n, f_kib, w_kib))
+            continue
         if grid != 256 * 256:  # launches below one item per CU (under-filled levels) are not the reported ones
             continue
         # (all levels launch 256 persistent workgroups: the average is over the variant's launches of the profiled command,
@@ -67,5 +72,16 @@ for (k, grid), (n, f_kib) in fetch.items():
                             "MI355X_MICROARCH.md; fabric-side L2 misses (Infinity-Cache hits included)"}
     if frames:
         res[label]["frames_per_launch"] = frames
+for sk, ents in big.items():
+    n = sum(e[0] for e in ents)
+    f_kib = sum(e[0] * e[1] for e in ents) / n
+    w_kib = sum(e[0] * e[2] for e in ents) / n
+    res[f"conv_wino3_kernel<{sk}> at 64^3 output"] = {
+        "fetch_bytes": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024), "dispatches": n, "fetch_size_raw_kib": f_kib,
+        "write_size_raw_kib": w_kib,
+        "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the command of scripts/gpu_pmc.sh, profiles/{tag}_fetch.csv "
+                  "+ _write.csv: the launches with >= 24 MiB on the raw counter (the 64^3 level; every level launches 256 persistent "
+                  "workgroups); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; fabric-side L2 misses (Infinity-Cache "
+                  "hits included)"}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1)[:2500])
