@@ -43,7 +43,8 @@
 
 // Development probes (tools/conv_ab builds extra copies of this file with -DW3_PROBE=<bits> -DW3_ENTRY=<name>): 1 no halo
 // requests / commits inside the stage loop, 2 no weight requests, 4 no patch reads / input transforms, 8 no MFMAs, 16 weight
-// requests into registers nobody waits for, 32 halo requests but no commits, 64 commits without the activation.
+// requests into registers nobody waits for, 32 halo requests but no commits, 64 commits without the activation, 128 the work
+// list in eight XCD lanes (see the kernel).
 #ifndef W3_PROBE
 #define W3_PROBE 0
 #endif
@@ -138,49 +139,58 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
   struct Item {
     int n, tz0, ty0, tx0, n0, split, cc_begin, cc_end, sk_begin, sk_end;
   };
-  auto decode = [&](int it, Item& I) {
-    int tile = it % ntiles;
-    int rest = it / ntiles;
-    I.n0 = (rest % ny) * 64;
-    I.split = rest / ny;
-    I.tx0 = (tile % ntx) << 3;
-    tile /= ntx;
-    I.ty0 = (tile % nty) << 3;
-    tile /= nty;
-    I.tz0 = (tile % ntz) * 2;
-    I.n = tile / ntz;
+  // Order of the work list: item q = (x tile, z tile, y tile, sample, cout block, split), x tile fastest - the 256 items in
+  // flight are one row of y tiles through all z.  Tried against it (round 4): y before z (a slab of 8 contiguous planes in flight)
+  // and eight XCD lanes (workgroup b, on XCD b % 8 by round-robin dispatch, owns the tile rows ty = b (mod 8), so that x / z
+  // neighbours meet in ONE L2): all three give the same step time (150.1 ... 150.6 denoise-steps/s) although the fabric sees
+  // every halo voxel 3.8 times (profiles/pmc_traffic.json) - at 1.8 TB/s the re-reads are served by the memory-side cache and
+  // hidden behind the MFMAs.  The lanes stay as a probe (W3_PROBE & 128).
+  const int X = ((W3_PROBE & 128) && (nty & 7) == 0 && (gridDim.x & 7) == 0) ? 8 : 1;
+  const int ntyh = nty / X;
+  const int lane_x = (int)blockIdx.x % X, G = (int)gridDim.x / X, nq = nitems / X;
+  auto chunks_of = [&](Item& I) {
     I.cc_begin = I.split * p.chunks_per_split;
     I.cc_end = min(I.cc_begin + p.chunks_per_split, ncc);
     const int nsk = SKIP ? (SCin + W3_BK - 1) / W3_BK : 0;
     I.sk_begin = min(I.split * p.skip_chunks_per_split, nsk);
     I.sk_end = min(I.sk_begin + p.skip_chunks_per_split, nsk);
   };
-  // The workgroup's next item = this one + gridDim.x: added digit by digit in the mixed radix (x tile, y tile, z tile,
-  // sample, cout block, split) - a handful of scalar adds and selects per item instead of five integer divisions (a uniform
-  // division is ~25 instructions, several of them on the vector pipe the MFMAs run on).
-  Item stride;  // gridDim.x in the same digits (tx0, ty0, tz0, n0 scaled like an item's)
-  decode((int)(gridDim.x % (unsigned)nitems), stride);  // (a grid >= the work list never advances)
+  auto decode = [&](int qi, Item& I, int lane_ofs) {
+    int t = qi;
+    I.tx0 = (t % ntx) << 3;
+    t /= ntx;
+    I.tz0 = (t % ntz) * 2;
+    t /= ntz;
+    I.ty0 = ((t % ntyh) * X + lane_ofs) << 3;
+    t /= ntyh;
+    I.n = t % p.N;
+    t /= p.N;
+    I.n0 = (t % ny) * 64;
+    I.split = t / ny;
+    chunks_of(I);
+  };
+  // The workgroup's next item = this one + G in its lane's list: added digit by digit in the mixed radix - a handful of scalar
+  // adds and selects per item instead of six integer divisions (a uniform division is ~25 instructions, several of them on the
+  // vector pipe the MFMAs run on).
+  Item stride;  // G in the same digits (scaled like an item's; no lane offset)
+  decode(G % (nq > 0 ? nq : 1), stride, 0);  // (a grid >= the work list never advances)
   auto advance = [&](const Item& a, Item& I) {
     int tx = a.tx0 + stride.tx0, c = tx >= p.OW ? 1 : 0;
     I.tx0 = tx - (c ? p.OW : 0);
-    int ty = a.ty0 + stride.ty0 + 8 * c;
-    c = ty >= p.OH ? 1 : 0;
-    I.ty0 = ty - (c ? p.OH : 0);
     int tz = a.tz0 + stride.tz0 + 2 * c;
     c = tz >= p.OD ? 1 : 0;
     I.tz0 = tz - (c ? p.OD : 0);
+    int ty = a.ty0 + stride.ty0 + 8 * X * c;
+    c = ty >= p.OH ? 1 : 0;
+    I.ty0 = ty - (c ? p.OH : 0);
     int n = a.n + stride.n + c;
     c = n >= p.N ? 1 : 0;
     I.n = n - (c ? p.N : 0);
     int nb = a.n0 + stride.n0 + 64 * c;
     c = nb >= 64 * ny ? 1 : 0;
     I.n0 = nb - (c ? 64 * ny : 0);
-    I.split = a.split + stride.split + c;  // (callers advance only while the item number stays below nitems)
-    I.cc_begin = I.split * p.chunks_per_split;
-    I.cc_end = min(I.cc_begin + p.chunks_per_split, ncc);
-    const int nsk = SKIP ? (SCin + W3_BK - 1) / W3_BK : 0;
-    I.sk_begin = min(I.split * p.skip_chunks_per_split, nsk);
-    I.sk_end = min(I.sk_begin + p.skip_chunks_per_split, nsk);
+    I.split = a.split + stride.split + c;  // (callers advance only while the item number stays below nq)
+    chunks_of(I);
   };
 
   // ---- producer side: item = ((y,x) column, channel quad); a thread holds the column's four planes.  A stage's four items
@@ -348,10 +358,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
   unsigned long long* dbg = p.dbg ? p.dbg + (int64_t)blockIdx.x * 8 : nullptr;
   if (dbg && tid == 0) dbg[0] = HOLO_PROBE_CLOCK();
 
-  int it = blockIdx.x;
-  if (it >= nitems) return;
+  int it = (int)blockIdx.x / X;  // position in the lane's list
+  if (it >= nq) return;
   Item cur, nxt;
-  decode(it, cur);
+  decode(it, cur, lane_x);
   // weights of (item, chunk): this wave's 16-Cout slice
   // (wave-uniform: the lane's 16 bytes are added at the request as a 32-bit vector offset to a scalar base)
   auto w_of = [&](const Item& I, int cc) { return (unsigned)((cc * wnsl + (I.n0 >> 4) + wn) * W3_WCHUNK) * 4u; };  // byte offset
@@ -407,8 +417,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       int ncc_ = cc + 1;
       nxt = cur;
       if (last_chunk) {
-        const int nit = it + (int)gridDim.x;
-        if (nit < nitems) {
+        const int nit = it + G;
+        if (nit < nq) {
           advance(cur, nxt);
           ncc_ = nxt.cc_begin;
         } else {
@@ -672,8 +682,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino3_kernel(ConvParams p) {
       dbg[3] = t_now;
       dbg[7] += 1;
     }
-    it += (int)gridDim.x;
-    if (it >= nitems) break;
+    it += G;
+    if (it >= nq) break;
     if (SKIP && cur.sk_end > cur.sk_begin) {  // the patch requested again behind the skip section: its x and y transforms
 #pragma unroll
       for (int a4 = 0; a4 < 4; ++a4) {

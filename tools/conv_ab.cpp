@@ -29,6 +29,7 @@ int conv_wino3_launch_p8(const ConvParams& p, void* stream);
 int conv_wino3_launch_p16(const ConvParams& p, void* stream);
 int conv_wino3_launch_p32(const ConvParams& p, void* stream);
 int conv_wino3_launch_p64(const ConvParams& p, void* stream);
+int conv_wino3_launch_p128(const ConvParams& p, void* stream);
 int conv_wino3_launch_tl(const ConvParams& p, void* stream);
 }  // namespace holo
 using namespace holo;
@@ -143,7 +144,9 @@ int main(int argc, char** argv) {
         printf("   form %d: planner chose wino=%d\n", form, q.wino);
         continue;
       }
-      for (int i = 0; i < 3; ++i)
+      // ~50 ms of the same launches first: the clocks of a short burst are 5 - 10 % below the sustained ones (a variant timed
+      // later in the process used to look that much faster than the first one)
+      for (int i = 0; i < 200; ++i)
         if (conv_launch(q, nullptr)) exit(1);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0, nullptr));
@@ -221,9 +224,10 @@ int main(int argc, char** argv) {
             {"everything but the MFMAs", conv_wino3_launch_p8},
             {"weight requests nobody waits for", conv_wino3_launch_p16},
             {"halo requests but no commits", conv_wino3_launch_p32},
-            {"commits without the activation", conv_wino3_launch_p64}};
+            {"commits without the activation", conv_wino3_launch_p64},
+            {"work list in eight XCD lanes", conv_wino3_launch_p128}};
         for (auto& pr : probes) {
-          for (int i = 0; i < 2; ++i) pr.fn(q, nullptr);
+          for (int i = 0; i < 100; ++i) pr.fn(q, nullptr);
           CK(hipDeviceSynchronize());
           CK(hipEventRecord(e0, nullptr));
           for (int i = 0; i < iters; ++i) pr.fn(q, nullptr);
