@@ -284,8 +284,8 @@ def dry_run(args) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=40,
                     help="timed 400x400 frames in the render leg: one render call of a whole fly-around (render_flyaround's "
                          "default n_flyaround_poses = 40, flyaround.py:50; generate_samples.py uses 75)")
