@@ -895,7 +895,7 @@ struct Planner {
       ops.push_back(op);
     }
     release(y);
-    if (getenv("HOLO_PLAN_DEBUG")) {  // development: what the plan launches
+    if (getenv("HOLO_DEBUG_PLAN")) {  // development: what the plan launches
       int n_fin = 0, n_conv = 0, n_split = 0;
       for (const Op& o : ops) {
         n_fin += o.kind == OP_FINAL;

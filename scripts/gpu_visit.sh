@@ -23,7 +23,7 @@ cat $OUT/render_probe.log
 echo "== probes: training step (forward + backward), view pooling forward / backward"
 timeout 200 python scripts/backward_probe.py 5 > $OUT/backward_probe.log 2>&1; tail -2 $OUT/backward_probe.log
 timeout 300 python scripts/viewpool_probe.py 16 64 > $OUT/viewpool_probe.log 2>&1; grep -E "view pooling|MLPMean" $OUT/viewpool_probe.log
-echo "== bench"; HOLO_PLAN_DEBUG=1 HOLO_BENCH_OPS=1 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; grep -E "per-op totals|\[plan\]" $OUT/bench.err | head -3
+echo "== bench"; HOLO_DEBUG_PLAN=1 HOLO_BENCH_OPS=1 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; grep -E "per-op totals|\[plan\]" $OUT/bench.err | head -3
 echo "== rocprofv3 kernel trace of the bench command"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err; echo "rocprof rc=$?" )
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
