@@ -2206,7 +2206,7 @@ constexpr int SGH = 4;  // activation chunks requested per staging batch (regist
 // weights are the bf16 plane packed for v_mfma_f32_16x16x32_bf16 (one 1 KB block per wave, tap and chunk), and one
 // MFMA per 16-voxel tile covers a chunk's 32 channels (eight fp32 ones otherwise).
 template <bool BF>
-__global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {  // (bf16: 40 KB of LDS, three workgroups per CU)
   constexpr int RW = BF ? 20 : LDK;  // LDS words per activation row
   __shared__ __attribute__((aligned(16))) float s_a[SG * SM_ROWS * RW];
   const int tid = threadIdx.x;
@@ -2412,17 +2412,20 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {
       if (g + h < kc_main_end) {  // uniform
 #pragma unroll
         for (int i = 0; i < SGH; ++i) load_a(i, h + i);
-        if (h + SGH >= SG || g + h + SGH >= kc_main_end) load_w();  // (uniform) the group's last batch
+        if (!BF && (h + SGH >= SG || g + h + SGH >= kc_main_end)) load_w();  // (uniform) the group's last batch
 #pragma unroll
         for (int i = 0; i < SGH; ++i) store_a(i, h + i);
       }
     }
+    // (bf16 mode: its launches are the large-M ones of the 128^3 net, throughput bound: the weights are requested behind the
+    //  stores, which keeps the kernel at 3 - 4 workgroups per CU instead of 2)
+    if (BF) load_w();
     __syncthreads();
     mfma_group(g, kc_main_end, bw);
   }
   // ---- the fused skip's chunks (p.skip_w; launches without one never enter): raw block input at the row's OWN voxel (stride 1,
   //      same resolution: conv_launch), zero for rows / channels beyond the ends, its own packed weights
-  if (kc_end > nmain) {
+  if (!BF && kc_end > nmain) {  // (fp32 mode only: unet_exec.cpp fuses the skip below 8^3 there)
     const float* skw_lane = (BF ? reinterpret_cast<const float*>(p.skip_w_bf) : p.skip_w) + (int64_t)((n0 >> 4) + wave) * WBLK + lane * 4;
     const int sk_lo = (kc_begin > nmain ? kc_begin : nmain) - nmain, sk_hi = kc_end - nmain;  // skip chunks [sk_lo, sk_hi)
     for (int g = sk_lo; g < sk_hi; g += SG) {
