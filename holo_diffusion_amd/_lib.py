@@ -98,6 +98,8 @@ SIGNATURES = {
     "holo_unet_set_dgrad_weight": (C.c_int, [_vp, C.c_char_p, _vp, _vp]),
     "holo_unet_backward_workspace_bytes": (C.c_size_t, [_vp, C.c_int]),
     "holo_unet_backward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_unet_forward_train": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_unet_backward_taped": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_unet_get_grad": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _vp, _vp]),
     "holo_ddpm_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "holo_tanh": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),

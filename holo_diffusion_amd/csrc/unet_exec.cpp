@@ -215,6 +215,7 @@ struct HoloUnet {
   size_t tws_need = 0;
   size_t gy_off = 0, gx_off = 0, y_off = 0;
   const int64_t* t_dev = nullptr;                            // timesteps of the running call (time_embed backward)
+  bool tape_valid = false;                                    // holo_unet_forward_train ran and nothing has consumed its tape
   std::map<int, size_t> tws_cache;
 };
 
@@ -1903,12 +1904,66 @@ size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch) {
   return b;
 }
 
+// The two halves of holo_unet_backward as entries of their own (ABI 4): a caller whose cotangent depends on the output - the
+// clamp of pred_xstart in HoloDiffusionModel.training_backward - runs the taped forward, forms grad_out from y, then the backward,
+// instead of paying a plain forward first.
+int holo_unet_forward_train(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!net || !x || !timesteps || !workspace || batch < 1) {
+    set_error("holo_unet_forward_train: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  net->tape_valid = false;
+  int rc = ensure_train_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->tws_need) {
+    set_error("holo_unet_forward_train: workspace too small (%zu < %zu)", workspace_bytes, net->tws_need);
+    net->tplan_batch = -1;
+    return HOLO_E_WORKSPACE;
+  }
+  net->t_dev = timesteps;
+  for (const Op& op : net->tops) {
+    if (op.kind == OP_OUT && !y) continue;
+    rc = run_op(net, op, batch, x, timesteps, y, stream);
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  net->tape_valid = true;
+  return 0;
+}
+
+int holo_unet_backward_taped(HoloUnet* net, int batch, const float* grad_out, float* grad_x, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  if (!net || !grad_out || !workspace || batch < 1) {
+    set_error("holo_unet_backward_taped: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (!net->tape_valid || net->tplan_batch != batch || net->tplan_ws != workspace || workspace_bytes < net->tws_need) {
+    set_error("holo_unet_backward_taped: no taped forward of this batch on this workspace (holo_unet_forward_train first)");
+    return HOLO_E_STATE;
+  }
+  net->tape_valid = false;  // the backward consumes the tape (gradient buffers share its workspace)
+  int rc;
+  const HoloUnetCfg& c = net->cfg;
+  const int64_t V = (int64_t)c.image_size * c.image_size * c.image_size;
+  if (ncdhw_to_ndhwc_launch(grad_out, (float*)((char*)workspace + net->gy_off), batch, c.out_channels, V, 0, stream))
+    return HOLO_E_INVALID;
+  for (auto& f : net->bops) {
+    rc = f(stream);
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  if (grad_x &&
+      ndhwc_to_ncdhw_launch((const float*)((char*)workspace + net->gx_off), grad_x, batch, c.in_channels, V, stream))
+    return HOLO_E_INVALID;
+  return 0;
+}
+
 int holo_unet_backward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, const float* grad_out, float* y,
                        float* grad_x, void* workspace, size_t workspace_bytes, void* stream) {
   if (!net || !x || !timesteps || !grad_out || !workspace || batch < 1) {
     set_error("holo_unet_backward: null/invalid argument");
     return HOLO_E_INVALID;
   }
+  net->tape_valid = false;
   int rc = ensure_train_plan(net, batch, workspace);
   if (rc) return rc;
   if (workspace_bytes < net->tws_need) {

@@ -301,16 +301,19 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         target_cameras = camera[list(range(n_targets))]
         rounds = []
 
-        def one_round(x0, t_key, n_key):
+        def one_round(x0, t_key, n_key, last):
             t = torch.as_tensor(rs[t_key], device=dev, dtype=torch.int64).reshape(x0.shape[0])
             x_t = self.diffusion.q_sample(x0, t, noise=rs[n_key].to(dev))
-            y = self.net_3d(x_t, t)
-            rounds.append((x_t, t, y))
+            # the LAST round's forward is the taped one: its backward runs first and consumes the tape (no second forward);
+            # an earlier round (bootstrap) is re-run by ``backward`` when its turn comes - the tape holds one forward
+            y = self.net_3d.forward_train(x_t, t) if last else self.net_3d(x_t, t)
+            rounds.append((x_t, t, y, last))
             return y.clamp(-1.0, 1.0)
 
-        grid = one_round(voxel_features.float(), "timesteps", "q_noise")
-        if rs["bootstrap"]:
-            grid = one_round(grid, "timesteps2", "q_noise2")
+        boot = bool(rs["bootstrap"])
+        grid = one_round(voxel_features.float(), "timesteps", "q_noise", not boot)
+        if boot:
+            grid = one_round(grid, "timesteps2", "q_noise2", True)
         for func in self._implicit_functions:
             func.bind_args(voxel_grid_features=grid)
         try:
@@ -322,9 +325,12 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
                 func.unbind_args()
         unet_grads: Dict[str, torch.Tensor] = {}
         g = g_grid
-        for x_t, t, y in reversed(rounds):
+        for x_t, t, y, taped in reversed(rounds):
             g_y = g * ((y >= -1.0) & (y <= 1.0)).to(g.dtype)  # torch.clamp passes the gradient inside [min, max]
-            _, g_x, ug = self.net_3d.backward(x_t, t, g_y)
+            if taped:
+                g_x, ug = self.net_3d.backward_taped(g_y)
+            else:
+                _, g_x, ug = self.net_3d.backward(x_t, t, g_y)
             for k, v in ug.items():
                 unet_grads[k] = v if k not in unet_grads else unet_grads[k] + v
             g = self.diffusion._extract(self.diffusion.sqrt_alphas_cumprod, t, g_x.shape) * g_x  # d q_sample / d x_start

@@ -286,13 +286,8 @@ class SimpleUnet3D(Unet3DBase):
         B = x.shape[0]
         if tuple(g.shape) != (B, self.out_channels) + tuple(x.shape[2:]):
             raise _lib.HoloError(f"grad_output must be {(B, self.out_channels) + tuple(x.shape[2:])}, got {tuple(g.shape)}")
-        nbytes = L.holo_unet_backward_workspace_bytes(h, B)
-        if nbytes == 0:
-            raise _lib.HoloError("holo_unet_backward_workspace_bytes: " + (L.holo_last_error() or b"").decode())
-        held = self.__dict__.get("_holo_train_ws")
-        if held is None or held.device != dev or held.numel() < nbytes:
-            held = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-            self.__dict__["_holo_train_ws"] = held
+        held = self._train_ws(h, B, dev)
+        self.__dict__.pop("_holo_tape", None)  # (this call re-tapes the workspace)
         y = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), device=dev)
         gx = torch.empty_like(x)
         st = runtime.stream_ptr(dev)
@@ -306,6 +301,66 @@ class SimpleUnet3D(Unet3DBase):
                        f"holo_unet_get_grad({k})")
             grads[k] = out
         return y, gx, grads
+
+    def _train_ws(self, h, B: int, dev):
+        L = runtime.lib()
+        nbytes = L.holo_unet_backward_workspace_bytes(h, B)
+        if nbytes == 0:
+            raise _lib.HoloError("holo_unet_backward_workspace_bytes: " + (L.holo_last_error() or b"").decode())
+        held = self.__dict__.get("_holo_train_ws")
+        if held is None or held.device != dev or held.numel() < nbytes:
+            held = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            self.__dict__["_holo_train_ws"] = held
+        return held
+
+    @torch.no_grad()
+    def forward_train(self, x: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """The taped forward (``holo_unet_forward_train``): returns y and leaves every intermediate in the training workspace
+        for ONE following ``backward_taped`` - for a cotangent that depends on y (the clamp in ``training_backward``), where
+        ``backward`` would pay a second forward.  fp32 mode only."""
+        runtime.require_device(x, "SimpleUnet3D.forward_train")
+        if self.compute_dtype != "f32":
+            raise _lib.HoloError("SimpleUnet3D.forward_train runs in the fp32 mode only")
+        dev = x.device
+        h = self._ensure_handle(dev, int(x.shape[2]))
+        self._ensure_dgrad_weights(dev)
+        L = runtime.lib()
+        x = x.contiguous().float()
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        B = x.shape[0]
+        held = self._train_ws(h, B, dev)
+        y = torch.empty((B, self.out_channels) + tuple(x.shape[2:]), device=dev)
+        _lib.check(L, L.holo_unet_forward_train(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(held),
+                                                held.numel(), runtime.stream_ptr(dev)), "holo_unet_forward_train")
+        self.__dict__["_holo_tape"] = (x, t, h)  # (kept alive: the backward reads the timesteps again)
+        return y
+
+    @torch.no_grad()
+    def backward_taped(self, grad_output: torch.Tensor, params=None):
+        """``(grad_x, {name: gradient})`` for the tape of the last ``forward_train`` (``holo_unet_backward_taped``)."""
+        tape = self.__dict__.pop("_holo_tape", None)
+        if tape is None:
+            raise _lib.HoloError("SimpleUnet3D.backward_taped: no taped forward (forward_train first)")
+        x, t, h = tape
+        dev = x.device
+        L = runtime.lib()
+        g = grad_output.contiguous().float()
+        B = x.shape[0]
+        if tuple(g.shape) != (B, self.out_channels) + tuple(x.shape[2:]):
+            raise _lib.HoloError(f"grad_output must be {(B, self.out_channels) + tuple(x.shape[2:])}, got {tuple(g.shape)}")
+        held = self.__dict__["_holo_train_ws"]
+        gx = torch.empty_like(x)
+        st = runtime.stream_ptr(dev)
+        _lib.check(L, L.holo_unet_backward_taped(h, B, runtime.ptr(g), runtime.ptr(gx), runtime.ptr(held), held.numel(), st),
+                   "holo_unet_backward_taped")
+        grads = {}
+        shapes = self.param_shapes()
+        for k in (params if params is not None else self._param_names):
+            out = torch.empty(shapes[k], device=dev)
+            _lib.check(L, L.holo_unet_get_grad(h, k.encode(), runtime.ptr(out), out.numel(), runtime.ptr(held), st),
+                       f"holo_unet_get_grad({k})")
+            grads[k] = out
+        return gx, grads
 
     def workspace_bytes(self, batch: int, device: torch.device) -> int:
         """Caller-owned HBM workspace of one forward at this batch size in the current compute mode (activations, GroupNorm

@@ -131,6 +131,16 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
 size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch);
 int holo_unet_backward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, const float* grad_out, float* y,
                        float* grad_x, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The two halves of holo_unet_backward as separate entries (ABI 4), for a cotangent that depends on the output (the clamp of
+ * pred_xstart in the training branch, holo_diffusion_model.py:400-418): holo_unet_forward_train runs the taped forward and
+ * writes y (may be NULL); holo_unet_backward_taped then runs the backward for grad_out on the SAME workspace and batch and
+ * consumes the tape (HOLO_E_STATE without a preceding forward_train; `timesteps` of the forward must still be alive).
+ * Gradients are fetched with holo_unet_get_grad as after holo_unet_backward. */
+int holo_unet_forward_train(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int holo_unet_backward_taped(HoloUnet* net, int batch, const float* grad_out, float* grad_x, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int holo_unet_get_grad(HoloUnet* net, const char* name, float* dst, int64_t numel, const void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------

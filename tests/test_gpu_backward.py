@@ -169,3 +169,26 @@ def test_plumbing_size_backward_vs_oracle_and_north_star_timing(gu):
     dt = time.perf_counter() - t0
     assert torch.isfinite(gx).all() and all(torch.isfinite(v).all() for v in grads.values())
     print(f"north-star net (64^3x32, 165 M parameters): forward + backward {dt * 1e3:.1f} ms")
+
+
+def test_forward_train_and_backward_taped_equal_backward(gu):
+    """holo_unet_forward_train + holo_unet_backward_taped (ABI 4) are the two halves of holo_unet_backward: the same output,
+    input gradient and parameter gradients bit for bit; the tape serves ONE backward; a plain forward in between (its own
+    workspace) does not disturb it."""
+    if os.environ.get("HOLO_TEST_EMU") == "1":
+        pytest.skip("backward tests run on the device")
+    cfg = uo.UNetCfg(image_size=8, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2, channel_mult=(1, 2),
+                     attention_resolutions=(2,), num_heads=2)
+    net, _ = gu.make_unet(cfg, seed=5)
+    shape = (1, cfg.in_channels) + (cfg.image_size,) * 3
+    x = torch.from_numpy(np_noise(1, shape)).to(gu.DEV)
+    t = torch.tensor([437], dtype=torch.int64, device=gu.DEV)
+    G = torch.from_numpy(np_noise(2, shape)).to(gu.DEV)
+    y0, gx0, pg0 = net.backward(x, t, G)
+    y1 = net.forward_train(x, t)
+    net(x, t)  # inference call between the halves
+    gx1, pg1 = net.backward_taped(G)
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    assert set(pg0) == set(pg1) and all(torch.equal(pg0[k], pg1[k]) for k in pg0)
+    with pytest.raises(hda.HoloError):
+        net.backward_taped(G)  # the tape is consumed
