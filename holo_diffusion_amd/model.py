@@ -287,7 +287,9 @@ class HoloDiffusionModel(ImplicitronModelBase, torch.nn.Module):
         (holo_unet_backward) -> q_sample's sqrt(alpha_bar_t) -> (bootstrap) the first round's clamp and denoiser again; the
         parameter gradients of the two rounds add up, as the reference's shared ``net_3d`` accumulates them.
         Returns ``{"unet": {name: grad}, "render_mlp": {name: grad}, "voxel_features": grad of the clean grid,
-        "voxel_grid": grad of the rendered grid}``.  The view-pooling branch (image_rgb inputs) has no backward here."""
+        "voxel_grid": grad of the rendered grid}``.  When the clean grid came from the view-pooling branch (image_rgb inputs),
+        ``pool_views_backward(image_features, source_cameras, out["voxel_features"])`` continues the chain to the mapper, the
+        aggregator and the source-view feature maps."""
         assert self.net_3d_enabled and self.diffusion_enabled, "training_backward: the diffusion branch"
         rs = dict(rng_streams)
         for k in ("timesteps", "q_noise", "bootstrap", "xys"):
