@@ -433,33 +433,60 @@ __global__ __launch_bounds__(256) void mm_head_kernel(MlpMeanBwdParams b) {
   }
 }
 
-// DPRE = (DH + dlogit l) lrelu'(PRE), in place of PRE and transposed into DPRET
+// DPRE = (DH + dlogit l) lrelu'(PRE), in place of PRE, and its transpose DPRET (the A operand of the split-K product with X):
+// a workgroup owns 64 rows x 128 hidden units, reads and writes them row-major (coalesced) and turns the tile through LDS so
+// that the transposed copy goes out as 64 consecutive rows per hidden unit (a plain per-element transposed store was 4 ms)
 __global__ __launch_bounds__(256) void mm_dpre_kernel(MlpMeanBwdParams b) {
+  __shared__ float tile[64 * 129];
   const MlpMeanParams& m = b.fwd;
-  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
-  const int64_t total = (int64_t)m.vp.n_views * P * 128;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i & 127);
-    const int64_t row = i >> 7;
-    const float dh = b.H[i] + b.DUL[row * b.FW + m.vp.F] * m.l[k];
-    const float d = b.PRE[i] > 0.f ? dh : 0.2f * dh;
-    b.PRE[i] = d;
-    b.DPRET[(int64_t)k * b.NRp + row] = d;
+  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R, NR = P * m.vp.n_views;
+  const int tid = threadIdx.x;
+  for (int64_t r0 = (int64_t)blockIdx.x * 64; r0 < NR; r0 += (int64_t)gridDim.x * 64) {
+    for (int e = tid; e < 64 * 128; e += 256) {
+      const int r = e >> 7, k = e & 127;
+      const int64_t row = r0 + r;
+      float d = 0.f;
+      if (row < NR) {
+        const int64_t i = row * 128 + k;
+        const float dh = b.H[i] + b.DUL[row * b.FW + m.vp.F] * m.l[k];
+        d = b.PRE[i] > 0.f ? dh : 0.2f * dh;
+        b.PRE[i] = d;
+      }
+      tile[r * 129 + k] = d;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 128; e += 256) {
+      const int r = e & 63, k = e >> 6;
+      if (r0 + r < NR) b.DPRET[(int64_t)k * b.NRp + r0 + r] = tile[r * 129 + k];
+    }
+    __syncthreads();
   }
 }
 
-// DC[p] = sum_v DPRE[v, p], and its transpose
+// DC[p] = sum_v DPRE[v, p], and its transpose (the same 64 x 128 tile turn)
 __global__ __launch_bounds__(256) void mm_dc_kernel(MlpMeanBwdParams b) {
+  __shared__ float tile[64 * 129];
   const MlpMeanParams& m = b.fwd;
   const int V = m.vp.n_views;
   const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * 128; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i & 127);
-    const int64_t p = i >> 7;
-    float s = 0.f;
-    for (int v = 0; v < V; ++v) s += b.PRE[((int64_t)v * P + p) * 128 + k];
-    b.DC[i] = s;
-    b.DCT[(int64_t)k * b.Pp + p] = s;
+  const int tid = threadIdx.x;
+  for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < P; p0 += (int64_t)gridDim.x * 64) {
+    for (int e = tid; e < 64 * 128; e += 256) {
+      const int r = e >> 7, k = e & 127;
+      const int64_t p = p0 + r;
+      float s = 0.f;
+      if (p < P) {
+        for (int v = 0; v < V; ++v) s += b.PRE[((int64_t)v * P + p) * 128 + k];
+        b.DC[p * 128 + k] = s;
+      }
+      tile[r * 129 + k] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 128; e += 256) {
+      const int r = e & 63, k = e >> 6;
+      if (p0 + r < P) b.DCT[(int64_t)k * b.Pp + p0 + r] = tile[r * 129 + k];
+    }
+    __syncthreads();
   }
 }
 
@@ -500,15 +527,24 @@ __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
   }
 }
 
-// column sums of a (rows, cols <= 256) matrix: block b sums its row range -> partial[b][cols]
+// column sums of a (rows, cols <= 256) matrix: block b sums its row range -> partial[b][cols].  256 / cols row lanes per block
+// (thread = (row lane, column): consecutive threads read consecutive columns), combined through LDS in lane order.
 __global__ __launch_bounds__(256) void mm_colsum_kernel(const float* __restrict__ src, int64_t rows, int cols, int ld,
                                                         float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int lanes = 256 / cols, tid = threadIdx.x;
+  const int c = tid % cols, rl = tid / cols;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-  if ((int)threadIdx.x < cols) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += src[r * ld + threadIdx.x];
-    partial[(int64_t)blockIdx.x * cols + threadIdx.x] = s;
+  float s = 0.f;
+  if (rl < lanes)
+    for (int64_t r = r0 + rl; r < r1; r += lanes) s += src[r * ld + c];
+  red[tid] = s;
+  __syncthreads();
+  if (tid < cols) {
+    float t = 0.f;
+    for (int l = 0; l < lanes; ++l) t += red[l * cols + tid];
+    partial[(int64_t)blockIdx.x * cols + tid] = t;
   }
 }
 
@@ -562,8 +598,8 @@ int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream) {
       HOLO_LAUNCH(mm_head_kernel, dim3(mm_blocks(P * 64)), dim3(256), stream, b);
       return 0;
     case 3:
-      HOLO_LAUNCH(mm_dpre_kernel, dim3(mm_blocks(NR * 128)), dim3(256), stream, b);
-      HOLO_LAUNCH(mm_dc_kernel, dim3(mm_blocks(P * 128)), dim3(256), stream, b);
+      HOLO_LAUNCH(mm_dpre_kernel, dim3(mm_blocks(NR * 4)), dim3(256), stream, b);  // one workgroup per 64 rows
+      HOLO_LAUNCH(mm_dc_kernel, dim3(mm_blocks(P * 4)), dim3(256), stream, b);
       return 0;
     case 4:
       HOLO_LAUNCH(mm_scatter_kernel, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);

@@ -622,7 +622,7 @@ int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, i
   // dG (rows 0..F-1) and dl (row F) = DULT H, split over the rows
   MM_TRY(mm_gemm(b.DULT, (int)L.NRp, b.H, 128, 1, part, 128, FW, 128, Kc, L.S, Kc, (int64_t)Kc * 128, (int64_t)FW * 128, stream));
   MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)FW * 128, dG, stream));
-  MM_TRY(mm_colsum_launch(b.DUL, L.NR, FW, FW, part, 256, dgl, stream));                                       // dg0 | dl0
+  MM_TRY(mm_colsum_launch(b.DUL, L.NR, FW, FW, part, 1024, dgl, stream));                                      // dg0 | dl0
   MM_TRY(mm_gemm(b.DUL, FW, b.fwd.g, 128, 1, b.H, 128, NR, 128, F, 1, 0, 0, 0, stream));                       // DH = DU G  (into H)
   MM_TRY(mm_bwd_step_launch(b, 3, stream));                                                                    // DPRE (in PRE), DPRET, DC, DCT
   MM_TRY(mm_gemm(b.DPRET, (int)L.NRp, b.X, dp, 1, part, dp, 128, dp, Kc, L.S, Kc, (int64_t)Kc * dp, (int64_t)128 * dp, stream));
