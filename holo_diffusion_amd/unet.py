@@ -14,6 +14,7 @@ so that ``state_dict()`` / ``load_state_dict()`` are interchangeable with the re
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional, Tuple
 
@@ -321,6 +322,10 @@ class SimpleUnet3D(Unet3DBase):
         runtime.require_device(x, "SimpleUnet3D.forward_train")
         if self.compute_dtype != "f32":
             raise _lib.HoloError("SimpleUnet3D.forward_train runs in the fp32 mode only")
+        if x.dim() != 5 or x.shape[1] != self.in_channels or len(set(x.shape[2:])) != 1 or \
+                x.shape[2] % (1 << (len(self.channel_mult) - 1)) or tuple(timesteps.shape) != (x.shape[0],):
+            raise _lib.HoloError(f"SimpleUnet3D.forward_train: expected (N,{self.in_channels},R,R,R) with R a multiple of "
+                                 f"{1 << (len(self.channel_mult) - 1)} and timesteps (N,), got {tuple(x.shape)}, {tuple(timesteps.shape)}")
         dev = x.device
         h = self._ensure_handle(dev, int(x.shape[2]))
         self._ensure_dgrad_weights(dev)
@@ -333,6 +338,7 @@ class SimpleUnet3D(Unet3DBase):
         _lib.check(L, L.holo_unet_forward_train(h, B, runtime.ptr(x), runtime.ptr(t), runtime.ptr(y), runtime.ptr(held),
                                                 held.numel(), runtime.stream_ptr(dev)), "holo_unet_forward_train")
         self.__dict__["_holo_tape"] = (x, t, h)  # (kept alive: the backward reads the timesteps again)
+        self.__dict__["_holo_tape_id"] = self.__dict__.get("_holo_tape_id", 0) + 1
         return y
 
     @torch.no_grad()
@@ -430,20 +436,32 @@ class SimpleUnet3D(Unet3DBase):
 
 
 class _HoloUnetFn(torch.autograd.Function):
-    """Autograd node of the HIP denoiser: forward = holo_unet_forward, backward = holo_unet_backward (which re-runs the
-    forward with every intermediate kept).  The parameters are inputs of the node so that their ``.grad`` is filled."""
+    """Autograd node of the HIP denoiser: forward = the taped forward (holo_unet_forward_train), backward =
+    holo_unet_backward_taped when the tape is still this node's, else holo_unet_backward (which re-runs the forward with every
+    intermediate kept).  The parameters are inputs of the node so that their ``.grad`` is filled."""
 
     @staticmethod
     def forward(ctx, net, x, timesteps, names, *params):
         ctx.net, ctx.names = net, names
         ctx.save_for_backward(x.detach(), timesteps.detach())
         ctx.x_needs = x.requires_grad
+        ctx.tape_id = None
         with torch.no_grad():
+            if net.compute_dtype == "f32" and not os.environ.get("HOLO_NO_AUTOGRAD_TAPE"):
+                # the taped forward: if nothing else uses the training workspace before this node's backward (another
+                # differentiable call, an explicit backward()), that backward needs no second forward
+                y = net.forward_train(x.detach(), timesteps)
+                ctx.tape_id = net.__dict__["_holo_tape_id"]
+                return y
             return net._forward_impl(x.detach(), timesteps)
 
     @staticmethod
     def backward(ctx, grad_y):
         x, t = ctx.saved_tensors
         want = [k for k, need in zip(ctx.names, ctx.needs_input_grad[4:]) if need]
-        _, gx, grads = ctx.net.backward(x, t, grad_y, params=want)
+        net = ctx.net
+        if ctx.tape_id is not None and "_holo_tape" in net.__dict__ and net.__dict__.get("_holo_tape_id") == ctx.tape_id:
+            gx, grads = net.backward_taped(grad_y, params=want)
+        else:
+            _, gx, grads = net.backward(x, t, grad_y, params=want)
         return (None, gx if ctx.x_needs else None, None, None) + tuple(grads.get(k) for k in ctx.names)
