@@ -84,6 +84,11 @@ class SimpleUnet3D(Unet3DBase):
     # the bf16 configurations, tolerance rtol 2e-2) or "f32_bf16x3" (fp32 operands split exactly into three bf16
     # terms, six bf16 MFMAs per product: fp32-accurate on the bf16 matrix cores) - holo_unet_set_compute_dtype
     compute_dtype: str = "f32"
+    # build-side extension: a differentiable call (grad mode on, a parameter or the input requires grad) runs the TAPED forward,
+    # which allocates the training workspace (every intermediate kept; 64^3 x 32: ~6 GB) and prepares the transposed
+    # convolution weights, so that loss.backward() needs no second forward.  False: such a call costs the inference
+    # workspace only and its backward re-runs the forward (holo_unet_backward).  (HOLO_NO_AUTOGRAD_TAPE=1: same, by env.)
+    autograd_tape: bool = True
 
     def __init__(self, **kwargs):
         torch.nn.Module.__init__(self)
@@ -167,6 +172,8 @@ class SimpleUnet3D(Unet3DBase):
                 runtime.sync_before_destroy(self._handle_device)
                 L.holo_unet_destroy(self._handle)
                 self._handle = None
+            # a tape of the old handle (forward_train) dies with it: backward_taped must not see the freed pointer
+            self.__dict__.pop("_holo_tape", None)
             h = C.c_void_p()
             cfg = self._cfg_struct(size)
             _lib.check(L, L.holo_unet_create(runtime.ctx(device), C.byref(cfg), C.byref(h)), "holo_unet_create")
@@ -196,6 +203,9 @@ class SimpleUnet3D(Unet3DBase):
         sd = dict(self._net.named_parameters())
         versions = self._poll_parameter_versions(sd)
         if self._dirty:
+            # re-packing the forward weights under a live tape would pair new weights with the old taped activations (and
+            # stale dgrad weights) in backward_taped: the tape is dropped, the autograd node then re-runs its forward
+            self.__dict__.pop("_holo_tape", None)
             st = runtime.stream_ptr(device)
             for k in self._param_names:
                 p = sd[k]
@@ -447,7 +457,8 @@ class _HoloUnetFn(torch.autograd.Function):
         ctx.x_needs = x.requires_grad
         ctx.tape_id = None
         with torch.no_grad():
-            if net.compute_dtype == "f32" and not os.environ.get("HOLO_NO_AUTOGRAD_TAPE"):
+            if net.compute_dtype == "f32" and getattr(net, "autograd_tape", True) and \
+                    not os.environ.get("HOLO_NO_AUTOGRAD_TAPE"):
                 # the taped forward: if nothing else uses the training workspace before this node's backward (another
                 # differentiable call, an explicit backward()), that backward needs no second forward
                 y = net.forward_train(x.detach(), timesteps)

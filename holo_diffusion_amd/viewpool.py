@@ -299,7 +299,15 @@ class ViewPooler(Configurable, torch.nn.Module):
         L = runtime.lib()
         params = {k: p for k, p in agg.named_parameters()}
         params["pooled_feature_mapper.weight"] = mapper_weight
-        params["pooled_feature_mapper.bias"] = mapper_bias if mapper_bias is not None else torch.zeros(F, device=dev)
+        if mapper_bias is None:  # one cached zero row (a fresh tensor per call would change the fingerprint below every time)
+            zb = agg.__dict__.get("_zero_mapper_bias")
+            if zb is None or zb.device != dev or zb.numel() != F:
+                zb = torch.zeros(F, device=dev)
+                agg.__dict__["_zero_mapper_bias"] = zb
+            mapper_bias_t = zb
+        else:
+            mapper_bias_t = mapper_bias
+        params["pooled_feature_mapper.bias"] = mapper_bias_t
         key = (dev, int(resol), float(volume_extent), F, tuple(int(a.channels) for a in arr))
         versions = tuple((k, p.data_ptr(), p._version) for k, p in params.items())
         if agg._native is None or agg._native[1] != key:

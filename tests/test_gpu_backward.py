@@ -193,3 +193,51 @@ def test_forward_train_and_backward_taped_equal_backward(gu):
     from holo_diffusion_amd._lib import HoloError
     with pytest.raises(HoloError):
         net.backward_taped(G)  # the tape is consumed
+
+
+def test_tape_does_not_survive_a_handle_switch_or_a_weight_update(gu):
+    """A tape belongs to ONE native handle and ONE set of packed weights (advisor, round 4): a forward at another grid size
+    between the two halves destroys and re-creates the handle, an in-place parameter update + any forward re-packs the
+    weights - in both cases `loss.backward()` must fall back to the full backward (same gradients as a fresh call), and an
+    explicit backward_taped must raise instead of handing the freed handle to the library."""
+    if os.environ.get("HOLO_TEST_EMU") == "1":
+        pytest.skip("backward tests run on the device")
+    from holo_diffusion_amd._lib import HoloError
+    cfg = uo.UNetCfg(image_size=8, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2, channel_mult=(1, 2),
+                     attention_resolutions=(2,), num_heads=2)
+    net, _ = gu.make_unet(cfg, seed=5)
+    shape = (1, cfg.in_channels) + (cfg.image_size,) * 3
+    x = torch.from_numpy(np_noise(1, shape)).to(gu.DEV)
+    x16 = torch.from_numpy(np_noise(3, (1, cfg.in_channels, 16, 16, 16))).to(gu.DEV)
+    t = torch.tensor([437], dtype=torch.int64, device=gu.DEV)
+    G = torch.from_numpy(np_noise(2, shape)).to(gu.DEV)
+    _, gx_ref, pg_ref = net.backward(x, t, G)
+    # (1) explicit halves with a size switch between them
+    net.forward_train(x, t)
+    with torch.no_grad():
+        net(x16, t)  # another plan: the 8^3 handle is destroyed
+    with pytest.raises(HoloError):
+        net.backward_taped(G)
+    # (2) the autograd node across a size switch: falls back to holo_unet_backward at the node's own size
+    net.requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = net(xr, t)
+    with torch.no_grad():
+        net(x16, t)
+    (y * G).sum().backward()
+    assert torch.equal(xr.grad, gx_ref)
+    for k, p in net._net.named_parameters():
+        assert torch.equal(p.grad, pg_ref[k]), k
+        p.grad = None
+    # (3) an in-place update + a forward between the halves: backward differentiates the UPDATED net, forward re-run
+    xr = x.clone().requires_grad_(True)
+    y = net(xr, t)
+    with torch.no_grad():
+        w = dict(net._net.named_parameters())["out.2.weight"]
+        w.mul_(0.5)
+        net(x, t)  # re-packs the forward weights
+    (y * G).sum().backward()
+    _, gx_new, pg_new = net.backward(x, t, G)
+    assert torch.equal(xr.grad, gx_new)
+    for k, p in net._net.named_parameters():
+        assert torch.equal(p.grad, pg_new[k]), k
