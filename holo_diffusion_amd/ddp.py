@@ -69,12 +69,25 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], group: Optional[dist.Pro
     return grads
 
 
+# parameter-gradient dicts of a training step, by producer: ``training_backward`` ("unet", "render_mlp") and
+# ``pool_views_backward`` ("pooled_feature_mapper", "feature_aggregator"); everything else in those dicts ("voxel_features" /
+# "voxel_grid", "image_features") is a per-rank ACTIVATION gradient and is never exchanged
+PARAMETER_GRADIENT_KEYS = ("unet", "render_mlp", "pooled_feature_mapper", "feature_aggregator")
+
+
 def allreduce_training_gradients(out: dict, group: Optional[dist.ProcessGroup] = None,
-                                 bucket_bytes: int = DEFAULT_BUCKET_BYTES) -> dict:
-    """The exchange for the dict ``HoloDiffusionModel.training_backward`` returns: the denoiser's and the RenderMLP's
-    parameter gradients are averaged over the ranks (one bucket sequence over both), the per-rank grid gradients are
-    left alone (every rank trains on its own scene batch)."""
-    merged = {("unet." + k): v for k, v in out["unet"].items()}
-    merged.update({("render_mlp." + k): v for k, v in out["render_mlp"].items()})
+                                 bucket_bytes: int = DEFAULT_BUCKET_BYTES, encoder: Optional[dict] = None) -> dict:
+    """The exchange for the dict ``HoloDiffusionModel.training_backward`` returns, optionally together with the dict of
+    ``HoloDiffusionModel.pool_views_backward`` (``encoder``; its entries may also already sit in ``out``): the denoiser's,
+    the RenderMLP's, the ``pooled_feature_mapper``'s and the learnt feature aggregator's parameter gradients are averaged
+    over the ranks in ONE bucket sequence (what DistributedDataParallel does for every parameter of the reference model,
+    experiment.py:255-260); the per-rank grid / feature-map gradients are left alone (every rank trains on its own scene
+    batch).  A ``None`` gradient (a bias-free mapper) is skipped - identically on every rank."""
+    merged: Dict[str, torch.Tensor] = {}
+    for src in (out, encoder or {}):
+        for group_name in PARAMETER_GRADIENT_KEYS:
+            for k, v in (src.get(group_name) or {}).items():
+                if v is not None:
+                    merged[group_name + "." + k] = v
     allreduce_gradients(merged, group=group, bucket_bytes=bucket_bytes, average=True)
     return out

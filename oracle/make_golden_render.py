@@ -11,7 +11,8 @@ PyTorch3D at module top, so none of them can be imported; but three pieces are p
   * ``RenderMLP.get_normals``        holo_voxel_grid_implicit_function.py:131-145 (autograd of the summed density)
   * ``HoloVoxelGridImplicitFunction.forward``  :182-269 (the in-tree body: dummy directions, normalisation, expansion over the
                                      points, [colour | view-point independent features] concat, aux normals)
-  * ``MLPMeanFeatureAggregator`` + ``_get_point_to_source_camera_ray_dirs``   custom_modules.py:162-334
+  * ``MLPMeanFeatureAggregator`` + ``_get_point_to_source_camera_ray_dirs``   custom_modules.py:162-334 (forward, and - under
+                                     torch autograd, with the model's mapper + tanh on top - its gradients)
   * ``_images_from_preds`` + ``_stack_images``                               flyaround.py:422-500
 
 This script takes their source text out of the reference files with ``ast`` (nothing is copied into the repository),
@@ -343,6 +344,103 @@ def golden_mlp_mean(ns):
     np.savez_compressed(os.path.join(GOLD, "ref_mlp_mean_aggregator.npz"), **out)
 
 
+def golden_mlp_mean_backward(ns):
+    """Gradients of the reference's ``MLPMeanFeatureAggregator`` (custom_modules.py:162-293, AST-executed) + the model's
+    ``pooled_feature_mapper`` + ``tanh`` (holo_diffusion_model.py:340-373: plain torch ops) under torch autograd, for a
+    random cotangent on the voxel grid -> tests/golden/ref_mlp_mean_backward.npz: what ``holo_mlp_mean_backward`` (and the
+    oracle's own autograd) are checked against.  The per-view samples the aggregator consumes come from the oracle's
+    restatement of PyTorch3D's ViewSampler (projection + bilinear grid_sample: UNPINNED, differentiable torch ops), so the
+    feature-map gradients chain the reference's aggregator gradient through the restated sampler."""
+    from oracle import viewpool_oracle as vo
+    R, n_src, Fdim, dim_out, n_hidden, n_harm, extent = 8, 3, 16, 24, 128, 3, 8.0
+    maps = {"res": torch.tanh(torch.from_numpy(np_noise(501, (n_src, 16, 20, 24)))),
+            "mask": torch.sigmoid(torch.from_numpy(np_noise(502, (n_src, 1, 30, 30)))),
+            "rgb": torch.sigmoid(torch.from_numpy(np_noise(503, (n_src, 3, 17, 13))))}
+    D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
+    cams = ro.simple_360_cameras(n_src, radius=6.0)
+    shapes = vo.mlp_mean_param_shapes(D, n_hidden, dim_out)
+    sd = synth_state_dict(shapes, 909)
+    for k in shapes:
+        if k.endswith("bias"):
+            sd[k] = 0.1 * torch.from_numpy(np_noise(len(k) + 40, shapes[k]))
+    mw = synth_state_dict({"w": (Fdim, dim_out)}, 19)["w"]
+    mb = 0.1 * torch.from_numpy(np_noise(14, (Fdim,)))
+    g = torch.from_numpy(np_noise(323, (1, Fdim, R, R, R)))
+    pts = vo.coord_grid(R, extent)
+    P = pts.shape[0]
+
+    def sampled_of(leaves):  # the oracle's ViewSampler restatement: {name: (1, n_src, P, C)}
+        ndc = torch.stack([vo.project_ndc(pts, cams["R"][v], cams["T"][v], cams["focal"][v], cams["pp"][v], 1e-2)
+                           for v in range(n_src)])
+        return {k: torch.stack([vo.ndc_grid_sample(f[v], ndc[v]) for v in range(n_src)])[None] for k, f in leaves.items()}
+
+    # REFERENCE QUIRK (recorded, not reproduced): with the class default checkpointed_mlp = True the MLP pass goes through
+    # torch.utils.checkpoint.checkpoint(_mlp_pass, feats_sampled, ray_dirs, aggr_weights) (custom_modules.py:266-272) whose
+    # only differentiable input is the DICT feats_sampled.  The re-entrant checkpoint - the only kind in the pinned
+    # torch 1.13.1 (environment.yaml:119) - looks for requires_grad among its TENSOR arguments only, finds none ("None of the
+    # inputs have requires_grad=True. Gradients will be None") and returns a detached output: in the released training setup
+    # the aggregator's parameters and the image features receive NO gradient through the pooled grid.  The gradients
+    # recorded here are those of the class body itself (checkpointed_mlp = False: the same arithmetic without the
+    # checkpoint wrapper), which is what holo_mlp_mean_backward computes; the detachment is asserted below on this torch.
+    import warnings
+    masks = torch.ones(1, n_src, P, 1)  # masked_sampling false (configs/hydrant.yaml view_sampler_args)
+    camera = Cameras(cams["R"], cams["T"])
+    aggs = {}
+    for ck in (True, False):
+        cls = type("MLPMeanFeatureAggregator", (ns["MLPMeanFeatureAggregator"],),
+                   dict(exclude_target_view=False, exclude_target_view_mask_features=False, n_hidden=n_hidden, dim_out=dim_out,
+                        n_harmonic_functions_ray=n_harm, checkpointed_mlp=ck))
+        a = cls.__new__(cls)
+        a.__post_init__()
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a(sampled_of(maps), masks, camera=camera, pts=pts[None])  # materialises the LazyLinear layers
+        assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == shapes
+        a.load_state_dict(sd)
+        aggs[ck] = a.train()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            detached = not aggs[True](sampled_of({k: v.clone().requires_grad_(True) for k, v in maps.items()}), masks,
+                                      camera=camera, pts=pts[None]).requires_grad
+        except Exception as e:  # a torch that refuses checkpoint() without use_reentrant
+            detached = None
+            print("checkpointed_mlp=True could not be executed on this torch:", type(e).__name__)
+    print(f"reference quirk: checkpointed_mlp=True returns a DETACHED aggregate under the re-entrant checkpoint: {detached}")
+    agg = aggs[False]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+    mwl, mbl = mw.clone().requires_grad_(True), mb.clone().requires_grad_(True)
+    aggregated = agg(sampled_of(leaves), masks, camera=camera, pts=pts[None])  # (1, 1, P, dim_out)
+    out = torch.tanh(F.linear(aggregated[0, 0], mwl, mbl).t().reshape(1, Fdim, R, R, R))
+    out.backward(g)
+    ref_p = {k: v.grad.clone() for k, v in agg.named_parameters()}
+    assert set(ref_p) == set(shapes) and all(v is not None for v in ref_p.values())
+    # the oracle's autograd on the same inputs (pins the oracle's BACKWARD to the reference class)
+    l2 = {k: v.clone().requires_grad_(True) for k, v in maps.items()}
+    psd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    mw2, mb2 = mw.clone().requires_grad_(True), mb.clone().requires_grad_(True)
+    o2 = vo.voxel_features_from_views_mlp_mean(l2, cams, psd, mw2, mb2, R, extent, n_harmonic=n_harm)
+    o2.backward(g)
+    worst = float((o2.detach() - out.detach()).abs().max())
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))  # noqa: E731
+    errs = {k: rel(psd[k].grad, ref_p[k]) for k in shapes}
+    errs.update({"maps." + k: rel(l2[k].grad, leaves[k].grad) for k in maps})
+    errs.update({"mapper.w": rel(mw2.grad, mwl.grad), "mapper.b": rel(mb2.grad, mbl.grad)})
+    print(f"MLPMeanFeatureAggregator backward: oracle forward vs reference {worst:.2e}; worst relative gradient difference "
+          f"{max(errs.values()):.2e} ({max(errs, key=errs.get)})")
+    assert worst < 3e-6 and max(errs.values()) < 2e-5, errs
+    res = {"dims": np.array([R, n_src, Fdim, dim_out, n_hidden, n_harm]), "volume_extent": np.array(extent), "cot": g.numpy(),
+           "out": out.detach().numpy(), "mapper.weight": mw.numpy(), "mapper.bias": mb.numpy(),
+           "grad.mapper.weight": mwl.grad.numpy(), "grad.mapper.bias": mbl.grad.numpy(),
+           "checkpointed_output_is_detached": np.array(-1 if detached is None else int(detached))}
+    res.update({"cam." + k: v.numpy() for k, v in cams.items()})
+    res.update({"maps." + k: v.numpy() for k, v in maps.items()})
+    res.update({"grad.maps." + k: v.grad.numpy() for k, v in leaves.items()})
+    res.update({"param." + k: v.numpy() for k, v in sd.items()})
+    res.update({"grad.param." + k: v.numpy() for k, v in ref_p.items()})
+    np.savez_compressed(os.path.join(GOLD, "ref_mlp_mean_backward.npz"), **res)
+
+
 def golden_images_from_preds(ns):
     from holo_diffusion_amd.flyaround_output import images_from_preds
     N, H, W = 2, 6, 8
@@ -408,6 +506,7 @@ def main():
     ns2 = build_namespace2(ns)
     golden_implicit_function(ns2)
     golden_mlp_mean(ns2)
+    golden_mlp_mean_backward(ns2)
     golden_images_from_preds(ns2)
 
     n = torch.nn.functional.normalize(torch.from_numpy(np_noise(7, (4, 3, 9, 13))), dim=1) * 0.9

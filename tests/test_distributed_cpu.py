@@ -96,6 +96,17 @@ def _ddp_worker(rank, world, port, bucket_bytes, q):
         allreduce_training_gradients(out, bucket_bytes=bucket_bytes)
         ok = ok and torch.allclose(out["render_mlp"]["w"], torch.full((5,), 0.5)) and \
             torch.allclose(out["unet"]["c"], 1.5 * base["c"]) and torch.all(out["voxel_grid"] == float(rank)).item()
+        # the encoder side (pool_views_backward): mapper + learnt aggregator are parameters, the feature maps are not
+        enc = {"image_features": {"res": torch.full((3,), float(rank))},
+               "pooled_feature_mapper": {"weight": torch.full((4, 6), float(2 * rank)), "bias": None},
+               "feature_aggregator": {"_last.weight": base["b.weight"] * (rank + 1)}}
+        out2 = {"unet": {"c": base["c"] * (rank + 1)}, "render_mlp": {}, "voxel_features": torch.full((2,), float(rank))}
+        allreduce_training_gradients(out2, bucket_bytes=bucket_bytes, encoder=enc)
+        ok = ok and torch.allclose(enc["pooled_feature_mapper"]["weight"], torch.full((4, 6), 1.0)) and \
+            enc["pooled_feature_mapper"]["bias"] is None and \
+            torch.allclose(enc["feature_aggregator"]["_last.weight"], 1.5 * base["b.weight"], rtol=1e-6, atol=1e-6) and \
+            torch.all(enc["image_features"]["res"] == float(rank)).item() and torch.allclose(out2["unet"]["c"], 1.5 * base["c"]) and \
+            torch.all(out2["voxel_features"] == float(rank)).item()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

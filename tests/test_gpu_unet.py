@@ -497,3 +497,105 @@ def test_repeated_forwards_are_bit_identical(gu, compute, image, batch):
             assert gu.rel_err(y, ref) < (2e-2 if compute == "bf16" else TOL)
         assert torch.equal(y, first), (compute, image, batch, i, float((y - first).abs().max()))
         del junk
+
+
+def _res_block_f64(sd, p, x, emb, slabs):
+    """ResBlock (unet.py:236-256, scale-shift norm) in float64 end to end - F.group_norm on doubles, not the reference's
+    fp32 GroupNorm32 - evaluated on the output planes of every (z0, z1) in ``slabs``: the second float64 convolution runs on
+    a slab's planes + one halo plane each side (the GroupNorm statistics need h on the whole grid, so the first
+    convolution is the full one, computed once)."""
+    import torch.nn.functional as F
+    d = {k: v.double() for k, v in sd.items() if k.startswith(p + ".")}
+    D = x.shape[2]
+    h = F.silu(F.group_norm(x, 32, d[p + ".in_layers.0.weight"], d[p + ".in_layers.0.bias"], eps=1e-5))
+    h = F.conv3d(h, d[p + ".in_layers.2.weight"], d[p + ".in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), d[p + ".emb_layers.1.weight"], d[p + ".emb_layers.1.bias"])[..., None, None, None]
+    scale, shift = torch.chunk(e, 2, dim=1)
+    h = F.silu(F.group_norm(h, 32, d[p + ".out_layers.0.weight"], d[p + ".out_layers.0.bias"], eps=1e-5) * (1 + scale) + shift)
+    outs = []
+    for z0, z1 in slabs:
+        lo, hi = max(z0 - 1, 0), min(z1 + 1, D)
+        pad = (1, 1, 1, 1, 1 if lo == z0 else 0, 1 if hi == z1 else 0)  # zero padding only at the true grid faces
+        y = F.conv3d(F.pad(h[:, :, lo:hi], pad), d[p + ".out_layers.3.weight"], d[p + ".out_layers.3.bias"])
+        xs = x[:, :, z0:z1]
+        if (p + ".skip_connection.weight") in d:
+            xs = F.conv3d(xs, d[p + ".skip_connection.weight"], d[p + ".skip_connection.bias"])
+        outs.append(xs + y)
+    return outs
+
+
+@pytest.mark.parametrize("image,cin,mc,mult,slab", [
+    (64, 32, 64, (1, 1, 1), 4),   # the 64^3 level of the north-star net: 64 -> 64 and (64 + 64) -> 64 with fused skip
+    (16, 16, 256, (1, 2), 8),     # long K: (512 + 256) -> 256 at 16^3 and (512 + 512) -> 512 at 8^3 (split-K): K = 27 x 1024
+])
+def test_three_axis_winograd_vs_float64(gu, image, cin, mc, mult, slab, monkeypatch):
+    """The accuracy claim of DESIGN.md for the F(2x2x2, 3x3x3) form, as a test: every single-ResBlock block of a net whose
+    stride-1 convolutions run on conv_wino3_kernel is compared with the SAME block evaluated in float64 on the kernel's own
+    block input (so nothing compounds and the figure is the block's own rounding), once for the default plan and once for
+    the direct (27-tap) kernels; the Winograd form may be at most 2x the direct form's error (+ 1e-7 of the block's scale)
+    and both stay below 2e-5 (observed 1e-6 ... 5e-6)."""
+    if gu.EMU:
+        image, cin, mc, mult, slab = 16, 16, 64, (1, 2), 4
+    cfg = uo.UNetCfg(image_size=image, in_channels=cin, out_channels=cin, model_channels=mc, num_res_blocks=1,
+                     channel_mult=mult, attention_resolutions=(), num_heads=2)
+    inputs, middle, outputs, _ = uo.unet_structure(cfg)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(23, (1, cin, image, image, image)))
+    t = torch.tensor([407], dtype=torch.int64)
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+
+    def block_errors(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net, sd = gu.make_unet(cfg, seed=31)
+        with torch.no_grad():
+            net(x.to(gu.DEV), t.to(gu.DEV))
+        emb = uo.time_embed(sd, cfg, t).double()
+        # block output shapes without running the oracle at the large size: channels from the structure, size from the level
+        fetched, errs, size, hs = {}, {}, image, []
+        def fetch(tag, ch, sz):
+            if tag not in fetched:
+                fetched[tag] = net.fetch_block(tag, (1, ch, sz, sz, sz)).cpu()
+            return fetched[tag]
+        prev = None
+        for i, layers in enumerate(inputs):
+            tag = f"input_blocks.{i}"
+            if any(b.kind == "down" for b in layers):
+                size //= 2
+            out = fetch(tag, layers[-1].cout, size)
+            if len(layers) == 1 and layers[0].kind == "res":
+                errs[tag] = (layers[0].prefix, prev, out)
+            hs.append((out, size))
+            prev = out
+        prev = fetch("middle_block", middle[-1].cout, size)
+        for i, layers in enumerate(outputs):
+            tag = f"output_blocks.{i}"
+            skip, ssize = hs.pop()
+            assert ssize == size
+            xin = torch.cat([prev, skip], dim=1)
+            osize = size * 2 if any(b.kind == "up" for b in layers) else size
+            out = fetch(tag, layers[-1].cout, osize)
+            if len(layers) == 1 and layers[0].kind == "res":
+                errs[tag] = (layers[0].prefix, xin, out)
+            size, prev = osize, out
+        res = {}
+        for tag, (p, xin, out) in errs.items():
+            D = xin.shape[2]
+            worst, scale = 0.0, 0.0
+            slabs = ((0, slab), (D // 2 - 1, D // 2 - 1 + slab), (D - slab, D)) if D > 2 * slab else ((0, D),)
+            for zs, ref in zip(slabs, _res_block_f64(sd, p, xin.double(), emb, slabs)):
+                worst = max(worst, float((out[:, :, zs[0]:zs[1]].double() - ref).abs().max()))
+                scale = max(scale, float(ref.abs().max()))
+            res[tag] = worst / scale
+        kinds = {o["kernel"] for o in net.time_ops(1, 1, gu.DEV) if o["op"] == "conv"} if not gu.EMU else set()
+        return res, kinds
+
+    e_w3, k_w3 = block_errors({"HOLO_CONV_WINO3_MIN_ITEMS": "1"})
+    e_dir, k_dir = block_errors({"HOLO_CONV_WINO3": "0", "HOLO_CONV_WINO": "0", "HOLO_CONV_WINO_SMALL": "0"})
+    if not gu.EMU:
+        assert "conv_wino3_kernel" in k_w3 and not any(k.startswith("conv_wino") for k in k_dir), (k_w3, k_dir)
+    assert e_w3 and set(e_w3) == set(e_dir)
+    for tag in e_w3:
+        print(f"  {tag}: three-axis Winograd {e_w3[tag]:.2e}, direct {e_dir[tag]:.2e} (relative to the block's scale, vs float64)")
+        assert e_w3[tag] < 2e-5 and e_dir[tag] < 2e-5, tag
+        assert e_w3[tag] <= 2.0 * e_dir[tag] + 1e-7, tag

@@ -299,6 +299,70 @@ def test_mlp_mean_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius,
         assert rel(got["image_features"][k], leaves[k].grad) < 1e-3, (k, rel(got["image_features"][k], leaves[k].grad))
 
 
+def _ref_mlp_mean_backward_fixture():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_mlp_mean_backward.npz"))
+    R, n_src, F, dim_out, n_hidden, n_harm = (int(v) for v in g["dims"])
+    pick = lambda pre: {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}  # noqa: E731
+    return g, (R, n_src, F, dim_out, n_hidden, n_harm), pick
+
+
+def test_oracle_mlp_mean_backward_vs_reference_gradients():
+    """tests/golden/ref_mlp_mean_backward.npz: gradients of the REFERENCE's MLPMeanFeatureAggregator (custom_modules.py:162-293,
+    AST-executed by oracle/make_golden_render.py) + pooled_feature_mapper + tanh under torch autograd.  The oracle's autograd
+    on the same inputs reproduces them (bit-equal when the fixture was written: 1e-6 here, another host's reductions), which
+    pins the checker of holo_mlp_mean_backward to the reference class.  The fixture also records the reference's
+    checkpoint quirk (checkpointed_mlp = True detaches the aggregate under the re-entrant checkpoint of torch 1.13.1)."""
+    g, (R, n_src, F, dim_out, n_hidden, n_harm), pick = _ref_mlp_mean_backward_fixture()
+    assert int(g["checkpointed_output_is_detached"]) == 1
+    cams = pick("cam.")
+    leaves = {k: v.clone().requires_grad_(True) for k, v in pick("maps.").items()}
+    psd = {k: v.clone().requires_grad_(True) for k, v in pick("param.").items()}
+    mw, mb = pick("mapper.")["weight"].clone().requires_grad_(True), pick("mapper.")["bias"].clone().requires_grad_(True)
+    out = vo.voxel_features_from_views_mlp_mean(leaves, cams, psd, mw, mb, R, float(g["volume_extent"]), n_harmonic=n_harm)
+    assert (out.detach() - torch.from_numpy(g["out"])).abs().max() < 2e-6
+    out.backward(torch.from_numpy(g["cot"]))
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))  # noqa: E731
+    for k, r in pick("grad.param.").items():
+        assert rel(psd[k].grad, r) < 1e-5, k
+    for k, r in pick("grad.maps.").items():
+        assert rel(leaves[k].grad, r) < 1e-5, k
+    assert rel(mw.grad, pick("grad.mapper.")["weight"]) < 1e-5 and rel(mb.grad, pick("grad.mapper.")["bias"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_mlp_mean_view_pool_backward_vs_reference_gradients():
+    """holo_mlp_mean_backward against the gradients of the reference class itself (the fixture above): every aggregator
+    parameter, the mapper and the three source-view feature maps at 1e-3 of each tensor's scale; forward at 1e-4."""
+    import tests.gpu_utils as gu
+    g, (R, n_src, F, dim_out, n_hidden, n_harm), pick = _ref_mlp_mean_backward_fixture()
+    cams_d, maps, sd = pick("cam."), pick("maps."), pick("param.")
+    model = hda.HoloDiffusionModel(
+        resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False, diffusion_enabled=False,
+        render_image_width=8, render_image_height=8, volume_extent=float(g["volume_extent"]),
+        view_pooler_args=dict(feature_aggregator_class_type="MLPMeanFeatureAggregator",
+                              feature_aggregator_MLPMeanFeatureAggregator_args=dict(
+                                  n_hidden=n_hidden, dim_out=dim_out, n_harmonic_functions_ray=n_harm)))
+    full = {"pooled_feature_mapper.weight": pick("mapper.")["weight"], "pooled_feature_mapper.bias": pick("mapper.")["bias"]}
+    full.update({"view_pooler.feature_aggregator." + k: v for k, v in sd.items()})
+    res = model.load_state_dict(full, strict=False)
+    assert not res.unexpected_keys
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    dev = {k: v.to(gu.DEV) for k, v in maps.items()}
+    out = model.pool_views_to_voxel_features(dev, cams.to(gu.DEV))
+    assert (out.cpu() - torch.from_numpy(g["out"])).abs().max() < 1e-4
+    got = model.pool_views_backward(dev, cams.to(gu.DEV), torch.from_numpy(g["cot"]).to(gu.DEV))
+    rel = lambda a, b: float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))  # noqa: E731
+    assert rel(got["pooled_feature_mapper"]["weight"], pick("grad.mapper.")["weight"]) < 1e-3
+    assert rel(got["pooled_feature_mapper"]["bias"], pick("grad.mapper.")["bias"]) < 1e-3
+    ref_p = pick("grad.param.")
+    assert set(got["feature_aggregator"]) == set(ref_p)
+    for k, r in ref_p.items():
+        assert rel(got["feature_aggregator"][k], r) < 1e-3, (k, rel(got["feature_aggregator"][k], r))
+    for k, r in pick("grad.maps.").items():
+        assert rel(got["image_features"][k], r) < 1e-3, (k, rel(got["image_features"][k], r))
+
+
 @pytest.mark.gpu
 def test_reconstruction_flyaround_from_a_dataset_sequence(tmp_path):
     """render_flyaround(dataset, sequence_name, model, sample_mode=False) - the reconstruction mode of
