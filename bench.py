@@ -118,14 +118,30 @@ def cpu_baseline(w, usd, msd, budget_s=30.0):
             x = orc.p_sample(model, x, torch.tensor([998 - i]), eps)["sample"]
         return n / (time.time() - t0), n
 
-    # all hardware threads (the 8d definition); torch's CPU conv3d/GEMM often stop scaling far below the thread count of
-    # the GPU box, so a second sample at <=32 threads is taken and the FASTER of the two is the reported baseline
-    by_threads = {}
-    sps, n = steps(hw_threads, budget_s * 0.35)
-    by_threads[hw_threads] = sps
+    # all hardware threads (the 8d definition) vs <= 32 threads: torch's CPU conv3d / GEMM stop scaling far below the thread
+    # count of the GPU box (round 4: ONE step at 256 threads took ~80 s of a 177 s driver run, 40x slower than at 32).  A probe
+    # at 16^3 (1/64 of the work, same net) decides whether the all-threads sample is worth taking at full size: it is taken
+    # only when the probe says all threads are not clearly slower; otherwise the probe's ratio is recorded and the <= 32
+    # thread sample is the baseline.  The FASTER of the samples taken is reported.
+    by_threads, probe, n2 = {}, None, 0
+    n = 0
     if hw_threads > 32:
-        sps2, n2 = steps(32, budget_s * 0.25)
+        pcfg = uo.UNetCfg(image_size=16, in_channels=w["feature_size"], out_channels=w["feature_size"],
+                          model_channels=w["model_channels"], num_res_blocks=2, channel_mult=w["channel_mult"],
+                          attention_resolutions=w["attention_resolutions"], num_heads=2)
+        px = torch.from_numpy(np_noise(3, (1, w["feature_size"], 16, 16, 16)))
+        probe = {}
+        for th in (32, hw_threads):
+            torch.set_num_threads(th)
+            uo.unet_forward(usd, pcfg, px, torch.tensor([500]))
+            t0 = time.time()
+            uo.unet_forward(usd, pcfg, px, torch.tensor([499]))
+            probe[str(th)] = 1.0 / max(time.time() - t0, 1e-6)
+        sps2, n2 = steps(32, budget_s * 0.5)
         by_threads[32] = sps2
+    if probe is None or probe[str(hw_threads)] >= 0.5 * probe["32"]:
+        sps, n = steps(hw_threads, budget_s * 0.35)
+        by_threads[hw_threads] = sps
     cores = max(by_threads, key=by_threads.get)
     steps_per_s = by_threads[cores]
     torch.set_num_threads(cores)
@@ -139,8 +155,12 @@ def cpu_baseline(w, usd, msd, budget_s=30.0):
     return {"value": steps_per_s, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
             "rays_per_sec": rays_per_s, "host_hw_threads": hw_threads, "host_physical_cores": phys,
             "steps_per_s_by_threads": {str(k): v for k, v in by_threads.items()},
-            "sample": f"oracle DDPM steps (UNet fwd + posterior) at {w['resol']}^3x{w['feature_size']} after 1 warm-up, "
-                      f"{n} timed at {hw_threads} threads" + (f" and {n2} at 32 threads" if hw_threads > 32 else "")
+            "thread_scaling_probe_16cubed_forwards_per_s": probe,
+            "sample": f"oracle DDPM steps (UNet fwd + posterior) at {w['resol']}^3x{w['feature_size']} after 1 warm-up: "
+                      + (f"{n} timed at {hw_threads} threads" if n else
+                         f"the all-threads ({hw_threads}) sample was skipped - a 16^3 probe ran {probe['32'] / probe[str(hw_threads)]:.1f}x "
+                         f"slower there than at 32 threads")
+                      + (f", {n2} timed at 32 threads" if n2 else "")
                       + f" (reported: {cores} threads, the faster); one {Hs}x{Ws} frame (64 coarse + 128 fine samples"
                       f"/ray) of a {w['resol']}^3 grid at {cores} threads; torch CPU"}
 
@@ -300,6 +320,9 @@ def main():
     ap.add_argument("--compute-dtype", choices=["f32", "bf16", "f32_bf16x3"], default="f32",
                     help="f32 = the reported line (reference arithmetic); bf16 = opt-in bf16 products / fp32 accumulate in "
                          "the 3x3x3 convolutions (side measurement for the bf16 configurations)")
+    ap.add_argument("--noise", choices=["device", "torch"], default="device",
+                    help="per-step noise of the timed chain: device = drawn inside the step kernel (holo_ddpm_step_philox, the "
+                         "perf mode); torch = torch.randn_like + holo_ddpm_step (the reference's draw; also timed as a side figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true", help="skip the 128^3 bf16 side workload (BASELINE configs[4] size)")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the side measurements of the opt-in arithmetic modes")
@@ -337,9 +360,14 @@ def main():
     img = torch.randn(*shape, device=device)
     ts = torch.arange(999, 999 - (K + Wm), -1, device=device, dtype=torch.int64).clamp_min(0)[:, None].contiguous()
 
-    def one_step(x, k):
+    diff.device_noise_seed, diff.device_noise_stream = 42, rank  # (perf mode: Philox noise inside the step kernel)
+    t_host = [max(999 - k, 0) for k in range(K + Wm)]
+
+    def one_step(x, k, mode=args.noise):
         t = ts[k]
         out = net(x, t)
+        if mode == "device":  # one kernel: clamp + posterior mean + in-kernel Philox noise; pred_xstart is not materialised
+            return diff._step_device_noise(x, t, out, t_host[k], True, want_pred=False)[0]
         eps = torch.randn_like(x)
         sample, _ = diff._step(x, t, out, eps, True)
         return sample
@@ -358,6 +386,18 @@ def main():
     dt = max_over_ranks(dt, world, device)
     assert torch.isfinite(img).all()
     steps_per_s = world * K / dt
+    # the other noise path over the same K timesteps (side figure, this rank only)
+    other_mode = "torch" if args.noise == "device" else "device"
+    with torch.no_grad():
+        xo = torch.randn(*shape, device=device)
+        for k in range(min(3, Wm)):
+            xo = one_step(xo, k, other_mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(Wm, Wm + K):
+            xo = one_step(xo, k, other_mode)
+        torch.cuda.synchronize()
+        steps_per_s_other = K / (time.perf_counter() - t0)
     per_rank_steps_per_s = [K / dt_own]
     if world > 1:  # every rank's own rate, gathered for the line rank 0 prints
         tr = torch.tensor([K / dt_own], dtype=torch.float64, device=device)
@@ -654,6 +694,10 @@ def main():
             "frame_gather": gather, "grad_exchange": grad_exchange,
             "rccl_world_size": (gather or {}).get("rccl_world_size", 1), "gather_ms": (gather or {}).get("gather_ms"),
             "per_rank_steps_per_s": per_rank_steps_per_s,
+            "step_noise": {"timed": args.noise, "what": {"device": "Philox4x32-10 + Box-Muller inside the step kernel "
+                                                                   "(holo_ddpm_step_philox; no randn launch, pred_xstart not written)",
+                                                         "torch": "torch.randn_like + holo_ddpm_step (the reference's draw)"}[args.noise],
+                           f"steps_per_s_with_{other_mode}_noise_one_rank": steps_per_s_other},
             "side_workloads": side,
             "opt_in_modes_not_reported": alt,
         }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
 HOLO_DTYPE_F32_BF16X3 = 2
-ABI_VERSION = 4  # include/holo_abi.h HOLO_ABI_VERSION
+ABI_VERSION = 5  # include/holo_abi.h HOLO_ABI_VERSION
 
 
 class HoloError(RuntimeError):
@@ -102,6 +102,8 @@ SIGNATURES = {
     "holo_unet_backward_taped": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_unet_get_grad": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _vp, _vp]),
     "holo_ddpm_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "holo_ddpm_step_philox": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int,
+                                        _vp, _vp, _vp, _vp]),
     "holo_tanh": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "holo_clip": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_int64, _vp]),
     "holo_renderer_create": (C.c_int, [_vp, C.POINTER(HoloRenderCfg), C.POINTER(_vp)]),

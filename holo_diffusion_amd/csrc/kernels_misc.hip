@@ -374,6 +374,81 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
   *reinterpret_cast<float4*>(pred + o) = m;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same update with the noise drawn IN the kernel (perf mode; gaussian_diffusion.py:498 `th.randn_like(x)`, :604): a
+// thread's four elements take the four outputs of ONE Philox4x32-10 block - counter (element quad low, high, sample,
+// stream offset), key (seed low, seed high) - turned into standard normals by two Box-Muller pairs.  A draw depends on
+// nothing but (seed, offset, sample, element): bit-reproducible whatever the launch geometry; no generator state, no
+// separate randn launch, and the 4 B / element of noise never cross HBM (optionally written out for tests).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+// two uniforms -> two standard normals; u1 in (0, 1): 24 bits + half a step, so the logarithm is finite (|z| <= 5.9)
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  z0 = r * cs;
+  z1 = r * sn;
+}
+
+__global__ __launch_bounds__(256) void ddpm_step_philox_kernel(const float* __restrict__ tables, int T,
+                                                               const int64_t* __restrict__ timesteps, int64_t per,
+                                                               const float* __restrict__ x_t,
+                                                               const float* __restrict__ model_out, uint32_t seed_lo,
+                                                               uint32_t seed_hi, uint32_t offset, int clip,
+                                                               float* __restrict__ sample, float* __restrict__ pred,
+                                                               float* __restrict__ noise_out) {
+  const int b = blockIdx.y;
+  int64_t tt = holo_ld_sys(timesteps + b);
+  if (tt < 0) tt = 0;
+  if (tt >= T) tt = T - 1;
+  const float c1 = holo_ld_sys(tables + tt * 4 + 0);
+  const float c2 = holo_ld_sys(tables + tt * 4 + 1);
+  const float lv = holo_ld_sys(tables + tt * 4 + 2);
+  const float sig = tt != 0 ? expf(0.5f * lv) : 0.f;
+  const int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = qd * 4;
+  if (i >= per) return;
+  const int64_t o = (int64_t)b * per + i;
+  const float4 x = *reinterpret_cast<const float4*>(x_t + o);
+  float4 m = *reinterpret_cast<const float4*>(model_out + o);
+  uint32_t rnd[4];
+  philox4x32_10((uint32_t)qd, (uint32_t)((uint64_t)qd >> 32), (uint32_t)b, offset, seed_lo, seed_hi, rnd);
+  float4 e;
+  box_muller(rnd[0], rnd[1], e.x, e.y);
+  box_muller(rnd[2], rnd[3], e.z, e.w);
+  if (clip) {
+    m.x = fminf(fmaxf(m.x, -1.f), 1.f);
+    m.y = fminf(fmaxf(m.y, -1.f), 1.f);
+    m.z = fminf(fmaxf(m.z, -1.f), 1.f);
+    m.w = fminf(fmaxf(m.w, -1.f), 1.f);
+  }
+  float4 s;
+  s.x = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.x), __fmul_rn(c2, x.x)), __fmul_rn(sig, e.x));
+  s.y = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.y), __fmul_rn(c2, x.y)), __fmul_rn(sig, e.y));
+  s.z = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.z), __fmul_rn(c2, x.z)), __fmul_rn(sig, e.z));
+  s.w = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.w), __fmul_rn(c2, x.w)), __fmul_rn(sig, e.w));
+  *reinterpret_cast<float4*>(sample + o) = s;
+  if (pred) *reinterpret_cast<float4*>(pred + o) = m;
+  if (noise_out) *reinterpret_cast<float4*>(noise_out + o) = e;
+}
+
 // copy of a SMALL caller-provided tensor (biases, GroupNorm affine parameters, ...) with system-scope loads (holo_ld_sys)
 __global__ __launch_bounds__(256) void copy_sys_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -586,6 +661,20 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
   dim3 grid((unsigned)cdiv(per / 4, 256), (unsigned)batch);
   HOLO_LAUNCH(ddpm_step_kernel, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, noise, clip, sample,
               pred_xstart);
+  return 0;
+}
+
+int ddpm_step_philox_launch(const float* tables, int T, const int64_t* timesteps, int batch, int64_t per, const float* x_t,
+                            const float* model_out, uint64_t seed, uint64_t offset, int clip, float* sample,
+                            float* pred_xstart, float* noise_out, void* stream) {
+  if (per & 3) {
+    set_error("ddpm_step: elems_per_sample must be a multiple of 4");
+    return -1;
+  }
+  dim3 grid((unsigned)cdiv(per / 4, 256), (unsigned)batch);
+  // (the high half of the offset goes into the key: counters stay distinct for any 64-bit stream offset)
+  HOLO_LAUNCH(ddpm_step_philox_kernel, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, (uint32_t)seed,
+              (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), (uint32_t)offset, clip, sample, pred_xstart, noise_out);
   return 0;
 }
 

@@ -68,6 +68,14 @@ class ImplicitronGaussianDiffusion(Configurable):
     model_mean_type: ModelMeanType = ModelMeanType.START_X
     model_var_type: ModelVarType = ModelVarType.FIXED_SMALL
     schedule_sampler_type: str = "uniform"
+    # build-side extension (not a reference field).  None (default): the per-step noise is ``torch.randn_like`` / the
+    # caller's ``noise_sampler`` - the reference's draw, the parity path.  An integer: PERF MODE - ``p_sample`` /
+    # ``p_sample_loop*`` draw the noise inside the step kernel (``holo_ddpm_step_philox``: Philox4x32-10 keyed on this
+    # seed, counter = (element, sample, timestep); no randn launch, the noise never crosses HBM).  Statistically
+    # equivalent to, not bit-equal with, torch's generator; the initial x_T still comes from torch.  ``device_noise_stream``
+    # separates chains that share a seed (generate.py passes the sample index).
+    device_noise_seed: Optional[int] = None
+    device_noise_stream: int = 0
 
     def __init__(self, **kwargs):
         apply_config(self, kwargs)
@@ -148,6 +156,25 @@ class ImplicitronGaussianDiffusion(Configurable):
                                        runtime.ptr(pred), runtime.stream_ptr(dev)), "holo_ddpm_step")
         return sample, pred
 
+    def _step_device_noise(self, x, t, model_output, timestep_index: int, clip_denoised, want_pred=True, want_noise=False):
+        """The step with in-kernel Philox noise (perf mode): (sample, pred_xstart | None, noise | None)."""
+        runtime.require_device(x, "ImplicitronGaussianDiffusion")
+        L = runtime.lib()
+        dev = x.device
+        x = x.contiguous()
+        model_output = model_output.contiguous()
+        sample = torch.empty_like(x)
+        pred = torch.empty_like(x) if want_pred else None
+        noise = torch.empty_like(x) if want_noise else None
+        # stream offset: (chain id, timestep) - distinct for every step of every chain that shares the seed
+        offset = (int(self.device_noise_stream) << 32) | (int(timestep_index) & 0xFFFFFFFF)
+        _lib.check(L, L.holo_ddpm_step_philox(
+            runtime.ctx(dev), runtime.ptr(self._tables_on(dev)), self.num_timesteps, runtime.ptr(t), x.shape[0], x[0].numel(),
+            runtime.ptr(x), runtime.ptr(model_output), int(self.device_noise_seed) & 0xFFFFFFFFFFFFFFFF, offset,
+            1 if clip_denoised else 0, runtime.ptr(sample), runtime.ptr(pred) if want_pred else None,
+            runtime.ptr(noise) if want_noise else None, runtime.stream_ptr(dev)), "holo_ddpm_step_philox")
+        return sample, pred, noise
+
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         if model_kwargs is None:
             model_kwargs = {}
@@ -176,6 +203,9 @@ class ImplicitronGaussianDiffusion(Configurable):
         model_output = model(x, t, **model_kwargs)
         if denoised_fn is not None:
             model_output = denoised_fn(model_output)
+        if noise_sampler is None and self.device_noise_seed is not None:  # perf mode: noise drawn inside the kernel
+            sample, pred, noise = self._step_device_noise(x, t, model_output, int(t[0].item()), clip_denoised)
+            return {"sample": sample, "pred_xstart": pred, "noise": noise}  # ("noise": None - it never left the kernel)
         if noise_sampler is not None:
             noise = noise_sampler(int(t[0].item()), x.shape, x.device)  # same host sync as the reference (:495-496)
         else:
@@ -225,11 +255,14 @@ class ImplicitronGaussianDiffusion(Configurable):
                 model_output = model(img, t, **model_kwargs)
                 if denoised_fn is not None:
                     model_output = denoised_fn(model_output)
-                if noise_sampler is not None:
+                if noise_sampler is None and self.device_noise_seed is not None:  # perf mode (no host sync: indices[k] is host-side)
+                    sample, pred, eps = self._step_device_noise(img, t, model_output, indices[k], clip_denoised)
+                elif noise_sampler is not None:
                     eps = noise_sampler(indices[k], img.shape, img.device)
+                    sample, pred = self._step(img, t, model_output, eps, clip_denoised)
                 else:
                     eps = torch.randn_like(img)
-                sample, pred = self._step(img, t, model_output, eps, clip_denoised)
+                    sample, pred = self._step(img, t, model_output, eps, clip_denoised)
                 yield {"sample": sample, "pred_xstart": pred, "noise": eps}
                 img = sample
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 4
+#define HOLO_ABI_VERSION 5
 
 enum {
   HOLO_OK = 0,
@@ -154,6 +154,16 @@ int holo_unet_get_grad(HoloUnet* net, const char* name, float* dst, int64_t nume
 int holo_ddpm_step(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
                    int64_t elems_per_sample, const float* x_t, const float* model_out, const float* noise,
                    int clip_denoised, float* sample, float* pred_xstart, void* stream);
+
+/* The same step with the noise drawn inside the kernel (ABI 5; perf mode of gaussian_diffusion.py:498 `th.randn_like(x)`
+ * / :604 - SURVEY 8d "on-device Philox"): element quad q of sample b takes the four outputs of Philox4x32-10 with
+ * counter (q low, q high, b, stream_offset low) and key (seed low, seed high ^ stream_offset high), as two Box-Muller
+ * pairs (24-bit uniforms, |z| <= 5.9).  Statistically equivalent to, NOT bit-equal with, torch's generator: parity
+ * tests keep holo_ddpm_step with injected noise.  pred_xstart and noise_out may be null (not written). */
+int holo_ddpm_step_philox(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
+                          int64_t elems_per_sample, const float* x_t, const float* model_out, uint64_t seed,
+                          uint64_t stream_offset, int clip_denoised, float* sample, float* pred_xstart, float* noise_out,
+                          void* stream);
 
 /* Elementwise helpers on the path: torch.tanh (holo_diffusion_model.py:425) and
  * torch.clip(x,-1,1) (holo_diffusion_model.py:186). */

@@ -80,6 +80,106 @@ def test_default_noise_path_runs_and_is_seeded(gu):
     assert torch.equal(a, b) and torch.isfinite(a).all()
 
 
+def _philox4x32_10(ctr, key):
+    """numpy statement of Philox4x32-10 (Salmon et al. 2011; the published constants): ctr (n,4) uint32, key (2,) -> (n,4)."""
+    c = [ctr[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & MASK, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def _philox_normals(seed, offset, batch, per):
+    """The draw of holo_ddpm_step_philox (include/holo_abi.h): float64 Box-Muller of the same 24-bit uniforms."""
+    out = np.empty((batch, per), dtype=np.float64)
+    q = np.arange(per // 4, dtype=np.uint64)
+    key = (seed & 0xFFFFFFFF, ((seed >> 32) ^ (offset >> 32)) & 0xFFFFFFFF)
+    for b in range(batch):
+        ctr = np.stack([q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full_like(q, b), np.full_like(q, offset & 0xFFFFFFFF)], axis=1)
+        r = _philox4x32_10(ctr.astype(np.uint32), key)
+        u = ((r >> 8).astype(np.float64) + 0.5) / 16777216.0
+        for j in (0, 2):
+            rad, ang = np.sqrt(-2.0 * np.log(u[:, j])), 2.0 * np.pi * u[:, j + 1]
+            out[b, j::4], out[b, j + 1::4] = rad * np.cos(ang), rad * np.sin(ang)
+    return out
+
+
+def test_philox_known_answer():
+    """The numpy statement above against the published known-answer vectors of Philox4x32-10 (Random123 kat_vectors)."""
+    z = _philox4x32_10(np.zeros((1, 4), np.uint32), (0, 0))[0]
+    assert [int(v) for v in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = _philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [int(v) for v in f] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    p = _philox4x32_10(np.array([[0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344]], np.uint32), (0xa4093822, 0x299f31d0))[0]
+    assert [int(v) for v in p] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_device_noise_step_kernel(gu):
+    """holo_ddpm_step_philox (perf mode): (1) the noise it reports is the documented Philox4x32-10 / Box-Muller draw
+    (numpy statement, pinned to the published known-answer vectors above) to float32 rounding of log / sin / cos; (2) the
+    sample is holo_ddpm_step of that noise BIT for bit; (3) draws depend on (seed, stream, timestep, sample, element) and
+    nothing else; (4) mean / variance / lag-1 correlation / 4th moment of 2 M draws are those of a standard normal."""
+    from holo_diffusion_amd import _lib, runtime
+    L = runtime.lib()
+    seed, stream = 0x1234567890ABCDEF, 3
+    diff = hda.ImplicitronGaussianDiffusion(device_noise_seed=seed, device_noise_stream=stream)
+    plain = hda.ImplicitronGaussianDiffusion()
+    shape = (2, 8, 8, 8, 8)
+    per = int(np.prod(shape[1:]))
+    x, mo = (torch.from_numpy(np_noise(s, shape)).to(gu.DEV) for s in (1, 2))
+    for tt in (999, 1, 0):
+        t = torch.tensor([tt, tt], device=gu.DEV)
+        s1, p1, e1 = diff._step_device_noise(x, t, mo, tt, True, want_noise=True)
+        want = _philox_normals(seed, (stream << 32) | tt, shape[0], per).reshape(shape)
+        assert np.abs(e1.cpu().numpy() - want).max() < 2e-5
+        s2, p2 = plain._step(x, t, mo, e1, True)
+        assert torch.equal(s1, s2) and torch.equal(p1, p2)
+        s3, p3, e3 = diff._step_device_noise(x, t, mo, tt, True, want_pred=False, want_noise=False)
+        assert torch.equal(s3, s1) and p3 is None and e3 is None
+    # independence of the draws: another timestep / stream / seed / sample gives another tensor
+    t = torch.tensor([5, 5], device=gu.DEV)
+    base = diff._step_device_noise(x, t, mo, 5, True, want_noise=True)[2]
+    assert not torch.equal(base[0], base[1])
+    assert not torch.equal(base, diff._step_device_noise(x, t, mo, 6, True, want_noise=True)[2])
+    other = hda.ImplicitronGaussianDiffusion(device_noise_seed=seed, device_noise_stream=stream + 1)
+    assert not torch.equal(base, other._step_device_noise(x, t, mo, 5, True, want_noise=True)[2])
+    other = hda.ImplicitronGaussianDiffusion(device_noise_seed=seed + 1, device_noise_stream=stream)
+    assert not torch.equal(base, other._step_device_noise(x, t, mo, 5, True, want_noise=True)[2])
+    # statistics
+    n = (1, 16, 16, 16, 16) if gu.EMU else (1, 32, 64, 32, 32)
+    big = torch.zeros(n, device=gu.DEV)
+    e = diff._step_device_noise(big, torch.tensor([7], device=gu.DEV), big, 7, True, want_noise=True)[2].double().reshape(-1).cpu()
+    N = e.numel()
+    tol = 5.0 / N ** 0.5  # five standard errors
+    assert abs(float(e.mean())) < tol and abs(float(e.var()) - 1.0) < 1.5 * tol
+    assert abs(float((e[1:] * e[:-1]).mean())) < tol and abs(float((e[4:] * e[:-4]).mean())) < tol
+    assert abs(float((e ** 4).mean()) - 3.0) < 10 * tol and float(e.abs().max()) < 5.95
+    assert abs(float((e > 0).double().mean()) - 0.5) < tol
+
+
+def test_device_noise_chain_is_reproducible(gu):
+    """p_sample_loop in the perf mode: same seed -> the same grid bit for bit (no generator state anywhere), another stream
+    -> another grid; torch's global generator plays no part in the per-step noise."""
+    net, _ = gu.make_unet(TINY_CFG)
+    shape = (1, TINY_CFG.in_channels) + (TINY_CFG.image_size,) * 3
+    x_T = torch.from_numpy(np_noise(41, shape)).to(gu.DEV)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        d1 = hda.ImplicitronGaussianDiffusion(device_noise_seed=11)
+        torch.manual_seed(1)
+        a = list(d1.p_sample_loop_progressive(net, shape, noise=x_T, max_iter=4))
+        torch.manual_seed(2)
+        b = d1.p_sample_loop(net, shape, noise=x_T, max_iter=4)
+        c = hda.ImplicitronGaussianDiffusion(device_noise_seed=11, device_noise_stream=1).p_sample_loop(net, shape, noise=x_T, max_iter=4)
+    assert all(s["noise"] is None and set(s) == {"sample", "pred_xstart", "noise"} for s in a)
+    assert torch.equal(a[-1]["sample"], b) and torch.isfinite(b).all() and not torch.equal(b, c)
+    out = d1.p_sample(net, x_T, torch.tensor([500], device=gu.DEV))
+    assert out["noise"] is None and torch.isfinite(out["sample"]).all()
+
+
 @pytest.mark.parametrize("compute", ["f32", "f32_bf16x3"])
 @pytest.mark.parametrize("T,max_iter", [(1000, 4), (20, None)])
 def test_sampler_trajectory_wide_net_both_modes_vs_oracle(gu, compute, T, max_iter):

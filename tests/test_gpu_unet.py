@@ -26,7 +26,7 @@ def gu():
 
 def test_native_library_loaded():
     lib = runtime.lib()
-    assert lib.holo_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.holo_abi_version() == _lib.ABI_VERSION == 5
     assert os.path.basename(_lib.LIB_PATH) == "libholo_mi355x.so"
 
 
