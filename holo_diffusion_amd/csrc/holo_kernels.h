@@ -62,7 +62,8 @@ struct ConvParams {
   int stagger_ticks;      // halo kernel: phase offset (100 MHz ticks) of the workgroup in the odd slot of a CU
   unsigned long long* dbg;  // optional timeline probe (scripts/conv_timeline.cpp): [tile][8] {t_start, t_first_halo,
                             // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
-  int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel
+  int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel,
+                          // 3 = streaming 1x1x1 kernel (large grids, raw input)
   // Winograd-in-depth form of the 128-voxel halo kernel (conv_wino_kernel): weights pre-transformed along kz,
   // U_xi = sum_kz G[xi][kz] w[kz], packed like w with 36 pseudo-taps xi*9 + ky*3 + kx; the fused skip as 2 pseudo-taps
   // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
@@ -261,6 +262,7 @@ struct RenderKernelParams {
   // their normals (null: normals are not rendered)
   float* val_ws;
   float* nrm_ws;
+  const float* dens_field;  // render2_kernel with normals: S[v] = w_dens . F[v] per voxel (density_field_launch); else null
   // outputs (per camera): CHW planes
   float* rgb;
   float* depth;
@@ -273,6 +275,7 @@ struct RenderKernelParams {
   unsigned long long* dbg;  // optional per-slot phase clocks [slot][8] (HOLO_RENDER_TIMELINE=1); null in production
   int split3;  // 1: RenderMLP products on the bf16 matrix cores from an exact 3-term bf16 split (feature_size 32 only)
   int* tile_ctr;  // render2_kernel: 8 zeroed counters (one per XCD range) for the dynamic tile hand-out; null = static stride
+  int tail_quads;  // render2_kernel, dynamic hand-out: this many LAST 4-ray tiles of every XCD range go out as single-ray items
   // training-mode rendering (n_rays > 0; render2_kernel only): every camera renders the SAME number of rays given as NDC
   // coordinates; outputs are (n_cams, 3, n_rays) / (n_cams, n_rays) planes.  Optional injected random streams (null =
   // deterministic): stratified coarse depths, stratified importance samples, density noise of both passes.
@@ -497,6 +500,7 @@ int implicit_eval_launch(const ImplicitEvalParams& p, void* stream);   // = dirs
 int implicit_dirs_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_points_launch(const ImplicitEvalParams& p, void* stream);
 int implicit_normals_launch(const ImplicitEvalParams& p, float* normals, void* stream);  // uses grid_cl, pts, n_points, mlp
+int density_field_launch(const float* grid_cl, const float* w_dens, int C, int64_t nvox, float* out, void* stream);
 int render_launch(const RenderKernelParams& p, void* stream, int n_workgroups);
 int render_waves_per_wg(int C, int n_fine, int with_normals, int split3 = 0, int train = 0);
 int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int train);

@@ -2538,6 +2538,97 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {  // 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming 1x1x1 convolution of a LARGE grid: a ResBlock's skip_connection (unet.py:222) on the 64^3 level as a launch
+// of its own, its output the residual of the block's second 3x3x3 convolution.  (Fused into that convolution as extra
+// pseudo-taps the 128-channel skip costs conv_wino3_kernel ~100 us per launch - its operands are scattered 16-byte reads -;
+// here it is a plain GEMM of M = 262 144 rows, K <= 128, N = 64 that runs at the rate its 200 MB cross the fabric.)
+// A wave owns ALL 64 output channels of a 16-row tile: the weights of its K x 64 block sit in registers for the whole launch
+// (NCH x 32 registers, the row-tile kernel's packed layout), the rows come straight from global memory - lane (lj, kq)
+// reads the 32 contiguous bytes (channels 8 kq .. +7 of row lj) of every 32-channel chunk, the next tile's rows under the
+// current tile's MFMAs -, no LDS, no barrier.  Raw input (no GroupNorm / activation), virtual concat of two sources.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, kq = lane >> 4;
+  const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
+  const int64_t ntile = M >> 4;
+  const int n0 = blockIdx.y * 64;
+  const int wnsl = p.CoutP >> 4;
+  // weights: [chunk][16-Cout slice][half][kq][lj][4] (wpack_block), 512 floats per (chunk, slice)
+  float4 bw[NCH][4][2];
+  {
+    const float* wl = p.w + (int64_t)(n0 >> 4) * 512 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) {
+        const float* wp = wl + ((int64_t)i * wnsl + sl) * 512;
+        bw[i][sl][0] = *reinterpret_cast<const float4*>(wp);
+        bw[i][sl][1] = *reinterpret_cast<const float4*>(wp + 256);
+      }
+  }
+  float bv[4];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) bv[sl] = p.bias ? p.bias[n0 + sl * 16 + lj] : 0.f;
+  // per chunk: source, row stride and channel offset of the lane's 8 channels (C0 is a multiple of 32 with two sources)
+  const float* csrc[NCH];
+  int cstr[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = i * 32 + kq * 8;
+    const bool second = p.src1 != nullptr && c >= p.C0;
+    csrc[i] = (second ? p.src1 + (c - p.C0) : p.src0 + c);
+    cstr[i] = second ? p.C1 : p.C0;
+  }
+  auto load_rows = [&](int64_t t, float4 (&a)[NCH][2]) {
+    const int64_t m = t * 16 + lj;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const float* r = csrc[i] + m * cstr[i];
+      a[i][0] = *reinterpret_cast<const float4*>(r);
+      a[i][1] = *reinterpret_cast<const float4*>(r + 4);
+    }
+  };
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  float4 A[2][NCH][2];
+  if (gw < ntile) load_rows(gw, A[0]);
+  int buf = 0;
+  for (int64_t t = gw; t < ntile; t += nw, buf ^= 1) {
+    if (t + nw < ntile) {
+      if (buf == 0) load_rows(t + nw, A[1]); else load_rows(t + nw, A[0]);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[sl][r] = 0.f;
+    auto tile = [&](const float4 (&a)[NCH][2]) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          // the four accumulators advance together, k-step by k-step (no MFMA waits on its predecessor's result)
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].x, bw[i][sl][h].x, acc[sl], 0, 0, 0);
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].y, bw[i][sl][h].y, acc[sl], 0, 0, 0);
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].z, bw[i][sl][h].z, acc[sl], 0, 0, 0);
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].w, bw[i][sl][h].w, acc[sl], 0, 0, 0);
+        }
+    };
+    if (buf == 0) tile(A[0]); else tile(A[1]);
+    // D: column lj = output channel, row 4 kq + r = row of the tile
+    float* o = p.out + (t * 16 + 4 * kq) * p.Cout + n0 + lj;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) o[(int64_t)r * p.Cout + sl * 16] = acc[sl][r] + bv[sl];
+  }
+}
+
 // s = b + sum over the splits of partial[k][i .. i+3], in the fixed order both reduce kernels share
 __device__ __forceinline__ float4 splitk_sum4(const float* __restrict__ partial, int nsplit, int64_t MC, int64_t i, float4 b) {
   float4 s = b;
@@ -2670,6 +2761,20 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1
                : 0;
+  // a 1x1x1 convolution of raw input over a LARGE grid (a ResBlock's skip_connection on the 64^3 level): the streaming GEMM
+  // (HOLO_CONV1X1_STREAM_MIN_M=<rows>: development knob, default 131 072 rows; 0 = off)
+  {
+    const char* e1 = getenv("HOLO_CONV1X1_STREAM_MIN_M");
+    const int64_t min_m = e1 ? atoll(e1) : 131072;
+    if (p.mode == 0 && min_m > 0 && M >= min_m && p.ksz == 1 && p.stride == 1 && !p.ups && !p.coef && !p.residual && !p.skip_w &&
+        p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && (p.Cout % 64) == 0 && (Cin % 32) == 0 && Cin >= 32 && Cin <= 128 &&  // (K x 64 weights in registers: 128 channels = 248 VGPRs)
+        (!p.src1 || (p.C0 % 32) == 0) && (M % 16) == 0 && p.ID == p.OD && p.IH == p.OH && p.IW == p.OW) {
+      p.mode = 3;
+      p.nsplit = 1;
+      p.chunks_per_split = ncc;
+      return 0;
+    }
+  }
   // 1x1x1, strided and deepest-level convs: row-tile kernel (also for the 32^3 stride-2 convolution with its 32 768 rows: the
   // per-tap gather kernel takes 118 us there, this one 95)
   if (p.mode == 0 && p.Cout >= 64) {
@@ -2931,6 +3036,25 @@ int conv_launch(const ConvParams& p, void* stream) {
       HOLO_HALO(2, 1, false);
     }
 #undef HOLO_HALO
+    }
+  } else if (p.mode == 3) {
+    if (p.stats || p.residual || p.coef || p.nsplit != 1) {
+      set_error("conv_launch: the streaming 1x1x1 kernel takes raw input and produces no statistics");
+      return -1;
+    }
+    // two workgroups per CU, every wave walks 16-row tiles with a stride of the whole grid
+    int64_t wgs = cdiv(M >> 4, 4 * 4);  // >= 4 tiles per wave
+    if (wgs > 512) wgs = 512;
+    if (wgs < 1) wgs = 1;
+    dim3 g3((unsigned)wgs, (unsigned)(p.Cout / 64));
+    switch (Cin / 32) {
+      case 1: HOLO_LAUNCH(conv1x1_stream_kernel<1>, g3, block, stream, p); break;
+      case 2: HOLO_LAUNCH(conv1x1_stream_kernel<2>, g3, block, stream, p); break;
+      case 3: HOLO_LAUNCH(conv1x1_stream_kernel<3>, g3, block, stream, p); break;
+      case 4: HOLO_LAUNCH(conv1x1_stream_kernel<4>, g3, block, stream, p); break;
+      default:
+        set_error("conv_launch: streaming 1x1x1 kernel: %d input channels", Cin);
+        return -1;
     }
   } else if (p.mode == 2) {
     if (M >= ((int64_t)1 << 31)) {

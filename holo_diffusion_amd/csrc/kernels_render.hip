@@ -152,11 +152,15 @@ __device__ __forceinline__ void dir_term(const MlpParams& m, float dx, float dy,
 // weights (zero for corners outside the grid, like grid_sample's backward), times LeakyReLU'.
 // HID: also store the sample's hidden features AFTER the LeakyReLU (RenderMLP's `mlp_feats`, the input of the
 // view-point independent feature head) to hid[0..HD) - the lane's 16 rows of a tile are four groups of 4 consecutive rows.
-template <int CH, bool SP = false, bool NRM = false, bool HID = false>
+// NRM = 2: the eight per-corner scalars s_c = w_dens . F_c are read from `sfield` (one float per voxel, density_field_kernel:
+// they depend on the grid and the folded density row only, not on the ray) instead of being formed per sample - 8 scalar
+// loads in place of 4 CH packed FMAs + the density row from LDS, and both lane halves hold the complete value (no exchange).
+template <int CH, bool SP = false, int NRM = 0, bool HID = false>
 __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float* __restrict__ grid, uint32_t lane_off,
                                            int R, float Rm1, float half_extent, float b_dens, int li, int lh, float px, float py,
                                            float pz, const float (&rdir)[3], float& sigma, float& cr, float& cg,
-                                           float& cb, float* nrm = nullptr, float* hid = nullptr) {
+                                           float& cb, float* nrm = nullptr, float* hid = nullptr,
+                                           const float* __restrict__ sfield = nullptr) {
   constexpr int C = 2 * CH;
   constexpr int LDW = C + 4;
   float gx = 0.f, gy = 0.f, gz = 0.f;  // NRM: this lane half's part of d(pre-activation)/d(voxel index)
@@ -194,8 +198,16 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
     const float dza = (NRM && fz0 >= 0.f && fz0 <= Rm1) ? -1.f : 0.f;
     const float dzb = (NRM && fz0 >= -1.f && fz0 <= Rm1 - 1.f) ? 1.f : 0.f;
     int lhn = lh;
-    if (NRM) HOLO_LAUNDER(lhn);
+    if (NRM == 1) HOLO_LAUNDER(lhn);
     const float4* wdp = reinterpret_cast<const float4*>(L.u + lhn * 4 * CH);  // the lane half's slice of the density row
+    float scf[8];  // NRM = 2: the corners' scalars, requested with the features
+    if (NRM == 2) {
+#pragma unroll
+      for (int corner = 0; corner < 8; ++corner) {
+        const int xx = (corner & 1) ? xb : xa, yy = ((corner >> 1) & 1) ? yb : ya, zz = (corner >> 2) ? zb : za;
+        scf[corner] = sfield[(uint32_t)((zz * R + yy) * R + xx)];
+      }
+    }
 #pragma unroll
     for (int corner = 0; corner < 8; ++corner) {
       const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
@@ -210,14 +222,14 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
         const float4 t = g[SP ? 4 * (v >> 1) + (v & 1) : v];  // SP: 8 channels of every 16-channel k-step
         fv[2 * v + 0] = pk_fma(w2, f32x2{t.x, t.y}, fv[2 * v + 0]);
         fv[2 * v + 1] = pk_fma(w2, f32x2{t.z, t.w}, fv[2 * v + 1]);
-        if (NRM) {
+        if (NRM == 1) {
           const float4 wd = wdp[v];
           sc2 = pk_fma(f32x2{wd.x, wd.y}, f32x2{t.x, t.y}, sc2);
           sc2 = pk_fma(f32x2{wd.z, wd.w}, f32x2{t.z, t.w}, sc2);
         }
       }
       if (NRM) {
-        const float sc = sc2.x + sc2.y;
+        const float sc = NRM == 2 ? scf[corner] : sc2.x + sc2.y;
         gx = fmaf(((dx ? dxb : dxa) * (dy ? wyb : wya)) * (dz ? wzb : wza), sc, gx);
         gy = fmaf(((dx ? wxb : wxa) * (dy ? dyb : dya)) * (dz ? wzb : wza), sc, gy);
         gz = fmaf(((dx ? wxb : wxa) * (dy ? wyb : wya)) * (dz ? dzb : dza), sc, gz);
@@ -345,9 +357,11 @@ __device__ __forceinline__ void eval_point(const MlpLds<CH, SP>& L, const float*
   cg = fast_sigmoid(leaky02(rp1 + rdir[1]));
   cb = fast_sigmoid(leaky02(rp2 + rdir[2]));
   if (NRM) {
-    gx += __shfl_xor(gx, 32);
-    gy += __shfl_xor(gy, 32);
-    gz += __shfl_xor(gz, 32);
+    if (NRM == 1) {  // (the two lane halves hold the two channel halves of every corner's scalar)
+      gx += __shfl_xor(gx, 32);
+      gy += __shfl_xor(gy, 32);
+      gz += __shfl_xor(gz, 32);
+    }
     // chain rule: LeakyReLU'(pre-activation) * d(voxel index)/d(world point); both factors positive, kept so that
     // F.normalize's eps acts as in torch
     const float k = ((dpart + b_dens) > 0.f ? 1.f : 0.2f) * (0.5f * Rm1 / half_extent);
@@ -463,7 +477,7 @@ __global__ __launch_bounds__((64 * render_waves<CH, ZCAP, NRM>())) void render_k
     const float zstep = (zmax - zmin) / (float)(nc - 1);
     auto zcoarse = [&](int i) { return lin_space(zmin, zmax, zstep, i, nc); };
     auto eval = [&](float z, float& sigma, float& cr, float& cg, float& cb, float* nv) {
-      eval_point<CH, SP, NRM>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
+      eval_point<CH, SP, NRM ? 1 : 0>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
                               org[1] + z * dir[1], org[2] + z * dir[2], rdir, sigma, cr, cg, cb, nv);
     };
     const int64_t ob = (int64_t)cam_i * npix + ray;  // output pixel (1-channel planes); rgb planes at 3*cam*npix + c*npix
@@ -805,30 +819,68 @@ __device__ __forceinline__ int wave_prev_i(int v, int lane) {
 }
 #endif
 
-template <int ZF>
+template <int ZF, bool NRM>
 struct Render2Wave {
   float4 cval[4][64];               // coarse samples (sigma_raw, r, g, b)
   float4 fval[4][ZF];               // new samples
   float zf[4][ZF];                  // new depths, ascending
   unsigned char isnew[64 + ZF];     // merged composite: 1 where the position of the merged list holds a NEW sample
   float rd[4][4];                   // per ray: radiance direction term
+  uint32_t cn[NRM ? 4 : 1][NRM ? 64 : 1];  // NRM: the samples' unit normals, octahedral snorm16 x 2 (r2_pack_normal)
+  uint32_t fn[NRM ? 4 : 1][NRM ? ZF : 1];
 };
 
-// waves per workgroup (= per CU): the per-wave rows are 9.4 KB (64 new samples per ray) / 14.6 KB (128); with the 40 KB
-// RenderMLP image of 32 grid features 12 / 8 waves fit (64 grid features: 73 KB image, 8 / 4 waves)
-template <int CH, int ZF>
-constexpr int render2_waves() { return ZF <= 64 ? (CH <= 16 ? 12 : 8) : (CH <= 16 ? 8 : 4); }
+// NRM (rendered normals, holo_multipass_ea.py:105-109; the released YAMLs' render_normals: true): a sample's normal
+// normalize(d density / d point) (eval_point<NRM>) has to wait in LDS for the sample's composite weight like its colour.
+// Three floats per sample would cost 6 KB per wave (12 -> 7 waves per CU); a unit vector is two numbers: the octahedral
+// map (project onto |x| + |y| + |z| = 1, fold the lower half over the diagonals) in snorm16 x 2 = ONE word per sample,
+// 2 KB per wave, 10 waves per CU.  Worst-case angular error 4e-5 (the composite's tolerance is 5e-4); the all-zero normal
+// of a point outside the grid (F.normalize of a zero gradient) has its own code.
+constexpr uint32_t R2_ZERO_NORMAL = 0x80008000u;
+__device__ __forceinline__ uint32_t r2_pack_normal(const float (&n)[3]) {
+  const float l1 = fabsf(n[0]) + fabsf(n[1]) + fabsf(n[2]);
+  if (!(l1 > 0.f)) return R2_ZERO_NORMAL;
+  const float inv = holo_rcp(l1);
+  float px = n[0] * inv, py = n[1] * inv;
+  if (n[2] < 0.f) {
+    const float qx = (1.f - fabsf(py)) * (px >= 0.f ? 1.f : -1.f), qy = (1.f - fabsf(px)) * (py >= 0.f ? 1.f : -1.f);
+    px = qx, py = qy;
+  }
+  const int ix = (int)rintf(fminf(fmaxf(px, -1.f), 1.f) * 32767.f), iy = (int)rintf(fminf(fmaxf(py, -1.f), 1.f) * 32767.f);
+  return ((uint32_t)ix & 0xffffu) | ((uint32_t)iy << 16);
+}
+__device__ __forceinline__ void r2_unpack_normal(uint32_t c, float (&n)[3]) {
+  const float px = (float)(short)(c & 0xffffu) * (1.f / 32767.f), py = (float)(short)(c >> 16) * (1.f / 32767.f);
+  const float z = 1.f - fabsf(px) - fabsf(py);
+  const float t = fmaxf(-z, 0.f);
+  const float x = px + (px >= 0.f ? -t : t), y = py + (py >= 0.f ? -t : t);
+  const float k = c == R2_ZERO_NORMAL ? 0.f : rsqrtf(x * x + y * y + z * z);
+  n[0] = x * k, n[1] = y * k, n[2] = z * k;
+}
 
-template <int CH, int ZF, bool TRAIN, int NW>
+// waves per workgroup (= per CU): the per-wave rows are 9.4 KB (64 new samples per ray) / 14.6 KB (128), + 2 KB with
+// normals; with the 40 KB RenderMLP image of 32 grid features 12 / 8 waves fit (64 grid features: 73 KB image, 8 / 4 waves)
+// NRM: built for <= 32 grid features and <= 64 new samples per ray (the BASELINE / released configurations; anything else
+// renders its normals on the ray-per-column kernel, render_rays_per_tile): 8 waves - two per SIMD, a 256-register budget
+// (the 10 waves the LDS would hold mean three per SIMD = 168 registers, and the normal's extra live values then spill
+// into scratch inside the evaluation: HOLO_RENDER2_NRM_NW=10 keeps that form for measurement)
+template <int CH, int ZF, bool NRM = false>
+constexpr int render2_waves() {
+  return NRM ? 8 : (ZF <= 64 ? (CH <= 16 ? 12 : 8) : (CH <= 16 ? 8 : 4));
+}
+
+template <int CH, int ZF, bool TRAIN, int NW, bool NRM = false>
 __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p) {
+  static_assert(!(TRAIN && NRM), "training-mode rendering returns no normals");
   struct Smem {
     MlpLds<CH, false> mlp;  // FIRST: everything the evaluation loop reads sits below 64 KB (16-bit ds_read offsets)
-    Render2Wave<ZF> w[NW];
+    Render2Wave<ZF, NRM> w[NW];
   };
   __shared__ __attribute__((aligned(16))) Smem s_mem;
+  static_assert(sizeof(Smem) <= 160 * 1024, "render2_kernel: LDS budget");
   MlpLds<CH, false>& s_mlp = s_mem.mlp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
-  Render2Wave<ZF>& S = s_mem.w[wave];
+  Render2Wave<ZF, NRM>& S = s_mem.w[wave];
   stage_mlp<CH, false>(s_mlp, p.mlp, tid, 64 * NW);
   __syncthreads();  // the only workgroup-level synchronisation: from here on the waves are independent workers
 
@@ -837,7 +889,6 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
   const float Rm1 = (float)(R - 1);
   const uint32_t lane_off = (uint32_t)lane_channel<CH, false>(lh, 0);
   const int nc = p.n_coarse, nf = p.n_fine, nb = nc - 1;
-  const int rq = li >> 3, dq = li & 7;  // evaluation mapping: ray of the tile, depth inside the 8-depth column group
   const int64_t ntiles = p.n_tiles;
   const int rays_per_cam = TRAIN ? p.train.n_rays : npix;
   const int tiles_per_cam = (rays_per_cam + 3) / 4;
@@ -858,18 +909,32 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
   // tile hand-out: DYNAMIC when the launch supplies counters (one per XCD range): a wave takes the next tile of its range
   // when it is done with the previous one, so a launch ends within ONE tile time of its average instead of on a whole
   // round of tiles (40 000 tiles on 3 072 resident waves are 13.02 rounds: 14 with a static stride); otherwise static.
-  auto next_tile = [&](int64_t prev) -> int64_t {
-    if (!p.tile_ctr) return prev < 0 ? x_lo + (int64_t)wg_in_x * NW + wave : prev + (int64_t)wgs_per_x * NW;
+  // The END of a range is handed out in finer pieces (dynamic hand-out only): its last `tail_quads` 4-ray tiles go out as
+  // four SINGLE-ray tiles each - 32 consecutive depths of one ray per evaluation instead of 8 depths of four rays, the same
+  // evaluations per ray, a quarter of the tile time - so a launch ends within a quarter tile of its average.  It is what a
+  // single-frame call (the reference's per-camera loop, flyaround.py:247-253) loses most: 13.02 rounds of 290 us tiles.
+  // A work item v of the range: v < nq - kf: 4-ray tile x_lo + v; else single ray (v - (nq - kf)) & 3 of a tail tile.
+  const int64_t nq = x_hi - x_lo;
+  const int64_t kf = p.tile_ctr ? (p.tail_quads < nq ? (int64_t)p.tail_quads : nq) : 0;
+  const int64_t nv = nq + 3 * kf;
+  auto next_item = [&](int64_t prev) -> int64_t {
+    if (!p.tile_ctr) return prev < 0 ? (int64_t)wg_in_x * NW + wave : prev + (int64_t)wgs_per_x * NW;
     int v = 0;
     if (lane == 0) v = atomicAdd(p.tile_ctr + my_x, 1);
     v = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)v), 0));
-    return x_lo + v;
+    return v;
   };
-  for (int64_t t = next_tile(-1); t < x_hi; t = next_tile(t)) {
+  for (int64_t v = next_item(-1); v < nv; v = next_item(v)) {
     if (dbg && lane == 0) tk = HOLO_PROBE_CLOCK();
+    const bool fine_item = v >= nq - kf;
+    const int64_t t = fine_item ? x_lo + (nq - kf) + ((v - (nq - kf)) >> 2) : x_lo + v;
+    const int sh = fine_item ? 5 : 3;          // lanes li >> sh share a ray; 1 << sh consecutive depths per evaluation
+    const int nr = 32 >> sh;                   // rays of this item: 4 or 1
+    const int dstep = 1 << sh;
+    const int rq = li >> sh, dq = li & (dstep - 1);  // evaluation mapping: ray of the item, depth inside the column group
     const int cam_i = (int)(t / tiles_per_cam);
     const RenderKernelParams::Cam& cam = p.cams[cam_i];
-    const int ray0 = (int)(t - (int64_t)cam_i * tiles_per_cam) * 4;
+    const int ray0 = (int)(t - (int64_t)cam_i * tiles_per_cam) * 4 + (fine_item ? (int)((v - (nq - kf)) & 3) : 0);
     // ---- ray setup; every lane computes the ray it needs in each role (the wave pays per instruction, not per lane)
     auto ray_of = [&](int rr, float (&org)[3], float (&dir)[3]) {
       const int ray = min(ray0 + rr, rays_per_cam - 1);
@@ -940,18 +1005,24 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const float u = holo_ld_sys(p.train.u_coarse + ((int64_t)cam_i * rays_per_cam + ray) * nc + i);
       return lo + (up - lo) * u;
     };
-    auto eval = [&](float z, float& sg, float& cr, float& cg, float& cb) {
-      eval_point<CH, false, false>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
-                                   org[1] + z * dir[1], org[2] + z * dir[2], rdir, sg, cr, cg, cb);
+    auto eval = [&](float z, float& sg, float& cr, float& cg, float& cb, uint32_t& ncode) {
+      float nv[3] = {0.f, 0.f, 0.f};
+      eval_point<CH, false, NRM ? 2 : 0>(s_mlp, p.grid_cl, lane_off, R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, org[0] + z * dir[0],
+                                         org[1] + z * dir[1], org[2] + z * dir[2], rdir, sg, cr, cg, cb, nv, nullptr, p.dens_field);
+      ncode = NRM ? r2_pack_normal(nv) : 0u;
     };
 
     stamp(0);
-    // ---- coarse evaluation: column groups of 8 consecutive depths
-    for (int j0 = 0; j0 < nc; j0 += 8) {
+    // ---- coarse evaluation: column groups of 8 (single-ray items: 32) consecutive depths
+    for (int j0 = 0; j0 < nc; j0 += dstep) {
       const int i = min(j0 + dq, nc - 1);
       float sg, cr, cg, cb;
-      eval(zcoarse_r(rq, i), sg, cr, cg, cb);
-      if (lh == 0 && j0 + dq < nc) S.cval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+      uint32_t ncode;
+      eval(zcoarse_r(rq, i), sg, cr, cg, cb, ncode);
+      if (lh == 0 && j0 + dq < nc) {
+        S.cval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+        if (NRM) S.cn[rq][j0 + dq] = ncode;
+      }
     }
     HOLO_WAVE_SYNC();
     stamp(1);
@@ -959,7 +1030,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
     // ---- per ray: coarse composite, cdf, inverse cdf (lane = depth index)
     const float ustep = 1.0f / (float)(nf - 1);
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < nr; ++rr) {
       const int ray = ray0 + rr;
       const bool active = ray < rays_per_cam;
       const int ic = min(lane, nc - 1);
@@ -986,6 +1057,17 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
           o[2 * (int64_t)rays_per_cam] = ab + (1.f - O) * p.bg[2];
           p.depth_c[ob] = ad;
           p.mask_c[ob] = O;
+        }
+        if (NRM && p.nrm_c) {  // rendered normals of the coarse pass: sum_i w_i n_i
+          float nn[3];
+          r2_unpack_normal(S.cn[rr][ic], nn);
+          const float anx = wave_sum_f(w * nn[0]), any_ = wave_sum_f(w * nn[1]), anz = wave_sum_f(w * nn[2]);
+          if (lane == 0 && active) {
+            float* on = p.nrm_c + (int64_t)cam_i * 3 * rays_per_cam + ray;
+            on[0 * (int64_t)rays_per_cam] = anx;
+            on[1 * (int64_t)rays_per_cam] = any_;
+            on[2 * (int64_t)rays_per_cam] = anz;
+          }
         }
       }
       // weights[1:-1] + eps -> pdf -> cdf (nb = nc-1 entries, cdf[0] = 0); running sums in double like torch's
@@ -1048,11 +1130,15 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
     stamp(2);
 
     // ---- evaluation of the new samples
-    for (int j0 = 0; j0 < nf; j0 += 8) {
+    for (int j0 = 0; j0 < nf; j0 += dstep) {
       const int k = min(j0 + dq, nf - 1);
       float sg, cr, cg, cb;
-      eval(S.zf[rq][k], sg, cr, cg, cb);
-      if (lh == 0 && j0 + dq < nf) S.fval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+      uint32_t ncode;
+      eval(S.zf[rq][k], sg, cr, cg, cb, ncode);
+      if (lh == 0 && j0 + dq < nf) {
+        S.fval[rq][j0 + dq] = make_float4(sg, cr, cg, cb);
+        if (NRM) S.fn[rq][j0 + dq] = ncode;
+      }
     }
     HOLO_WAVE_SYNC();
     stamp(3);
@@ -1061,7 +1147,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
     //      coarse sample goes first on a tie)
     const int nm = nc + nf;
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
+    for (int rr = 0; rr < nr; ++rr) {
       const int ray = ray0 + rr;
       const bool active = ray < rays_per_cam;
       const float* zrow = S.zf[rr];
@@ -1107,12 +1193,14 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       int nbefore = wave_scan_incl_i(cnt, lane) - cnt;
       float xs[3], zz[4];
       float4 vv[3];
+      uint32_t ncd[3] = {0u, 0u, 0u};
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int q = 3 * lane + e;
         const int qc = q < nm ? q : nm - 1;
         const int id = f[e] ? min(nbefore, nf - 1) : min(max(qc - nbefore, 0), nc - 1);
         vv[e] = f[e] ? S.fval[rr][id] : S.cval[rr][id];
+        if (NRM) ncd[e] = f[e] ? S.fn[rr][id] : S.cn[rr][id];
         zz[e] = f[e] ? zrow[id] : zcoarse_r(rr, id);
         nbefore += f[e];
       }
@@ -1141,7 +1229,7 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       const double l3 = (double)xs[0] + (double)xs[1] + (double)xs[2];
       const double incl = wave_scan_incl_d(l3, lane);
       double run = wave_prev_d(incl, lane);  // sum of all x before this lane's first position
-      float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f;
+      float ar = 0.f, ag = 0.f, ab = 0.f, ad = 0.f, anx = 0.f, any_ = 0.f, anz = 0.f;
 #pragma unroll
       for (int e = 0; e < 3; ++e) {
         const int q = 3 * lane + e;
@@ -1151,6 +1239,13 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         ag = fmaf(w, vv[e].z, ag);
         ab = fmaf(w, vv[e].w, ab);
         ad = fmaf(w, zz[e], ad);
+        if (NRM) {
+          float nn[3];
+          r2_unpack_normal(ncd[e], nn);
+          anx = fmaf(w, nn[0], anx);
+          any_ = fmaf(w, nn[1], any_);
+          anz = fmaf(w, nn[2], anz);
+        }
         run += (double)xs[e];
       }
       const float O = 1.f - __expf(-(float)wave_last_d(incl));
@@ -1158,6 +1253,11 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
       ag = wave_sum_f(ag);
       ab = wave_sum_f(ab);
       ad = wave_sum_f(ad);
+      if (NRM && p.nrm) {
+        anx = wave_sum_f(anx);
+        any_ = wave_sum_f(any_);
+        anz = wave_sum_f(anz);
+      }
       if (lane == 0 && active) {
         const int64_t ob = (int64_t)cam_i * rays_per_cam + ray;
         float* o = p.rgb + (int64_t)cam_i * 3 * rays_per_cam + ray;
@@ -1166,12 +1266,38 @@ __global__ __launch_bounds__((64 * NW)) void render2_kernel(RenderKernelParams p
         o[2 * (int64_t)rays_per_cam] = ab + (1.f - O) * p.bg[2];
         p.depth[ob] = ad;
         p.mask[ob] = O;
+        if (NRM && p.nrm) {
+          float* on = p.nrm + (int64_t)cam_i * 3 * rays_per_cam + ray;
+          on[0 * (int64_t)rays_per_cam] = anx;
+          on[1 * (int64_t)rays_per_cam] = any_;
+          on[2 * (int64_t)rays_per_cam] = anz;
+        }
       }
       HOLO_WAVE_SYNC();  // the flag row is rewritten for the next ray
     }
     stamp(5);
     if (dbg && lane == 0) dbg[4] += 1;
   }
+}
+
+// S[v] = w_dens . F[v]: the folded density row applied to every voxel of the channels-last grid (one thread per voxel) - the
+// per-corner scalars of the analytic normal (eval_point<NRM = 2>).  33.5 MB read, 1 MB written, once per render call.
+__global__ __launch_bounds__(256) void density_field_kernel(const float* __restrict__ grid_cl, const float* __restrict__ w_dens,
+                                                            int C, int64_t nvox, float* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nvox) return;
+  const float4* g = reinterpret_cast<const float4*>(grid_cl + v * C);
+  const float4* w = reinterpret_cast<const float4*>(w_dens);
+  // the same pairing as the in-kernel form (even / odd channel partial sums), so both forms round alike
+  float se = 0.f, so = 0.f;
+  for (int q = 0; q < C / 4; ++q) {
+    const float4 t = g[q], a = w[q];
+    se = fmaf(a.x, t.x, se);
+    so = fmaf(a.y, t.y, so);
+    se = fmaf(a.z, t.z, se);
+    so = fmaf(a.w, t.w, so);
+  }
+  out[v] = se + so;
 }
 
 // radiance direction term per ray direction (one thread per direction)
@@ -1210,7 +1336,7 @@ __global__ __launch_bounds__(256, (CH <= 32 ? 2 : 1)) void implicit_eval_kernel(
     const int64_t di = ii / p.pts_per_dir;
     const float rdir[3] = {p.rdir[di * 3 + 0], p.rdir[di * 3 + 1], p.rdir[di * 3 + 2]};
     float sg, cr, cg, cb;
-    eval_point<CH, false, false, HID>(s_mlp, p.grid_cl, lane_off, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz,
+    eval_point<CH, false, 0, HID>(s_mlp, p.grid_cl, lane_off, p.R, Rm1, p.half_extent, p.mlp.b_dens, li, lh, px, py, pz,
                                       rdir, sg, cr, cg, cb, nullptr, (HID && active) ? p.hidden + (i - p.point0) * HD : nullptr);
     if (active && lh == 0) {
       p.densities[i] = sg;
@@ -1320,8 +1446,16 @@ int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void*
 
 // waves per workgroup of render2_kernel at run time (HOLO_RENDER2_NW=8: development knob, the 8-wave form of the
 // 12-wave configurations)
-static int render2_waves_rt(int C, int n_fine) {
+static int render2_waves_rt(int C, int n_fine, int with_normals = 0) {
   const int ch = C / 2;
+  (void)ch;
+  if (with_normals) {  // render2_waves<CH, 64, true>(); HOLO_RENDER2_NRM_NW=10: the three-waves-per-SIMD form (development knob)
+#ifndef HOLO_EMU
+    static const char* en = getenv("HOLO_RENDER2_NRM_NW");
+    if (en && atoi(en) == 10) return 10;
+#endif
+    return 8;
+  }
   int nw = n_fine <= 64 ? (ch <= 16 ? 12 : 8) : (ch <= 16 ? 8 : 4);
 #ifndef HOLO_EMU
   static const char* e = getenv("HOLO_RENDER2_NW");
@@ -1332,12 +1466,27 @@ static int render2_waves_rt(int C, int n_fine) {
 
 template <int CH, bool SP>
 static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs) {
-  const bool nrm = p.nrm_ws != nullptr;
+  const bool nrm = p.nrm != nullptr || p.nrm_c != nullptr;
   if (render_rays_per_tile(2 * CH, p.n_fine, nrm ? 1 : 0, SP ? 1 : 0, p.train.n_rays > 0 ? 1 : 0) == 4) {
-    // the (ray, depth)-tiled kernel: no normals, exact fp32
+    // the (ray, depth)-tiled kernel: exact fp32, with or without rendered normals
     const int nw = render2_waves_rt(2 * CH, p.n_fine);
 #define HOLO_R2(ZFV, TRV, NWV) HOLO_LAUNCH((render2_kernel<CH, ZFV, TRV, NWV>), dim3((unsigned)n_wgs), dim3(64 * NWV), stream, p)
-    if (p.train.n_rays > 0) {
+    if (nrm) {
+      if (p.train.n_rays > 0) {
+        set_error("render: training-mode rendering returns no normals");
+        return -1;
+      }
+      if constexpr (CH <= 16) {
+        if (render2_waves_rt(2 * CH, p.n_fine, 1) == 10) {
+          HOLO_LAUNCH((render2_kernel<CH, 64, false, 10, true>), dim3((unsigned)n_wgs), dim3(640), stream, p);
+        } else {
+          HOLO_LAUNCH((render2_kernel<CH, 64, false, 8, true>), dim3((unsigned)n_wgs), dim3(512), stream, p);
+        }
+      } else {
+        set_error("render: rendered normals of %d grid features run on the ray-per-column kernel", 2 * CH);
+        return -1;
+      }
+    } else if (p.train.n_rays > 0) {
       if (p.n_fine <= 64) {
         if (nw == 12) HOLO_R2(64, true, (render2_waves<CH, 64>())); else HOLO_R2(64, true, 8);
       } else {
@@ -1367,13 +1516,13 @@ static int render_launch_t(const RenderKernelParams& p, void* stream, int n_wgs)
   return 0;
 }
 
-// rays of one wave tile: 4 on the (ray, depth)-tiled kernel, 32 on the ray-per-column kernel (rendered normals, the
-// bf16x3 split arithmetic, and - development knob HOLO_RENDER_V1=1 - everything)
+// rays of one wave tile: 4 on the (ray, depth)-tiled kernel, 32 on the ray-per-column kernel (the bf16x3 split arithmetic
+// and - development knob HOLO_RENDER_V1=1 - everything)
 int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int train) {
-  (void)C;
-  (void)n_fine;
   if (train) return 4;
-  if (with_normals || split3) return 32;
+  if (split3) return 32;
+  // rendered normals: on the (ray, depth)-tiled kernel for the BASELINE / released shapes (round 5), else ray-per-column
+  if (with_normals && (C > 32 || n_fine > 64)) return 32;
 #ifndef HOLO_EMU
   static const bool v1 = getenv("HOLO_RENDER_V1") != nullptr;
   if (v1) return 32;
@@ -1384,12 +1533,21 @@ int render_rays_per_tile(int C, int n_fine, int with_normals, int split3, int tr
 // waves per workgroup of the persistent kernel for this configuration (the scratch has one slot per resident wave)
 int render_waves_per_wg(int C, int n_fine, int with_normals, int split3, int train) {
   const bool z64 = n_fine <= 64;
-  if (render_rays_per_tile(C, n_fine, with_normals, split3, train) == 4) return render2_waves_rt(C, n_fine);
+  if (render_rays_per_tile(C, n_fine, with_normals, split3, train) == 4) return render2_waves_rt(C, n_fine, with_normals);
   if (C <= 32) {
     if (with_normals) return z64 ? render_waves<16, 64, true>() : render_waves<16, 128, true>();
     return z64 ? render_waves<16, 64, false>() : render_waves<16, 128, false>();
   }
   return z64 ? render_waves<32, 64, false>() : render_waves<32, 128, false>();
+}
+
+int density_field_launch(const float* grid_cl, const float* w_dens, int C, int64_t nvox, float* out, void* stream) {
+  if (C & 3) {
+    set_error("density_field: feature_size must be a multiple of 4");
+    return -1;
+  }
+  HOLO_LAUNCH(density_field_kernel, dim3((unsigned)cdiv(nvox, 256)), dim3(256), stream, grid_cl, w_dens, C, nvox, out);
+  return 0;
 }
 
 int render_launch(const RenderKernelParams& p, void* stream, int n_wgs) {

@@ -315,10 +315,16 @@ int holo_renderer_set_compute_dtype(HoloRenderer* r, int dtype) {
   return 0;
 }
 
+// the per-voxel scalars w_dens . F[v] of the rendered normals on the (ray, depth)-tiled kernel (behind everything else)
+static size_t dens_field_bytes(const HoloRenderer* r) {
+  const size_t R = (size_t)r->cfg.resol;
+  return ((R * R * R * sizeof(float)) + 255) & ~(size_t)255;
+}
+
 size_t holo_render_workspace_bytes(const HoloRenderer* r, int n_cameras, int with_normals) {
   (void)n_cameras;  // the scratch is per resident wave: any number of cameras renders out of the same buffer
   if (!r) return 0;
-  return grid_cl_bytes(r) + val_ws_bytes(r, with_normals) * (with_normals ? 2 : 1) + 256;
+  return grid_cl_bytes(r) + val_ws_bytes(r, with_normals) * (with_normals ? 2 : 1) + 256 + (with_normals ? dens_field_bytes(r) : 0);
 }
 
 int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, int n_cameras, float* images,
@@ -349,6 +355,13 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
   if (rc) return HOLO_E_INVALID;
   const int H = c.image_height, Wd = c.image_width;
   const int64_t npix = (int64_t)H * Wd;
+  float* dens_field = nullptr;
+  if (want_nrm && render_rays_per_tile(C, c.n_pts_fine, 1, split3_active(r), 0) == 4) {
+    MlpParams mp;
+    fill_mlp(r, mp);
+    dens_field = (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r, 1) * 2 + 256);
+    if (density_field_launch(grid_cl, mp.w_dens, C, (int64_t)R * R * R, dens_field, stream)) return HOLO_E_INVALID;
+  }
   // frames per launch: the launch parameters hold MAX_CAMS cameras; more cameras are split EVENLY over the launches
   // (40 frames = 20 + 20, not 32 + 8: every launch then ends on an almost full round of wave tiles)
   const int n_launches = (n_cameras + RenderKernelParams::MAX_CAMS - 1) / RenderKernelParams::MAX_CAMS;
@@ -394,6 +407,7 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     p.split3 = sp3;
     p.val_ws = (float*)((char*)workspace + grid_cl_bytes(r));
     p.nrm_ws = want_nrm ? (float*)((char*)workspace + grid_cl_bytes(r) + val_ws_bytes(r, 1)) : nullptr;
+    p.dens_field = dens_field;
     p.rgb = images + (size_t)c0 * 3 * npix;  // the kernel adds the per-frame offsets
     p.depth = depths + (size_t)c0 * npix;
     p.mask = masks + (size_t)c0 * npix;
@@ -417,6 +431,16 @@ int holo_render(HoloRenderer* r, const float* grid, const HoloCamera* cameras, i
     if (rays_per_tile == 4 && !static_tiles) {  // dynamic tile hand-out: the counters live in the (otherwise unused) scratch area
       p.tile_ctr = (int*)p.val_ws;
       HIP_TRY(hipMemsetAsync(p.tile_ctr, 0, 8 * sizeof(int), (hipStream_t)stream));
+      // the end of every XCD range in single-ray items: about two rounds of them on the range's resident waves
+      // (HOLO_RENDER_TAIL=<quads per range>: development knob, 0 = off)
+      const int ranges = p.xcd > 1 ? p.xcd : 1;
+      p.tail_quads = (n_wgs * waves_per_wg / ranges) / 2;
+#ifndef HOLO_EMU
+      static const char* tq = getenv("HOLO_RENDER_TAIL");
+      if (tq) p.tail_quads = atoi(tq);
+#else
+      p.tail_quads = 3;  // (the emulation's tiny frames: a few tail tiles in every test)
+#endif
     }
     const int nslots = n_wgs * waves_per_wg;
 #ifndef HOLO_EMU

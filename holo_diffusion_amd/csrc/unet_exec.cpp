@@ -582,8 +582,18 @@ struct Planner {
     // (the bf16x3 kernel has no fused-skip variant: its skip connection runs as a separate fp32 1x1x1 conv)
     // (below 8^3 the convolution runs on the row-tile kernel, which takes the skip's channels as extra K chunks: exact-fp32
     //  mode; four launches + four reduces less at the 4^3 level of the north-star net)
-    const bool fuse_skip = has_skip && ((R % 8) == 0 || (u->compute_mode == 0 && R < 8)) && b.cout >= 64 && u->compute_mode != 2 &&
-                           !getenv("HOLO_NO_SKIP_FUSION");
+    bool fuse_skip = has_skip && ((R % 8) == 0 || (u->compute_mode == 0 && R < 8)) && b.cout >= 64 && u->compute_mode != 2 &&
+                     !getenv("HOLO_NO_SKIP_FUSION");
+    // development knob: from this grid size on the skip runs as its own 1x1x1 launch whose output is the second
+    // convolution's residual (A/B of the fused form on the wide levels)
+    // From 64^3 on (exact-fp32 mode) the skip runs as its own streaming 1x1x1 launch (conv1x1_stream_kernel) whose output is the
+    // second convolution's residual: measured on the north-star net, fused 305 us per launch against 208 (plain) + ~45.
+    // HOLO_SKIP_FUSION_BELOW_R=<R>: development knob for the threshold (A/B of the two forms)
+    {
+      const char* mr = getenv("HOLO_SKIP_FUSION_BELOW_R");
+      const int below = mr ? atoi(mr) : 64;
+      if (fuse_skip && u->compute_mode == 0 && R >= below && (b.cin % 32) == 0 && b.cin <= 128 && (b.cout % 64) == 0) fuse_skip = false;
+    }
     if (has_skip && !fuse_skip) {
       s = new_act(b.cout, R);
       emit_conv(x0, x1, R, 0, R, 1, 1, P(u, p + ".skip_connection.weight"), P(u, p + ".skip_connection.bias"), 0,
@@ -1784,7 +1794,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
+        t.kernel = c.mode == 3 ? 7 : c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

@@ -214,6 +214,87 @@ def _render_flyaround(model, n_flyaround_poses: int = 40, up: Tuple[float, float
     return out
 
 
+def _select_cameras(cams, idx: Sequence[int]):
+    return cams[list(idx)]
+
+
+@torch.no_grad()
+def render_views_sharded(model, voxel_features: Optional[torch.Tensor], cams, src_rank: int = 0,
+                         device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+    """Camera sharding of ONE grid's turntable over the ranks of the process group (last paragraph; the
+    per-camera loop of flyaround.py:240-253 has no dependence between cameras): the grid - 33.5 MB at 64^3 x 32, one
+    broadcast from the rank that sampled it - goes to every rank, rank r renders cameras r, r + N, r + 2N, ... in one
+    ``render_views`` call (the t = 0 refinement runs on every rank: deterministic kernels, bit-equal grids, and the idle
+    GPUs cost nothing), and one ``all_gather`` per output puts all frames on all ranks, in camera order.  Bit for bit the
+    single-rank ``model.render_views(voxel_features, cams)``: a frame does not depend on which other frames share its
+    launch (tests/test_gpu_configs.py::test_teddybear_30_view_turntable_in_one_call).  ``voxel_features`` is read on
+    ``src_rank`` only (pass None elsewhere).  A single-process run is a plain ``render_views``."""
+    rank, world = dist_info()
+    if world == 1:
+        return model.render_views(voxel_features, cams)
+    if device is None:
+        device = voxel_features.device if voxel_features is not None else torch.device("cuda", torch.cuda.current_device())
+    shape = torch.zeros(5, dtype=torch.int64, device=device)
+    if rank == src_rank:
+        shape.copy_(torch.tensor(voxel_features.shape, dtype=torch.int64))
+    dist.broadcast(shape, src=src_rank)
+    vf = voxel_features.contiguous().float() if rank == src_rank else torch.empty(tuple(int(v) for v in shape), device=device)
+    dist.broadcast(vf, src=src_rank)
+    n = len(cams)
+    mine = shard_indices(n, rank, world)
+    local: Dict[str, Dict[int, torch.Tensor]] = {}
+    keys = ["images_render", "depths_render", "masks_render"]
+    if mine:
+        out = model.render_views(vf, _select_cameras(cams, mine))
+        keys = [k for k in out if k.endswith("_render")]
+        for k in keys:
+            local[k] = {idx: out[k][slot] for slot, idx in enumerate(mine)}
+    H, W = model.render_image_height, model.render_image_width
+    chans = {"images_render": 3, "normals_render": 3}
+    # (every rank must issue the same collectives: the key list of a rank without cameras comes from rank 0's)
+    klist = [keys if rank == 0 else None]
+    dist.broadcast_object_list(klist, src=0)
+    res = {}
+    for k in klist[0]:
+        res[k] = gather_frames(local.get(k, {}), n, (chans.get(k, 1), H, W), device)
+    return res
+
+
+@torch.no_grad()
+def render_progressive_turntable_sharded(model, n_views: int = 30, steps_per_render: int = 1,
+                                         up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
+                                         camera_elevation: float = -30.0 * (2 * math.pi / 360), camera_focal_length: float = 3.2,
+                                         hemispherical_radius: float = 10, max_angle: float = 2 * math.pi,
+                                         device: torch.device = torch.device("cuda"), sampler_kwargs: Optional[dict] = None,
+                                         src_rank: int = 0):
+    """``render_progressive_turntable`` with the cameras of every render sharded over the ranks (configs[3], teddybear.yaml
+    - raymarcher-bound: the denoising chain is sequential and stays on ``src_rank``, the 30 views after each step are
+    independent).  Every rank iterates this generator; all of them receive all frames; ``voxel_features`` is the
+    broadcast grid."""
+    rank, world = dist_info()
+    cams = get_simple_360_camera_trajectory(max_angle, n_views, camera_elevation, hemispherical_radius, up,
+                                            camera_focal_length).to(device)
+    gen = model.sample_random_voxel_features_progressive(**dict(sampler_kwargs or {})) if rank == src_rank else None
+    while True:
+        vf = None
+        if rank == src_rank:
+            for _ in range(max(1, steps_per_render)):
+                try:
+                    vf = next(gen)
+                except StopIteration:
+                    break
+        if world > 1:  # the chain's owner tells the others whether another render follows
+            flag = torch.tensor([1 if vf is not None else 0], dtype=torch.int64, device=device)
+            dist.broadcast(flag, src=src_rank)
+            if int(flag.item()) == 0:
+                return
+        elif vf is None:
+            return
+        out = render_views_sharded(model, vf, cams, src_rank=src_rank, device=device)
+        out["voxel_features"] = vf
+        yield out
+
+
 @torch.no_grad()
 def render_progressive_turntable(model, n_views: int = 30, steps_per_render: int = 1,
                                  up: Tuple[float, float, float] = (0.0, -1.0, 0.0),
@@ -248,9 +329,12 @@ def generate_samples(model, num_samples: int = 2, n_eval_cameras: int = 25 * 3, 
                      up: Tuple[float, float, float] = CANONICAL_CO3D_UP_AXIS,
                      camera_elevation: float = -30.0 * (2 * math.pi / 360),
                      progressive_sampling_steps_per_render: int = -1, device: Optional[torch.device] = None,
-                     gather: bool = True, sampler_kwargs: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+                     gather: bool = True, sampler_kwargs: Optional[dict] = None,
+                     device_noise: bool = False) -> Dict[str, torch.Tensor]:
     """Sharded counterpart of generate_samples.py:105-138.  Every rank renders its own samples; with
-    ``gather`` all ranks end up with the frames of all samples."""
+    ``gather`` all ranks end up with the frames of all samples.  ``device_noise`` (build-side extension, default off): the
+    per-step noise of every chain is drawn inside the step kernel (``ImplicitronGaussianDiffusion.device_noise_seed`` =
+    ``seed``, stream = sample index) instead of by ``torch.randn_like``; x_T still comes from the per-sample torch seed."""
     rank, world = dist_info()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -259,8 +343,11 @@ def generate_samples(model, num_samples: int = 2, n_eval_cameras: int = 25 * 3, 
     local_dep: Dict[int, torch.Tensor] = {}
     local_msk: Dict[int, torch.Tensor] = {}
     H, W = model.render_image_height, model.render_image_width
+    diffusion = getattr(model, "diffusion", None)
     for i in mine:
         torch.manual_seed(seed + i)  # per-sample seed
+        if device_noise and diffusion is not None and hasattr(diffusion, "device_noise_seed"):
+            diffusion.device_noise_seed, diffusion.device_noise_stream = int(seed), int(i)
         out = render_flyaround(model, n_flyaround_poses=n_eval_cameras, up=up, camera_elevation=camera_elevation,
                                device=device,
                                progressive_sampling_steps_per_render=progressive_sampling_steps_per_render,
@@ -281,7 +368,8 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
                                      up: Tuple[float, float, float] = CANONICAL_CO3D_UP_AXIS,
                                      camera_elevation: float = -30.0 * (2 * math.pi / 360),
                                      progressive_sampling_steps_per_render: int = -1, save_frames: bool = True,
-                                     device: Optional[torch.device] = None, load_fn=None) -> Dict[str, torch.Tensor]:
+                                     device: Optional[torch.device] = None, load_fn=None,
+                                     device_noise: bool = False) -> Dict[str, torch.Tensor]:
     """``generate_samples(exp_dir=...)`` of the reference script (generate_samples.py:37-138) on the HIP path:
     experiment directory -> model (``checkpoint.load_experiment``) -> sharded sampling + fly-around renders.
 
@@ -302,7 +390,8 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
                          "(net_3d_enabled and diffusion_enabled)")
     out = generate_samples(model, num_samples=num_samples, n_eval_cameras=n_eval_cameras, seed=seed, up=up,
                            camera_elevation=camera_elevation,
-                           progressive_sampling_steps_per_render=progressive_sampling_steps_per_render, device=device)
+                           progressive_sampling_steps_per_render=progressive_sampling_steps_per_render, device=device,
+                           device_noise=device_noise)
     if save_frames and rank == 0:
         from .flyaround_output import export_flyaround_frames
         os.makedirs(output_directory, exist_ok=True)
@@ -324,7 +413,8 @@ def generate_samples_from_experiment(exp_dir: str, output_directory: Optional[st
 CLI_DEFAULTS = dict(exp_dir="", output_directory=None, render_size=None, video_size=(256, 256), camera_path="simple_360",
                     n_eval_cameras=25 * 3, num_samples=2, seed=3, trajectory_scale=1.3, up=CANONICAL_CO3D_UP_AXIS,
                     camera_elevation=-30.0 * (2 * math.pi / 360), progressive_sampling_steps_per_render=-1,
-                    save_voxel_features=True)
+                    save_voxel_features=True,
+                    device_noise=False)  # (build-side extension: in-kernel Philox noise per denoising step, generate_samples)
 
 
 def parse_cli(argv: Sequence[str]) -> Dict[str, object]:
@@ -380,7 +470,7 @@ def main(argv: Optional[Sequence[str]] = None, load_fn=None) -> int:
                 n_eval_cameras=int(cfg["n_eval_cameras"]), num_samples=int(cfg["num_samples"]), seed=int(cfg["seed"]),
                 up=tuple(cfg["up"]), camera_elevation=float(cfg["camera_elevation"]),
                 progressive_sampling_steps_per_render=int(cfg["progressive_sampling_steps_per_render"]), device=device,
-                load_fn=load_fn)
+                load_fn=load_fn, device_noise=bool(cfg["device_noise"]))
         if rank == 0:
             img = out["images_render"]
             print(f"generate: {int(cfg['num_samples'])} samples x {int(cfg['n_eval_cameras'])} frames "

@@ -132,3 +132,74 @@ def test_gradient_allreduce_single_process_is_identity():
     from holo_diffusion_amd.ddp import allreduce_gradients
     g = {"w": torch.arange(6.0).reshape(2, 3)}
     assert allreduce_gradients(g) is g and torch.equal(g["w"], torch.arange(6.0).reshape(2, 3))
+
+
+# ---- camera sharding of one grid's turntable (optional row; generate.render_views_sharded) --------------
+class _TurntableStub(torch.nn.Module):
+    """A deterministic stand-in for HoloDiffusionModel.render_views (CPU): every frame is a function of the grid and of ITS
+    camera only - the property the real renderer has (test_teddybear_30_view_turntable_in_one_call)."""
+    render_image_height, render_image_width = 6, 5
+
+    def __init__(self, n_steps=3, normals=False):
+        super().__init__()
+        self.n_steps, self.normals = n_steps, normals
+
+    def render_views(self, vf, cams):
+        n, H, W = len(cams), self.render_image_height, self.render_image_width
+        base = (vf.double().sum() * 1e-3 + cams.T.double().sum(dim=1) + cams.R.double().reshape(n, -1)[:, 1]).float()
+        img = base[:, None, None, None] + torch.arange(3 * H * W, dtype=torch.float32).reshape(1, 3, H, W) / 7.0
+        out = {"images_render": img, "depths_render": img[:, :1] * 2.0, "masks_render": torch.sigmoid(img[:, 1:2])}
+        if self.normals:
+            out["normals_render"] = -img
+        return out
+
+    def sample_random_voxel_features_progressive(self, **kw):
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, 4, 3, 3, 3, generator=g)
+        for k in range(self.n_steps):
+            x = x * 0.5 + k
+            yield x.clone()
+
+
+def _turntable_worker(rank, world, port, n_views, normals, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from holo_diffusion_amd.cameras import get_simple_360_camera_trajectory
+        from holo_diffusion_amd.generate import render_progressive_turntable_sharded, render_views_sharded
+        import math
+        dev = torch.device("cpu")
+        model = _TurntableStub(normals=normals)
+        cams = get_simple_360_camera_trajectory(2 * math.pi, n_views, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2)  # (the driver's defaults)
+        vf = torch.arange(108, dtype=torch.float32).reshape(1, 4, 3, 3, 3) if rank == 0 else None
+        got = render_views_sharded(model, vf, cams, src_rank=0, device=dev)
+        want = model.render_views(torch.arange(108, dtype=torch.float32).reshape(1, 4, 3, 3, 3), cams)
+        ok = set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+        # the progressive driver: chain on rank 0, every rank receives every step's frames and the broadcast grid
+        steps = list(render_progressive_turntable_sharded(model, n_views=n_views, steps_per_render=1, device=dev))
+        ref_grids = list(model.sample_random_voxel_features_progressive())
+        ok = ok and len(steps) == len(ref_grids)
+        for s, g in zip(steps, ref_grids):
+            w = model.render_views(g, cams)
+            ok = ok and all(torch.equal(s[k], w[k]) for k in w)
+            ok = ok and (s["voxel_features"] is None or torch.equal(s["voxel_features"], g))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_camera_sharded_turntable_gloo_world2_equals_single_rank():
+    """30-view turntable of one grid over 2 ranks: broadcast of the grid, cameras k mod N, one all_gather per output -
+    bit for bit the single-rank call, also when a rank has no camera (1 view) and with rendered normals."""
+    ctx = mp.get_context("spawn")
+    for j, (n_views, normals) in enumerate(((30, False), (5, True), (1, False))):
+        q = ctx.Queue()
+        port = 33100 + (os.getpid() + 7 * j) % 2000
+        procs = [ctx.Process(target=_turntable_worker, args=(r, 2, port, n_views, normals, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(2))
+        for p in procs:
+            p.join(timeout=60)
+        assert res == [(0, True), (1, True)], (n_views, normals, res)

@@ -154,6 +154,40 @@ def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kerne
     assert gu.rel_err(y2, y.cpu()) < 1e-5
 
 
+def test_streaming_skip_connection_blockwise(gu, monkeypatch):
+    """conv1x1_stream_kernel - a ResBlock's 1x1x1 skip_connection (unet.py:222) as a launch of its own, the form the 64^3
+    level of the north-star net runs (its output is the residual of the block's second convolution) - forced onto a small
+    grid: every block output against the pinned oracle at the per-op tolerance, a plain and a virtual-concat input (64 -> 128
+    on the way down, (64 + 64) -> 64 on the way up; the blocks with more than 128 input channels keep the fused form), and
+    equal to the all-fused plan up to rounding."""
+    monkeypatch.setenv("HOLO_SKIP_FUSION_BELOW_R", "8")
+    monkeypatch.setenv("HOLO_CONV1X1_STREAM_MIN_M", "64")
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+    cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=1, channel_mult=(1, 2),
+                     attention_resolutions=(), num_heads=2)
+    net, sd = gu.make_unet(cfg, seed=61)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(29, (2, 16, 16, 16, 16)))
+    t = torch.tensor([77, 901], dtype=torch.int64)
+    trace = {}
+    ref = uo.unet_forward(sd, cfg, x, t, trace)
+    with torch.no_grad():
+        y = net(x.to(gu.DEV), t.to(gu.DEV))
+    assert gu.rel_err(y, ref) < 1e-4
+    for tag, r in trace.items():
+        if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
+            assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 1e-4, tag
+    if not gu.EMU:
+        ops = [o for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv"]
+        assert sum(o["kernel"] == "conv1x1_stream_kernel" for o in ops) == 2, [(o["kernel"], o["ksz"], o["cin"]) for o in ops]
+        assert sum(bool(o["fused_skip"]) for o in ops) == 3  # (256, 192, 192 input channels)
+    monkeypatch.setenv("HOLO_SKIP_FUSION_BELOW_R", "1000")  # the fused form on the same net
+    net2, _ = gu.make_unet(cfg, seed=61)
+    with torch.no_grad():
+        y2 = net2(x.to(gu.DEV), t.to(gu.DEV))
+    assert gu.rel_err(y2, y.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("tag,cfg,compute", [("plumb32x16", PLUMB_CFG, "f32"), ("north64x32", NORTH_CFG, "f32"),
                                              ("north64x32", NORTH_CFG, "f32_bf16x3")])
 def test_full_size_unet_vs_reference_digest(gu, golden_dir, tag, cfg, compute):
