@@ -365,13 +365,19 @@ def main():
 
     def one_step(x, k, mode=args.noise):
         t = ts[k]
-        out = net(x, t)
-        if mode == "device":  # one kernel: clamp + posterior mean + in-kernel Philox noise; pred_xstart is not materialised
+        if mode == "device":
+            # the perf chain of ImplicitronGaussianDiffusion.p_sample_loop(device_noise_seed=...): the grid stays in the
+            # library's channels-last layout (no layout pass either side of the UNet), one step kernel: clamp + posterior
+            # mean + in-kernel Philox noise; pred_xstart is not materialised
+            out = net.forward_channels_last(x, t)
             return diff._step_device_noise(x, t, out, t_host[k], True, want_pred=False)[0]
+        out = net(x, t)
         eps = torch.randn_like(x)
         sample, _ = diff._step(x, t, out, eps, True)
         return sample
 
+    if args.noise == "device":
+        img = img.permute(0, 2, 3, 4, 1).contiguous()  # (the chain's one conversion; back after the timed steps)
     with torch.no_grad():
         for k in range(Wm):
             img = one_step(img, k)
@@ -384,12 +390,16 @@ def main():
         barrier_sync(world)
         dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, device)
+    if args.noise == "device":
+        img = img.permute(0, 4, 1, 2, 3).contiguous()
     assert torch.isfinite(img).all()
     steps_per_s = world * K / dt
     # the other noise path over the same K timesteps (side figure, this rank only)
     other_mode = "torch" if args.noise == "device" else "device"
     with torch.no_grad():
         xo = torch.randn(*shape, device=device)
+        if other_mode == "device":
+            xo = xo.permute(0, 2, 3, 4, 1).contiguous()
         for k in range(min(3, Wm)):
             xo = one_step(xo, k, other_mode)
         torch.cuda.synchronize()
@@ -694,7 +704,8 @@ def main():
             "frame_gather": gather, "grad_exchange": grad_exchange,
             "rccl_world_size": (gather or {}).get("rccl_world_size", 1), "gather_ms": (gather or {}).get("gather_ms"),
             "per_rank_steps_per_s": per_rank_steps_per_s,
-            "step_noise": {"timed": args.noise, "what": {"device": "Philox4x32-10 + Box-Muller inside the step kernel "
+            "step_noise": {"timed": args.noise, "what": {"device": "the sampler's perf chain: grid kept channels-last (holo_unet_forward_cl, no layout "
+                                                                   "passes), Philox4x32-10 + Box-Muller noise inside the step kernel "
                                                                    "(holo_ddpm_step_philox; no randn launch, pred_xstart not written)",
                                                          "torch": "torch.randn_like + holo_ddpm_step (the reference's draw)"}[args.noise],
                            f"steps_per_s_with_{other_mode}_noise_one_rank": steps_per_s_other},

@@ -90,6 +90,7 @@ SIGNATURES = {
     "holo_unet_set_compute_dtype": (C.c_int, [_vp, C.c_int]),
     "holo_unet_workspace_bytes": (C.c_size_t, [_vp, C.c_int]),
     "holo_unet_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "holo_unet_forward_cl": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "holo_unet_fetch_block": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _i64p, _vp, _vp]),
     "holo_unet_time_convs": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.c_int, _vp, C.POINTER(C.c_float),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]),

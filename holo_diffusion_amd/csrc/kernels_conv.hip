@@ -2568,9 +2568,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvParams p) {
         bw[i][sl][1] = *reinterpret_cast<const float4*>(wp + 256);
       }
   }
-  float bv[4];
+  // The product is formed TRANSPOSED (A operand = the weights, rows = output channels; B operand = the tile's rows, columns
+  // = voxels): a lane then holds 4 CONSECUTIVE output channels (D rows 4 kq + r) of voxel lj, so the tile leaves as four
+  // 16-byte stores per lane instead of sixteen 4-byte ones.
+  float4 bv[4];
 #pragma unroll
-  for (int sl = 0; sl < 4; ++sl) bv[sl] = p.bias ? p.bias[n0 + sl * 16 + lj] : 0.f;
+  for (int sl = 0; sl < 4; ++sl)
+    bv[sl] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + sl * 16 + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
   // per chunk: source, row stride and channel offset of the lane's 8 channels (C0 is a multiple of 32 with two sources)
   const float* csrc[NCH];
   int cstr[NCH];
@@ -2610,22 +2614,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvParams p) {
         for (int h = 0; h < 2; ++h) {
           // the four accumulators advance together, k-step by k-step (no MFMA waits on its predecessor's result)
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].x, bw[i][sl][h].x, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].x, a[i][h].x, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].y, bw[i][sl][h].y, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].y, a[i][h].y, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].z, bw[i][sl][h].z, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].z, a[i][h].z, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].w, bw[i][sl][h].w, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].w, a[i][h].w, acc[sl], 0, 0, 0);
         }
     };
     if (buf == 0) tile(A[0]); else tile(A[1]);
-    // D: column lj = output channel, row 4 kq + r = row of the tile
-    float* o = p.out + (t * 16 + 4 * kq) * p.Cout + n0 + lj;
+    // D: column lj = voxel of the tile, rows 4 kq + r = output channels of the slice
+    float* o = p.out + (t * 16 + lj) * p.Cout + n0 + 4 * kq;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) o[(int64_t)r * p.Cout + sl * 16] = acc[sl][r] + bv[sl];
+    for (int sl = 0; sl < 4; ++sl)
+      *reinterpret_cast<float4*>(o + sl * 16) =
+          make_float4(acc[sl][0] + bv[sl].x, acc[sl][1] + bv[sl].y, acc[sl][2] + bv[sl].z, acc[sl][3] + bv[sl].w);
   }
 }
 

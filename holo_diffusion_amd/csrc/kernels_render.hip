@@ -861,12 +861,13 @@ __device__ __forceinline__ void r2_unpack_normal(uint32_t c, float (&n)[3]) {
 // waves per workgroup (= per CU): the per-wave rows are 9.4 KB (64 new samples per ray) / 14.6 KB (128), + 2 KB with
 // normals; with the 40 KB RenderMLP image of 32 grid features 12 / 8 waves fit (64 grid features: 73 KB image, 8 / 4 waves)
 // NRM: built for <= 32 grid features and <= 64 new samples per ray (the BASELINE / released configurations; anything else
-// renders its normals on the ray-per-column kernel, render_rays_per_tile): 8 waves - two per SIMD, a 256-register budget
-// (the 10 waves the LDS would hold mean three per SIMD = 168 registers, and the normal's extra live values then spill
-// into scratch inside the evaluation: HOLO_RENDER2_NRM_NW=10 keeps that form for measurement)
+// renders its normals on the ray-per-column kernel, render_rays_per_tile).  10 waves per CU (what the LDS holds): with the
+// per-corner scalars read from the density scalar field the evaluation fits the 168 registers of three waves per SIMD
+// (84 bytes of scratch outside the MFMA loops; with the scalars formed per sample it was 580 bytes and 25 M rays/s).
+// Measured at 400^2, 8 frames: 40.2 M rays/s on 10 waves, 39.0 M on 8 (HOLO_RENDER2_NRM_NW=8, the emulation's choice)
 template <int CH, int ZF, bool NRM = false>
 constexpr int render2_waves() {
-  return NRM ? 8 : (ZF <= 64 ? (CH <= 16 ? 12 : 8) : (CH <= 16 ? 8 : 4));
+  return NRM ? 10 : (ZF <= 64 ? (CH <= 16 ? 12 : 8) : (CH <= 16 ? 8 : 4));
 }
 
 template <int CH, int ZF, bool TRAIN, int NW, bool NRM = false>
@@ -1449,12 +1450,14 @@ int bias_leaky_launch(float* y, const float* bias, int64_t rows, int cols, void*
 static int render2_waves_rt(int C, int n_fine, int with_normals = 0) {
   const int ch = C / 2;
   (void)ch;
-  if (with_normals) {  // render2_waves<CH, 64, true>(); HOLO_RENDER2_NRM_NW=10: the three-waves-per-SIMD form (development knob)
+  if (with_normals) {  // render2_waves<CH, 64, true>(); HOLO_RENDER2_NRM_NW=8: the two-waves-per-SIMD form (development knob)
 #ifndef HOLO_EMU
     static const char* en = getenv("HOLO_RENDER2_NRM_NW");
-    if (en && atoi(en) == 10) return 10;
-#endif
+    if (en && atoi(en) == 8) return 8;
+    return 10;
+#else
     return 8;
+#endif
   }
   int nw = n_fine <= 64 ? (ch <= 16 ? 12 : 8) : (ch <= 16 ? 8 : 4);
 #ifndef HOLO_EMU

@@ -1690,6 +1690,59 @@ int holo_unet_forward(HoloUnet* net, int batch, const float* x, const int64_t* t
   return 0;
 }
 
+int holo_unet_forward_cl(HoloUnet* net, int batch, const float* x_cl, const int64_t* timesteps, float* y_cl, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!net || !x_cl || !timesteps || !y_cl || !workspace || batch < 1) {
+    set_error("holo_unet_forward_cl: null/invalid argument");
+    return HOLO_E_INVALID;
+  }
+  if (net->compute_mode == 1) {
+    set_error("holo_unet_forward_cl: the bf16 storage mode converts its input in the layout pass (use holo_unet_forward)");
+    return HOLO_E_UNSUPPORTED;
+  }
+  int rc = ensure_plan(net, batch, workspace);
+  if (rc) return rc;
+  if (workspace_bytes < net->ws_need) {
+    set_error("holo_unet_forward_cl: workspace too small (%zu < %zu)", workspace_bytes, net->ws_need);
+    return HOLO_E_WORKSPACE;
+  }
+  // the plan's own input / output buffers: every convolution that reads the one or writes the other is pointed at the
+  // caller's channels-last tensors instead, and the two layout passes are skipped
+  // (by POSITION in the op list, not by address: the arena hands the input buffer's memory to later activations)
+  const float* in_buf = nullptr;
+  const float* out_buf = nullptr;
+  int first_conv = -1, last_conv = -1;
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op& op = net->ops[i];
+    if (op.kind == OP_IN) in_buf = op.o0;
+    if (op.kind == OP_OUT) out_buf = op.f0;
+    if (op.kind == OP_CONV) {
+      if (first_conv < 0 && in_buf) first_conv = (int)i;
+      last_conv = (int)i;
+    }
+  }
+  if (first_conv < 0 || !in_buf || !out_buf || net->ops[first_conv].conv.src0 != in_buf || net->ops[first_conv].conv.src1 ||
+      net->ops[last_conv].conv.out != out_buf || net->ops[last_conv].conv.nsplit != 1 || net->ops[first_conv].conv.nsplit != 1 ||
+      first_conv == last_conv) {
+    set_error("holo_unet_forward_cl: this plan's first / last convolution cannot take the caller's tensors");
+    return HOLO_E_UNSUPPORTED;
+  }
+  for (size_t i = 0; i < net->ops.size(); ++i) {
+    const Op& op = net->ops[i];
+    if (op.kind == OP_IN || op.kind == OP_OUT) continue;
+    if ((int)i == first_conv || (int)i == last_conv) {
+      Op o2 = op;
+      if ((int)i == first_conv) o2.conv.src0 = x_cl;
+      if ((int)i == last_conv) o2.conv.out = y_cl;
+      rc = run_op(net, o2, batch, x_cl, timesteps, y_cl, stream);
+    } else {
+      rc = run_op(net, op, batch, x_cl, timesteps, y_cl, stream);
+    }
+    if (rc) return rc < 0 ? rc : HOLO_E_INVALID;
+  }
+  return 0;
+}
+
 int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t dst_capacity, int64_t* numel,
                           void* workspace, void* stream) {
   if (!net || !tag || !dst || !workspace) {

@@ -225,7 +225,9 @@ class ImplicitronGaussianDiffusion(Configurable):
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False, max_iter=None,
-                                  noise_sampler=None) -> Iterator[dict]:
+                                  noise_sampler=None, _materialize_every_step: bool = True) -> Iterator[dict]:
+        """``_materialize_every_step`` (internal, used by ``p_sample_loop``): in the channels-last perf chain (below) yield
+        the steps' tensors as NCDHW VIEWS of the channels-last buffers instead of contiguous copies."""
         if cond_fn is not None:
             raise NotImplementedError("cond_fn guidance is not supported")
         if device is None:
@@ -249,6 +251,24 @@ class ImplicitronGaussianDiffusion(Configurable):
                 it = tqdm(it)
             except Exception:
                 pass
+        # Perf mode (device_noise_seed): the chain stays in the library's channels-last layout - the step kernel is elementwise,
+        # hence layout-agnostic, and SimpleUnet3D.forward_channels_last runs without its two layout passes: one conversion
+        # at the start of the chain, one per materialised sample (progressive callers get NCDHW-contiguous tensors as ever).
+        use_cl = (self.device_noise_seed is not None and noise_sampler is None and denoised_fn is None and not model_kwargs
+                  and hasattr(model, "forward_channels_last") and getattr(model, "compute_dtype", "f32") != "bf16"
+                  and getattr(model, "in_channels", None) == shape[1] and img.is_cuda)
+        if use_cl:
+            as_ncdhw = (lambda a: a.permute(0, 4, 1, 2, 3).contiguous()) if _materialize_every_step else \
+                (lambda a: a.permute(0, 4, 1, 2, 3))
+            with torch.no_grad():
+                img_cl = img.float().permute(0, 2, 3, 4, 1).contiguous()
+                for k in it:
+                    t = ts_all[k]
+                    out_cl = model.forward_channels_last(img_cl, t)
+                    sample_cl, pred_cl, _ = self._step_device_noise(img_cl, t, out_cl, indices[k], clip_denoised)
+                    yield {"sample": as_ncdhw(sample_cl), "pred_xstart": as_ncdhw(pred_cl), "noise": None}
+                    img_cl = sample_cl
+            return
         with torch.no_grad():
             for k in it:
                 t = ts_all[k]
@@ -274,10 +294,13 @@ class ImplicitronGaussianDiffusion(Configurable):
         for sample in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                      denoised_fn=denoised_fn, cond_fn=cond_fn,
                                                      model_kwargs=model_kwargs, device=device, progress=progress,
-                                                     max_iter=max_iter, noise_sampler=noise_sampler):
+                                                     max_iter=max_iter, noise_sampler=noise_sampler,
+                                                     _materialize_every_step=return_all_samples):
             if return_all_samples:
                 samples.append(sample)
             final = sample["sample"]
+        if final is not None and not final.is_contiguous():
+            final = final.contiguous()  # (the channels-last perf chain: one conversion at the end of the chain)
         return (final, samples) if return_all_samples else final
 
     def training_losses(self, *args, **kwargs):

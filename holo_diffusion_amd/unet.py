@@ -259,6 +259,31 @@ class SimpleUnet3D(Unet3DBase):
                                           ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward")
         return y
 
+    @torch.no_grad()
+    def forward_channels_last(self, x_cl: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """``forward`` on channels-last tensors (``holo_unet_forward_cl``): ``x_cl`` is (N, R, R, R, C) contiguous fp32 - the
+        library's own layout -, so is the result; the two layout passes of a plain call do not run.  The sampler's perf mode
+        keeps its chain in this form (``ImplicitronGaussianDiffusion.p_sample_loop`` with ``device_noise_seed``)."""
+        runtime.require_device(x_cl, "SimpleUnet3D.forward_channels_last")
+        if self.compute_dtype == "bf16":
+            raise _lib.HoloError("SimpleUnet3D.forward_channels_last: not in the bf16 storage mode")
+        if x_cl.dim() != 5 or x_cl.shape[4] != self.in_channels or len(set(x_cl.shape[1:4])) != 1 or \
+                x_cl.shape[1] % (1 << (len(self.channel_mult) - 1)) or not x_cl.is_contiguous() or x_cl.dtype != torch.float32:
+            raise _lib.HoloError(f"SimpleUnet3D.forward_channels_last: expected a contiguous float32 (N,R,R,R,{self.in_channels}), "
+                                 f"got {tuple(x_cl.shape)} {x_cl.dtype}")
+        dev = x_cl.device
+        h = self._ensure_handle(dev, int(x_cl.shape[1]))
+        L = runtime.lib()
+        t = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        B = x_cl.shape[0]
+        if t.shape != (B,):
+            raise _lib.HoloError("SimpleUnet3D.forward_channels_last: timesteps must have shape (N,)")
+        ws = runtime.workspace(self, dev, L.holo_unet_workspace_bytes(h, B))
+        y = torch.empty(tuple(x_cl.shape[:4]) + (self.out_channels,), dtype=torch.float32, device=dev)
+        _lib.check(L, L.holo_unet_forward_cl(h, B, runtime.ptr(x_cl), runtime.ptr(t), runtime.ptr(y), runtime.ptr(ws),
+                                             ws.numel(), runtime.stream_ptr(dev)), "holo_unet_forward_cl")
+        return y
+
     # ---- backward (SURVEY.md 8f-4) -------------------------------------------------------------
     def _ensure_dgrad_weights(self, device: torch.device) -> None:
         """Weights of the transposed convolutions (holo_unet_set_dgrad_weight), re-prepared when a parameter changed."""

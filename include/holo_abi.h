@@ -107,6 +107,13 @@ size_t holo_unet_workspace_bytes(HoloUnet* net, int batch);
 int holo_unet_forward(HoloUnet* net, int batch, const float* x, const int64_t* timesteps, float* y,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward on CHANNELS-LAST tensors (ABI 5): x_cl / y_cl are (N, R, R, R, C) fp32 - the layout the library works in -
+ * so the two layout passes of holo_unet_forward (NCDHW -> channels-last of x, back of y) do not run: the first convolution
+ * reads x_cl and the last one writes y_cl directly.  For sampling chains that stay on the device (holo_ddpm_step* is
+ * elementwise, hence layout-agnostic): the chain converts once at its start and once at its end.  fp32 / bf16x3 modes. */
+int holo_unet_forward_cl(HoloUnet* net, int batch, const float* x_cl, const int64_t* timesteps, float* y_cl, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Debug/parity hook: copy an intermediate block output (NCDHW) of the LAST forward into `dst`.
  * tag = "input_blocks.<i>", "middle_block", "output_blocks.<i>".  Returns element count in *numel. */
 int holo_unet_fetch_block(HoloUnet* net, const char* tag, float* dst, int64_t dst_capacity, int64_t* numel,

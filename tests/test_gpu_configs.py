@@ -272,7 +272,10 @@ def test_north_star_sampler_chain_vs_oracle(gu, T, max_iter):
         wide64 = [o_ for o_ in ops if o_["out_dim"] == 64 and o_["ksz"] == 3 and o_["stride"] == 1 and o_["cout"] >= 64]
         assert len(wide64) >= 12 and all(o_["kernel"] == "conv_wino3_kernel" for o_ in wide64), \
             [(o_["kernel"], o_["cin"], o_["cout"]) for o_ in wide64]
-        assert any(o_["fused_skip"] for o_ in wide64)
+        # the up path's 1x1x1 skip connections of the 64^3 level: their own streaming launches (the second convolution's residual)
+        skips64 = [o_ for o_ in ops if o_["out_dim"] == 64 and o_["ksz"] == 1]
+        assert len(skips64) == 3 and all(o_["kernel"] == "conv1x1_stream_kernel" for o_ in skips64), skips64
+        assert any(o_["fused_skip"] for o_ in w3)  # (fused into the convolution on the smaller levels)
         assert any(o_["nsplit"] > 1 for o_ in w3), "no split-K launch of conv_wino3_kernel in the default plan"
         assert any(o_["nsplit"] > 1 and o_["kernel"] == "conv_small_kernel" for o_ in ops)  # the weight-streaming 4^3 level
 

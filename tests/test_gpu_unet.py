@@ -154,6 +154,23 @@ def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kerne
     assert gu.rel_err(y2, y.cpu()) < 1e-5
 
 
+def test_forward_channels_last_equals_forward(gu):
+    """holo_unet_forward_cl (ABI 5): the forward on (N, R, R, R, C) tensors - the first convolution reads the caller's tensor, the
+    last one writes the caller's tensor, no layout pass - is bit-equal to the NCDHW call; batch 2; also after a plain call on
+    the same handle (the two entries share the plan)."""
+    net, _ = gu.make_unet(TINY_CFG)
+    x = torch.cat([seeded_input(TINY_CFG, 21), seeded_input(TINY_CFG, 22)]).to(gu.DEV)
+    t = torch.tensor([640, 3], device=gu.DEV)
+    y = net(x, t)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous()
+    y_cl = net.forward_channels_last(x_cl, t)
+    assert y_cl.shape == x_cl.shape and torch.equal(y_cl.permute(0, 4, 1, 2, 3), y)
+    assert torch.equal(net(x, t), y) and torch.equal(net.forward_channels_last(x_cl, t), y_cl)
+    from holo_diffusion_amd._lib import HoloError
+    with pytest.raises(HoloError):
+        net.forward_channels_last(x, t)  # an NCDHW tensor is not (N, R, R, R, C)
+
+
 def test_streaming_skip_connection_blockwise(gu, monkeypatch):
     """conv1x1_stream_kernel - a ResBlock's 1x1x1 skip_connection (unet.py:222) as a launch of its own, the form the 64^3
     level of the north-star net runs (its output is the residual of the block's second convolution) - forced onto a small
