@@ -429,12 +429,16 @@ struct MlpMeanBwdParams {
   const float* gout;  // (1, F, R, R, R)
   int FW;             // width of a DUL row: F values of du, dlogit at column F, zero padding to a multiple of 4
   int64_t NRp, Pp;
+  // the row buffers hold ONE chunk of voxels [p0, p0 + Pc) of the Pall = R^3 (rows = view * Pc + local voxel): the workspace
+  // does not grow with the grid (holo_mlp_mean_backward walks the chunks, the parameter gradients add up in chunk order)
+  int64_t p0, Pc, Pall;
   float *X, *MEAN, *CM, *PRE, *H, *U, *DUL, *DULT, *DPRET, *DC, *DCT, *DX, *DCA;
   float* gfeat[ViewPoolParams::MAX_FEATS];
 };
 int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream);
-int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream);
-int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream);
+int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream,
+                     int accumulate = 0);
+int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream, int accumulate = 0);
 int nchw_to_nhwc_pad_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
 int transpose_small_launch(const float* in, float* out, int rows, int cols, void* stream);
 // ---------------------------------------------------------------------------------------------

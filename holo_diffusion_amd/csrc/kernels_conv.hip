@@ -2542,31 +2542,27 @@ __global__ __launch_bounds__(256, 2) void conv_small_kernel(ConvParams p) {  // 
 // Streaming 1x1x1 convolution of a LARGE grid: a ResBlock's skip_connection (unet.py:222) on the 64^3 level as a launch
 // of its own, its output the residual of the block's second 3x3x3 convolution.  (Fused into that convolution as extra
 // pseudo-taps the 128-channel skip costs conv_wino3_kernel ~100 us per launch - its operands are scattered 16-byte reads -;
-// here it is a plain GEMM of M = 262 144 rows, K <= 128, N = 64 that runs at the rate its 200 MB cross the fabric.)
-// A wave owns ALL 64 output channels of a 16-row tile: the weights of its K x 64 block sit in registers for the whole launch
-// (NCH x 32 registers, the row-tile kernel's packed layout), the rows come straight from global memory - lane (lj, kq)
-// reads the 32 contiguous bytes (channels 8 kq .. +7 of row lj) of every 32-channel chunk, the next tile's rows under the
-// current tile's MFMAs -, no LDS, no barrier.  Raw input (no GroupNorm / activation), virtual concat of two sources.
+// here it is a plain GEMM of M = 262 144 rows, K <= 256, N = 64 that runs at the rate its 200 MB cross the fabric.)
+// A wave owns ALL 64 output channels of a 16-row tile: the K x 64 weight block (the row-tile kernel's packed layout) sits in
+// LDS for the whole launch (32 KB at K = 128; it was first held in registers: 248 of them, which left room for ONE tile of
+// rows in flight per wave and 3.1 TB/s), the rows come straight from global memory - lane (lj, kq) reads the 32 contiguous
+// bytes (channels 8 kq .. +7 of row lj) of every 32-channel chunk, FOUR tiles ahead of the MFMAs that consume them -, one
+// barrier at the start.  Raw input (no GroupNorm / activation), virtual concat of two sources.
 // ---------------------------------------------------------------------------------------------
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvParams p) {
+  constexpr int DEPTH = NCH <= 4 ? 4 : 2;  // row tiles in flight per wave (the ring of A registers: DEPTH x NCH x 8)
+  // the K x 64 weight block of the workgroup, in the row-tile kernel's packed order: [chunk][16-Cout slice][half][lane][4]
+  __shared__ __attribute__((aligned(16))) float s_w[NCH * 4 * 2 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lj = lane & 15, kq = lane >> 4;
   const int64_t M = (int64_t)p.N * p.OD * p.OH * p.OW;
   const int64_t ntile = M >> 4;
   const int n0 = blockIdx.y * 64;
   const int wnsl = p.CoutP >> 4;
-  // weights: [chunk][16-Cout slice][half][kq][lj][4] (wpack_block), 512 floats per (chunk, slice)
-  float4 bw[NCH][4][2];
-  {
-    const float* wl = p.w + (int64_t)(n0 >> 4) * 512 + lane * 4;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i)
-#pragma unroll
-      for (int sl = 0; sl < 4; ++sl) {
-        const float* wp = wl + ((int64_t)i * wnsl + sl) * 512;
-        bw[i][sl][0] = *reinterpret_cast<const float4*>(wp);
-        bw[i][sl][1] = *reinterpret_cast<const float4*>(wp + 256);
-      }
+  for (int i = tid; i < NCH * 4 * 2 * 64; i += 256) {  // 16-byte pieces: (chunk, slice, half, lane)
+    const int ln = i & 63, h = (i >> 6) & 1, sl = (i >> 7) & 3, ch = i >> 9;
+    *reinterpret_cast<float4*>(s_w + i * 4) =
+        *reinterpret_cast<const float4*>(p.w + ((int64_t)ch * wnsl + (n0 >> 4) + sl) * 512 + h * 256 + ln * 4);
   }
   // The product is formed TRANSPOSED (A operand = the weights, rows = output channels; B operand = the tile's rows, columns
   // = voxels): a lane then holds 4 CONSECUTIVE output channels (D rows 4 kq + r) of voxel lj, so the tile leaves as four
@@ -2595,41 +2591,50 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvParams p) {
     }
   };
   const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
-  float4 A[2][NCH][2];
-  if (gw < ntile) load_rows(gw, A[0]);
-  int buf = 0;
-  for (int64_t t = gw; t < ntile; t += nw, buf ^= 1) {
-    if (t + nw < ntile) {
-      if (buf == 0) load_rows(t + nw, A[1]); else load_rows(t + nw, A[0]);
-    }
-    f32x4 acc[4];
+  float4 A[DEPTH][NCH][2];
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
+  for (int j = 0; j < DEPTH - 1; ++j)
+    if (gw + j * nw < ntile) load_rows(gw + j * nw, A[j]);
+  __syncthreads();  // the weights are in LDS (the only barrier of the kernel)
+  for (int64_t t0 = gw; t0 < ntile; t0 += DEPTH * nw) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[sl][r] = 0.f;
-    auto tile = [&](const float4 (&a)[NCH][2]) {
+    for (int j = 0; j < DEPTH; ++j) {
+      const int64_t t = t0 + j * nw;
+      if (t >= ntile) break;  // (uniform)
+      if (t + (DEPTH - 1) * nw < ntile) load_rows(t + (DEPTH - 1) * nw, A[(j + DEPTH - 1) % DEPTH]);
+      int lw = lane * 4;
+      HOLO_LAUNDER(lw);  // (the weight reads are loop invariant: hoisted, they would take NCH x 32 registers again)
+      const float* wl = s_w + lw;
+      f32x4 acc[4];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[sl][r] = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          float4 bw[4];
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) bw[sl] = *reinterpret_cast<const float4*>(wl + ((i * 4 + sl) * 2 + h) * 256);
+          const float4 a = A[j][i][h];
           // the four accumulators advance together, k-step by k-step (no MFMA waits on its predecessor's result)
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].x, a[i][h].x, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[sl].x, a.x, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].y, a[i][h].y, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[sl].y, a.y, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].z, a[i][h].z, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[sl].z, a.z, acc[sl], 0, 0, 0);
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[i][sl][h].w, a[i][h].w, acc[sl], 0, 0, 0);
+          for (int sl = 0; sl < 4; ++sl) acc[sl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[sl].w, a.w, acc[sl], 0, 0, 0);
         }
-    };
-    if (buf == 0) tile(A[0]); else tile(A[1]);
-    // D: column lj = voxel of the tile, rows 4 kq + r = output channels of the slice
-    float* o = p.out + (t * 16 + lj) * p.Cout + n0 + 4 * kq;
+      // D: column lj = voxel of the tile, rows 4 kq + r = output channels of the slice
+      float* o = p.out + (t * 16 + lj) * p.Cout + n0 + 4 * kq;
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl)
-      *reinterpret_cast<float4*>(o + sl * 16) =
-          make_float4(acc[sl][0] + bv[sl].x, acc[sl][1] + bv[sl].y, acc[sl][2] + bv[sl].z, acc[sl][3] + bv[sl].w);
+      for (int sl = 0; sl < 4; ++sl)
+        *reinterpret_cast<float4*>(o + sl * 16) =
+            make_float4(acc[sl][0] + bv[sl].x, acc[sl][1] + bv[sl].y, acc[sl][2] + bv[sl].z, acc[sl][3] + bv[sl].w);
+    }
   }
 }
 
@@ -2771,7 +2776,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     const char* e1 = getenv("HOLO_CONV1X1_STREAM_MIN_M");
     const int64_t min_m = e1 ? atoll(e1) : 131072;
     if (p.mode == 0 && min_m > 0 && M >= min_m && p.ksz == 1 && p.stride == 1 && !p.ups && !p.coef && !p.residual && !p.skip_w &&
-        p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && (p.Cout % 64) == 0 && (Cin % 32) == 0 && Cin >= 32 && Cin <= 128 &&  // (K x 64 weights in registers: 128 channels = 248 VGPRs)
+        p.bf16 == 0 && !p.in_bf16 && !p.out_bf16 && (p.Cout % 64) == 0 && (Cin % 32) == 0 && Cin >= 32 && Cin <= 256 &&
         (!p.src1 || (p.C0 % 32) == 0) && (M % 16) == 0 && p.ID == p.OD && p.IH == p.OH && p.IW == p.OW) {
       p.mode = 3;
       p.nsplit = 1;
@@ -2784,7 +2789,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
   if (p.mode == 0 && p.Cout >= 64) {
     p.mode = 2;
     const int64_t t2 = cdiv(M, SM_ROWS) * cdiv(p.Cout, 64);
-    const int64_t tgt = 2 * (int64_t)num_cus;
+    const char* st = getenv("HOLO_SMALL_SPLIT_TARGET");  // development knob: workgroups per CU the split-K aims at (default 2)
+    const int64_t tgt = (st && atoi(st) > 0 ? atoi(st) : 2) * (int64_t)num_cus;
     nsplit = t2 < tgt ? (int)cdiv(tgt, t2) : 1;
     // (a fused 1x1x1 skip: its chunks follow the (tap, chunk) list; stride 1 and no upsampling there: conv_launch)
     const int nall = nchunks + (p.skip_w ? (int)cdiv(p.skip_C0 + p.skip_C1, BK) : 0);
@@ -3056,6 +3062,10 @@ int conv_launch(const ConvParams& p, void* stream) {
       case 2: HOLO_LAUNCH(conv1x1_stream_kernel<2>, g3, block, stream, p); break;
       case 3: HOLO_LAUNCH(conv1x1_stream_kernel<3>, g3, block, stream, p); break;
       case 4: HOLO_LAUNCH(conv1x1_stream_kernel<4>, g3, block, stream, p); break;
+      case 5: HOLO_LAUNCH(conv1x1_stream_kernel<5>, g3, block, stream, p); break;
+      case 6: HOLO_LAUNCH(conv1x1_stream_kernel<6>, g3, block, stream, p); break;
+      case 7: HOLO_LAUNCH(conv1x1_stream_kernel<7>, g3, block, stream, p); break;
+      case 8: HOLO_LAUNCH(conv1x1_stream_kernel<8>, g3, block, stream, p); break;
       default:
         set_error("conv_launch: streaming 1x1x1 kernel: %d input channels", Cin);
         return -1;

@@ -22,6 +22,8 @@
 // atomics and are not).
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -62,11 +64,35 @@ __device__ __forceinline__ void sample4(const float* base, const Tap& t, float (
   s[3] = t00.w * t.w00 + t01.w * t.w01 + t10.w * t.w10 + t11.w * t.w11;
 }
 
+// TILED (the default; round 5): the scatter of the small multi-channel maps goes through LDS.  The plain form issues one
+// hardware atomic per (voxel, view, channel, bilinear tap) - 1.1 G of them at 64^3 x 16 views, 15.7 ms against a 0.8 ms
+// forward - although neighbouring voxels land on the same few pixels of a 64^2 ... 8^2 map.  Here a workgroup owns BRICKS of
+// 64 voxels (four 16-voxel runs: (y, y + 1) x (z, z + 1) when the grid allows it), phase 1 is the kernel above for the
+// brick's four groups - its pass 2 only for the maps that stay on direct atomics (one- / three-channel maps at image
+// resolution: about one pixel per voxel, nothing to merge) - and leaves (mu, dmu', 2 dvar) per voxel and channel of the
+// tiled maps in LDS; phase 2 walks the views: bounding box of the brick's taps per map, contributions summed by LDS atomics
+// into a tile of at most 256 pixels x 16 channels per map (the storage of the agg / dagg tiles, dead by then), ONE global
+// atomic per touched (pixel, channel).  A footprint that does not fit its tile (a camera inside the volume) falls back to
+// direct atomics for that (view, map).
+constexpr int VB_BRICK = 64;       // voxels per brick
+constexpr int VB_LC = 64;          // channels of the tiled maps, padded, per voxel
+constexpr int VB_TPX = 256;        // pixels per tile
+constexpr int VB_TMAPS = 4;        // tiled maps
+
+template <bool TILED>
 __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b) {
   const ViewPoolParams& p = b.fwd;
-  __shared__ float s_agg[16 * ViewPoolParams::MAX_AGG];   // [voxel][aggregated feature]
-  __shared__ float s_dagg[16 * ViewPoolParams::MAX_AGG];  // [voxel][d loss / d aggregated feature]
+  // [voxel][aggregated feature] and [voxel][d loss / d aggregated feature]; phase 2 (TILED) re-uses the pair as the four tiles
+  __shared__ __attribute__((aligned(16))) float s_pair[2 * 16 * ViewPoolParams::MAX_AGG];
+  float* const s_agg = s_pair;
+  float* const s_dagg = s_pair + 16 * ViewPoolParams::MAX_AGG;
   __shared__ float s_dz[16 * VB_F];
+  __shared__ float s_mu[TILED ? VB_BRICK * VB_LC : 1], s_dmu[TILED ? VB_BRICK * VB_LC : 1], s_dv2[TILED ? VB_BRICK * VB_LC : 1];
+  __shared__ float s_ndcx[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1], s_ndcy[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1],
+      s_wD[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1];
+  __shared__ int s_box[TILED ? VB_BRICK * 4 : 1];  // per voxel: x0, x1, y0, y1 of its taps in the current (view, map)
+  __shared__ int s_bbox[VB_TMAPS][6];               // per tiled map: x0, y0, width, height, fits, -
+  static_assert(2 * 16 * ViewPoolParams::MAX_AGG >= VB_TMAPS * VB_TPX * 16, "the tiles live in the agg / dagg storage");
   const int tid = threadIdx.x;
   const int vl = tid >> 4, ql = tid & 15;
   const int R = p.R;
@@ -76,6 +102,34 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
   auto lin = [&](int i) { return (i < R / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(R - 1 - i)) * p.half_extent; };
   const float std_floor = sqrtf(1e-4f);
 
+  // which maps are tiled (uniform): several channels, at most 16 padded, not above 128^2; their channels in a packed list
+  int tmap_of[ViewPoolParams::MAX_FEATS], tlc0[ViewPoolParams::MAX_FEATS];  // tile slot / first packed channel, -1 = direct atomics
+  int n_tiled = 0, n_lc = 0;
+#pragma unroll
+  for (int k = 0; k < ViewPoolParams::MAX_FEATS; ++k) {
+    tmap_of[k] = -1, tlc0[k] = 0;
+    if (TILED && k < p.n_feats && b.want_feats && b.gfeat[k]) {
+      const ViewPoolParams::Feat& f = p.feat[k];
+      if (f.C >= 4 && f.Cp <= 16 && f.H * f.W <= 128 * 128 && n_tiled < VB_TMAPS && n_lc + f.Cp <= VB_LC) {
+        tmap_of[k] = n_tiled++;
+        tlc0[k] = n_lc;
+        n_lc += f.Cp;
+      }
+    }
+  }
+  // bricks: four groups; (y, y + 1) x (z, z + 1) neighbours of an x run when a group is an x run (R % 16 == 0, R even), else
+  // four consecutive groups
+  const bool xrun = TILED && (R % 16) == 0 && (R % 2) == 0;
+  const int gpr = xrun ? R / 16 : 1;  // groups per x row
+  const int64_t nbricks = TILED ? (xrun ? (int64_t)gpr * (R / 2) * (R / 2) : (ngroups + 3) / 4) : ngroups;
+  auto group_of = [&](int64_t brick, int gi) -> int64_t {
+    if (!TILED) return brick;
+    if (!xrun) return brick * 4 + gi;
+    const int64_t xg = brick % gpr, y2 = (brick / gpr) % (R / 2), z2 = brick / ((int64_t)gpr * (R / 2));
+    const int64_t y = 2 * y2 + (gi & 1), z = 2 * z2 + (gi >> 1);
+    return (z * R + y) * gpr + xg;
+  };
+
   float dM[2][VB_F];  // rows a = tid, tid + 256 of d M^T
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -83,10 +137,13 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
     for (int o = 0; o < VB_F; ++o) dM[h][o] = 0.f;
   float db = 0.f;  // thread tid < F: d bias[tid]
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t v = grp * 16 + vl;
-    const bool vok = v < nvox;
-    const int64_t vc = vok ? v : nvox - 1;
+  for (int64_t brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
+  for (int gi = 0; gi < (TILED ? 4 : 1); ++gi) {
+    const int64_t grp = group_of(brick, gi);
+    const bool gok = grp < ngroups;  // (uniform; a ragged last brick)
+    const int64_t v = (gok ? grp : 0) * 16 + vl;
+    const bool vok = gok && v < nvox;
+    const int64_t vc = v < nvox ? v : nvox - 1;
     const int x = (int)(vc % R), y = (int)((vc / R) % R), z = (int)(vc / ((int64_t)R * R));
     const float px = lin(x), py = lin(y), pz = lin(z);
     float ndcx[ViewPoolParams::MAX_VIEWS], ndcy[ViewPoolParams::MAX_VIEWS], wv[ViewPoolParams::MAX_VIEWS];
@@ -112,6 +169,15 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       S0 += wv[vi];
     }
     const float D = fmaxf(S0, 1e-2f);
+    if (TILED && ql == 0) {  // the voxel's projections and weights for phase 2
+#pragma unroll 1
+      for (int vi = 0; vi < p.n_views; ++vi) {
+        const int bi = (gi * 16 + vl) * ViewPoolParams::MAX_VIEWS + vi;
+        s_ndcx[bi] = ndcx[vi];
+        s_ndcy[bi] = ndcy[vi];
+        s_wD[bi] = vok ? wv[vi] / D : 0.f;
+      }
+    }
 
     // ---- pass 1: the forward's aggregation, [AVG | STD] per key into the LDS tile
     for (int q = ql; q < p.n_quads; q += 16) {
@@ -176,7 +242,8 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       for (int pv = 0; pv < 16; ++pv) db += s_dz[pv * VB_F + tid];
     }
     __syncthreads();
-    // ---- pass 2: the samples again, dx per view, scattered through the bilinear weights
+    // ---- pass 2: the samples again, dx per view, scattered through the bilinear weights (tiled maps: only the per-voxel
+    //      terms, for phase 2)
     if (b.want_feats) {
       for (int q = ql; q < p.n_quads; q += 16) {
         int k = 0;
@@ -196,6 +263,12 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
           const float dsd = s_dagg[ia + f.C];
           dvar2[e] = (cok && sd > std_floor) ? dsd / sd : 0.f;  // 2 dvar = dstd / std
           dmu[e] = cok ? s_dagg[ia] - dvar2[e] * mu[e] * (D - S0) / D : 0.f;
+        }
+        if (TILED && tmap_of[k] >= 0) {
+          const int li = (gi * 16 + vl) * VB_LC + tlc0[k] + cq * 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s_mu[li + e] = mu[e], s_dmu[li + e] = dmu[e], s_dv2[li + e] = dvar2[e];
+          continue;
         }
 #pragma unroll 1
         for (int vi = 0; vi < p.n_views; ++vi) {
@@ -219,7 +292,91 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       }
     }
     __syncthreads();  // the LDS tiles are rewritten by the next group
+  }  // groups of the brick
+  // ---- phase 2 (TILED): the brick's contributions to the tiled maps, view by view
+  if (TILED && n_tiled > 0) {
+    float* const s_tile = s_pair;  // [slot][pixel][Cp] (slot stride VB_TPX * 16)
+#pragma unroll 1
+    for (int vi = 0; vi < p.n_views; ++vi) {
+#pragma unroll 1
+      for (int k = 0; k < p.n_feats; ++k) {
+        const int slot = tmap_of[k];
+        if (slot < 0) continue;
+        const ViewPoolParams::Feat& f = p.feat[k];
+        // bounding box of the brick's taps (pixel coordinates; taps of zero weight included: harmless)
+        if (tid < VB_BRICK) {
+          const Tap t = tap_of(f, s_ndcx[tid * ViewPoolParams::MAX_VIEWS + vi], s_ndcy[tid * ViewPoolParams::MAX_VIEWS + vi]);
+          const int p00 = t.o00 / f.Cp, p11 = t.o11 / f.Cp;
+          s_box[tid * 4 + 0] = p00 % f.W;
+          s_box[tid * 4 + 1] = p11 % f.W;
+          s_box[tid * 4 + 2] = p00 / f.W;
+          s_box[tid * 4 + 3] = p11 / f.W;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3];
+          for (int i = 1; i < VB_BRICK; ++i) {
+            x0 = min(x0, s_box[i * 4 + 0]);
+            x1 = max(x1, s_box[i * 4 + 1]);
+            y0 = min(y0, s_box[i * 4 + 2]);
+            y1 = max(y1, s_box[i * 4 + 3]);
+          }
+          const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+          s_bbox[slot][0] = x0, s_bbox[slot][1] = y0, s_bbox[slot][2] = bw, s_bbox[slot][3] = bh;
+          s_bbox[slot][4] = (bw > 0 && bh > 0 && bw * bh <= VB_TPX) ? 1 : 0;
+        }
+        __syncthreads();
+        const int bx0 = s_bbox[slot][0], by0 = s_bbox[slot][1], bw = s_bbox[slot][2], bh = s_bbox[slot][3];
+        const bool fits = s_bbox[slot][4] != 0;
+        float* tile = s_tile + slot * (VB_TPX * 16);
+        const int nt = fits ? bw * bh * f.Cp : 0;
+        for (int i = tid; i < nt; i += 256) tile[i] = 0.f;
+        __syncthreads();
+        const int nq = f.Cp / 4;
+        float* gmap = b.gfeat[k];
+        for (int it = tid; it < VB_BRICK * nq; it += 256) {
+          const int bv = it / nq, cq = it - bv * nq;
+          const float wD = s_wD[bv * ViewPoolParams::MAX_VIEWS + vi];
+          if (wD == 0.f) continue;
+          const Tap t = tap_of(f, s_ndcx[bv * ViewPoolParams::MAX_VIEWS + vi], s_ndcy[bv * ViewPoolParams::MAX_VIEWS + vi]);
+          const int64_t vbase = ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
+          float s[4];
+          sample4(f.data + vbase, t, s);
+          const int li = bv * VB_LC + tlc0[k] + cq * 4;
+          const int offs[4] = {t.o00, t.o01, t.o10, t.o11};
+          const float ws[4] = {t.w00, t.w01, t.w10, t.w11};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dx = wD * (s_dmu[li + e] + s_dv2[li + e] * (s[e] - s_mu[li + e]));
+            if (dx == 0.f) continue;
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+              if (ws[tp] == 0.f) continue;
+              if (fits) {
+                const int pxl = offs[tp] / f.Cp;
+                const int ti = ((pxl / f.W - by0) * bw + (pxl % f.W - bx0)) * f.Cp + cq * 4 + e;
+                atomicAdd(tile + ti, ws[tp] * dx);  // ds_add_f32
+              } else {
+                HOLO_ATOMIC_ADD_F32(gmap + vbase + e + offs[tp], ws[tp] * dx);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        // flush: one global atomic per touched (pixel, channel)
+        for (int i = tid; i < nt; i += 256) {
+          const float val = tile[i];
+          if (val != 0.f) {
+            const int c = i % f.Cp, pxl = i / f.Cp;
+            const int yy = by0 + pxl / bw, xx = bx0 + pxl % bw;
+            HOLO_ATOMIC_ADD_F32(gmap + (((int64_t)vi * f.H + yy) * f.W + xx) * f.Cp + c, val);
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
+  }  // bricks
   // ---- per-workgroup partials: [wg][A * F (+ F)] in the (A, F) order of the transposed weight
   float* part = b.partial + (int64_t)blockIdx.x * ((int64_t)p.A * p.F + p.F);
 #pragma unroll
@@ -304,7 +461,7 @@ __global__ __launch_bounds__(256) void mm_gather_kernel(MlpMeanBwdParams b) {
   const MlpMeanParams& m = b.fwd;
   const ViewPoolParams& vp = m.vp;
   const int dq = m.dp >> 2;
-  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const int64_t P = b.Pc;  // voxels of this chunk (rows = view * Pc + local voxel)
   const int64_t total = (int64_t)vp.n_views * P * dq;
   const int nh = m.n_harmonic;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -312,7 +469,7 @@ __global__ __launch_bounds__(256) void mm_gather_kernel(MlpMeanBwdParams b) {
     const int64_t row = i / dq;
     const int vi = (int)(row / P);
     const int64_t p = row - (int64_t)vi * P;
-    const VoxelProj pr = project_voxel(vp, vi, p);
+    const VoxelProj pr = project_voxel(vp, vi, b.p0 + p);
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     bool done = false;
     for (int k = 0; k < vp.n_feats && !done; ++k) {
@@ -351,7 +508,7 @@ __global__ __launch_bounds__(256) void mm_gather_kernel(MlpMeanBwdParams b) {
 __global__ __launch_bounds__(256) void mm_mean_kernel(MlpMeanBwdParams b) {
   const MlpMeanParams& m = b.fwd;
   const int dq = m.dp >> 2, V = m.vp.n_views;
-  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const int64_t P = b.Pc;
   const float inv = 1.f / fmaxf((float)V, 1e-2f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P * dq; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i % dq);
@@ -368,7 +525,7 @@ __global__ __launch_bounds__(256) void mm_mean_kernel(MlpMeanBwdParams b) {
 // PRE[row] += CM[p] + b';  H = LeakyReLU_0.2(PRE)
 __global__ __launch_bounds__(256) void mm_hidden_kernel(MlpMeanBwdParams b) {
   const MlpMeanParams& m = b.fwd;
-  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const int64_t P = b.Pc;
   const int64_t total = (int64_t)m.vp.n_views * P * 32;  // 128 / 4 quads per row
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(i & 31);
@@ -388,7 +545,7 @@ __global__ __launch_bounds__(256) void mm_head_kernel(MlpMeanBwdParams b) {
   const MlpMeanParams& m = b.fwd;
   const ViewPoolParams& vp = m.vp;
   const int lane = threadIdx.x & 63, F = vp.F, V = vp.n_views, FW = b.FW;
-  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const int64_t P = b.Pc;  // voxels of this chunk (rows = view * Pc + local voxel)
   const float l_lo = m.l[lane], l_hi = m.l[lane + 64];
   for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < P; p += (int64_t)gridDim.x * 4) {
     float logit[ViewPoolParams::MAX_VIEWS], a[ViewPoolParams::MAX_VIEWS], u[ViewPoolParams::MAX_VIEWS];
@@ -413,7 +570,7 @@ __global__ __launch_bounds__(256) void mm_head_kernel(MlpMeanBwdParams b) {
       z = fmaf(a[v], u[v], z);
     }
     const float out = tanhf(z);
-    const float dz = lane < F ? b.gout[(int64_t)lane * P + p] * (1.f - out * out) : 0.f;
+    const float dz = lane < F ? b.gout[(int64_t)lane * b.Pall + b.p0 + p] * (1.f - out * out) : 0.f;
     float s = 0.f, da[ViewPoolParams::MAX_VIEWS];
     for (int v = 0; v < V; ++v) {
       float part = dz * u[v];
@@ -439,7 +596,7 @@ __global__ __launch_bounds__(256) void mm_head_kernel(MlpMeanBwdParams b) {
 __global__ __launch_bounds__(256) void mm_dpre_kernel(MlpMeanBwdParams b) {
   __shared__ float tile[64 * 129];
   const MlpMeanParams& m = b.fwd;
-  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R, NR = P * m.vp.n_views;
+  const int64_t P = b.Pc, NR = P * m.vp.n_views;
   const int tid = threadIdx.x;
   for (int64_t r0 = (int64_t)blockIdx.x * 64; r0 < NR; r0 += (int64_t)gridDim.x * 64) {
     for (int e = tid; e < 64 * 128; e += 256) {
@@ -468,7 +625,7 @@ __global__ __launch_bounds__(256) void mm_dc_kernel(MlpMeanBwdParams b) {
   __shared__ float tile[64 * 129];
   const MlpMeanParams& m = b.fwd;
   const int V = m.vp.n_views;
-  const int64_t P = (int64_t)m.vp.R * m.vp.R * m.vp.R;
+  const int64_t P = b.Pc;
   const int tid = threadIdx.x;
   for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < P; p0 += (int64_t)gridDim.x * 64) {
     for (int e = tid; e < 64 * 128; e += 256) {
@@ -495,7 +652,7 @@ __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
   const MlpMeanParams& m = b.fwd;
   const ViewPoolParams& vp = m.vp;
   const int fq = m.emb0 >> 2;  // feature quads come first in the padded order
-  const int64_t P = (int64_t)vp.R * vp.R * vp.R;
+  const int64_t P = b.Pc;  // voxels of this chunk (rows = view * Pc + local voxel)
   const int64_t total = (int64_t)vp.n_views * P * fq;
   const float inv = 1.f / fmaxf((float)vp.n_views, 1e-2f);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -511,7 +668,7 @@ __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
     const float4 dx = *reinterpret_cast<const float4*>(b.DX + row * m.dp + q * 4);
     const float4 dc = *reinterpret_cast<const float4*>(b.DCA + p * m.dp + q * 4);
     const float g4[4] = {dx.x + dc.x * inv, dx.y + dc.y * inv, dx.z + dc.z * inv, dx.w + dc.w * inv};
-    const VoxelProj pr = project_voxel(vp, vi, p);
+    const VoxelProj pr = project_voxel(vp, vi, b.p0 + p);
     const Tap t = tap_of(f, pr.ndcx, pr.ndcy);
     const int cq = q - f.quad0;
     float* base = gmap + ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
@@ -548,12 +705,12 @@ __global__ __launch_bounds__(256) void mm_colsum_kernel(const float* __restrict_
   }
 }
 
-// out[i] = sum_s partial[s][i], s in order
+// out[i] (+)= sum_s partial[s][i], s in order
 __global__ __launch_bounds__(256) void mm_sum_partials_kernel(const float* __restrict__ partial, int S, int64_t n,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
+  float s = accumulate ? out[i] : 0.f;  // (the voxel chunks of holo_mlp_mean_backward add up in chunk order: deterministic)
   for (int k = 0; k < S; ++k) s += partial[(int64_t)k * n + i];
   out[i] = s;
 }
@@ -565,7 +722,16 @@ int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
     set_error("view_pool_backward: feature_size <= %d and <= 512 aggregated features (got %d, %d)", VB_F, b.fwd.F, b.fwd.A);
     return -1;
   }
-  HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
+#ifndef HOLO_EMU
+  static const bool v1 = getenv("HOLO_VIEWPOOL_BWD_V1") != nullptr;  // development knob: every map on direct atomics
+#else
+  const bool v1 = false;
+#endif
+  if (v1) {
+    HOLO_LAUNCH(view_pool_bwd_kernel<false>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+  } else {
+    HOLO_LAUNCH(view_pool_bwd_kernel<true>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+  }
   const int per = b.fwd.A * b.fwd.F + b.fwd.F;
   HOLO_LAUNCH(viewpool_partial_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), stream, (const float*)b.partial, n_wgs,
               b.fwd.A, b.fwd.F, b.dW, b.dbias);
@@ -585,7 +751,7 @@ static unsigned mm_blocks(int64_t total) {
   return (unsigned)(bl < 1 ? 1 : (bl > 65535 ? 65535 : bl));
 }
 int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream) {
-  const int64_t P = (int64_t)b.fwd.vp.R * b.fwd.vp.R * b.fwd.vp.R, NR = P * b.fwd.vp.n_views;
+  const int64_t P = b.Pc, NR = P * b.fwd.vp.n_views;
   switch (step) {
     case 0:
       HOLO_LAUNCH(mm_gather_kernel, dim3(mm_blocks(NR * (b.fwd.dp / 4))), dim3(256), stream, b);
@@ -607,17 +773,18 @@ int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream) {
   }
   return -1;
 }
-int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream) {
+int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream,
+                     int accumulate) {
   if (cols > 256) {
     set_error("mm_colsum: at most 256 columns");
     return -1;
   }
   HOLO_LAUNCH(mm_colsum_kernel, dim3((unsigned)n_blocks), dim3(256), stream, src, rows, cols, ld, partial);
-  HOLO_LAUNCH(mm_sum_partials_kernel, dim3(1), dim3(256), stream, (const float*)partial, n_blocks, (int64_t)cols, out);
+  HOLO_LAUNCH(mm_sum_partials_kernel, dim3(1), dim3(256), stream, (const float*)partial, n_blocks, (int64_t)cols, out, accumulate);
   return 0;
 }
-int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream) {
-  HOLO_LAUNCH(mm_sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream, partial, S, n, out);
+int mm_sum_partials_launch(const float* partial, int S, int64_t n, float* out, void* stream, int accumulate) {
+  HOLO_LAUNCH(mm_sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream, partial, S, n, out, accumulate);
   return 0;
 }
 

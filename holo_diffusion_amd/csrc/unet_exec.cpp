@@ -592,7 +592,7 @@ struct Planner {
     {
       const char* mr = getenv("HOLO_SKIP_FUSION_BELOW_R");
       const int below = mr ? atoi(mr) : 64;
-      if (fuse_skip && u->compute_mode == 0 && R >= below && (b.cin % 32) == 0 && b.cin <= 128 && (b.cout % 64) == 0) fuse_skip = false;
+      if (fuse_skip && u->compute_mode == 0 && R >= below && (b.cin % 32) == 0 && b.cin <= 256 && (b.cout % 64) == 0) fuse_skip = false;
     }
     if (has_skip && !fuse_skip) {
       s = new_act(b.cout, R);

@@ -483,7 +483,9 @@ static int mlp_mean_fill(HoloMlpMeanPooler* h, const HoloViewFeature* feats, int
 
 // ---- backward (kernels_viewpool_bwd.hip: the MLPMean section).  Workspace layout, shared by the size query and the run.
 struct MmBwdLayout {
-  int64_t P, NR, NRp, Pp;
+  int64_t P, NR, NRp, Pp;  // per CHUNK of voxels
+  int64_t Pall;
+  int nchunks;
   int S, S2, FW, dp;
   size_t maps, gmaps, X, MEAN, CM, PRE, H, U, DUL, DULT, DPRET, DC, DCT, DX, DCA, part, fold, total;
 };
@@ -491,7 +493,20 @@ static MmBwdLayout mm_bwd_layout(const HoloMlpMeanPooler* h, const HoloViewFeatu
   MmBwdLayout L;
   memset(&L, 0, sizeof L);
   const int R = h->cfg.resol, F = h->cfg.feature_size;
-  L.P = (int64_t)R * R * R;
+  // the row buffers hold one CHUNK of voxels (all chunks the same size: the padding of the split-K operands stays valid):
+  // the largest power-of-two fraction of the grid that is at most the target (32 768 voxels: ~0.1 GB of rows per source view)
+  L.Pall = (int64_t)R * R * R;
+  L.nchunks = 1;
+  {
+#ifndef HOLO_EMU
+    const char* e = getenv("HOLO_MLP_MEAN_BWD_CHUNK");  // development / test knob: target voxels per chunk
+    const int64_t target = e && atoll(e) > 0 ? atoll(e) : 32768;
+#else
+    const int64_t target = 2048;  // (the emulation's small grids: two chunks at 16^3)
+#endif
+    while (L.Pall / L.nchunks > target && (L.Pall % (2 * L.nchunks)) == 0) L.nchunks *= 2;
+  }
+  L.P = L.Pall / L.nchunks;
   L.NR = L.P * n_views;
   L.dp = h->dp;
   L.FW = (F + 1 + 3) / 4 * 4;
@@ -612,30 +627,38 @@ int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, i
   do {                                 \
     if (x) return HOLO_E_INVALID;      \
   } while (0)
-  // forward recomputation
-  MM_TRY(mm_bwd_step_launch(b, 0, stream));                                                                    // X, MEAN
-  MM_TRY(mm_gemm(b.MEAN, dp, b.fwd.am, dp, 0, b.CM, 128, P, 128, dp, 1, 0, 0, 0, stream));                     // CM = MEAN Am^T
-  MM_TRY(mm_gemm(b.X, dp, b.fwd.a, dp, 0, b.PRE, 128, NR, 128, dp, 1, 0, 0, 0, stream));                       // PRE = X A^T
-  MM_TRY(mm_bwd_step_launch(b, 1, stream));                                                                    // + CM + b', H
-  MM_TRY(mm_gemm(b.H, 128, b.fwd.g, 128, 0, b.U, FW, NR, F, 128, 1, 0, 0, 0, stream));                         // U = H G^T
-  MM_TRY(mm_bwd_step_launch(b, 2, stream));                                                                    // DUL, DULT
-  // dG (rows 0..F-1) and dl (row F) = DULT H, split over the rows
-  MM_TRY(mm_gemm(b.DULT, (int)L.NRp, b.H, 128, 1, part, 128, FW, 128, Kc, L.S, Kc, (int64_t)Kc * 128, (int64_t)FW * 128, stream));
-  MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)FW * 128, dG, stream));
-  MM_TRY(mm_colsum_launch(b.DUL, L.NR, FW, FW, part, 1024, dgl, stream));                                      // dg0 | dl0
-  MM_TRY(mm_gemm(b.DUL, FW, b.fwd.g, 128, 1, b.H, 128, NR, 128, F, 1, 0, 0, 0, stream));                       // DH = DU G  (into H)
-  MM_TRY(mm_bwd_step_launch(b, 3, stream));                                                                    // DPRE (in PRE), DPRET, DC, DCT
-  MM_TRY(mm_gemm(b.DPRET, (int)L.NRp, b.X, dp, 1, part, dp, 128, dp, Kc, L.S, Kc, (int64_t)Kc * dp, (int64_t)128 * dp, stream));
-  MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)128 * dp, dA, stream));
-  MM_TRY(mm_gemm(b.DCT, (int)L.Pp, b.MEAN, dp, 1, part, dp, 128, dp, Kc2, L.S2, Kc2, (int64_t)Kc2 * dp, (int64_t)128 * dp, stream));
-  MM_TRY(mm_sum_partials_launch(part, L.S2, (int64_t)128 * dp, dAm, stream));
-  MM_TRY(mm_colsum_launch(b.DC, L.P, 128, 128, part, 256, dcb, stream));
   bool want = false;
   for (int k = 0; k < n_feats; ++k) want |= b.gfeat[k] != nullptr;
+  b.Pc = L.P;
+  b.Pall = L.Pall;
+  for (int ck = 0; ck < L.nchunks; ++ck) {
+    b.p0 = (int64_t)ck * L.P;
+    const int acc = ck > 0 ? 1 : 0;  // the parameter gradients of the chunks add up in chunk order
+    // forward recomputation
+    MM_TRY(mm_bwd_step_launch(b, 0, stream));                                                                    // X, MEAN
+    MM_TRY(mm_gemm(b.MEAN, dp, b.fwd.am, dp, 0, b.CM, 128, P, 128, dp, 1, 0, 0, 0, stream));                     // CM = MEAN Am^T
+    MM_TRY(mm_gemm(b.X, dp, b.fwd.a, dp, 0, b.PRE, 128, NR, 128, dp, 1, 0, 0, 0, stream));                       // PRE = X A^T
+    MM_TRY(mm_bwd_step_launch(b, 1, stream));                                                                    // + CM + b', H
+    MM_TRY(mm_gemm(b.H, 128, b.fwd.g, 128, 0, b.U, FW, NR, F, 128, 1, 0, 0, 0, stream));                         // U = H G^T
+    MM_TRY(mm_bwd_step_launch(b, 2, stream));                                                                    // DUL, DULT
+    // dG (rows 0..F-1) and dl (row F) = DULT H, split over the rows
+    MM_TRY(mm_gemm(b.DULT, (int)L.NRp, b.H, 128, 1, part, 128, FW, 128, Kc, L.S, Kc, (int64_t)Kc * 128, (int64_t)FW * 128, stream));
+    MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)FW * 128, dG, stream, acc));
+    MM_TRY(mm_colsum_launch(b.DUL, L.NR, FW, FW, part, 1024, dgl, stream, acc));                                 // dg0 | dl0
+    MM_TRY(mm_gemm(b.DUL, FW, b.fwd.g, 128, 1, b.H, 128, NR, 128, F, 1, 0, 0, 0, stream));                       // DH = DU G  (into H)
+    MM_TRY(mm_bwd_step_launch(b, 3, stream));                                                                    // DPRE (in PRE), DPRET, DC, DCT
+    MM_TRY(mm_gemm(b.DPRET, (int)L.NRp, b.X, dp, 1, part, dp, 128, dp, Kc, L.S, Kc, (int64_t)Kc * dp, (int64_t)128 * dp, stream));
+    MM_TRY(mm_sum_partials_launch(part, L.S, (int64_t)128 * dp, dA, stream, acc));
+    MM_TRY(mm_gemm(b.DCT, (int)L.Pp, b.MEAN, dp, 1, part, dp, 128, dp, Kc2, L.S2, Kc2, (int64_t)Kc2 * dp, (int64_t)128 * dp, stream));
+    MM_TRY(mm_sum_partials_launch(part, L.S2, (int64_t)128 * dp, dAm, stream, acc));
+    MM_TRY(mm_colsum_launch(b.DC, L.P, 128, 128, part, 256, dcb, stream, acc));
+    if (want) {
+      MM_TRY(mm_gemm(b.PRE, 128, b.fwd.a, dp, 1, b.DX, dp, NR, dp, 128, 1, 0, 0, 0, stream));                    // DX = DPRE A
+      MM_TRY(mm_gemm(b.DC, 128, b.fwd.am, dp, 1, b.DCA, dp, P, dp, 128, 1, 0, 0, 0, stream));                    // DCA = DC Am
+      MM_TRY(mm_bwd_step_launch(b, 4, stream));
+    }
+  }
   if (want) {
-    MM_TRY(mm_gemm(b.PRE, 128, b.fwd.a, dp, 1, b.DX, dp, NR, dp, 128, 1, 0, 0, 0, stream));                    // DX = DPRE A
-    MM_TRY(mm_gemm(b.DC, 128, b.fwd.am, dp, 1, b.DCA, dp, P, dp, 128, 1, 0, 0, 0, stream));                    // DCA = DC Am
-    MM_TRY(mm_bwd_step_launch(b, 4, stream));
     for (int k = 0; k < n_feats; ++k)
       if (b.gfeat[k]) {
         const ViewPoolParams::Feat& f = b.fwd.vp.feat[k];

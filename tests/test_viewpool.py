@@ -330,10 +330,15 @@ def test_oracle_mlp_mean_backward_vs_reference_gradients():
 
 
 @pytest.mark.gpu
-def test_mlp_mean_view_pool_backward_vs_reference_gradients():
+@pytest.mark.parametrize("chunk", [None, "128"])
+def test_mlp_mean_view_pool_backward_vs_reference_gradients(chunk, monkeypatch):
     """holo_mlp_mean_backward against the gradients of the reference class itself (the fixture above): every aggregator
-    parameter, the mapper and the three source-view feature maps at 1e-3 of each tensor's scale; forward at 1e-4."""
+    parameter, the mapper and the three source-view feature maps at 1e-3 of each tensor's scale; forward at 1e-4.
+    ``chunk``: the backward walks the grid in voxel chunks (its workspace does not grow with the grid) - four chunks of the
+    8^3 grid here, the parameter gradients adding up across them."""
     import tests.gpu_utils as gu
+    if chunk:
+        monkeypatch.setenv("HOLO_MLP_MEAN_BWD_CHUNK", chunk)
     g, (R, n_src, F, dim_out, n_hidden, n_harm), pick = _ref_mlp_mean_backward_fixture()
     cams_d, maps, sd = pick("cam."), pick("maps."), pick("param.")
     model = hda.HoloDiffusionModel(
