@@ -363,8 +363,12 @@ def main():
     diff.device_noise_seed, diff.device_noise_stream = 42, rank  # (perf mode: Philox noise inside the step kernel)
     t_host = [max(999 - k, 0) for k in range(K + Wm)]
 
+    cl_chain = args.compute_dtype != "bf16"  # (the bf16 storage mode converts its input in the layout pass: NCDHW chain there)
+
     def one_step(x, k, mode=args.noise):
         t = ts[k]
+        if mode == "device" and not cl_chain:
+            return diff._step_device_noise(x, t, net(x, t), t_host[k], True, want_pred=False)[0]
         if mode == "device":
             # the perf chain of ImplicitronGaussianDiffusion.p_sample_loop(device_noise_seed=...): the grid stays in the
             # library's channels-last layout (no layout pass either side of the UNet), one step kernel: clamp + posterior
@@ -376,7 +380,7 @@ def main():
         sample, _ = diff._step(x, t, out, eps, True)
         return sample
 
-    if args.noise == "device":
+    if args.noise == "device" and cl_chain:
         img = img.permute(0, 2, 3, 4, 1).contiguous()  # (the chain's one conversion; back after the timed steps)
     with torch.no_grad():
         for k in range(Wm):
@@ -390,7 +394,7 @@ def main():
         barrier_sync(world)
         dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, device)
-    if args.noise == "device":
+    if args.noise == "device" and cl_chain:
         img = img.permute(0, 4, 1, 2, 3).contiguous()
     assert torch.isfinite(img).all()
     steps_per_s = world * K / dt
@@ -398,7 +402,7 @@ def main():
     other_mode = "torch" if args.noise == "device" else "device"
     with torch.no_grad():
         xo = torch.randn(*shape, device=device)
-        if other_mode == "device":
+        if other_mode == "device" and cl_chain:
             xo = xo.permute(0, 2, 3, 4, 1).contiguous()
         for k in range(min(3, Wm)):
             xo = one_step(xo, k, other_mode)
@@ -449,6 +453,24 @@ def main():
             barrier_sync(world)
             dtr40 = max_over_ranks(time.perf_counter() - t0, world, device)
         rays_per_s_40 = world * F40 * H * W / dtr40
+
+    # the same call with rendered normals (the released YAMLs' render_normals: true): normals of both passes composited
+    # inside render2_kernel<.., NRM> (density scalar field + octahedral normals in LDS)
+    rays_per_s_nrm = None
+    try:
+        fn0 = model._implicit_functions[0]._fn
+        fn0.render_normals = True
+        with torch.no_grad():
+            model.render_views(vf, cams_f)
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            outn = model.render_views(vf, cams_f)
+            barrier_sync(world)
+            dtn = max_over_ranks(time.perf_counter() - t0, world, device)
+        assert "normals_render" in outn and torch.isfinite(outn["normals_render"]).all()
+        rays_per_s_nrm = world * F * H * W / dtn
+    finally:
+        model._implicit_functions[0]._fn.render_normals = False
 
     # ---------------- roofline of the dominant kernel, hipEvents on the launch stream (holo_unet_time_ops)
     roof = None
@@ -686,6 +708,7 @@ def main():
                        + f"{F} frames @{H}x{W}, 64 coarse + 128 fine samples/ray",
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
+            "rays_per_sec_with_normals": rays_per_s_nrm,
             "rays_per_sec_second_call_size": rays_per_s_40, "second_call_frames": F40,
             "ms_per_frame_second_call_size": (1e3 * dtr40 / F40) if F40 > 0 else None,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,

@@ -20,6 +20,10 @@
 // workgroup's voxel groups (thread t owns rows a = t, t + 256 of M^T: 2 x F values) and written once as a per-workgroup
 // partial; viewpool_partial_reduce_kernel sums the partials in a fixed order (deterministic; the feature-map gradients are
 // atomics and are not).
+// (Round 5 built the obvious cure for the 1.1 G atomics - bricks of 64 voxels, the four 16-channel maps accumulated per view in
+// LDS tiles over the brick's bounding box, one global atomic per touched (pixel, channel): 7x fewer atomics - and measured it
+// on MI355X at 64^3 x 16 views: 16.3 ms against 15.5 ms for this kernel (7.5 ms at 4 views: ~4.8 ms + 0.67 ms per view).  The
+// atomic COUNT is not what bounds it; the tiled form's barriers and second gather cost what its atomics saved.  Removed.)
 #include <stdint.h>
 
 #include <stdlib.h>
@@ -64,35 +68,11 @@ __device__ __forceinline__ void sample4(const float* base, const Tap& t, float (
   s[3] = t00.w * t.w00 + t01.w * t.w01 + t10.w * t.w10 + t11.w * t.w11;
 }
 
-// TILED (the default; round 5): the scatter of the small multi-channel maps goes through LDS.  The plain form issues one
-// hardware atomic per (voxel, view, channel, bilinear tap) - 1.1 G of them at 64^3 x 16 views, 15.7 ms against a 0.8 ms
-// forward - although neighbouring voxels land on the same few pixels of a 64^2 ... 8^2 map.  Here a workgroup owns BRICKS of
-// 64 voxels (four 16-voxel runs: (y, y + 1) x (z, z + 1) when the grid allows it), phase 1 is the kernel above for the
-// brick's four groups - its pass 2 only for the maps that stay on direct atomics (one- / three-channel maps at image
-// resolution: about one pixel per voxel, nothing to merge) - and leaves (mu, dmu', 2 dvar) per voxel and channel of the
-// tiled maps in LDS; phase 2 walks the views: bounding box of the brick's taps per map, contributions summed by LDS atomics
-// into a tile of at most 256 pixels x 16 channels per map (the storage of the agg / dagg tiles, dead by then), ONE global
-// atomic per touched (pixel, channel).  A footprint that does not fit its tile (a camera inside the volume) falls back to
-// direct atomics for that (view, map).
-constexpr int VB_BRICK = 64;       // voxels per brick
-constexpr int VB_LC = 64;          // channels of the tiled maps, padded, per voxel
-constexpr int VB_TPX = 256;        // pixels per tile
-constexpr int VB_TMAPS = 4;        // tiled maps
-
-template <bool TILED>
 __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b) {
   const ViewPoolParams& p = b.fwd;
-  // [voxel][aggregated feature] and [voxel][d loss / d aggregated feature]; phase 2 (TILED) re-uses the pair as the four tiles
-  __shared__ __attribute__((aligned(16))) float s_pair[2 * 16 * ViewPoolParams::MAX_AGG];
-  float* const s_agg = s_pair;
-  float* const s_dagg = s_pair + 16 * ViewPoolParams::MAX_AGG;
+  __shared__ float s_agg[16 * ViewPoolParams::MAX_AGG];   // [voxel][aggregated feature]
+  __shared__ float s_dagg[16 * ViewPoolParams::MAX_AGG];  // [voxel][d loss / d aggregated feature]
   __shared__ float s_dz[16 * VB_F];
-  __shared__ float s_mu[TILED ? VB_BRICK * VB_LC : 1], s_dmu[TILED ? VB_BRICK * VB_LC : 1], s_dv2[TILED ? VB_BRICK * VB_LC : 1];
-  __shared__ float s_ndcx[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1], s_ndcy[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1],
-      s_wD[TILED ? VB_BRICK * ViewPoolParams::MAX_VIEWS : 1];
-  __shared__ int s_box[TILED ? VB_BRICK * 4 : 1];  // per voxel: x0, x1, y0, y1 of its taps in the current (view, map)
-  __shared__ int s_bbox[VB_TMAPS][6];               // per tiled map: x0, y0, width, height, fits, -
-  static_assert(2 * 16 * ViewPoolParams::MAX_AGG >= VB_TMAPS * VB_TPX * 16, "the tiles live in the agg / dagg storage");
   const int tid = threadIdx.x;
   const int vl = tid >> 4, ql = tid & 15;
   const int R = p.R;
@@ -102,34 +82,6 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
   auto lin = [&](int i) { return (i < R / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(R - 1 - i)) * p.half_extent; };
   const float std_floor = sqrtf(1e-4f);
 
-  // which maps are tiled (uniform): several channels, at most 16 padded, not above 128^2; their channels in a packed list
-  int tmap_of[ViewPoolParams::MAX_FEATS], tlc0[ViewPoolParams::MAX_FEATS];  // tile slot / first packed channel, -1 = direct atomics
-  int n_tiled = 0, n_lc = 0;
-#pragma unroll
-  for (int k = 0; k < ViewPoolParams::MAX_FEATS; ++k) {
-    tmap_of[k] = -1, tlc0[k] = 0;
-    if (TILED && k < p.n_feats && b.want_feats && b.gfeat[k]) {
-      const ViewPoolParams::Feat& f = p.feat[k];
-      if (f.C >= 4 && f.Cp <= 16 && f.H * f.W <= 128 * 128 && n_tiled < VB_TMAPS && n_lc + f.Cp <= VB_LC) {
-        tmap_of[k] = n_tiled++;
-        tlc0[k] = n_lc;
-        n_lc += f.Cp;
-      }
-    }
-  }
-  // bricks: four groups; (y, y + 1) x (z, z + 1) neighbours of an x run when a group is an x run (R % 16 == 0, R even), else
-  // four consecutive groups
-  const bool xrun = TILED && (R % 16) == 0 && (R % 2) == 0;
-  const int gpr = xrun ? R / 16 : 1;  // groups per x row
-  const int64_t nbricks = TILED ? (xrun ? (int64_t)gpr * (R / 2) * (R / 2) : (ngroups + 3) / 4) : ngroups;
-  auto group_of = [&](int64_t brick, int gi) -> int64_t {
-    if (!TILED) return brick;
-    if (!xrun) return brick * 4 + gi;
-    const int64_t xg = brick % gpr, y2 = (brick / gpr) % (R / 2), z2 = brick / ((int64_t)gpr * (R / 2));
-    const int64_t y = 2 * y2 + (gi & 1), z = 2 * z2 + (gi >> 1);
-    return (z * R + y) * gpr + xg;
-  };
-
   float dM[2][VB_F];  // rows a = tid, tid + 256 of d M^T
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -137,13 +89,10 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
     for (int o = 0; o < VB_F; ++o) dM[h][o] = 0.f;
   float db = 0.f;  // thread tid < F: d bias[tid]
 
-  for (int64_t brick = blockIdx.x; brick < nbricks; brick += gridDim.x) {
-  for (int gi = 0; gi < (TILED ? 4 : 1); ++gi) {
-    const int64_t grp = group_of(brick, gi);
-    const bool gok = grp < ngroups;  // (uniform; a ragged last brick)
-    const int64_t v = (gok ? grp : 0) * 16 + vl;
-    const bool vok = gok && v < nvox;
-    const int64_t vc = v < nvox ? v : nvox - 1;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t v = grp * 16 + vl;
+    const bool vok = v < nvox;
+    const int64_t vc = vok ? v : nvox - 1;
     const int x = (int)(vc % R), y = (int)((vc / R) % R), z = (int)(vc / ((int64_t)R * R));
     const float px = lin(x), py = lin(y), pz = lin(z);
     float ndcx[ViewPoolParams::MAX_VIEWS], ndcy[ViewPoolParams::MAX_VIEWS], wv[ViewPoolParams::MAX_VIEWS];
@@ -169,15 +118,6 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       S0 += wv[vi];
     }
     const float D = fmaxf(S0, 1e-2f);
-    if (TILED && ql == 0) {  // the voxel's projections and weights for phase 2
-#pragma unroll 1
-      for (int vi = 0; vi < p.n_views; ++vi) {
-        const int bi = (gi * 16 + vl) * ViewPoolParams::MAX_VIEWS + vi;
-        s_ndcx[bi] = ndcx[vi];
-        s_ndcy[bi] = ndcy[vi];
-        s_wD[bi] = vok ? wv[vi] / D : 0.f;
-      }
-    }
 
     // ---- pass 1: the forward's aggregation, [AVG | STD] per key into the LDS tile
     for (int q = ql; q < p.n_quads; q += 16) {
@@ -242,8 +182,7 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       for (int pv = 0; pv < 16; ++pv) db += s_dz[pv * VB_F + tid];
     }
     __syncthreads();
-    // ---- pass 2: the samples again, dx per view, scattered through the bilinear weights (tiled maps: only the per-voxel
-    //      terms, for phase 2)
+    // ---- pass 2: the samples again, dx per view, scattered through the bilinear weights
     if (b.want_feats) {
       for (int q = ql; q < p.n_quads; q += 16) {
         int k = 0;
@@ -263,12 +202,6 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
           const float dsd = s_dagg[ia + f.C];
           dvar2[e] = (cok && sd > std_floor) ? dsd / sd : 0.f;  // 2 dvar = dstd / std
           dmu[e] = cok ? s_dagg[ia] - dvar2[e] * mu[e] * (D - S0) / D : 0.f;
-        }
-        if (TILED && tmap_of[k] >= 0) {
-          const int li = (gi * 16 + vl) * VB_LC + tlc0[k] + cq * 4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s_mu[li + e] = mu[e], s_dmu[li + e] = dmu[e], s_dv2[li + e] = dvar2[e];
-          continue;
         }
 #pragma unroll 1
         for (int vi = 0; vi < p.n_views; ++vi) {
@@ -292,91 +225,7 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
       }
     }
     __syncthreads();  // the LDS tiles are rewritten by the next group
-  }  // groups of the brick
-  // ---- phase 2 (TILED): the brick's contributions to the tiled maps, view by view
-  if (TILED && n_tiled > 0) {
-    float* const s_tile = s_pair;  // [slot][pixel][Cp] (slot stride VB_TPX * 16)
-#pragma unroll 1
-    for (int vi = 0; vi < p.n_views; ++vi) {
-#pragma unroll 1
-      for (int k = 0; k < p.n_feats; ++k) {
-        const int slot = tmap_of[k];
-        if (slot < 0) continue;
-        const ViewPoolParams::Feat& f = p.feat[k];
-        // bounding box of the brick's taps (pixel coordinates; taps of zero weight included: harmless)
-        if (tid < VB_BRICK) {
-          const Tap t = tap_of(f, s_ndcx[tid * ViewPoolParams::MAX_VIEWS + vi], s_ndcy[tid * ViewPoolParams::MAX_VIEWS + vi]);
-          const int p00 = t.o00 / f.Cp, p11 = t.o11 / f.Cp;
-          s_box[tid * 4 + 0] = p00 % f.W;
-          s_box[tid * 4 + 1] = p11 % f.W;
-          s_box[tid * 4 + 2] = p00 / f.W;
-          s_box[tid * 4 + 3] = p11 / f.W;
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int x0 = s_box[0], x1 = s_box[1], y0 = s_box[2], y1 = s_box[3];
-          for (int i = 1; i < VB_BRICK; ++i) {
-            x0 = min(x0, s_box[i * 4 + 0]);
-            x1 = max(x1, s_box[i * 4 + 1]);
-            y0 = min(y0, s_box[i * 4 + 2]);
-            y1 = max(y1, s_box[i * 4 + 3]);
-          }
-          const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-          s_bbox[slot][0] = x0, s_bbox[slot][1] = y0, s_bbox[slot][2] = bw, s_bbox[slot][3] = bh;
-          s_bbox[slot][4] = (bw > 0 && bh > 0 && bw * bh <= VB_TPX) ? 1 : 0;
-        }
-        __syncthreads();
-        const int bx0 = s_bbox[slot][0], by0 = s_bbox[slot][1], bw = s_bbox[slot][2], bh = s_bbox[slot][3];
-        const bool fits = s_bbox[slot][4] != 0;
-        float* tile = s_tile + slot * (VB_TPX * 16);
-        const int nt = fits ? bw * bh * f.Cp : 0;
-        for (int i = tid; i < nt; i += 256) tile[i] = 0.f;
-        __syncthreads();
-        const int nq = f.Cp / 4;
-        float* gmap = b.gfeat[k];
-        for (int it = tid; it < VB_BRICK * nq; it += 256) {
-          const int bv = it / nq, cq = it - bv * nq;
-          const float wD = s_wD[bv * ViewPoolParams::MAX_VIEWS + vi];
-          if (wD == 0.f) continue;
-          const Tap t = tap_of(f, s_ndcx[bv * ViewPoolParams::MAX_VIEWS + vi], s_ndcy[bv * ViewPoolParams::MAX_VIEWS + vi]);
-          const int64_t vbase = ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
-          float s[4];
-          sample4(f.data + vbase, t, s);
-          const int li = bv * VB_LC + tlc0[k] + cq * 4;
-          const int offs[4] = {t.o00, t.o01, t.o10, t.o11};
-          const float ws[4] = {t.w00, t.w01, t.w10, t.w11};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dx = wD * (s_dmu[li + e] + s_dv2[li + e] * (s[e] - s_mu[li + e]));
-            if (dx == 0.f) continue;
-#pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-              if (ws[tp] == 0.f) continue;
-              if (fits) {
-                const int pxl = offs[tp] / f.Cp;
-                const int ti = ((pxl / f.W - by0) * bw + (pxl % f.W - bx0)) * f.Cp + cq * 4 + e;
-                atomicAdd(tile + ti, ws[tp] * dx);  // ds_add_f32
-              } else {
-                HOLO_ATOMIC_ADD_F32(gmap + vbase + e + offs[tp], ws[tp] * dx);
-              }
-            }
-          }
-        }
-        __syncthreads();
-        // flush: one global atomic per touched (pixel, channel)
-        for (int i = tid; i < nt; i += 256) {
-          const float val = tile[i];
-          if (val != 0.f) {
-            const int c = i % f.Cp, pxl = i / f.Cp;
-            const int yy = by0 + pxl / bw, xx = bx0 + pxl % bw;
-            HOLO_ATOMIC_ADD_F32(gmap + (((int64_t)vi * f.H + yy) * f.W + xx) * f.Cp + c, val);
-          }
-        }
-        __syncthreads();
-      }
-    }
   }
-  }  // bricks
   // ---- per-workgroup partials: [wg][A * F (+ F)] in the (A, F) order of the transposed weight
   float* part = b.partial + (int64_t)blockIdx.x * ((int64_t)p.A * p.F + p.F);
 #pragma unroll
@@ -722,16 +571,7 @@ int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
     set_error("view_pool_backward: feature_size <= %d and <= 512 aggregated features (got %d, %d)", VB_F, b.fwd.F, b.fwd.A);
     return -1;
   }
-#ifndef HOLO_EMU
-  static const bool v1 = getenv("HOLO_VIEWPOOL_BWD_V1") != nullptr;  // development knob: every map on direct atomics
-#else
-  const bool v1 = false;
-#endif
-  if (v1) {
-    HOLO_LAUNCH(view_pool_bwd_kernel<false>, dim3((unsigned)n_wgs), dim3(256), stream, b);
-  } else {
-    HOLO_LAUNCH(view_pool_bwd_kernel<true>, dim3((unsigned)n_wgs), dim3(256), stream, b);
-  }
+  HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
   const int per = b.fwd.A * b.fwd.F + b.fwd.F;
   HOLO_LAUNCH(viewpool_partial_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), stream, (const float*)b.partial, n_wgs,
               b.fwd.A, b.fwd.F, b.dW, b.dbias);
