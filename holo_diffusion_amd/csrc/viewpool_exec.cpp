@@ -494,15 +494,19 @@ static MmBwdLayout mm_bwd_layout(const HoloMlpMeanPooler* h, const HoloViewFeatu
   memset(&L, 0, sizeof L);
   const int R = h->cfg.resol, F = h->cfg.feature_size;
   // the row buffers hold one CHUNK of voxels (all chunks the same size: the padding of the split-K operands stays valid):
-  // the largest power-of-two fraction of the grid that is at most the target (65 536 voxels: ~0.2 GB of rows per source view; 32 768 measured 17.2 ms against 14.0 ms un-chunked at 64^3 x 4 views - the launches of eight passes)
+  // the largest power-of-two fraction of the grid whose rows fit a 4 GiB budget (~2.5 KB per (voxel, view): 64^3 x 4 views
+  // runs in one pass - 3.5 GB, 14.0 ms; chunked it measured 16.8 ms in 4 passes, 17.2 ms in 8 -, 64^3 x 16 views in four
+  // passes of 65 536 voxels instead of 14 GB).  HOLO_MLP_MEAN_BWD_CHUNK=<voxels>: development / test knob
   L.Pall = (int64_t)R * R * R;
   L.nchunks = 1;
   {
+    const int64_t row_bytes = (int64_t)(2 * h->dp + 3 * 128 + 3 * ((F + 1 + 3) / 4 * 4)) * 4 * n_views;
+    int64_t target = ((int64_t)4 << 30) / (row_bytes > 0 ? row_bytes : 1);
 #ifndef HOLO_EMU
-    const char* e = getenv("HOLO_MLP_MEAN_BWD_CHUNK");  // development / test knob: target voxels per chunk
-    const int64_t target = e && atoll(e) > 0 ? atoll(e) : 65536;
+    const char* e = getenv("HOLO_MLP_MEAN_BWD_CHUNK");
+    if (e && atoll(e) > 0) target = atoll(e);
 #else
-    const int64_t target = 2048;  // (the emulation's small grids: two chunks at 16^3)
+    target = 2048;  // (the emulation's small grids: two chunks at 16^3)
 #endif
     while (L.Pall / L.nchunks > target && (L.Pall % (2 * L.nchunks)) == 0) L.nchunks *= 2;
   }
