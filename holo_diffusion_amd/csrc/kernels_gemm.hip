@@ -279,10 +279,18 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(AttnParams p) {
       kreg[4 * v + 3] = t.w;
     }
   };
-  // V operands of a key tile: row kappa(r) + 4*lh, channel ct*32 + li.  They are requested ONE TILE AHEAD of their use (two
-  // register sets): with one wave per SIMD nothing else hides the L2 round trip of 32 scalar loads per tile (round 5: the
-  // loads of the current tile used to be issued behind its S^T MFMAs and waited for after the softmax)
-  auto load_v = [&](int kt, float (&vreg)[NCT][16]) {
+  load_k(0);
+  for (int kt = 0; kt < ntile; ++kt) {
+    // S^T tile
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < CHH; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[ks], qreg[ks], s, 0, 0, 0);
+    // V operands of this tile: row kappa(r) + 4*lh, channel ct*32 + li   (issued before the softmax math).
+    // (Round 5 requested them one key tile AHEAD into a second register set - nothing else hides their L2 round trip with
+    // one wave per SIMD -: 96.3 us per call at T = 4096 against 85.9 us for this form, 151.7 vs 153.5 steps/s.  Reverted.)
+    float vreg[NCT][16];
 #pragma unroll
     for (int t = 0; t < NCT; ++t) {
       const int c = t * 32 + li;
@@ -294,19 +302,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(AttnParams p) {
         vreg[t][r] = c < CH ? v : 0.f;
       }
     }
-  };
-  float vA[NCT][16], vB[NCT][16];
-  auto step = [&](int kt, float (&vcur)[NCT][16], float (&vnext)[NCT][16]) {
-    // S^T tile
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < CHH; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[ks], qreg[ks], s, 0, 0, 0);
-    if (kt + 1 < ntile) {
-      load_v(kt + 1, vnext);
-      load_k(kt + 1);
-    }
+    if (kt + 1 < ntile) load_k(kt + 1);
     // online softmax for this lane's query
     float mt = s[0];
 #pragma unroll
@@ -330,13 +326,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int t = 0; t < NCT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur[t][r], s[r], oacc[t], 0, 0, 0);
-  };
-  load_k(0);
-  load_v(0, vA);
-  for (int kt = 0; kt < ntile; kt += 2) {
-    step(kt, vA, vB);
-    if (kt + 1 < ntile) step(kt + 1, vB, vA);
+      for (int t = 0; t < NCT; ++t) oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[t][r], s[r], oacc[t], 0, 0, 0);
   }
 
   // ---- merge the four key ranges
