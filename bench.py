@@ -553,6 +553,27 @@ def main():
                                 "launches": v["n"], "ms": v["ms"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                 "tflops_executed": v["fexec"] / (v["ms"] * 1e-3) / 1e12}
                                for k, v in sorted(variants.items(), key=lambda kv: -kv[1]["ms"])]}
+        # the HBM-bound kernel of the step: the streaming 1x1x1 skip connections of the 64^3 level (conv1x1_stream_kernel):
+        # algorithmic bytes = input + output + weights, each once, over the average launch time (hipEvents, as above)
+        st = [o for o in all_ops if o["op"] == "conv" and o.get("kernel") == "conv1x1_stream_kernel"]
+        if st:
+            by = sum(4.0 * (o["out_dim"] ** 3 * (o["cin"] + o["cout"]) + o["cin"] * o["cout"]) for o in st) / len(st)
+            ms_ = sum(o["ms"] for o in st) / len(st)
+            tr = None
+            try:
+                ent = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get(f"conv1x1_stream_kernel<{st[0]['cin'] // 32}>")
+                if ent and args.workload == "north":
+                    tr = {"bytes_per_launch": ent["fetch_bytes"] + ent["write_bytes"], "fetch_bytes": ent["fetch_bytes"],
+                          "write_bytes": ent["write_bytes"], "algorithmic_bytes_per_launch": by, "source": ent.get("source")}
+            except (OSError, ValueError):
+                pass
+            roof["hbm_bound_kernel"] = {"bound": "hbm", "kernel": f"conv1x1_stream_kernel<{st[0]['cin'] // 32}> at {st[0]['out_dim']}^3 "
+                                        f"({st[0]['cin']} -> {st[0]['cout']}: a ResBlock's 1x1x1 skip_connection as a launch of its own)",
+                                        "achieved": by / (ms_ * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                        "frac": by / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBPS, "traffic": tr,
+                                        "launches_per_forward": len(st), "avg_launch_ms": ms_,
+                                        "algorithmic_bytes_per_launch": by,
+                                        "tflops": sum(o["flops"] for o in st) / sum(o["ms"] for o in st) / 1e9}
         if os.environ.get("HOLO_BENCH_OPS"):
             for o in all_ops:
                 print("# op", json.dumps({**o, "tflops": o["flops"] / (o["ms"] * 1e-3) / 1e12}), file=sys.stderr)
@@ -682,7 +703,8 @@ def main():
         mlp_flops_per_ray = samples * (2 * 257 * C + 2 * 3 * 256 + 2 * 3 * 27)
         render_traffic = None
         try:  # fabric-side bytes per FRAME of the render kernel from the committed PMC pass
-            ent = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json"))).get("render2_kernel<16, 64, false, 12>")
+            pmc_all = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+            ent = pmc_all.get("render2_kernel<16, 64, false, 12, false>") or pmc_all.get("render2_kernel<16, 64, false, 12>")
             if ent and args.workload == "north":
                 fpl = ent.get("frames_per_launch", 1)
                 render_traffic = {"bytes_per_frame": (ent["fetch_bytes"] + ent["write_bytes"]) / fpl,
@@ -715,7 +737,7 @@ def main():
             "unet_workspace_bytes": net.workspace_bytes(1, device),
             "roofline": roof,
             "roofline_render": {"bound": "mfma+gather", "traffic": render_traffic,
-                                "kernel": "render2_kernel<16, 64, false, 12> (persistent: one 12-wave workgroup per CU walks the "
+                                "kernel": "render2_kernel<16, 64, false, 12, false> (persistent: one 12-wave workgroup per CU walks the "
                                           "4-ray x 8-depth wave tiles of all frames of the call; per-ray values stay in LDS)",
                                 "evaluations_per_ray_executed": samples, "evaluations_per_ray_reference": samples_ref,
                                 "logical_gather_GBps": gather_bytes_per_ray * rays_per_s / world / 1e9,

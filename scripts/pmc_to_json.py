@@ -59,6 +59,11 @@ for (k, grid), (n, f_kib) in fetch.items():
         # (all levels launch 256 persistent workgroups: the average is over the variant's launches of the profiled command,
         #  dominated by the 64^3 level - 9 of 17 for <false, true>)
         label = f"conv_wino3_kernel<{m3.group(1)}, {m3.group(2)}> (256 persistent workgroups, all levels)"
+    elif "conv1x1_stream_kernel" in k:
+        ms = re.search(r"conv1x1_stream_kernel<(\d)>", k)
+        label = f"conv1x1_stream_kernel<{ms.group(1)}>"
+    elif "ddpm_step_philox_kernel" in k:
+        label = "ddpm_step_philox_kernel"
     elif "render2_kernel" in k or "render_kernel" in k:
         mr = re.search(r"(render2?_kernel)<([^>]*)>", k)
         label = f"{mr.group(1)}<{mr.group(2)}>"
@@ -80,7 +85,7 @@ for sk, ents in big.items():
         "fetch_bytes": int(f_kib * 1024 * 2), "write_bytes": int(w_kib * 1024), "dispatches": n, "fetch_size_raw_kib": f_kib,
         "write_size_raw_kib": w_kib,
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the command of scripts/gpu_pmc.sh, profiles/{tag}_fetch.csv "
-                  "+ _write.csv: the launches with >= 24 MiB on the raw counter (the 64^3 level; every level launches 256 persistent "
+                  "+ _write.csv: the launches with >= 48 MiB on the raw counter (the 64^3 level; every level launches 256 persistent "
                   "workgroups); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md; fabric-side L2 misses (Infinity-Cache "
                   "hits included)"}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
