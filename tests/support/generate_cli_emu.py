@@ -13,6 +13,21 @@ os.environ["HOLO_TEST_EMU"] = "1"
 import tests.conftest  # noqa: E402,F401  (HOLO_TEST_EMU=1: binds the emulation library, lets the plugin work on CPU tensors)
 from holo_diffusion_amd import generate as gen  # noqa: E402
 
+# HOLO_TEST_MAX_ITER=<n> (test knob of THIS launcher): every sampling chain is subsampled to n of its steps
+# (p_sample_loop's own max_iter, gaussian_diffusion.py:608-621) so that the emulated end-to-end run fits a CPU suite
+if os.environ.get("HOLO_TEST_MAX_ITER"):
+    import functools
+
+    from holo_diffusion_amd.diffusion import ImplicitronGaussianDiffusion as _D
+    _orig = _D.p_sample_loop_progressive
+
+    @functools.wraps(_orig)
+    def _capped(self, *a, **k):
+        if k.get("max_iter") is None:
+            k["max_iter"] = int(os.environ["HOLO_TEST_MAX_ITER"])
+        return _orig(self, *a, **k)
+    _D.p_sample_loop_progressive = _capped
+
 if __name__ == "__main__":
     # (gen.init_distributed picks gloo + CPU tensors by itself when no HIP device is visible)
     raise SystemExit(gen.main(sys.argv[1:]))

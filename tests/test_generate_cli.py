@@ -67,29 +67,49 @@ def test_generate_cli_world2_gloo_equals_single_process(tmp_path):
     assert not torch.equal(a0, a1)
 
 
+_HAVE_EMU = os.path.isfile(os.path.join(REPO, "tests", "emu", "libholo_emu.so"))
+
+
+@pytest.mark.skipif(not _HAVE_EMU, reason="needs the host emulation library (`make -C holo_diffusion_amd/csrc emu`)")
+def test_generate_cli_world2_gloo_on_the_emulated_kernels_short(tmp_path):
+    """The multi-rank product entry with the REAL model on the host emulation of the kernels, cheap enough for every CPU
+    suite: chains subsampled to 2 of their 20 steps (the launcher's HOLO_TEST_MAX_ITER), 2 samples over 2 ranks, 2 cameras at
+    8 x 8 - equal, bit for bit, to the single-process run."""
+    _emulated_cli_case(tmp_path, max_iter=2, tiny=True)
+
+
 @pytest.mark.slow
-@pytest.mark.skipif(os.environ.get("HOLO_TEST_EMU_SLOW") != "1" or not os.path.isfile(os.path.join(REPO, "tests", "emu", "libholo_emu.so")),
+@pytest.mark.skipif(os.environ.get("HOLO_TEST_EMU_SLOW") != "1" or not _HAVE_EMU,
                     reason="opt-in (HOLO_TEST_EMU_SLOW=1 + `make -C holo_diffusion_amd/csrc emu`): ~15 minutes of host emulation")
 def test_generate_cli_world2_gloo_on_the_emulated_kernels(tmp_path):
+    """The same with the whole 20-step schedule."""
+    _emulated_cli_case(tmp_path, max_iter=None)
+
+
+def _emulated_cli_case(tmp_path, max_iter, tiny=False):
     """The same entry with the REAL model on the host emulation of the kernels (tests/support/generate_cli_emu.py): a
-    2-step DDPM schedule on an 8^3 x 16 grid, 2 samples sharded over 2 ranks, frames gathered over gloo - equal, bit for bit,
+    20-step DDPM schedule on an 8^3 x 16 grid, 2 samples sharded over 2 ranks, frames gathered over gloo - equal, bit for bit,
     to the single-process run of the same samples (per-sample seeds seed + i), and different between samples."""
     from holo_diffusion_amd import checkpoint as ck
     import holo_diffusion_amd as hda
     from tests.test_checkpoint_loading import _expconfig, _reference_like_state
     d = tmp_path / "exp"
     d.mkdir()
-    cfg = _expconfig(resol=8, feat=16, mc=32)
+    cfg = _expconfig(resol=4 if tiny else 8, feat=16, mc=32)
     margs = cfg["model_factory_ImplicitronModelFactory_args"]["model_HoloDiffusionModel_args"]
     margs["diffusion_args"]["num_steps"] = 20  # (the shortest schedule whose scaled linear betas stay <= 1)
+    if tiny:  # one level, one ResBlock per side, the middle block's attention at T = 64: a forward of a dozen small launches
+        margs["net_3d_SimpleUnet3D_args"].update(num_res_blocks=1, channel_mult=[1], attention_resolutions=[])
     with open(d / "expconfig.yaml", "w") as f:
         yaml.safe_dump(cfg, f)
     kw, _ = ck.model_args_from_expconfig(ck.read_expconfig(str(d))[0])
     torch.save(_reference_like_state(hda.HoloDiffusionModel(**kw), 11), str(d / "model_epoch_00000001.pth"))
     script = os.path.join(REPO, "tests", "support", "generate_cli_emu.py")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    if max_iter:
+        env["HOLO_TEST_MAX_ITER"] = str(max_iter)
     args = ["num_samples=2", "n_eval_cameras=2", "render_size=[8,8]", "seed=5"]
-    port = 29700 + os.getpid() % 1500
+    port = 29700 + os.getpid() % 1500 + (0 if max_iter else 3)
 
     def run(cmd):
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=3000, env=env)
