@@ -39,6 +39,7 @@ constexpr int VB_F = 32;  // output features held per thread for dM (pooled_feat
 struct Tap {
   int o00, o01, o10, o11;  // element offsets of the four taps inside one view's (H, W, Cp) map, channel 0
   float w00, w01, w10, w11;
+  int key;                 // the bilinear cell (floor of the sample position, both axes), > 0: equal keys = the same four taps
 };
 
 // ndc_grid_sample's tap geometry (kernels_viewpool.hip: view_pool_kernel)
@@ -56,6 +57,8 @@ __device__ __forceinline__ Tap tap_of(const ViewPoolParams::Feat& f, float ndcx,
   Tap t;
   t.o00 = (y0 * f.W + x0) * f.Cp, t.o01 = (y0 * f.W + x1) * f.Cp, t.o10 = (y1 * f.W + x0) * f.Cp, t.o11 = (y1 * f.W + x1) * f.Cp;
   t.w00 = wx0 * wy0, t.w01 = wx1 * wy0, t.w10 = wx0 * wy1, t.w11 = wx1 * wy1;
+  // (positions far outside the map share the border keys: all their weights are zero)
+  t.key = (((int)fminf(fmaxf(fy0, -2.f), fH + 1.f) + 3) << 16) | ((int)fminf(fmaxf(fx0, -2.f), fW + 1.f) + 3);
   return t;
 }
 
@@ -237,14 +240,315 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
   if (tid < p.F) part[(int64_t)p.A * p.F + tid] = db;
 }
 
-// dW (F, A) and db (F) from the per-workgroup partials, summed in workgroup order
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same backward built for OCCUPANCY (round 5, second form; the default where it applies: A + 1 <= VB2_AMAX aggregated
+// features, F <= 32).  What bounded the kernel above was not its atomics but its shape: 2 x F d-weight values per thread in
+// registers across the workgroup's lifetime (273 registers: ONE wave per SIMD), 66 KB of LDS tiles sized for 512 aggregated
+// features, every lane of a voxel projecting the voxel into all views itself (16 x redundant) with the results in
+// dynamically indexed private arrays (scratch), all behind dependent gathers.  Here:
+//   * the 16 lanes of a voxel project it into ONE view each; NDC and angular weight of the (voxel, view) pairs sit in LDS;
+//   * d M^T += agg^T dz (K = the group's 16 voxels) runs on the matrix cores: v_mfma_f32_16x16x4_f32, the A x F result
+//     as <= 6 accumulator tiles per wave (24 registers), a constant-1 column behind the aggregated features makes row A of
+//     the product the bias gradient;
+//   * LDS tiles at the stride the call needs (161 floats): 26 KB, four workgroups (16 waves) per CU at <= 128 registers.
+// Same arithmetic per voxel, same partial layout ([A][F] | [F]) and reduce as above.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int VB2_AMAX = 160;       // columns of the aggregated tile (A features + the constant 1, zero beyond): 10 MFMA row tiles
+constexpr int VB2_AS = VB2_AMAX + 1;  // LDS row stride (odd: the 16 voxels of a column read land in 16 banks)
+constexpr int VB2_ZS = VB_F + 1;
+
+
+// value of lane + D inside the 16-lane row (0 beyond the row's end): DPP row_shl on the device, a shuffle in the host emulation
+#ifndef HOLO_EMU
+template <int D>
+__device__ __forceinline__ float row_next_f(float v, int) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x100 + D, 0xf, 0xf, false));
+}
+template <int D>
+__device__ __forceinline__ int row_next_i(int v, int) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 + D, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int row_prev_i(int v, int) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }
+#else
+template <int D>
+__device__ __forceinline__ float row_next_f(float v, int lane) {
+  const float o = __shfl(v, (lane & 15) + D < 16 ? lane + D : lane);
+  return (lane & 15) + D < 16 ? o : 0.f;
+}
+template <int D>
+__device__ __forceinline__ int row_next_i(int v, int lane) {
+  const float o = __shfl(__uint_as_float((uint32_t)v), (lane & 15) + D < 16 ? lane + D : lane);
+  return (lane & 15) + D < 16 ? (int)__float_as_uint(o) : 0;
+}
+__device__ __forceinline__ int row_prev_i(int v, int lane) {
+  const float o = __shfl(__uint_as_float((uint32_t)v), (lane & 15) >= 1 ? lane - 1 : lane);
+  return (lane & 15) >= 1 ? (int)__float_as_uint(o) : 0;
+}
+#endif
+// one step of the segmented sum along a row: c[i] += c[i + D] where lane + D carries the same key (runs of equal keys are
+// contiguous, so after D = 1, 2, 4, 8 the first lane of a run holds the run's total)
+template <int D>
+__device__ __forceinline__ void seg_step(float (&c)[16], int key, int lane) {
+  const float m = row_next_i<D>(key, lane) == key ? 1.f : 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c[i] = fmaf(row_next_f<D>(c[i], lane), m, c[i]);
+}
+// WPS: waves per SIMD the register allocation aims at (3: 168 registers, no scratch; 4: 128 registers + 168 bytes of scratch)
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdParams b) {
+  const ViewPoolParams& p = b.fwd;
+  __shared__ float s_agg[16 * VB2_AS];   // [voxel][aggregated feature | 1 | 0 ...]
+  __shared__ float s_dagg[16 * VB2_AS];  // [voxel][d loss / d aggregated feature]
+  __shared__ float s_dz[16 * VB2_ZS];    // [voxel][d loss / d mapper output] (zero beyond F)
+  __shared__ float s_ndcx[16 * 16], s_ndcy[16 * 16], s_w[16 * 16];  // [voxel][view]
+  const int tid = threadIdx.x;
+  const int vl = tid >> 4, ql = tid & 15;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int R = p.R;
+  const int64_t nvox = (int64_t)R * R * R;
+  const int64_t ngroups = (nvox + 15) / 16;
+  const float step = 2.0f / (float)(R - 1);
+  auto lin = [&](int i) { return (i < R / 2 ? -1.0f + step * (float)i : 1.0f - step * (float)(R - 1 - i)) * p.half_extent; };
+  const float std_floor = sqrtf(1e-4f);
+  const int A = p.A, F = p.F;
+
+  // the constant parts of the tiles: 1 behind the aggregated features (bias gradient), zeros beyond; dz columns beyond F
+  for (int i = tid; i < 16 * VB2_AS; i += 256) {
+    const int a = i % VB2_AS;
+    s_agg[i] = a == A ? 1.f : 0.f;
+  }
+  for (int i = tid; i < 16 * VB2_ZS; i += 256) s_dz[i] = 0.f;
+
+  // d M^T tiles of this wave: row tiles mt = wave, wave + 4, wave + 8 (< 10) x both column tiles
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_mt = (A + 1 + 15) >> 4;  // row tiles that hold anything
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t v = grp * 16 + vl;
+    const bool vok = v < nvox;
+    const int64_t vc = vok ? v : nvox - 1;
+    const int x = (int)(vc % R), y = (int)((vc / R) % R), z = (int)(vc / ((int64_t)R * R));
+    const float px = lin(x), py = lin(y), pz = lin(z);
+    // ---- lane ql: view ql of the voxel (direction of view 0 by every lane itself)
+    {
+      const ViewPoolParams::Cam& c0 = p.cams[0];
+      float d0x = px - c0.centre[0], d0y = py - c0.centre[1], d0z = pz - c0.centre[2];
+      const float n0 = fmaxf(sqrtf(d0x * d0x + d0y * d0y + d0z * d0z), 1e-12f);
+      d0x /= n0;
+      d0y /= n0;
+      d0z /= n0;
+      const int vi = ql < p.n_views ? ql : 0;
+      const ViewPoolParams::Cam& c = p.cams[vi];
+      const float cx = px * c.Rm[0] + py * c.Rm[3] + pz * c.Rm[6] + c.T[0];
+      const float cy = px * c.Rm[1] + py * c.Rm[4] + pz * c.Rm[7] + c.T[1];
+      float cz = px * c.Rm[2] + py * c.Rm[5] + pz * c.Rm[8] + c.T[2];
+      if (fabsf(cz) < p.proj_eps) cz = cz < 0.f ? -p.proj_eps : p.proj_eps;
+      float dx = px - c.centre[0], dy = py - c.centre[1], dz = pz - c.centre[2];
+      const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+      dx /= nrm;
+      dy /= nrm;
+      dz /= nrm;
+      float a = 0.5f * ((dx * d0x + dy * d0y + dz * d0z) + 1.0f);
+      if (p.gamma != 1.0f) a = powf(a, p.gamma);
+      s_ndcx[vl * 16 + ql] = c.focal[0] * cx / cz + c.pp[0];
+      s_ndcy[vl * 16 + ql] = c.focal[1] * cy / cz + c.pp[1];
+      s_w[vl * 16 + ql] = ql < p.n_views ? fmaxf(a, p.min_weight) : 0.f;
+    }
+    __syncthreads();
+    float S0 = 0.f;
+    for (int vi = 0; vi < p.n_views; ++vi) S0 += s_w[vl * 16 + vi];  // (view order, as the forward sums it)
+    const float D = fmaxf(S0, 1e-2f);
+
+    // ---- pass 1: the forward's aggregation, [AVG | STD] per key into the LDS tile
+    for (int q = ql; q < p.n_quads; q += 16) {
+      int k = 0;
+      while (k + 1 < p.n_feats && q >= p.feat[k + 1].quad0) ++k;
+      const ViewPoolParams::Feat& f = p.feat[k];
+      const int cq = q - f.quad0;
+      float S1[4] = {0.f, 0.f, 0.f, 0.f}, S2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int vi = 0; vi < p.n_views; ++vi) {
+        const Tap t = tap_of(f, s_ndcx[vl * 16 + vi], s_ndcy[vl * 16 + vi]);
+        const float w = s_w[vl * 16 + vi];
+        float s[4];
+        sample4(f.data + ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4, t, s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          S1[e] = fmaf(w, s[e], S1[e]);
+          S2[e] = fmaf(w * s[e], s[e], S2[e]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = cq * 4 + e;
+        if (c < f.C) {
+          const float mu = S1[e] / D;
+          const float var = (S2[e] - 2.f * mu * S1[e] + mu * mu * S0) / D;
+          s_agg[vl * VB2_AS + f.out0 + c] = mu;
+          s_agg[vl * VB2_AS + f.out0 + f.C + c] = sqrtf(fmaxf(var, 1e-4f));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- mapper forward, tanh, dz = g (1 - out^2); voxels beyond the grid contribute nothing
+    for (int o = ql; o < F; o += 16) {
+      float z0 = p.bias ? p.bias[o] : 0.f, z1 = 0.f;
+      int a = 0;
+      for (; a + 1 < A; a += 2) {  // two chains
+        z0 = fmaf(s_agg[vl * VB2_AS + a], p.wt[(int64_t)a * F + o], z0);
+        z1 = fmaf(s_agg[vl * VB2_AS + a + 1], p.wt[(int64_t)(a + 1) * F + o], z1);
+      }
+      if (a < A) z0 = fmaf(s_agg[vl * VB2_AS + a], p.wt[(int64_t)a * F + o], z0);
+      const float out = tanhf(z0 + z1);
+      const float g = vok ? b.gout[(int64_t)o * nvox + v] : 0.f;
+      s_dz[vl * VB2_ZS + o] = g * (1.f - out * out);
+    }
+    __syncthreads();
+    // ---- dagg = M^T dz (the lane's aggregated features a = ql, ql + 16, ...)
+    if (b.want_feats) {
+      for (int a = ql; a < A; a += 16) {
+        float d0 = 0.f, d1 = 0.f;
+        int o = 0;
+        for (; o + 1 < F; o += 2) {
+          d0 = fmaf(p.wt[(int64_t)a * F + o], s_dz[vl * VB2_ZS + o], d0);
+          d1 = fmaf(p.wt[(int64_t)a * F + o + 1], s_dz[vl * VB2_ZS + o + 1], d1);
+        }
+        if (o < F) d0 = fmaf(p.wt[(int64_t)a * F + o], s_dz[vl * VB2_ZS + o], d0);
+        s_dagg[vl * VB2_AS + a] = d0 + d1;
+      }
+    }
+    // ---- d M^T (+ d bias as row A) += agg^T dz over the group's 16 voxels: D[m = feature][n = output], k = voxel
+    {
+      const int mrow = lane & 15, kq = lane >> 4;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int vox = ks * 4 + kq;
+        const float b0 = s_dz[vox * VB2_ZS + mrow], b1 = s_dz[vox * VB2_ZS + 16 + mrow];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int mt = wave + 4 * i;
+          if (mt < n_mt) {  // (wave-uniform)
+            const float av = s_agg[vox * VB2_AS + mt * 16 + mrow];
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[i][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- pass 2: the samples again, dx per view, scattered through the bilinear weights.  Thread layout turned round: a
+    //      16-lane ROW = the group's 16 voxels (consecutive in x) for ONE channel quad, so voxels that land in the same
+    //      bilinear cell of a map - most of a row on the coarse maps - sit in neighbouring lanes: their 4 taps x 4 channels
+    //      are summed along the row (segmented by cell) and only a run's first lane issues atomics.  (Measured on MI355X
+    //      with every voxel issuing its own: the 16-channel maps at 64^2 / 32^2 / 16^2 / 8^2 cost 0.9 / 1.4 / 2.1 / 3.1 ms
+    //      of atomics for the same count - same-address contention, not the count, is what the atomics cost.)
+    if (b.want_feats) {
+      const int prow = tid >> 4, pv = tid & 15;
+      const int64_t v2 = grp * 16 + pv;
+      const bool vok2 = v2 < nvox;
+      float S02 = 0.f;
+      for (int vi = 0; vi < p.n_views; ++vi) S02 += s_w[pv * 16 + vi];
+      const float D2 = fmaxf(S02, 1e-2f);
+      for (int q0 = 0; q0 < p.n_quads; q0 += 16) {  // (uniform trip count: the votes below need every lane)
+        const int qq = q0 + prow;
+        const int q = qq < p.n_quads ? qq : p.n_quads - 1;
+        int k = 0;
+        while (k + 1 < p.n_feats && q >= p.feat[k + 1].quad0) ++k;
+        const ViewPoolParams::Feat& f = p.feat[k];
+        float* gmap = b.gfeat[k];
+        const bool act = qq < p.n_quads && gmap != nullptr &&
+                         !(b.want_feats == 2 || (b.want_feats >= 10 && b.want_feats - 10 != k));  // (development probes)
+        const int cq = q - f.quad0;
+        float mu[4], dmu[4], dvar2[4];  // dvar2 = 2 dvar
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = cq * 4 + e;
+          const bool cok = c < f.C;
+          const int ia = pv * VB2_AS + f.out0 + (cok ? c : 0);
+          mu[e] = s_agg[ia];
+          const float sd = s_agg[ia + f.C];
+          const float dsd = s_dagg[ia + f.C];
+          dvar2[e] = (cok && sd > std_floor) ? dsd / sd : 0.f;  // 2 dvar = dstd / std
+          dmu[e] = cok ? s_dagg[ia] - dvar2[e] * mu[e] * (D2 - S02) / D2 : 0.f;
+        }
+#pragma unroll 1
+        for (int vi = 0; vi < p.n_views; ++vi) {
+          const Tap t = tap_of(f, s_ndcx[pv * 16 + vi], s_ndcy[pv * 16 + vi]);
+          const int64_t vbase = ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
+          float s[4];
+          sample4(f.data + vbase, t, s);
+          const float wD = vok2 ? s_w[pv * 16 + vi] / D2 : 0.f;
+          float c[16];  // [tap][channel]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dx = wD * (dmu[e] + dvar2[e] * (s[e] - mu[e]));
+            c[e] = t.w00 * dx;
+            c[4 + e] = t.w01 * dx;
+            c[8 + e] = t.w10 * dx;
+            c[12 + e] = t.w11 * dx;
+          }
+          const int key = t.key;
+          const int key_next = row_next_i<1>(key, lane);
+          if (__any(act && key_next == key)) {  // some voxels of a row share a cell: sum along the runs
+            seg_step<1>(c, key, lane);
+            seg_step<2>(c, key, lane);
+            seg_step<4>(c, key, lane);
+            seg_step<8>(c, key, lane);
+          }
+          const bool head = row_prev_i(key, lane) != key;  // (lane 0 of a row: 0 is no key)
+          if (act && head) {
+            float* g = gmap + vbase;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (c[e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o00 + e, c[e]);
+              if (c[4 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o01 + e, c[4 + e]);
+              if (c[8 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o10 + e, c[8 + e]);
+              if (c[12 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o11 + e, c[12 + e]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // the LDS tiles are rewritten by the next group
+  }
+  // ---- per-workgroup partials: rows 0 .. A of the product = [A][F] d M^T followed by the F values of d bias
+  float* part = b.partial + (int64_t)blockIdx.x * ((int64_t)A * F + F);
+  const int col = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int mt = wave + 4 * i;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = mt * 16 + 4 * (lane >> 4) + r, o = j * 16 + col;
+        if (mt < n_mt && a <= A && o < F) part[(int64_t)a * F + o] = acc[i][j][r];
+      }
+  }
+}
+
+// dW (F, A) and db (F) from the per-workgroup partials: 64 elements per workgroup, its four waves sum a quarter of the
+// partials each in workgroup order, the four sums are added in wave order (fixed order: deterministic)
 __global__ __launch_bounds__(256) void viewpool_partial_reduce_kernel(const float* __restrict__ partial, int n_wgs, int A, int F,
                                                                       float* __restrict__ dW, float* __restrict__ dbias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_part[4 * 64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
   const int per = A * F + F;
-  if (i >= per) return;
+  const int chunk = (n_wgs + 3) / 4;
+  const int w0 = sl * chunk, w1 = min(w0 + chunk, n_wgs);
   float s = 0.f;
-  for (int w = 0; w < n_wgs; ++w) s += partial[(int64_t)w * per + i];
+  if (i < per)
+    for (int w = w0; w < w1; ++w) s += partial[(int64_t)w * per + i];
+  s_part[sl * 64 + e] = s;
+  __syncthreads();
+  if (sl != 0 || i >= per) return;
+  s = ((s_part[e] + s_part[64 + e]) + s_part[128 + e]) + s_part[192 + e];
   if (i < A * F) {
     const int a = i / F, o = i - a * F;
     if (dW) dW[(int64_t)o * A + a] = s;
@@ -566,14 +870,29 @@ __global__ __launch_bounds__(256) void mm_sum_partials_kernel(const float* __res
 
 }  // namespace
 
-int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
+int view_pool_bwd_launch(const ViewPoolBwdParams& b_in, int n_wgs, void* stream) {
+  const ViewPoolBwdParams& b = b_in;
   if (b.fwd.F > VB_F || b.fwd.A > 512) {
     set_error("view_pool_backward: feature_size <= %d and <= 512 aggregated features (got %d, %d)", VB_F, b.fwd.F, b.fwd.A);
     return -1;
   }
-  HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
+  // (HOLO_VIEWPOOL_BWD_V1=1: the register-accumulating form on every call - development knob)
+  const char* ev = getenv("HOLO_VIEWPOOL_BWD_V1");
+  const bool v1 = ev && ev[0] == '1';
+  if (!v1 && b.fwd.A + 1 <= VB2_AMAX && b.fwd.n_views <= 16) {
+    ViewPoolBwdParams b = b_in;
+    const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // development probe: 2 = pass 2 without its atomics, 0 = no pass 2
+    if (ep && b.want_feats) b.want_feats = atoi(ep);
+    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 4 = the 128-register build
+    if (eo && eo[0] == '4')
+      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+    else
+      HOLO_LAUNCH(view_pool_bwd2_kernel<3>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+  } else {
+    HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
+  }
   const int per = b.fwd.A * b.fwd.F + b.fwd.F;
-  HOLO_LAUNCH(viewpool_partial_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), stream, (const float*)b.partial, n_wgs,
+  HOLO_LAUNCH(viewpool_partial_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), stream, (const float*)b.partial, n_wgs,
               b.fwd.A, b.fwd.F, b.dW, b.dbias);
   return 0;
 }

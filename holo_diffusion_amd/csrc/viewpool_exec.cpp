@@ -134,7 +134,7 @@ int holo_view_pool(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const HoloViewFeatu
 //      then the per-workgroup partials of d weight / d bias.
 static int view_pool_bwd_wgs(HoloCtx* ctx, int resol) {
   const int64_t groups = ((int64_t)resol * resol * resol + 15) / 16;
-  int64_t n = 2 * (int64_t)ctx->num_cus;
+  int64_t n = 4 * (int64_t)ctx->num_cus;  // (view_pool_bwd2_kernel: four resident workgroups per CU)
   return (int)(groups < n ? groups : n);
 }
 
