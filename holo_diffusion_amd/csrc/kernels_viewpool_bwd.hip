@@ -20,10 +20,11 @@
 // workgroup's voxel groups (thread t owns rows a = t, t + 256 of M^T: 2 x F values) and written once as a per-workgroup
 // partial; viewpool_partial_reduce_kernel sums the partials in a fixed order (deterministic; the feature-map gradients are
 // atomics and are not).
-// (Round 5 built the obvious cure for the 1.1 G atomics - bricks of 64 voxels, the four 16-channel maps accumulated per view in
-// LDS tiles over the brick's bounding box, one global atomic per touched (pixel, channel): 7x fewer atomics - and measured it
-// on MI355X at 64^3 x 16 views: 16.3 ms against 15.5 ms for this kernel (7.5 ms at 4 views: ~4.8 ms + 0.67 ms per view).  The
-// atomic COUNT is not what bounds it; the tiled form's barriers and second gather cost what its atomics saved.  Removed.)
+// (Round 5, first attempt at the 1.1 G atomics: bricks of 64 voxels, the four 16-channel maps accumulated per view in LDS
+// tiles over the brick's bounding box, one global atomic per touched (pixel, channel) - 7x fewer global atomics, 16.3 ms
+// against 15.5 ms: the LDS atomics met the same same-address contention.  Removed.  Second form: view_pool_bwd2_kernel
+// below - occupancy first, then a segmented sum along rows of voxels in front of the atomics: 7.5 ms.  The kernel in this
+// first half stays for calls beyond the second form's limits.)
 #include <stdint.h>
 
 #include <stdlib.h>
@@ -242,16 +243,23 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same backward built for OCCUPANCY (round 5, second form; the default where it applies: A + 1 <= VB2_AMAX aggregated
-// features, F <= 32).  What bounded the kernel above was not its atomics but its shape: 2 x F d-weight values per thread in
-// registers across the workgroup's lifetime (273 registers: ONE wave per SIMD), 66 KB of LDS tiles sized for 512 aggregated
-// features, every lane of a voxel projecting the voxel into all views itself (16 x redundant) with the results in
-// dynamically indexed private arrays (scratch), all behind dependent gathers.  Here:
-//   * the 16 lanes of a voxel project it into ONE view each; NDC and angular weight of the (voxel, view) pairs sit in LDS;
-//   * d M^T += agg^T dz (K = the group's 16 voxels) runs on the matrix cores: v_mfma_f32_16x16x4_f32, the A x F result
-//     as <= 6 accumulator tiles per wave (24 registers), a constant-1 column behind the aggregated features makes row A of
-//     the product the bias gradient;
-//   * LDS tiles at the stride the call needs (161 floats): 26 KB, four workgroups (16 waves) per CU at <= 128 registers.
+// The same backward, second form (round 5; the default where it applies: A + 1 <= VB2_AMAX aggregated features, F <= 32).
+// Measured on MI355X at 64^3 x 16 views with development probes (HOLO_VIEWPOOL_BWD_PROBE): everything but pass 2 1.2 ms,
+// pass 2 without its atomics 2.5 ms, with them 13.9 ms - and the atomics of ONE 16-channel map alone cost 0.9 / 1.4 / 2.1 /
+// 3.1 ms at 64^2 / 32^2 / 16^2 / 8^2 for the same count: same-address contention (neighbouring voxels land in the same
+// bilinear cell of a coarse map) is what they cost.  So:
+//   * pass 2 runs with the layout turned round - a 16-lane row = the group's 16 voxels (consecutive in x) for one channel
+//     quad - and sums the 4 taps x 4 channels of voxels that share a cell along the row (DPP row shifts, segmented by the
+//     cell key) before the run's first lane issues the atomics: 1.14 G -> ~0.4 G atomics, none of them contended inside a
+//     wave: 13.9 -> 7.5 ms;
+//   * shape: the 16 lanes of a voxel project it into ONE view each (NDC and angular weight of the (voxel, view) pairs in
+//     LDS, no dynamically indexed private arrays); d M^T += agg^T dz (K = the group's 16 voxels) on the matrix cores
+//     (v_mfma_f32_16x16x4_f32, <= 6 accumulator tiles per wave, a constant-1 column behind the aggregated features makes
+//     row A of the product the bias gradient) instead of 2 x F values per thread in registers for the workgroup's lifetime;
+//     LDS tiles at the stride the call needs (161 floats): 26 KB and 128 registers, four workgroups (16 waves) per CU where
+//     the first form runs one wave per SIMD (on its own this changed little: 14.9 -> 13.9 ms).
+// What is left is the rate at which a CU issues atomics (~0.4 G of them in ~5 ms, behind the same address unit as the
+// gathers): fewer would need voxel groups shaped along each view's own direction.
 // Same arithmetic per voxel, same partial layout ([A][F] | [F]) and reduce as above.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int VB2_AMAX = 160;       // columns of the aggregated tile (A features + the constant 1, zero beyond): 10 MFMA row tiles
@@ -294,7 +302,7 @@ __device__ __forceinline__ void seg_step(float (&c)[16], int key, int lane) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) c[i] = fmaf(row_next_f<D>(c[i], lane), m, c[i]);
 }
-// WPS: waves per SIMD the register allocation aims at (3: 168 registers, no scratch; 4: 128 registers + 168 bytes of scratch)
+// WPS: waves per SIMD the register allocation aims at (4, the default: 128 registers + 172 bytes of scratch; 3: 166 registers)
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdParams b) {
   const ViewPoolParams& p = b.fwd;
@@ -883,11 +891,11 @@ int view_pool_bwd_launch(const ViewPoolBwdParams& b_in, int n_wgs, void* stream)
     ViewPoolBwdParams b = b_in;
     const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // development probe: 2 = pass 2 without its atomics, 0 = no pass 2
     if (ep && b.want_feats) b.want_feats = atoi(ep);
-    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 4 = the 128-register build
-    if (eo && eo[0] == '4')
-      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, b);
-    else
+    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 3 = the 168-register build (measured 8.3 vs 7.5 ms)
+    if (eo && eo[0] == '3')
       HOLO_LAUNCH(view_pool_bwd2_kernel<3>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+    else
+      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, b);
   } else {
     HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
   }
