@@ -23,7 +23,8 @@
 // (Round 5, first attempt at the 1.1 G atomics: bricks of 64 voxels, the four 16-channel maps accumulated per view in LDS
 // tiles over the brick's bounding box, one global atomic per touched (pixel, channel) - 7x fewer global atomics, 16.3 ms
 // against 15.5 ms: the LDS atomics met the same same-address contention.  Removed.  Second form: view_pool_bwd2_kernel
-// below - occupancy first, then a segmented sum along rows of voxels in front of the atomics: 7.5 ms.  The kernel in this
+// below - occupancy first, then a segmented sum along rows of voxels in front of the atomics, then the
+// atomics issued as whole pixels: 3.9 ms.  The kernel in this
 // first half stays for calls beyond the second form's limits.)
 #include <stdint.h>
 
@@ -250,21 +251,24 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
 // bilinear cell of a coarse map) is what they cost.  So:
 //   * pass 2 runs with the layout turned round - a 16-lane row = the group's 16 voxels (consecutive in x) for one channel
 //     quad - and sums the 4 taps x 4 channels of voxels that share a cell along the row (DPP row shifts, segmented by the
-//     cell key) before the run's first lane issues the atomics: 1.14 G -> ~0.4 G atomics, none of them contended inside a
-//     wave: 13.9 -> 7.5 ms;
+//     cell key) before anything is issued: 1.14 G -> ~0.4 G atomics, none of them contended inside a wave: 13.9 -> 7.5 ms;
+//   * the runs' sums are issued TRANSPOSED through a row-private LDS tile: one run per instruction, lane j = (tap j / 4,
+//     channel j % 4), the four rows of a wave (the four channel quads of the same pixels) completing 64-byte pixels.  Issued
+//     from the run's first lane they were 16 one-word instructions that visited the same two or three cache lines again
+//     and again (the first tap's four instructions alone cost 0.5 ms, all sixteen 5 ms): 7.5 -> 3.9 ms;
 //   * shape: the 16 lanes of a voxel project it into ONE view each (NDC and angular weight of the (voxel, view) pairs in
 //     LDS, no dynamically indexed private arrays); d M^T += agg^T dz (K = the group's 16 voxels) on the matrix cores
 //     (v_mfma_f32_16x16x4_f32, <= 6 accumulator tiles per wave, a constant-1 column behind the aggregated features makes
 //     row A of the product the bias gradient) instead of 2 x F values per thread in registers for the workgroup's lifetime;
 //     LDS tiles at the stride the call needs (161 floats): 26 KB and 128 registers, four workgroups (16 waves) per CU where
 //     the first form runs one wave per SIMD (on its own this changed little: 14.9 -> 13.9 ms).
-// What is left is the rate at which a CU issues atomics (~0.4 G of them in ~5 ms, behind the same address unit as the
-// gathers): fewer would need voxel groups shaped along each view's own direction.
+// What is left: 2.5 ms of gathers and arithmetic (1.2 ms of it the forward's work again), 1.4 ms of atomics.
 // Same arithmetic per voxel, same partial layout ([A][F] | [F]) and reduce as above.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int VB2_AMAX = 160;       // columns of the aggregated tile (A features + the constant 1, zero beyond): 10 MFMA row tiles
 constexpr int VB2_AS = VB2_AMAX + 1;  // LDS row stride (odd: the 16 voxels of a column read land in 16 banks)
 constexpr int VB2_ZS = VB_F + 1;
+constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
 
 
 // value of lane + D inside the 16-lane row (0 beyond the row's end): DPP row_shl on the device, a shuffle in the host emulation
@@ -278,7 +282,16 @@ __device__ __forceinline__ int row_next_i(int v, int) {
   return __builtin_amdgcn_update_dpp(0, v, 0x100 + D, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int row_prev_i(int v, int) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); }
+template <int D>
+__device__ __forceinline__ int row_back_i(int v, int) {  // value of lane - D inside the row, 0 before the row's first lane
+  return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, false);
+}
 #else
+template <int D>
+__device__ __forceinline__ int row_back_i(int v, int lane) {
+  const float o = __shfl(__uint_as_float((uint32_t)v), (lane & 15) >= D ? lane - D : lane);
+  return (lane & 15) >= D ? (int)__float_as_uint(o) : 0;
+}
 template <int D>
 __device__ __forceinline__ float row_next_f(float v, int lane) {
   const float o = __shfl(v, (lane & 15) + D < 16 ? lane + D : lane);
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdPar
   __shared__ float s_dagg[16 * VB2_AS];  // [voxel][d loss / d aggregated feature]
   __shared__ float s_dz[16 * VB2_ZS];    // [voxel][d loss / d mapper output] (zero beyond F)
   __shared__ float s_ndcx[16 * 16], s_ndcy[16 * 16], s_w[16 * 16];  // [voxel][view]
+  __shared__ __attribute__((aligned(16))) float s_stage[16 * VB2_STAGE * 20];  // pass 2: [row][run][16 sums | 4 tap offsets]
   const int tid = threadIdx.x;
   const int vl = tid >> 4, ql = tid & 15;
   const int lane = tid & 63, wave = tid >> 6;
@@ -508,16 +522,43 @@ __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdPar
             seg_step<4>(c, key, lane);
             seg_step<8>(c, key, lane);
           }
-          const bool head = row_prev_i(key, lane) != key;  // (lane 0 of a row: 0 is no key)
-          if (act && head) {
-            float* g = gmap + vbase;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (c[e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o00 + e, c[e]);
-              if (c[4 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o01 + e, c[4 + e]);
-              if (c[8 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o10 + e, c[8 + e]);
-              if (c[12 + e] != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o11 + e, c[12 + e]);
+          const bool head = act && row_prev_i(key, lane) != key;  // first lane of a run (lane 0 of a row: 0 is no key)
+          // The runs' sums go out TRANSPOSED: a run's first lane holds 16 sums for 4 pixels; issued from there they would be
+          // 16 instructions of one word per run, each visiting the same two or three cache lines again (measured: the first
+          // tap's four instructions alone cost 0.5 ms, all sixteen 5 ms).  Staged through a row-private LDS tile instead,
+          // the row's 16 lanes issue ONE run per instruction - lane j = (tap j / 4, channel j % 4) - and the four rows of a
+          // wave (the four channel quads of the same pixels) complete 64-byte pixels: as many instructions as the row has
+          // runs, every cache line visited once per run.
+          int inc = head ? 1 : 0;
+          inc += row_back_i<1>(inc, lane);
+          inc += row_back_i<2>(inc, lane);
+          inc += row_back_i<4>(inc, lane);
+          inc += row_back_i<8>(inc, lane);
+          const int hidx = inc - (head ? 1 : 0);  // runs in front of this lane's
+          const int nh = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)inc), lane | 15));  // runs of the row
+          float* st = s_stage + prow * (VB2_STAGE * 20);
+          const int vb = (int)vbase;  // (a view's maps stay far below 2^31 elements)
+          for (int r0 = 0; __any(r0 < nh); r0 += VB2_STAGE) {
+            if (head && hidx >= r0 && hidx < r0 + VB2_STAGE) {
+              float* d = st + (hidx - r0) * 20;
+              *reinterpret_cast<float4*>(d) = make_float4(c[0], c[1], c[2], c[3]);
+              *reinterpret_cast<float4*>(d + 4) = make_float4(c[4], c[5], c[6], c[7]);
+              *reinterpret_cast<float4*>(d + 8) = make_float4(c[8], c[9], c[10], c[11]);
+              *reinterpret_cast<float4*>(d + 12) = make_float4(c[12], c[13], c[14], c[15]);
+              *reinterpret_cast<float4*>(d + 16) =
+                  make_float4(__uint_as_float((uint32_t)(vb + t.o00)), __uint_as_float((uint32_t)(vb + t.o01)),
+                              __uint_as_float((uint32_t)(vb + t.o10)), __uint_as_float((uint32_t)(vb + t.o11)));
             }
+            HOLO_WAVE_SYNC();
+            const int cnt = nh - r0 < VB2_STAGE ? nh - r0 : VB2_STAGE;
+            for (int i = 0; __any(i < cnt); ++i) {
+              if (i < cnt) {
+                const float val = st[i * 20 + pv];
+                const int off = (int)__float_as_uint(st[i * 20 + 16 + (pv >> 2)]) + (pv & 3);
+                if (val != 0.f) HOLO_ATOMIC_ADD_F32(gmap + off, val);
+              }
+            }
+            HOLO_WAVE_SYNC();  // the tile is rewritten by the next round / the next view
           }
         }
       }
