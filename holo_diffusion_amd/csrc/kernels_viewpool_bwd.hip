@@ -268,7 +268,6 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
 constexpr int VB2_AMAX = 160;       // columns of the aggregated tile (A features + the constant 1, zero beyond): 10 MFMA row tiles
 constexpr int VB2_AS = VB2_AMAX + 1;  // LDS row stride (odd: the 16 voxels of a column read land in 16 banks)
 constexpr int VB2_ZS = VB_F + 1;
-constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
 
 
 // value of lane + D inside the 16-lane row (0 beyond the row's end): DPP row_shl on the device, a shuffle in the host emulation
@@ -315,6 +314,60 @@ __device__ __forceinline__ void seg_step(float (&c)[16], int key, int lane) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) c[i] = fmaf(row_next_f<D>(c[i], lane), m, c[i]);
 }
+
+constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
+// Scatter of one 16-lane row: lane = one voxel's 4 taps x 4 channels c[tap * 4 + channel] for the bilinear cell t of ONE
+// feature-map view (element offset vb, channel quad included), act = the lane has something to add.  Every lane of the
+// wave calls it; st = the row's private LDS tile (VB2_STAGE * 20 floats).
+//   1. voxels of the row that share a cell are summed along the row (runs of equal keys are contiguous: the voxels of a
+//      row are consecutive in x), the run's first lane holds the total;
+//   2. the totals go out TRANSPOSED: issued from a run's first lane they would be 16 instructions of one word per run, each
+//      visiting the same two or three cache lines again (measured in view_pool_bwd2_kernel: the first tap's four
+//      instructions alone cost 0.5 ms, all sixteen 5 ms).  Staged through the tile, the row's 16 lanes issue ONE run per
+//      instruction - lane j = (tap j / 4, channel j % 4) - and rows of a wave that carry neighbouring channel quads of the
+//      same pixels complete 64-byte pixels: as many instructions as the row has runs, every cache line visited once per run.
+__device__ __forceinline__ void row_scatter(float (&c)[16], const Tap& t, int vb, float* gmap, bool act, int lane, float* st) {
+  const int pv = lane & 15;
+  const int key = t.key;
+  const int key_next = row_next_i<1>(key, lane);
+  if (__any(act && key_next == key)) {  // some voxels of a row share a cell: sum along the runs
+    seg_step<1>(c, key, lane);
+    seg_step<2>(c, key, lane);
+    seg_step<4>(c, key, lane);
+    seg_step<8>(c, key, lane);
+  }
+  const bool head = act && row_prev_i(key, lane) != key;  // first lane of a run (lane 0 of a row: 0 is no key)
+  int inc = head ? 1 : 0;
+  inc += row_back_i<1>(inc, lane);
+  inc += row_back_i<2>(inc, lane);
+  inc += row_back_i<4>(inc, lane);
+  inc += row_back_i<8>(inc, lane);
+  const int hidx = inc - (head ? 1 : 0);  // runs in front of this lane's
+  const int nh = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)inc), lane | 15));  // runs of the row
+  for (int r0 = 0; __any(r0 < nh); r0 += VB2_STAGE) {
+    if (head && hidx >= r0 && hidx < r0 + VB2_STAGE) {
+      float* d = st + (hidx - r0) * 20;
+      *reinterpret_cast<float4*>(d) = make_float4(c[0], c[1], c[2], c[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(c[4], c[5], c[6], c[7]);
+      *reinterpret_cast<float4*>(d + 8) = make_float4(c[8], c[9], c[10], c[11]);
+      *reinterpret_cast<float4*>(d + 12) = make_float4(c[12], c[13], c[14], c[15]);
+      *reinterpret_cast<float4*>(d + 16) =
+          make_float4(__uint_as_float((uint32_t)(vb + t.o00)), __uint_as_float((uint32_t)(vb + t.o01)),
+                      __uint_as_float((uint32_t)(vb + t.o10)), __uint_as_float((uint32_t)(vb + t.o11)));
+    }
+    HOLO_WAVE_SYNC();
+    const int cnt = nh - r0 < VB2_STAGE ? nh - r0 : VB2_STAGE;
+    for (int i = 0; __any(i < cnt); ++i) {
+      if (i < cnt) {
+        const float val = st[i * 20 + pv];
+        const int off = (int)__float_as_uint(st[i * 20 + 16 + (pv >> 2)]) + (pv & 3);
+        if (val != 0.f) HOLO_ATOMIC_ADD_F32(gmap + off, val);
+      }
+    }
+    HOLO_WAVE_SYNC();  // the tile is rewritten by the next round / the next call
+  }
+}
+
 // WPS: waves per SIMD the register allocation aims at (4, the default: 128 registers + 172 bytes of scratch; 3: 166 registers)
 template <int WPS>
 __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdParams b) {
@@ -514,52 +567,7 @@ __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdPar
             c[8 + e] = t.w10 * dx;
             c[12 + e] = t.w11 * dx;
           }
-          const int key = t.key;
-          const int key_next = row_next_i<1>(key, lane);
-          if (__any(act && key_next == key)) {  // some voxels of a row share a cell: sum along the runs
-            seg_step<1>(c, key, lane);
-            seg_step<2>(c, key, lane);
-            seg_step<4>(c, key, lane);
-            seg_step<8>(c, key, lane);
-          }
-          const bool head = act && row_prev_i(key, lane) != key;  // first lane of a run (lane 0 of a row: 0 is no key)
-          // The runs' sums go out TRANSPOSED: a run's first lane holds 16 sums for 4 pixels; issued from there they would be
-          // 16 instructions of one word per run, each visiting the same two or three cache lines again (measured: the first
-          // tap's four instructions alone cost 0.5 ms, all sixteen 5 ms).  Staged through a row-private LDS tile instead,
-          // the row's 16 lanes issue ONE run per instruction - lane j = (tap j / 4, channel j % 4) - and the four rows of a
-          // wave (the four channel quads of the same pixels) complete 64-byte pixels: as many instructions as the row has
-          // runs, every cache line visited once per run.
-          int inc = head ? 1 : 0;
-          inc += row_back_i<1>(inc, lane);
-          inc += row_back_i<2>(inc, lane);
-          inc += row_back_i<4>(inc, lane);
-          inc += row_back_i<8>(inc, lane);
-          const int hidx = inc - (head ? 1 : 0);  // runs in front of this lane's
-          const int nh = (int)__float_as_uint(__shfl(__uint_as_float((uint32_t)inc), lane | 15));  // runs of the row
-          float* st = s_stage + prow * (VB2_STAGE * 20);
-          const int vb = (int)vbase;  // (a view's maps stay far below 2^31 elements)
-          for (int r0 = 0; __any(r0 < nh); r0 += VB2_STAGE) {
-            if (head && hidx >= r0 && hidx < r0 + VB2_STAGE) {
-              float* d = st + (hidx - r0) * 20;
-              *reinterpret_cast<float4*>(d) = make_float4(c[0], c[1], c[2], c[3]);
-              *reinterpret_cast<float4*>(d + 4) = make_float4(c[4], c[5], c[6], c[7]);
-              *reinterpret_cast<float4*>(d + 8) = make_float4(c[8], c[9], c[10], c[11]);
-              *reinterpret_cast<float4*>(d + 12) = make_float4(c[12], c[13], c[14], c[15]);
-              *reinterpret_cast<float4*>(d + 16) =
-                  make_float4(__uint_as_float((uint32_t)(vb + t.o00)), __uint_as_float((uint32_t)(vb + t.o01)),
-                              __uint_as_float((uint32_t)(vb + t.o10)), __uint_as_float((uint32_t)(vb + t.o11)));
-            }
-            HOLO_WAVE_SYNC();
-            const int cnt = nh - r0 < VB2_STAGE ? nh - r0 : VB2_STAGE;
-            for (int i = 0; __any(i < cnt); ++i) {
-              if (i < cnt) {
-                const float val = st[i * 20 + pv];
-                const int off = (int)__float_as_uint(st[i * 20 + 16 + (pv >> 2)]) + (pv & 3);
-                if (val != 0.f) HOLO_ATOMIC_ADD_F32(gmap + off, val);
-              }
-            }
-            HOLO_WAVE_SYNC();  // the tile is rewritten by the next round / the next view
-          }
+          row_scatter(c, t, (int)vbase, gmap, act, lane, s_stage + prow * (VB2_STAGE * 20));  // (a view's maps stay far below 2^31 elements)
         }
       }
     }
@@ -849,40 +857,56 @@ __global__ __launch_bounds__(256) void mm_dc_kernel(MlpMeanBwdParams b) {
   }
 }
 
-// d x_v = DX[row] + DCA[p] / max(V, 1e-2): the feature columns through the bilinear taps into the channels-last gradient maps
+// d x_v = DX[row] + DCA[p] / max(V, 1e-2): the feature columns through the bilinear taps into the channels-last gradient maps.
+// Thread layout and scatter of view_pool_bwd2_kernel's pass 2 (row_scatter): a 16-lane row = 16 consecutive voxels of one
+// view for one channel quad (round 5: every thread issuing its own 16 atomics took 5.6 ms of the 14 ms backward at 64^3 x 4
+// views).  Row items = (view, group of 16 voxels, quad), quad fastest: the four rows of a wave read 64 contiguous bytes of a
+// DX row and complete 64-byte pixels in the scatter.
 __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
+  __shared__ __attribute__((aligned(16))) float s_stage[16 * VB2_STAGE * 20];
   const MlpMeanParams& m = b.fwd;
   const ViewPoolParams& vp = m.vp;
+  const int tid = threadIdx.x, lane = tid & 63, prow = tid >> 4, pv = tid & 15;
   const int fq = m.emb0 >> 2;  // feature quads come first in the padded order
-  const int64_t P = b.Pc;  // voxels of this chunk (rows = view * Pc + local voxel)
-  const int64_t total = (int64_t)vp.n_views * P * fq;
+  const int64_t P = b.Pc;      // voxels of this chunk (rows = view * Pc + local voxel)
+  const int64_t ngrp = (P + 15) / 16;
+  const int64_t nitems = (int64_t)vp.n_views * ngrp * fq;
   const float inv = 1.f / fmaxf((float)vp.n_views, 1e-2f);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % fq);
-    const int64_t row = i / fq;
-    const int vi = (int)(row / P);
-    const int64_t p = row - (int64_t)vi * P;
+  float* st = s_stage + prow * (VB2_STAGE * 20);
+  for (int64_t base = (int64_t)blockIdx.x * 16; base < nitems; base += (int64_t)gridDim.x * 16) {  // (uniform trip count)
+    const int64_t item = base + prow;
+    const int64_t itc = item < nitems ? item : nitems - 1;
+    const int q = (int)(itc % fq);
+    const int64_t tg = itc / fq;
+    const int64_t g = tg % ngrp;
+    const int vi = (int)(tg / ngrp);
+    const int64_t pl = g * 16 + pv;
+    const int64_t p = pl < P ? pl : P - 1;
+    const int64_t row = (int64_t)vi * P + p;
     int k = 0;
     while (k + 1 < vp.n_feats && q >= vp.feat[k + 1].quad0) ++k;
     const ViewPoolParams::Feat& f = vp.feat[k];
     float* gmap = b.gfeat[k];
-    if (!gmap) continue;
+    const bool act = item < nitems && pl < P && gmap != nullptr;
     const float4 dx = *reinterpret_cast<const float4*>(b.DX + row * m.dp + q * 4);
     const float4 dc = *reinterpret_cast<const float4*>(b.DCA + p * m.dp + q * 4);
-    const float g4[4] = {dx.x + dc.x * inv, dx.y + dc.y * inv, dx.z + dc.z * inv, dx.w + dc.w * inv};
+    const int cq = q - f.quad0;
+    float g4[4] = {dx.x + dc.x * inv, dx.y + dc.y * inv, dx.z + dc.z * inv, dx.w + dc.w * inv};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (!act || cq * 4 + e >= f.C) g4[e] = 0.f;
     const VoxelProj pr = project_voxel(vp, vi, b.p0 + p);
     const Tap t = tap_of(f, pr.ndcx, pr.ndcy);
-    const int cq = q - f.quad0;
-    float* base = gmap + ((int64_t)vi * f.H * f.W) * f.Cp + cq * 4;
+    float c[16];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (cq * 4 + e < f.C && g4[e] != 0.f) {
-        if (t.w00 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o00, t.w00 * g4[e]);
-        if (t.w01 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o01, t.w01 * g4[e]);
-        if (t.w10 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o10, t.w10 * g4[e]);
-        if (t.w11 != 0.f) HOLO_ATOMIC_ADD_F32(base + e + t.o11, t.w11 * g4[e]);
-      }
+      c[e] = t.w00 * g4[e];
+      c[4 + e] = t.w01 * g4[e];
+      c[8 + e] = t.w10 * g4[e];
+      c[12 + e] = t.w11 * g4[e];
     }
+    const int vb = (int)(((int64_t)vi * f.H * f.W) * f.Cp + cq * 4);
+    row_scatter(c, t, vb, gmap, act, lane, st);
   }
 }
 
