@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void rbwd_scatter_kernel(RenderBwdChunk p) {
   const float g = p.GFT[(int64_t)c * p.ld + pt];
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    if (t.w[k] != 0.f) atomicAdd(p.ggrid_cl + (int64_t)t.v[k] * p.C + c, t.w[k] * g);
+    if (t.w[k] != 0.f) HOLO_ATOMIC_ADD_F32(p.ggrid_cl + (int64_t)t.v[k] * p.C + c, t.w[k] * g);  // (the hardware instruction, not atomicAdd's compare-and-swap loop)
 }
 
 }  // namespace
