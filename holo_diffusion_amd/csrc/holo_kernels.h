@@ -490,6 +490,7 @@ int gn_bwd_launch(const GnBwdParams& p, void* stream);
 int add_launch(float* dst, const float* src, int64_t n, int accumulate, void* stream);
 int split_cat_launch(const float* g, float* g0, float* g1, int64_t M, int C0, int C1, int acc0, int acc1, void* stream);
 int sumpool2_launch(const float* gup, float* gin, int N, int R, int C, int accumulate, void* stream);
+int zero_insert2_launch(const float* gy, float* out, int N, int Rs, int C, void* stream);  // (Rs = the coarse edge, out: (2 Rs)^3)
 int conv_dgrad_s2_launch(const float* gy, const float* wt, float* gx, int N, int RI, int RO, int Ci, int Co, int accumulate,
                          void* stream);
 int attn_ds_launch(const float* P, float* dP, int64_t rows, int cols, void* stream);

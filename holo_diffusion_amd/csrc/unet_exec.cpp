@@ -989,14 +989,16 @@ struct TrainPlanner {
   }
 
   // dgrad of a stride-1 conv (3x3x3 pad 1 or 1x1x1): out[M][cin] = conv(gy[M][cout], flipped weights)
-  void emit_dgrad(size_t gy_off, int cout, int R, const std::string& wname, int cin, int ksz, size_t out_off) {
+  void emit_dgrad(size_t gy_off, int cout, int R, const std::string& wname, int cin, int ksz, size_t out_off,
+                  bool accumulate = false) {
     const float* w = dgw(wname);
     if (!w) return;
     Act g;
     g.off = gy_off;
     g.C = cout;
     g.R = R;
-    pl.emit_conv(g, nullptr, R, 0, R, 1, ksz, w, nullptr, 0, false, 0, nullptr, ptr<float>(out_off), cin);
+    pl.emit_conv(g, nullptr, R, 0, R, 1, ksz, w, nullptr, 0, false, 0, accumulate ? ptr<float>(out_off) : nullptr,
+                 ptr<float>(out_off), cin);
     Op op = pl.ops.back();
     pl.ops.pop_back();
     ConvParams cp = op.conv;
@@ -1218,9 +1220,19 @@ struct TrainPlanner {
       const float* wt = dgw(wn);
       if (!wt) return;
       const int Nn = N;
-      bops.push_back([goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax](void* st) {
-        return conv_dgrad_s2_launch(goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax, st);
-      });
+      static const char* zi = getenv("HOLO_DGRAD_S2_DIRECT");  // development knob: 1 = conv_dgrad_s2_kernel everywhere
+      if (!(zi && zi[0] == '1') && u->dgrad_w.count(wn + "#s1") && Ri == 2 * Ro && (Ri % 8) == 0) {
+        // zero insertion + the stride-1 transposed convolution on the forward's conv kernels (8x the multiply-adds, on the
+        // Winograd kernels: 0.24 instead of 1.35 ms at 64^3 <- 32^3)
+        const size_t gz_off = alloc((size_t)N * vox(Ri) * cout * sizeof(float));
+        float* gz = ptr<float>(gz_off);
+        bops.push_back([goutp, gz, Nn, Ro, cout](void* st) { return zero_insert2_launch(goutp, gz, Nn, Ro, cout, st); });
+        emit_dgrad(gz_off, cout, Ri, wn + "#s1", cin, 3, gx_off, ax != 0);
+      } else {
+        bops.push_back([goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax](void* st) {
+          return conv_dgrad_s2_launch(goutp, wt, gx, Nn, Ri, Ro, cin, cout, ax, st);
+        });
+      }
       emit_wgrad(gout, cout, t.x0, nullptr, Ri, 0, Ro, 2, 3, 0, false, 0, wn, bn);
     } else {  // B_UP: conv at the fine size of the nearest-upsampled input
       const int64_t Mf = (int64_t)N * vox(Ro);
@@ -1895,9 +1907,16 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
   const bool down = nm.size() > 10 && nm.compare(nm.size() - 10, 10, ".op.weight") == 0;  // Downsample: stride 2
   // transposed convolution: Cout' = Ci, Cin' = Co
   const size_t packed = down ? (size_t)T * Co * Ci : (size_t)T * pad_cout(Ci) * pad_cin(Co);
-  float*& dst = net->dgrad_w[nm];
-  if (!dst) HIP_TRY(hipMalloc((void**)&dst, packed * sizeof(float)));
-  if (down) return weight_tco_ci_launch((const float*)dev_ptr, dst, Co, Ci, T, stream) ? HOLO_E_INVALID : 0;
+  if (down) {  // [tap][co][ci] for conv_dgrad_s2_kernel (the fallback), then the stride-1 form below under "<name>#s1":
+               // the transposed stride-2 convolution runs as zero insertion + the stride-1 transposed convolution
+    float*& d2 = net->dgrad_w[nm];
+    if (!d2) HIP_TRY(hipMalloc((void**)&d2, packed * sizeof(float)));
+    if (weight_tco_ci_launch((const float*)dev_ptr, d2, Co, Ci, T, stream)) return HOLO_E_INVALID;
+    if ((Co & 3) || (Ci & 3)) return 0;
+  }
+  const std::string key = down ? nm + "#s1" : nm;
+  float*& dst = net->dgrad_w[key];
+  if (!dst) HIP_TRY(hipMalloc((void**)&dst, (size_t)T * pad_cout(Ci) * pad_cin(Co) * sizeof(float)));
   if (net->dgrad_tmp_floats < (size_t)s.numel) {
     if (net->dgrad_tmp) {
       HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1915,8 +1934,8 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
   const bool wino_on = !(we && (we[0] == '0' || we[0] == '1'));
   if (wino_on && net->compute_mode == 0 && T == 27 && (Ci % 64) == 0 && Ci <= 768 && Co <= 768) {
     const size_t per_tap = (size_t)pad_cout(Ci) * pad_cin(Co);
-    float*& w1 = net->dgrad_wino[nm];
-    float*& w2 = net->dgrad_wino2[nm];
+    float*& w1 = net->dgrad_wino[key];
+    float*& w2 = net->dgrad_wino2[key];
     if (!w1 || !w2) {  // a plan sized before these copies existed chose other kernels (and scratch sizes)
       net->tws_cache.clear();
       net->tplan_batch = -1;
@@ -1930,7 +1949,7 @@ int holo_unet_set_dgrad_weight(HoloUnet* net, const char* name, const void* dev_
     // ... and on conv_wino3_kernel where the forward convolutions do (transposed: output channels = the forward's inputs)
     static const char* w3e = getenv("HOLO_CONV_WINO3");
     if (!(w3e && w3e[0] == '0') && Ci <= 256 && Co <= 768) {
-      float*& w3 = net->dgrad_wino3[nm];
+      float*& w3 = net->dgrad_wino3[key];
       if (!w3) {
         net->tws_cache.clear();
         net->tplan_batch = -1;
@@ -1954,7 +1973,12 @@ size_t holo_unet_backward_workspace_bytes(HoloUnet* net, int batch) {
   // a sizing pass must not fail on missing transposed weights: it only allocates
   std::map<std::string, float*> saved = net->dgrad_w;
   for (auto& s : net->params)
-    if ((s.kind == P_CONV3 || s.kind == P_CONV1) && !net->dgrad_w.count(s.name)) net->dgrad_w[s.name] = (float*)(uintptr_t)256;
+    if (s.kind == P_CONV3 || s.kind == P_CONV1) {
+      if (!net->dgrad_w.count(s.name)) net->dgrad_w[s.name] = (float*)(uintptr_t)256;
+      const bool down = s.name.size() > 10 && s.name.compare(s.name.size() - 10, 10, ".op.weight") == 0;
+      if (down && !(s.shape[0] & 3) && !(s.shape[1] & 3) && !net->dgrad_w.count(s.name + "#s1"))
+        net->dgrad_w[s.name + "#s1"] = (float*)(uintptr_t)256;
+    }
   const int rc = tp.build();
   net->dgrad_w = saved;
   net->grad_off = keep;
