@@ -392,8 +392,17 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restr
   const int cl = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double s = 0.0;
-  if (c < C)
-    for (int b = sub; b < nb; b += 8) s += part[(int64_t)b * C + c];
+  if (c < C) {  // eight loads in flight, added in slab order (this kernel is nothing but their latency: 104 launches per step)
+    int b = sub;
+    for (; b + 56 < nb; b += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 8 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nb; b += 8) s += part[(int64_t)b * C + c];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (sub == 0 && c < C) {
@@ -481,12 +490,27 @@ __global__ __launch_bounds__(256) void gn_bwd_group_kernel(GnBwdParams p, int nb
     for (int cb = 0; cb < Cin; cb += 256) {
       const int c = cb + c0;
       double s1 = 0.0, s2 = 0.0;
-      if (sub < nsub && c < Cin)
-        for (int b = sub; b < nblk; b += nsub) {
+      if (sub < nsub && c < Cin) {
+        // ONE workgroup walks up to 512 slabs: eight 16-byte loads in flight, added in slab order (one load per iteration
+        // made the 64^3 launches 130 us of pure latency)
+        int b = sub;
+        for (; b + 7 * nsub < nblk; b += 8 * nsub) {
+          double2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            v[u] = *reinterpret_cast<const double2*>(p.part + (((int64_t)(b + u * nsub) * p.N + n) * Cin + c) * 2);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s1 += v[u].x;
+            s2 += v[u].y;
+          }
+        }
+        for (; b < nblk; b += nsub) {
           const double* d = p.part + (((int64_t)b * p.N + n) * Cin + c) * 2;
           s1 += d[0];
           s2 += d[1];
         }
+      }
       if (nsub > 1) {
         R[2 * threadIdx.x] = s1;
         R[2 * threadIdx.x + 1] = s2;
