@@ -306,8 +306,8 @@ __device__ __forceinline__ int row_prev_i(int v, int lane) {
   return (lane & 15) >= 1 ? (int)__float_as_uint(o) : 0;
 }
 #endif
-// one step of the segmented sum along a row: c[i] += c[i + D] where lane + D carries the same key (runs of equal keys are
-// contiguous, so after D = 1, 2, 4, 8 the first lane of a run holds the run's total)
+// one step of the segmented sum along a row: c[i] += c[i + D] where lane + D carries the same run number (run numbers rise
+// along the row, so equal numbers D apart mean one run in between: after D = 1, 2, 4, 8 a run's first lane holds its total)
 template <int D>
 __device__ __forceinline__ void seg_step(float (&c)[16], int key, int lane) {
   const float m = row_next_i<D>(key, lane) == key ? 1.f : 0.f;
@@ -319,8 +319,8 @@ constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
 // Scatter of one 16-lane row: lane = one voxel's 4 taps x 4 channels c[tap * 4 + channel] for the bilinear cell t of ONE
 // feature-map view (element offset vb, channel quad included), act = the lane has something to add.  Every lane of the
 // wave calls it; st = the row's private LDS tile (VB2_STAGE * 20 floats).
-//   1. voxels of the row that share a cell are summed along the row (runs of equal keys are contiguous: the voxels of a
-//      row are consecutive in x), the run's first lane holds the total;
+//   1. voxels of the row that share a cell with their neighbours are summed along the row (maximal contiguous runs of equal
+//      keys: the voxels of a row are consecutive in x), the run's first lane holds the total;
 //   2. the totals go out TRANSPOSED: issued from a run's first lane they would be 16 instructions of one word per run, each
 //      visiting the same two or three cache lines again (measured in view_pool_bwd2_kernel: the first tap's four
 //      instructions alone cost 0.5 ms, all sixteen 5 ms).  Staged through the tile, the row's 16 lanes issue ONE run per
@@ -329,14 +329,22 @@ constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
 __device__ __forceinline__ void row_scatter(float (&c)[16], const Tap& t, int vb, float* gmap, bool act, int lane, float* st) {
   const int pv = lane & 15;
   const int key = t.key;
-  const int key_next = row_next_i<1>(key, lane);
-  if (__any(act && key_next == key)) {  // some voxels of a row share a cell: sum along the runs
-    seg_step<1>(c, key, lane);
-    seg_step<2>(c, key, lane);
-    seg_step<4>(c, key, lane);
-    seg_step<8>(c, key, lane);
+  // runs = maximal CONTIGUOUS stretches of equal keys, numbered along the row (rid).  The sums are segmented by the run number,
+  // not by the key: on a grid narrower than a row (R = 8: a row is two lines of voxels) the second line comes back to the first
+  // line's cells, and equal keys across the gap must stay two runs - each is issued by its own first lane.
+  const bool rhead = row_prev_i(key, lane) != key;  // first lane of a run (lane 0 of a row: 0 is no key)
+  int rid = rhead ? 1 : 0;
+  rid += row_back_i<1>(rid, lane);
+  rid += row_back_i<2>(rid, lane);
+  rid += row_back_i<4>(rid, lane);
+  rid += row_back_i<8>(rid, lane);
+  if (__any(act && !rhead)) {  // some voxels of a row share a cell with their neighbour: sum along the runs
+    seg_step<1>(c, rid, lane);
+    seg_step<2>(c, rid, lane);
+    seg_step<4>(c, rid, lane);
+    seg_step<8>(c, rid, lane);
   }
-  const bool head = act && row_prev_i(key, lane) != key;  // first lane of a run (lane 0 of a row: 0 is no key)
+  const bool head = act && rhead;
   int inc = head ? 1 : 0;
   inc += row_back_i<1>(inc, lane);
   inc += row_back_i<2>(inc, lane);

@@ -143,6 +143,46 @@ def test_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius, gamma):
 
 
 @pytest.mark.gpu
+def test_view_pool_backward_released_channel_structure(monkeypatch):
+    """The released configuration's channel structure (configs/apple.yaml:166-196: four 16-channel ResNet stages + mask + image =
+    18 channel quads, 136 aggregated features) at small map sizes: the scatter's rows walk the quads in TWO rounds (16 + 2), the
+    second with fourteen idle rows, and most voxels of a row share a bilinear cell on the coarse maps (the segmented sums, the
+    staged whole-pixel atomics) - against autograd through the oracle, and the first-form kernel (HOLO_VIEWPOOL_BWD_V1=1)
+    against the same reference."""
+    import tests.gpu_utils as gu
+    R, n_src, F = 8, 4, 32
+    feats = {f"res{i}": torch.tanh(torch.from_numpy(np_noise(70 + i, (n_src, 16, s, s + 2)))) for i, s in enumerate((12, 9, 5, 3))}
+    feats["mask"] = torch.sigmoid(torch.from_numpy(np_noise(75, (n_src, 1, 20, 20))))
+    feats["rgb"] = torch.sigmoid(torch.from_numpy(np_noise(76, (n_src, 3, 20, 20))))
+    A = 2 * sum(v.shape[1] for v in feats.values())
+    assert A == 136
+    cams_d = _cams(n_src, radius=6.0)
+    w = synth_state_dict({"w": (F, A), "b": (F,)}, 9)
+    w["b"] = 0.1 * torch.from_numpy(np_noise(4, (F,)))
+    g = torch.from_numpy(np_noise(123, (1, F, R, R, R)))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    mw, mb = w["w"].clone().requires_grad_(True), w["b"].clone().requires_grad_(True)
+    vo.voxel_features_from_views(leaves, cams_d, mw, mb, R, 8.0).backward(g)
+    model = hda.HoloDiffusionModel(resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False,
+                                   diffusion_enabled=False, render_image_width=8, render_image_height=8)
+    model.load_state_dict({"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}, strict=False)
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    dev_feats = {k: v.to(gu.DEV) for k, v in feats.items()}
+
+    def rel(a, b):
+        return float((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    for v1 in ("0", "1"):
+        monkeypatch.setenv("HOLO_VIEWPOOL_BWD_V1", v1)
+        got = model.pool_views_backward(dev_feats, cams.to(gu.DEV), g.to(gu.DEV))
+        assert rel(got["pooled_feature_mapper"]["weight"], mw.grad) < 1e-3, v1
+        assert rel(got["pooled_feature_mapper"]["bias"], mb.grad) < 1e-3, v1
+        for k in feats:
+            assert float(leaves[k].grad.abs().max()) > 0
+            assert rel(got["image_features"][k], leaves[k].grad) < 1e-3, (v1, k, rel(got["image_features"][k], leaves[k].grad))
+
+
+@pytest.mark.gpu
 def test_model_forward_from_source_views():
     """HoloDiffusionModel.forward with source-view features (the reconstruction entry, holo_diffusion_model.py:327-374):
     camera batch = [target, sources...]; the pooled grid goes through tanh(net_3d(., 0)) and the renderer like a
