@@ -64,10 +64,12 @@ def test_aggregator_closed_forms():
 
 
 # --------------------------------------------------------------------------------------------------------------
-def _synthetic_views(n_src, seed):
-    feats = {"res": torch.tanh(torch.from_numpy(np_noise(seed, (n_src, 16, 20, 24)))),
-             "mask": torch.sigmoid(torch.from_numpy(np_noise(seed + 1, (n_src, 1, 30, 30)))),
-             "rgb": torch.sigmoid(torch.from_numpy(np_noise(seed + 2, (n_src, 3, 17, 13))))}
+def _synthetic_views(n_src, seed, coarse=False):
+    """coarse: maps of a few pixels - most voxels of a line (and, on an 8^3 grid, of the next line) share a bilinear cell."""
+    s0, s1, s2 = ((4, 6), (5, 5), (3, 4)) if coarse else ((20, 24), (30, 30), (17, 13))
+    feats = {"res": torch.tanh(torch.from_numpy(np_noise(seed, (n_src, 16) + s0))),
+             "mask": torch.sigmoid(torch.from_numpy(np_noise(seed + 1, (n_src, 1) + s1))),
+             "rgb": torch.sigmoid(torch.from_numpy(np_noise(seed + 2, (n_src, 3) + s2)))}
     A = 2 * (16 + 1 + 3)
     return feats, A
 
@@ -262,7 +264,7 @@ def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_har
     the matrix cores + softmax over views + mapper + tanh, one kernel) against the oracle, whose aggregator is bit-equal
     to the reference class (tests/golden/ref_mlp_mean_aggregator.npz); cameras far, near and INSIDE the bounding sphere."""
     import tests.gpu_utils as gu
-    feats, _ = _synthetic_views(n_src, 150 + R)
+    feats, _ = _synthetic_views(n_src, 150 + R, coarse=coarse)  # (coarse: the scatter's runs of voxels in one cell, wrapped rows)
     D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
     cams_d = _cams(n_src, radius=radius)
     shapes = vo.mlp_mean_param_shapes(D, 128, dim_out)
@@ -291,8 +293,9 @@ def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_har
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("R,n_src,radius,F,dim_out,n_harm", [(8, 3, 10.0, 16, 24, 3), (16, 5, 6.0, 32, 128, 3), (8, 9, 3.0, 16, 128, 2)])
-def test_mlp_mean_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius, F, dim_out, n_harm):
+@pytest.mark.parametrize("R,n_src,radius,F,dim_out,n_harm,coarse", [(8, 3, 10.0, 16, 24, 3, False), (16, 5, 6.0, 32, 128, 3, False),
+                                                                     (8, 9, 3.0, 16, 128, 2, False), (8, 3, 8.0, 16, 24, 3, True)])
+def test_mlp_mean_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius, F, dim_out, n_harm, coarse):
     """holo_mlp_mean_backward against torch autograd through the oracle (whose aggregator is bit-equal to the reference
     class): gradients of every aggregator parameter, of pooled_feature_mapper and of the three source-view feature maps for a
     random cotangent on the grid; the geometries of the forward test.  LeakyReLU kink: a hidden pre-activation within float32
