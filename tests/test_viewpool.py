@@ -264,7 +264,7 @@ def test_mlp_mean_view_pool_kernel_vs_oracle(R, n_src, radius, F, dim_out, n_har
     the matrix cores + softmax over views + mapper + tanh, one kernel) against the oracle, whose aggregator is bit-equal
     to the reference class (tests/golden/ref_mlp_mean_aggregator.npz); cameras far, near and INSIDE the bounding sphere."""
     import tests.gpu_utils as gu
-    feats, _ = _synthetic_views(n_src, 150 + R, coarse=coarse)  # (coarse: the scatter's runs of voxels in one cell, wrapped rows)
+    feats, _ = _synthetic_views(n_src, 150 + R)
     D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
     cams_d = _cams(n_src, radius=radius)
     shapes = vo.mlp_mean_param_shapes(D, 128, dim_out)
@@ -301,7 +301,7 @@ def test_mlp_mean_view_pool_backward_vs_autograd_of_the_oracle(R, n_src, radius,
     random cotangent on the grid; the geometries of the forward test.  LeakyReLU kink: a hidden pre-activation within float32
     rounding of zero takes the other slope on one side - one unit of one (voxel, view) row, far below the tolerance."""
     import tests.gpu_utils as gu
-    feats, _ = _synthetic_views(n_src, 150 + R)
+    feats, _ = _synthetic_views(n_src, 150 + R, coarse=coarse)  # (coarse: the scatter's runs of voxels in one cell, wrapped rows)
     D = 16 + 1 + 3 + 3 * (2 * n_harm + 1)
     cams_d = _cams(n_src, radius=radius)
     shapes = vo.mlp_mean_param_shapes(D, 128, dim_out)
