@@ -960,7 +960,7 @@ int conv_wgrad_launch(const WgradParams& p, float* dw, int accumulate, int num_c
   const int64_t n = (int64_t)p.Cout * Cin * p.ntaps;
   if (wgrad_rows_ok(p)) {
     const int64_t tiles = ((int64_t)p.Cout * Cin + 63) / 64;
-    static const char* rt = getenv("HOLO_WGRAD_REDUCE_TILE_MIN");  // development knob: tiles from which the tile form runs
+    const char* rt = getenv("HOLO_WGRAD_REDUCE_TILE_MIN");  // development / test knob: tiles from which the tile form runs
     const int64_t tmin = rt ? atoll(rt) : 1024;
     if (tiles >= tmin && p.ntaps <= 28) {
       HOLO_LAUNCH(wgrad_reduce_tile_kernel, dim3((unsigned)(tiles < 8192 ? tiles : 8192)), dim3(256), stream, p.partial, dw, p.Cout,

@@ -1220,7 +1220,7 @@ struct TrainPlanner {
       const float* wt = dgw(wn);
       if (!wt) return;
       const int Nn = N;
-      static const char* zi = getenv("HOLO_DGRAD_S2_DIRECT");  // development knob: 1 = conv_dgrad_s2_kernel everywhere
+      const char* zi = getenv("HOLO_DGRAD_S2_DIRECT");  // development / test knob: 1 = conv_dgrad_s2_kernel everywhere
       if (!(zi && zi[0] == '1') && u->dgrad_w.count(wn + "#s1") && Ri == 2 * Ro && (Ri % 8) == 0) {
         // zero insertion + the stride-1 transposed convolution on the forward's conv kernels (8x the multiply-adds, on the
         // Winograd kernels: 0.24 instead of 1.35 ms at 64^3 <- 32^3)

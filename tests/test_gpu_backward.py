@@ -41,13 +41,19 @@ def _check(got, ref, name, rtol=1e-3, floor=1e-12):
     assert err <= rtol * max(scale, floor), (name, err, scale)
 
 
-@pytest.mark.parametrize("cfg_name,batch", [("tiny", 2), ("wide", 1), ("deep", 1)])
-def test_unet_backward_vs_oracle_autograd(gu, cfg_name, batch):
+@pytest.mark.parametrize("cfg_name,batch", [("tiny", 2), ("wide", 1), ("deep", 1), ("wide-tiled-reduce", 1), ("deep-direct-s2", 1)])
+def test_unet_backward_vs_oracle_autograd(gu, cfg_name, batch, monkeypatch):
     """Every parameter gradient and the input gradient of three small nets: `tiny` (32 channels, attention on both levels,
     1x1 skip connections), `wide` (64 channels: LDS-halo forward kernels, fused skip, split-K) and `deep` (three levels:
     two Down / Upsample pairs, concat groups that straddle the two sources)."""
     if os.environ.get("HOLO_TEST_EMU") == "1":
         pytest.skip("backward tests run on the device")
+    if cfg_name == "wide-tiled-reduce":  # the weight-gradient reduce's tile form (large weights only by default) on small ones
+        monkeypatch.setenv("HOLO_WGRAD_REDUCE_TILE_MIN", "1")
+        cfg_name = "wide"
+    if cfg_name == "deep-direct-s2":  # the scalar transposed stride-2 convolution (the default is zero insertion + stride 1)
+        monkeypatch.setenv("HOLO_DGRAD_S2_DIRECT", "1")
+        cfg_name = "deep"
     cfg = {"tiny": TINY_CFG,
            "wide": uo.UNetCfg(image_size=8, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2,
                               channel_mult=(1, 2), attention_resolutions=(2,), num_heads=2),
