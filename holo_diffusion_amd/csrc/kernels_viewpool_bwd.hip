@@ -951,24 +951,24 @@ __global__ __launch_bounds__(256) void mm_sum_partials_kernel(const float* __res
 
 }  // namespace
 
-int view_pool_bwd_launch(const ViewPoolBwdParams& b_in, int n_wgs, void* stream) {
-  const ViewPoolBwdParams& b = b_in;
+int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
   if (b.fwd.F > VB_F || b.fwd.A > 512) {
     set_error("view_pool_backward: feature_size <= %d and <= 512 aggregated features (got %d, %d)", VB_F, b.fwd.F, b.fwd.A);
     return -1;
   }
-  // (HOLO_VIEWPOOL_BWD_V1=1: the register-accumulating form on every call - development knob)
+  // (HOLO_VIEWPOOL_BWD_V1=1: the register-accumulating form on every call - development / test knob)
   const char* ev = getenv("HOLO_VIEWPOOL_BWD_V1");
   const bool v1 = ev && ev[0] == '1';
-  if (!v1 && b.fwd.A + 1 <= VB2_AMAX && b.fwd.n_views <= 16) {
-    ViewPoolBwdParams b = b_in;
-    const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // development probe: 2 = pass 2 without its atomics, 0 = no pass 2
-    if (ep && b.want_feats) b.want_feats = atoi(ep);
-    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 3 = the 168-register build (measured 8.3 vs 7.5 ms)
+  if (!v1 && b.fwd.A + 1 <= VB2_AMAX) {
+    ViewPoolBwdParams q = b;
+    const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // development probes (timing only): 0 no pass 2, 2 pass 2 without
+                                                          // its atomics, 10 + k the atomics of map k alone
+    if (ep && q.want_feats) q.want_feats = atoi(ep);
+    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 3 = the 166-register build (measured 6.3 vs 3.9 ms)
     if (eo && eo[0] == '3')
-      HOLO_LAUNCH(view_pool_bwd2_kernel<3>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+      HOLO_LAUNCH(view_pool_bwd2_kernel<3>, dim3((unsigned)n_wgs), dim3(256), stream, q);
     else
-      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, q);
   } else {
     HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
   }
