@@ -15,7 +15,7 @@ from .render import (  # noqa: F401
 from .model import HoloDiffusionModel  # noqa: F401
 from .cameras import PerspectiveCameras, look_at_view_transform, get_simple_360_camera_trajectory  # noqa: F401
 from .viewpool import ViewPooler, AngleWeightedReductionFeatureAggregator  # noqa: F401,E402
-from . import checkpoint, flyaround_output, generate, model, render, viewpool  # noqa: F401,E402
+from . import checkpoint, flyaround_output, generate, model, render, runtime, viewpool  # noqa: F401,E402
 from .checkpoint import load_experiment  # noqa: F401,E402
 
 __all__ = ["registry", "SimpleUnet3D", "Unet3DBase", "ImplicitronGaussianDiffusion", "HoloVoxelGridImplicitFunction",

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libholo_mi355x.so")
 HOLO_DTYPE_F32 = 0
 HOLO_DTYPE_BF16 = 1
 HOLO_DTYPE_F32_BF16X3 = 2
-ABI_VERSION = 5  # include/holo_abi.h HOLO_ABI_VERSION
+ABI_VERSION = 6  # include/holo_abi.h HOLO_ABI_VERSION
 
 
 class HoloError(RuntimeError):
@@ -82,6 +82,8 @@ SIGNATURES = {
     "holo_last_error": (C.c_char_p, []),
     "holo_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "holo_ctx_destroy": (C.c_int, [_vp]),
+    "holo_ctx_set_deterministic": (C.c_int, [_vp, C.c_int]),
+    "holo_ctx_get_deterministic": (C.c_int, [_vp]),
     "holo_unet_create": (C.c_int, [_vp, C.POINTER(HoloUnetCfg), C.POINTER(_vp)]),
     "holo_unet_destroy": (C.c_int, [_vp]),
     "holo_unet_num_params": (C.c_int, [_vp]),

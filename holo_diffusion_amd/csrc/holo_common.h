@@ -161,6 +161,20 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uin
   l = pack_bf16x2(r0 - bf_lo_f32(m), r1 - bf_hi_f32(m));
 }
 
+// ---- order-independent scatter-add (the deterministic mode of the scatter kernels, holo_ctx_set_deterministic): the values
+// are added as 64-bit fixed-point integers (integer addition commutes, so the sum does not depend on the order the
+// atomics land in), with the binary point placed from the largest magnitude that will be added: |v| < 2^(e+1) is scaled to
+// |q| < 2^HOLO_FIX_BITS, which leaves 2^(63 - HOLO_FIX_BITS) = 8 M worst-case addends per element and quantises every
+// addend to 2^-HOLO_FIX_BITS of that largest magnitude (fp32 rounds a sum of that size to 2^-24).
+#define HOLO_FIX_BITS 40
+// maxbits = bit pattern of max |v| (non-negative floats order like their bit patterns: atomicMax on uint32_t)
+__device__ __forceinline__ int holo_fix_shift(uint32_t maxbits) { return HOLO_FIX_BITS - 1 - ((int)((maxbits >> 23) & 0xffu) - 127); }
+__device__ __forceinline__ void holo_fix_add(long long* p, float v, int shift) {
+  const long long q = (long long)rint(ldexp((double)v, shift));
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+}
+__device__ __forceinline__ float holo_fix_value(long long q, int shift) { return (float)ldexp((double)q, -shift); }
+
 namespace holo {
 
 // thread-local error string shared by all translation units

@@ -8,6 +8,7 @@
 struct HoloCtx {
   int device;
   int num_cus;
+  int deterministic = 0;  // holo_ctx_set_deterministic: scatter-adds of the backward entries in fixed point (order-independent)
 };
 
 namespace holo {
@@ -339,7 +340,13 @@ struct RenderBwdChunk {
   const float *g_rgb, *g_depth, *g_mask, *g_rgb_c, *g_depth_c, *g_mask_c;  // any may be null (= zero)
   float bg[3];
   float background_opacity;
+  // deterministic mode (null otherwise): the scatter adds fixed-point integers into gfix [voxel][C], scaled from *gfix_max =
+  // bits of max |GFT| of the chunk (rbwd_absmax_launch), and rbwd_fix_flush_launch adds the chunk's sums to ggrid_cl
+  long long* gfix;
+  uint32_t* gfix_max;
 };
+int rbwd_absmax_launch(const RenderBwdChunk& p, void* stream);
+int rbwd_fix_flush_launch(const RenderBwdChunk& p, void* stream);
 int rbwd_rays_launch(const RenderBwdRays& p, void* stream);
 int rbwd_gather_launch(const RenderBwdChunk& p, void* stream);
 int rbwd_point_fwd_launch(const RenderBwdChunk& p, void* stream);
@@ -403,9 +410,15 @@ struct ViewPoolBwdParams {
   float* partial;  // [n_wgs][A * F + F]
   float* dW;       // (F, A) or null
   float* dbias;    // (F) or null
+  // deterministic mode (holo_ctx_set_deterministic; null otherwise): zeroed 64-bit fixed-point images of the gradient maps
+  // and one word per map for the bits of its largest addend (the launch runs twice: measure, then add)
+  long long* gfix[ViewPoolParams::MAX_FEATS];
+  uint32_t* fix_max;  // [MAX_FEATS], zeroed
 };
 int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream);
 int nhwc_pad_to_nchw_launch(const float* in, float* out, int n, int C, int Cp, int64_t HW, void* stream);
+// deterministic mode: in (+)= value of the fixed-point image (binary point from *maxbits), the image zeroed again
+int fix_flush_launch(long long* fix, const uint32_t* maxbits, float* out, int64_t n, void* stream);
 // MLPMeanFeatureAggregator path (kernels_viewpool.hip): the folded aggregator + mapper (viewpool_exec.cpp); vp carries the
 // views, the feature maps (quad0 = first quad in the kernel's padded channel order), R, F, proj_eps and the output
 struct MlpMeanParams {
@@ -434,6 +447,8 @@ struct MlpMeanBwdParams {
   int64_t p0, Pc, Pall;
   float *X, *MEAN, *CM, *PRE, *H, *U, *DUL, *DULT, *DPRET, *DC, *DCT, *DX, *DCA;
   float* gfeat[ViewPoolParams::MAX_FEATS];
+  long long* gfix[ViewPoolParams::MAX_FEATS];  // deterministic mode, as in ViewPoolBwdParams (per chunk of voxels)
+  uint32_t* fix_max;
 };
 int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream);
 int mm_colsum_launch(const float* src, int64_t rows, int cols, int ld, float* partial, int n_blocks, float* out, void* stream,

@@ -15,7 +15,8 @@
 //   per point: radiance head + LeakyReLU backward, YT <- d pre-activation     (rbwd_point_bwd_kernel)
 //   GFT [C][n]    = We^T YT     gradient of the features                      (GEMM 2)
 //   dWe [Hp][C]   = YT F        (GEMM 3, split over the points)   dWr_h [Hd][4] = AT GR   (GEMM 4)
-//   scatter-add of GFT through the trilinear weights (atomicAdd, as grid_sample's backward)   (rbwd_scatter_kernel)
+//   scatter-add of GFT through the trilinear weights (atomicAdd, as grid_sample's backward; in the deterministic mode of
+//   holo_ctx_set_deterministic as order-independent fixed-point sums)                        (rbwd_scatter_kernel)
 // The folded weights' gradients are unfolded to the four Linear layers on the host in float64 (render_exec.cpp).
 #include <math.h>
 #include <string.h>
@@ -306,7 +307,10 @@ __global__ __launch_bounds__(256) void rbwd_rowsum_kernel(const float* __restric
   if (threadIdx.x == 0) out[h] = (accumulate ? out[h] : 0.f) + (float)red[0];
 }
 
-// scatter-add of the feature gradients through the trilinear weights: one thread per (point, channel), channel fastest
+// scatter-add of the feature gradients through the trilinear weights: one thread per (point, channel), channel fastest.
+// FIXED (the deterministic mode): the same products added as fixed-point integers (holo_common.h) - the sum of a chunk no
+// longer depends on the order the atomics land in; the binary point comes from the chunk's max |GFT| (trilinear weights <= 1).
+template <bool FIXED>
 __global__ __launch_bounds__(256) void rbwd_scatter_kernel(RenderBwdChunk p) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n * p.C) return;
@@ -317,9 +321,54 @@ __global__ __launch_bounds__(256) void rbwd_scatter_kernel(RenderBwdChunk p) {
   Tri t;
   tri_setup(px, py, pz, p.half_extent, p.R, t);
   const float g = p.GFT[(int64_t)c * p.ld + pt];
+  if (FIXED) {
+    const uint32_t mb = *p.gfix_max;
+    if (mb == 0u || mb >= 0x7f800000u) return;  // nothing to add / not finite (the flush writes NaN)
+    const int shift = holo_fix_shift(mb);
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (t.w[k] != 0.f) HOLO_ATOMIC_ADD_F32(p.ggrid_cl + (int64_t)t.v[k] * p.C + c, t.w[k] * g);  // (the hardware instruction, not atomicAdd's compare-and-swap loop)
+    for (int k = 0; k < 8; ++k)
+      if (t.w[k] != 0.f) holo_fix_add(p.gfix + (int64_t)t.v[k] * p.C + c, t.w[k] * g, shift);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (t.w[k] != 0.f) HOLO_ATOMIC_ADD_F32(p.ggrid_cl + (int64_t)t.v[k] * p.C + c, t.w[k] * g);  // (the hardware instruction, not atomicAdd's compare-and-swap loop)
+  }
+}
+
+// deterministic mode, stage 1: bits of max |GFT| over the chunk's points (a maximum does not depend on the order either)
+__global__ __launch_bounds__(256) void rbwd_absmax_kernel(RenderBwdChunk p) {
+  __shared__ uint32_t red[256];
+  uint32_t m = 0u;
+  const int64_t total = p.n * p.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t c = i / p.n, pt = i - c * p.n;
+    const uint32_t b = __float_as_uint(p.GFT[c * p.ld + pt]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + o] ? red[threadIdx.x] : red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0]) atomicMax(p.gfix_max, red[0]);
+}
+// deterministic mode, stage 3: the chunk's sums leave the integer buffer (which is zero again afterwards) - chunks are added
+// to the gradient in chunk order
+__global__ __launch_bounds__(256) void rbwd_fix_flush_kernel(RenderBwdChunk p, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t mb = *p.gfix_max;
+  if (mb == 0u) return;
+  if (mb >= 0x7f800000u) {
+    p.ggrid_cl[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  const long long q = p.gfix[i];
+  if (q != 0) {
+    p.ggrid_cl[i] += holo_fix_value(q, holo_fix_shift(mb));
+    p.gfix[i] = 0;
+  }
 }
 
 }  // namespace
@@ -355,7 +404,20 @@ int rbwd_rowsum_launch(const float* YT, int64_t ld, int64_t n, int rows, float* 
   return 0;
 }
 int rbwd_scatter_launch(const RenderBwdChunk& p, void* stream) {
-  HOLO_LAUNCH(rbwd_scatter_kernel, dim3((unsigned)((p.n * p.C + 255) / 256)), dim3(256), stream, p);
+  if (p.gfix)
+    HOLO_LAUNCH(rbwd_scatter_kernel<true>, dim3((unsigned)((p.n * p.C + 255) / 256)), dim3(256), stream, p);
+  else
+    HOLO_LAUNCH(rbwd_scatter_kernel<false>, dim3((unsigned)((p.n * p.C + 255) / 256)), dim3(256), stream, p);
+  return 0;
+}
+int rbwd_absmax_launch(const RenderBwdChunk& p, void* stream) {
+  const int64_t blocks = (p.n * p.C + 255) / 256;
+  HOLO_LAUNCH(rbwd_absmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), stream, p);
+  return 0;
+}
+int rbwd_fix_flush_launch(const RenderBwdChunk& p, void* stream) {
+  const int64_t total = (int64_t)p.R * p.R * p.R * p.C;
+  HOLO_LAUNCH(rbwd_fix_flush_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, p, total);
   return 0;
 }
 

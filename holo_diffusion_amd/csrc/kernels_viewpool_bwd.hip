@@ -28,6 +28,7 @@
 // first half stays for calls beyond the second form's limits.)
 #include <stdint.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "holo_common.h"
@@ -73,8 +74,47 @@ __device__ __forceinline__ void sample4(const float* base, const Tap& t, float (
   s[3] = t00.w * t.w00 + t01.w * t.w01 + t10.w * t.w10 + t11.w * t.w11;
 }
 
+// Where a scatter kernel's sums go.  MODE 0 (default): hardware fp32 atomics on the gradient map.  The deterministic mode
+// (holo_ctx_set_deterministic) runs a launch twice: MODE 1 only measures - the bits of the largest |addend| of every map, LDS
+// word first, one global atomicMax per workgroup and map at the end - and MODE 2 adds the same values as 64-bit fixed-point
+// integers whose binary point comes from that maximum (holo_common.h: the sums no longer depend on the order of the atomics).
+struct ScatterDst {
+  float* f32;
+  long long* fix;
+  int shift;
+  uint32_t* lmax;
+};
+template <int MODE, typename P>
+__device__ __forceinline__ ScatterDst scatter_dst(const P& b, int k, uint32_t* s_max) {
+  ScatterDst d;
+  d.f32 = b.gfeat[k];
+  d.fix = MODE == 2 ? b.gfix[k] : nullptr;
+  d.shift = 0;
+  if (MODE == 2) {
+    const uint32_t mb = b.fix_max[k];
+    d.shift = holo_fix_shift(mb);
+    if (mb == 0u || mb >= 0x7f800000u) d.fix = nullptr;  // nothing to add / not finite (fix_flush_kernel writes NaN)
+  }
+  d.lmax = s_max + k;
+  return d;
+}
+template <int MODE>
+__device__ __forceinline__ void scatter_add(const ScatterDst& d, int64_t off, float val, uint32_t& vmax) {
+  if (MODE == 0) {
+    HOLO_ATOMIC_ADD_F32(d.f32 + off, val);
+  } else if (MODE == 1) {
+    const uint32_t bits = __float_as_uint(val) & 0x7fffffffu;
+    vmax = bits > vmax ? bits : vmax;
+  } else if (d.fix) {
+    holo_fix_add(d.fix + off, val, d.shift);
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b) {
   const ViewPoolParams& p = b.fwd;
+  __shared__ uint32_t s_max[ViewPoolParams::MAX_FEATS];
+  if (MODE == 1 && threadIdx.x < ViewPoolParams::MAX_FEATS) s_max[threadIdx.x] = 0u;
   __shared__ float s_agg[16 * ViewPoolParams::MAX_AGG];   // [voxel][aggregated feature]
   __shared__ float s_dagg[16 * ViewPoolParams::MAX_AGG];  // [voxel][d loss / d aggregated feature]
   __shared__ float s_dz[16 * VB_F];
@@ -193,8 +233,9 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
         int k = 0;
         while (k + 1 < p.n_feats && q >= p.feat[k + 1].quad0) ++k;
         const ViewPoolParams::Feat& f = p.feat[k];
-        float* gmap = b.gfeat[k];
-        if (!gmap) continue;
+        if (!b.gfeat[k]) continue;
+        const ScatterDst dst = scatter_dst<MODE>(b, k, s_max);
+        uint32_t vmax = 0u;
         const int cq = q - f.quad0;
         float mu[4], dmu[4], dvar2[4];  // dvar2 = 2 dvar
 #pragma unroll
@@ -219,17 +260,22 @@ __global__ __launch_bounds__(256) void view_pool_bwd_kernel(ViewPoolBwdParams b)
           for (int e = 0; e < 4; ++e) {
             const float dx = wD * (dmu[e] + dvar2[e] * (s[e] - mu[e]));
             if (dx != 0.f) {
-              float* g = gmap + vbase + e;
-              if (t.w00 != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o00, t.w00 * dx);
-              if (t.w01 != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o01, t.w01 * dx);
-              if (t.w10 != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o10, t.w10 * dx);
-              if (t.w11 != 0.f) HOLO_ATOMIC_ADD_F32(g + t.o11, t.w11 * dx);
+              const int64_t g = vbase + e;
+              if (t.w00 != 0.f) scatter_add<MODE>(dst, g + t.o00, t.w00 * dx, vmax);
+              if (t.w01 != 0.f) scatter_add<MODE>(dst, g + t.o01, t.w01 * dx, vmax);
+              if (t.w10 != 0.f) scatter_add<MODE>(dst, g + t.o10, t.w10 * dx, vmax);
+              if (t.w11 != 0.f) scatter_add<MODE>(dst, g + t.o11, t.w11 * dx, vmax);
             }
           }
         }
+        if (MODE == 1 && vmax) atomicMax(dst.lmax, vmax);
       }
     }
     __syncthreads();  // the LDS tiles are rewritten by the next group
+  }
+  if (MODE == 1) {  // the measuring pass leaves the maxima and nothing else
+    if (tid < p.n_feats && s_max[tid]) atomicMax(b.fix_max + tid, s_max[tid]);
+    return;
   }
   // ---- per-workgroup partials: [wg][A * F (+ F)] in the (A, F) order of the transposed weight
   float* part = b.partial + (int64_t)blockIdx.x * ((int64_t)p.A * p.F + p.F);
@@ -326,7 +372,9 @@ constexpr int VB2_STAGE = 8;  // runs of a row staged per round of the scatter
 //      instructions alone cost 0.5 ms, all sixteen 5 ms).  Staged through the tile, the row's 16 lanes issue ONE run per
 //      instruction - lane j = (tap j / 4, channel j % 4) - and rows of a wave that carry neighbouring channel quads of the
 //      same pixels complete 64-byte pixels: as many instructions as the row has runs, every cache line visited once per run.
-__device__ __forceinline__ void row_scatter(float (&c)[16], const Tap& t, int vb, float* gmap, bool act, int lane, float* st) {
+template <int MODE>
+__device__ __forceinline__ void row_scatter(float (&c)[16], const Tap& t, int vb, const ScatterDst& dst, bool act, int lane, float* st) {
+  uint32_t vmax = 0u;
   const int pv = lane & 15;
   const int key = t.key;
   // runs = maximal CONTIGUOUS stretches of equal keys, numbered along the row (rid).  The sums are segmented by the run number,
@@ -369,17 +417,20 @@ __device__ __forceinline__ void row_scatter(float (&c)[16], const Tap& t, int vb
       if (i < cnt) {
         const float val = st[i * 20 + pv];
         const int off = (int)__float_as_uint(st[i * 20 + 16 + (pv >> 2)]) + (pv & 3);
-        if (val != 0.f) HOLO_ATOMIC_ADD_F32(gmap + off, val);
+        if (val != 0.f) scatter_add<MODE>(dst, off, val, vmax);
       }
     }
     HOLO_WAVE_SYNC();  // the tile is rewritten by the next round / the next call
   }
+  if (MODE == 1 && vmax) atomicMax(dst.lmax, vmax);
 }
 
 // WPS: waves per SIMD the register allocation aims at (4, the default: 128 registers + 172 bytes of scratch; 3: 166 registers)
-template <int WPS>
+template <int WPS, int MODE>
 __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdParams b) {
   const ViewPoolParams& p = b.fwd;
+  __shared__ uint32_t s_max[ViewPoolParams::MAX_FEATS];
+  if (MODE == 1 && threadIdx.x < ViewPoolParams::MAX_FEATS) s_max[threadIdx.x] = 0u;
   __shared__ float s_agg[16 * VB2_AS];   // [voxel][aggregated feature | 1 | 0 ...]
   __shared__ float s_dagg[16 * VB2_AS];  // [voxel][d loss / d aggregated feature]
   __shared__ float s_dz[16 * VB2_ZS];    // [voxel][d loss / d mapper output] (zero beyond F)
@@ -543,9 +594,12 @@ __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdPar
         int k = 0;
         while (k + 1 < p.n_feats && q >= p.feat[k + 1].quad0) ++k;
         const ViewPoolParams::Feat& f = p.feat[k];
-        float* gmap = b.gfeat[k];
-        const bool act = qq < p.n_quads && gmap != nullptr &&
-                         !(b.want_feats == 2 || (b.want_feats >= 10 && b.want_feats - 10 != k));  // (development probes)
+        const ScatterDst dst = scatter_dst<MODE>(b, k, s_max);
+#ifdef HOLO_DEV_PROBES  // (timing probes of a development build: want_feats 2 = pass 2 without its atomics, 10 + k = map k alone)
+        const bool act = qq < p.n_quads && dst.f32 != nullptr && !(b.want_feats == 2 || (b.want_feats >= 10 && b.want_feats - 10 != k));
+#else
+        const bool act = qq < p.n_quads && dst.f32 != nullptr;
+#endif
         const int cq = q - f.quad0;
         float mu[4], dmu[4], dvar2[4];  // dvar2 = 2 dvar
 #pragma unroll
@@ -575,11 +629,15 @@ __global__ __launch_bounds__(256, WPS) void view_pool_bwd2_kernel(ViewPoolBwdPar
             c[8 + e] = t.w10 * dx;
             c[12 + e] = t.w11 * dx;
           }
-          row_scatter(c, t, (int)vbase, gmap, act, lane, s_stage + prow * (VB2_STAGE * 20));  // (a view's maps stay far below 2^31 elements)
+          row_scatter<MODE>(c, t, (int)vbase, dst, act, lane, s_stage + prow * (VB2_STAGE * 20));  // (a view's maps stay far below 2^31 elements)
         }
       }
     }
     __syncthreads();  // the LDS tiles are rewritten by the next group
+  }
+  if (MODE == 1) {  // the measuring pass leaves the maxima and nothing else
+    if (tid < p.n_feats && s_max[tid]) atomicMax(b.fix_max + tid, s_max[tid]);
+    return;
   }
   // ---- per-workgroup partials: rows 0 .. A of the product = [A][F] d M^T followed by the F values of d bias
   float* part = b.partial + (int64_t)blockIdx.x * ((int64_t)A * F + F);
@@ -870,7 +928,11 @@ __global__ __launch_bounds__(256) void mm_dc_kernel(MlpMeanBwdParams b) {
 // view for one channel quad (round 5: every thread issuing its own 16 atomics took 5.6 ms of the 14 ms backward at 64^3 x 4
 // views).  Row items = (view, group of 16 voxels, quad), quad fastest: the four rows of a wave read 64 contiguous bytes of a
 // DX row and complete 64-byte pixels in the scatter.
+template <int MODE>
 __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
+  __shared__ uint32_t s_max[ViewPoolParams::MAX_FEATS];
+  if (MODE == 1 && threadIdx.x < ViewPoolParams::MAX_FEATS) s_max[threadIdx.x] = 0u;
+  if (MODE == 1) __syncthreads();
   __shared__ __attribute__((aligned(16))) float s_stage[16 * VB2_STAGE * 20];
   const MlpMeanParams& m = b.fwd;
   const ViewPoolParams& vp = m.vp;
@@ -894,8 +956,8 @@ __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
     int k = 0;
     while (k + 1 < vp.n_feats && q >= vp.feat[k + 1].quad0) ++k;
     const ViewPoolParams::Feat& f = vp.feat[k];
-    float* gmap = b.gfeat[k];
-    const bool act = item < nitems && pl < P && gmap != nullptr;
+    const ScatterDst dst = scatter_dst<MODE>(b, k, s_max);
+    const bool act = item < nitems && pl < P && dst.f32 != nullptr;
     const float4 dx = *reinterpret_cast<const float4*>(b.DX + row * m.dp + q * 4);
     const float4 dc = *reinterpret_cast<const float4*>(b.DCA + p * m.dp + q * 4);
     const int cq = q - f.quad0;
@@ -914,7 +976,29 @@ __global__ __launch_bounds__(256) void mm_scatter_kernel(MlpMeanBwdParams b) {
       c[12 + e] = t.w11 * g4[e];
     }
     const int vb = (int)(((int64_t)vi * f.H * f.W) * f.Cp + cq * 4);
-    row_scatter(c, t, vb, gmap, act, lane, st);
+    row_scatter<MODE>(c, t, vb, dst, act, lane, st);
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    if (tid < vp.n_feats && s_max[tid]) atomicMax(b.fix_max + tid, s_max[tid]);
+  }
+}
+
+// deterministic mode: the sums leave the fixed-point image (zero again afterwards) and are ADDED to the float map
+__global__ __launch_bounds__(256) void fix_flush_kernel(long long* __restrict__ fix, const uint32_t* __restrict__ maxbits,
+                                                        float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mb = *maxbits;
+  if (mb == 0u) return;
+  if (mb >= 0x7f800000u) {
+    out[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
+  const long long q = fix[i];
+  if (q != 0) {
+    out[i] += holo_fix_value(q, holo_fix_shift(mb));
+    fix[i] = 0;
   }
 }
 
@@ -956,21 +1040,34 @@ int view_pool_bwd_launch(const ViewPoolBwdParams& b, int n_wgs, void* stream) {
     set_error("view_pool_backward: feature_size <= %d and <= 512 aggregated features (got %d, %d)", VB_F, b.fwd.F, b.fwd.A);
     return -1;
   }
-  // (HOLO_VIEWPOOL_BWD_V1=1: the register-accumulating form on every call - development / test knob)
+  // (HOLO_VIEWPOOL_BWD_V1=1: the register-accumulating form on every call - the knob tests/test_viewpool.py flips per call)
   const char* ev = getenv("HOLO_VIEWPOOL_BWD_V1");
   const bool v1 = ev && ev[0] == '1';
+  const bool fixed = b.want_feats && b.fix_max != nullptr;  // deterministic mode: measure the addends, then add in fixed point
   if (!v1 && b.fwd.A + 1 <= VB2_AMAX) {
     ViewPoolBwdParams q = b;
-    const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // development probes (timing only): 0 no pass 2, 2 pass 2 without
-                                                          // its atomics, 10 + k the atomics of map k alone
-    if (ep && q.want_feats) q.want_feats = atoi(ep);
-    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // development knob: 3 = the 166-register build (measured 6.3 vs 3.9 ms)
-    if (eo && eo[0] == '3')
-      HOLO_LAUNCH(view_pool_bwd2_kernel<3>, dim3((unsigned)n_wgs), dim3(256), stream, q);
-    else
-      HOLO_LAUNCH(view_pool_bwd2_kernel<4>, dim3((unsigned)n_wgs), dim3(256), stream, q);
+#ifdef HOLO_DEV_PROBES  // timing probes of a development build only (-DHOLO_DEV_PROBES): they DROP gradients
+    const char* ep = getenv("HOLO_VIEWPOOL_BWD_PROBE");  // 0 no pass 2, 2 pass 2 without its atomics, 10 + k the atomics of map k alone
+    if (ep && q.want_feats) {
+      q.want_feats = atoi(ep);
+      fprintf(stderr, "[holo] HOLO_VIEWPOOL_BWD_PROBE=%d: feature-map gradients are INCOMPLETE (timing probe)\n", q.want_feats);
+    }
+    const char* eo = getenv("HOLO_VIEWPOOL_BWD_OCC");  // 3 = the 166-register build (measured 6.3 vs 3.9 ms)
+    if (eo && eo[0] == '3' && !fixed) {
+      HOLO_LAUNCH((view_pool_bwd2_kernel<3, 0>), dim3((unsigned)n_wgs), dim3(256), stream, q);
+    } else
+#endif
+    if (fixed) {
+      HOLO_LAUNCH((view_pool_bwd2_kernel<4, 1>), dim3((unsigned)n_wgs), dim3(256), stream, q);
+      HOLO_LAUNCH((view_pool_bwd2_kernel<4, 2>), dim3((unsigned)n_wgs), dim3(256), stream, q);
+    } else {
+      HOLO_LAUNCH((view_pool_bwd2_kernel<4, 0>), dim3((unsigned)n_wgs), dim3(256), stream, q);
+    }
+  } else if (fixed) {
+    HOLO_LAUNCH(view_pool_bwd_kernel<1>, dim3((unsigned)n_wgs), dim3(256), stream, b);
+    HOLO_LAUNCH(view_pool_bwd_kernel<2>, dim3((unsigned)n_wgs), dim3(256), stream, b);
   } else {
-    HOLO_LAUNCH(view_pool_bwd_kernel, dim3((unsigned)n_wgs), dim3(256), stream, b);
+    HOLO_LAUNCH(view_pool_bwd_kernel<0>, dim3((unsigned)n_wgs), dim3(256), stream, b);
   }
   const int per = b.fwd.A * b.fwd.F + b.fwd.F;
   HOLO_LAUNCH(viewpool_partial_reduce_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), stream, (const float*)b.partial, n_wgs,
@@ -983,6 +1080,11 @@ int nhwc_pad_to_nchw_launch(const float* in, float* out, int n, int C, int Cp, i
   int64_t blocks = (total + 255) / 256;
   if (blocks > 65535) blocks = 65535;
   HOLO_LAUNCH(nhwc_pad_to_nchw_kernel, dim3((unsigned)blocks), dim3(256), stream, in, out, C, Cp, HW, total);
+  return 0;
+}
+
+int fix_flush_launch(long long* fix, const uint32_t* maxbits, float* out, int64_t n, void* stream) {
+  HOLO_LAUNCH(fix_flush_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream, fix, maxbits, out, n);
   return 0;
 }
 
@@ -1008,7 +1110,12 @@ int mm_bwd_step_launch(const MlpMeanBwdParams& b, int step, void* stream) {
       HOLO_LAUNCH(mm_dc_kernel, dim3(mm_blocks(P * 4)), dim3(256), stream, b);
       return 0;
     case 4:
-      HOLO_LAUNCH(mm_scatter_kernel, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);
+      if (b.fix_max) {  // deterministic mode: measure the addends, then add in fixed point
+        HOLO_LAUNCH(mm_scatter_kernel<1>, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);
+        HOLO_LAUNCH(mm_scatter_kernel<2>, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);
+      } else {
+        HOLO_LAUNCH(mm_scatter_kernel<0>, dim3(mm_blocks(NR * (b.fwd.emb0 / 4))), dim3(256), stream, b);
+      }
       return 0;
   }
   return -1;

@@ -703,7 +703,8 @@ struct RbwdLayout {
   int64_t NR, nm, cap, rays_per_chunk;
   int Hd, Hp, C, S;
   size_t o_ggrid, o_fwd, o_zm, o_flags, o_rays, o_grray, o_F, o_YT, o_AT, o_GFT, o_val, o_drad, o_gval, o_GR, o_tmp, o_part,
-      o_dWe, o_dbe, o_partr, o_dWrh, o_dir, total;
+      o_dWe, o_dbe, o_partr, o_dWrh, o_dir, o_gmax, o_gfix, total;
+  bool fixed;  // the deterministic mode of the grid scatter (holo_ctx_set_deterministic)
 };
 size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 RbwdLayout rbwd_layout(const HoloRenderer* r, int n_cameras, int n_rays) {
@@ -746,6 +747,9 @@ RbwdLayout rbwd_layout(const HoloRenderer* r, int n_cameras, int n_rays) {
   L.o_partr = take((size_t)L.S * L.Hd * 4 * sizeof(float));
   L.o_dWrh = take((size_t)L.Hd * 4 * sizeof(float));
   L.o_dir = take(128 * sizeof(float));
+  L.o_gmax = take(256);
+  L.fixed = r->ctx && r->ctx->deterministic;
+  L.o_gfix = L.fixed ? take(2 * grid_cl_bytes(r)) : o;  // 64-bit fixed-point image of the grid gradient
   L.total = o + 256;
   return L;
 }
@@ -812,6 +816,7 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
 
   if (ncdhw_to_ndhwc_launch(grid, grid_cl, 1, C, (int64_t)R * R * R, 0, stream)) return HOLO_E_INVALID;
   HIP_TRY(hipMemsetAsync(ggrid_cl, 0, grid_cl_bytes(r), st));
+  if (L.fixed) HIP_TRY(hipMemsetAsync(ws + L.o_gfix, 0, 2 * grid_cl_bytes(r), st));
   HIP_TRY(hipMemsetAsync(ws + L.o_AT, 0, (size_t)Hp * L.cap * sizeof(float), st));
   // 1. the forward pass once more: the merged depth list of every ray
   float* fwd = (float*)(ws + L.o_fwd);
@@ -845,6 +850,8 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
   memset(&p, 0, sizeof p);
   p.grid_cl = grid_cl;
   p.ggrid_cl = ggrid_cl;
+  p.gfix = L.fixed ? (long long*)(ws + L.o_gfix) : nullptr;
+  p.gfix_max = (uint32_t*)(ws + L.o_gmax);
   p.R = R;
   p.C = C;
   p.half_extent = 0.5f * (float)(R - 1) * (c.volume_extent / (float)R);
@@ -918,7 +925,12 @@ int holo_render_rays_backward(HoloRenderer* r, const float* grid, const HoloCame
     g.C = partr, g.ldc = 4, g.sc0 = (int64_t)Hd * 4, g.nb0 = L.S, g.M = Hd, g.Nn = 4, g.K = Ks;
     if (gemm_launch(g, stream)) return HOLO_E_INVALID;
     if (partial_reduce_launch(partr, dWrh, (int64_t)Hd * 4, L.S, first ? 0 : 1, stream)) return HOLO_E_INVALID;
+    if (L.fixed) {  // max |GFT| of the chunk -> fixed-point sums -> added to the gradient in chunk order
+      HIP_TRY(hipMemsetAsync(p.gfix_max, 0, sizeof(uint32_t), st));
+      if (rbwd_absmax_launch(p, stream)) return HOLO_E_INVALID;
+    }
     if (rbwd_scatter_launch(p, stream)) return HOLO_E_INVALID;
+    if (L.fixed && rbwd_fix_flush_launch(p, stream)) return HOLO_E_INVALID;
     first = 0;
   }
   if (rbwd_dir_grad_launch(p.gr_ray, rays, L.NR, ddir, stream)) return HOLO_E_INVALID;

@@ -1428,6 +1428,15 @@ int holo_ctx_destroy(HoloCtx* ctx) {
   delete ctx;
   return 0;
 }
+int holo_ctx_set_deterministic(HoloCtx* ctx, int on) {
+  if (!ctx) {
+    set_error("holo_ctx_set_deterministic: null context");
+    return HOLO_E_INVALID;
+  }
+  ctx->deterministic = on ? 1 : 0;
+  return 0;
+}
+int holo_ctx_get_deterministic(const HoloCtx* ctx) { return ctx ? ctx->deterministic : 0; }
 
 int holo_unet_create(HoloCtx* ctx, const HoloUnetCfg* cfg, HoloUnet** out) {
   if (!ctx || !cfg || !out) {

@@ -149,6 +149,13 @@ size_t holo_view_pool_backward_workspace_bytes(HoloCtx* ctx, const HoloViewPoolC
     sumC += feats[k].channels;
   }
   b += align256((size_t)view_pool_bwd_wgs(ctx, cfg->resol) * ((size_t)2 * sumC * cfg->feature_size + cfg->feature_size) * sizeof(float));
+  if (ctx->deterministic) {  // 64-bit fixed-point images of the gradient maps + one word per map (holo_ctx_set_deterministic)
+    for (int k = 0; k < n_feats; ++k) {
+      const size_t Cp = (size_t)((feats[k].channels + 3) / 4 * 4);
+      b += align256((size_t)n_views * feats[k].height * feats[k].width * Cp * sizeof(long long));
+    }
+    b += 256;
+  }
   return b + 256;
 }
 
@@ -183,12 +190,29 @@ int holo_view_pool_backward(HoloCtx* ctx, const HoloViewPoolCfg* cfg, const Holo
   }
   const int n_wgs = view_pool_bwd_wgs(ctx, cfg->resol);
   b.partial = (float*)ws;
+  ws += align256((size_t)n_wgs * ((size_t)b.fwd.A * b.fwd.F + b.fwd.F) * sizeof(float));
   b.dW = grad_mapper_weight;
   b.dbias = grad_mapper_bias;
+  if (ctx->deterministic && b.want_feats) {
+    char* w0 = ws;
+    for (int k = 0; k < n_feats; ++k) {
+      const ViewPoolParams::Feat& f = b.fwd.feat[k];
+      if (b.gfeat[k]) b.gfix[k] = (long long*)ws;
+      ws += align256((size_t)n_views * f.H * f.W * f.Cp * sizeof(long long));
+    }
+    b.fix_max = (uint32_t*)ws;
+    ws += 256;
+    if (hipMemsetAsync(w0, 0, (size_t)(ws - w0), (hipStream_t)stream) != hipSuccess) {
+      set_error("holo_view_pool_backward: hipMemsetAsync failed");
+      return HOLO_E_HIP;
+    }
+  }
   if (view_pool_bwd_launch(b, n_wgs, stream)) return HOLO_E_UNSUPPORTED;
   for (int k = 0; k < n_feats; ++k)
     if (b.gfeat[k]) {
       const ViewPoolParams::Feat& f = b.fwd.feat[k];
+      if (b.gfix[k] && fix_flush_launch(b.gfix[k], b.fix_max + k, b.gfeat[k], (int64_t)n_views * f.H * f.W * f.Cp, stream))
+        return HOLO_E_INVALID;
       if (nhwc_pad_to_nchw_launch(b.gfeat[k], grad_feats[k], n_views, f.C, f.Cp, (int64_t)f.H * f.W, stream)) return HOLO_E_INVALID;
     }
   return 0;
@@ -487,7 +511,8 @@ struct MmBwdLayout {
   int64_t Pall;
   int nchunks;
   int S, S2, FW, dp;
-  size_t maps, gmaps, X, MEAN, CM, PRE, H, U, DUL, DULT, DPRET, DC, DCT, DX, DCA, part, fold, total;
+  size_t maps, gmaps, X, MEAN, CM, PRE, H, U, DUL, DULT, DPRET, DC, DCT, DX, DCA, part, fold, gfix, fixmax, total;
+  bool fixed;  // deterministic mode (holo_ctx_set_deterministic): fixed-point images of the gradient maps
 };
 static MmBwdLayout mm_bwd_layout(const HoloMlpMeanPooler* h, const HoloViewFeature* feats, int n_feats, int n_views) {
   MmBwdLayout L;
@@ -551,6 +576,9 @@ static MmBwdLayout mm_bwd_layout(const HoloMlpMeanPooler* h, const HoloViewFeatu
   const size_t pcol = (size_t)256 * 256;
   L.part = take(pa > pam ? (pa > pg ? (pa > pcol ? pa : pcol) : (pg > pcol ? pg : pcol)) : (pam > pg ? (pam > pcol ? pam : pcol) : (pg > pcol ? pg : pcol)));
   L.fold = take((size_t)2 * 128 * L.dp + 128 + (size_t)L.FW * 128 + L.FW);  // dA | dAm | dcb | dGext | dg0 dl0
+  L.fixed = h->ctx && h->ctx->deterministic;
+  L.gfix = L.fixed ? take(2 * mapf) : off;
+  L.fixmax = L.fixed ? take(64) : off;
   L.total = off + 256;
   return L;
 }
@@ -621,6 +649,15 @@ int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, i
       if (grad_feats && grad_feats[k]) b.gfeat[k] = (float*)g;
       g += align256((size_t)n_views * f.H * f.W * f.Cp * sizeof(float));
     }
+    if (L.fixed) {
+      char* gx = base + L.gfix;
+      for (int k = 0; k < n_feats; ++k) {
+        const ViewPoolParams::Feat& f = b.fwd.vp.feat[k];
+        if (b.gfeat[k]) b.gfix[k] = (long long*)gx;
+        gx += 2 * align256((size_t)n_views * f.H * f.W * f.Cp * sizeof(float));
+      }
+      b.fix_max = (uint32_t*)(base + L.fixmax);
+    }
   }
   float* part = fp(L.part);
   float* fold = fp(L.fold);
@@ -659,7 +696,14 @@ int holo_mlp_mean_backward(HoloMlpMeanPooler* h, const HoloViewFeature* feats, i
     if (want) {
       MM_TRY(mm_gemm(b.PRE, 128, b.fwd.a, dp, 1, b.DX, dp, NR, dp, 128, 1, 0, 0, 0, stream));                    // DX = DPRE A
       MM_TRY(mm_gemm(b.DC, 128, b.fwd.am, dp, 1, b.DCA, dp, P, dp, 128, 1, 0, 0, 0, stream));                    // DCA = DC Am
+      if (L.fixed && ck > 0) HIP_TRY(hipMemsetAsync(b.fix_max, 0, 64, st));  // every chunk has its own binary point
       MM_TRY(mm_bwd_step_launch(b, 4, stream));
+      if (L.fixed)  // the chunk's sums are added to the gradient maps in chunk order
+        for (int k = 0; k < n_feats; ++k)
+          if (b.gfix[k]) {
+            const ViewPoolParams::Feat& f = b.fwd.vp.feat[k];
+            MM_TRY(fix_flush_launch(b.gfix[k], b.fix_max + k, b.gfeat[k], (int64_t)n_views * f.H * f.W * f.Cp, stream));
+          }
     }
   }
   if (want) {

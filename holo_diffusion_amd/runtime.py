@@ -4,6 +4,7 @@ PyTorch is used here for device memory and streams only (one process per GPU; se
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Dict, Tuple
 
@@ -33,6 +34,27 @@ def ctx(device: torch.device) -> C.c_void_p:
         _lib.check(L, L.holo_ctx_create(int(idx), C.byref(h)), "holo_ctx_create")
         _CTX[idx] = h
     return _CTX[idx]
+
+
+def set_deterministic(on: bool, device: torch.device = None) -> bool:
+    """Deterministic mode of the scatter-adding backward entries (holo_ctx_set_deterministic, include/holo_abi.h): the grid
+    gradient of the renderer's backward and the feature-map gradients of the view-pooling backwards are summed in fixed
+    point, bit-identical from run to run.  Returns the previous setting."""
+    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    L, h = lib(), ctx(device)
+    prev = bool(L.holo_ctx_get_deterministic(h))
+    _lib.check(L, L.holo_ctx_set_deterministic(h, 1 if on else 0), "holo_ctx_set_deterministic")
+    return prev
+
+
+@contextlib.contextmanager
+def deterministic(on: bool = True, device: torch.device = None):
+    """``with runtime.deterministic():`` - the mode above for the calls inside the block."""
+    prev = set_deterministic(on, device)
+    try:
+        yield
+    finally:
+        set_deterministic(prev, device)
 
 
 def stream_ptr(device: torch.device) -> C.c_void_p:

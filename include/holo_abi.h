@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define HOLO_ABI_VERSION 5
+#define HOLO_ABI_VERSION 6
 
 enum {
   HOLO_OK = 0,
@@ -51,6 +51,17 @@ const char* holo_last_error(void);
 /* One context per process per GPU (one process per GPU). */
 int holo_ctx_create(int device_id, HoloCtx** out);
 int holo_ctx_destroy(HoloCtx* ctx);
+
+/* Deterministic mode of the backward entries that scatter-add (ABI 6).  The reference's autograd scatters with atomic adds
+ * (grid_sample's backward on CUDA is order-dependent in the same way); by default so do holo_render_rays_backward (grid
+ * gradient), holo_view_pool_backward and holo_mlp_mean_backward (feature-map gradients): hardware fp32 atomics, sums that
+ * differ in their last bits from run to run.  With on != 0 every such scatter of handles created from `ctx` adds 64-bit
+ * FIXED-POINT integers instead (binary point from the largest magnitude of the launch, 2^-40 of it per addend; integer
+ * addition commutes), so two calls on the same inputs return bit-identical gradients.  Costs one extra pass over the
+ * scattered values and an 8-byte image of the destination in the workspace (re-query *_workspace_bytes after switching).
+ * Everything else in the library is deterministic in both modes (fixed-order partial sums). */
+int holo_ctx_set_deterministic(HoloCtx* ctx, int on);
+int holo_ctx_get_deterministic(const HoloCtx* ctx);
 
 /* ------------------------------------------------------------------------------------------
  * Denoiser.  Replaces SimpleUnet3D / UNetModel:

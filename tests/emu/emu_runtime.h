@@ -289,6 +289,18 @@ static inline float atomicAdd(float* p, float v) {
   *p = o + v;
   return o;
 }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
+  unsigned long long o = *p;
+  *p = o + v;
+  return o;
+}
+static inline unsigned int atomicMax(unsigned int* p, unsigned int v) {
+  std::lock_guard<std::mutex> lk(emu::g_atomic_mutex);
+  unsigned int o = *p;
+  if (v > o) *p = v;
+  return o;
+}
 
 static inline float emu_expf(float x) { return std::exp(x); }
 #define __expf(x) emu_expf(x)

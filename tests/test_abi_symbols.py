@@ -41,7 +41,7 @@ def test_python_binding_covers_the_header(lib):
     from holo_diffusion_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     _lib.bind(lib)
-    assert lib.holo_abi_version() == 5
+    assert lib.holo_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():

@@ -172,6 +172,50 @@ def test_render_backward_needs_the_forward_draws(gu):
         model.renderer.backward_training(bundle, list(model._implicit_functions), {}, {"features": torch.zeros(2, 5, 1, 3)})
 
 
+DET_CASES = [(12, 10, 16, 8, 2, 13)] if EMU else [(12, 10, 16, 8, 2, 13), (24, 20, 32, 16, 3, 37), (64, 64, 32, 32, 4, 700)]
+
+
+@pytest.mark.parametrize("P,Pf,C,R,n_cam,n_rays", DET_CASES)
+def test_deterministic_scatter_mode_of_the_render_backward(gu, P, Pf, C, R, n_cam, n_rays):
+    """holo_ctx_set_deterministic: the grid gradient's trilinear scatter-add as 64-bit fixed-point sums.  Two calls are
+    bit-identical (the last case spans several 65 536-point chunks, each with its own binary point), the result sits within
+    fp32 summation noise of the default mode's (hardware fp32 atomics, order-dependent), whose own run-to-run spread is
+    printed next to it, and the parameter gradients - fixed-order sums in both modes - do not change at all."""
+    from holo_diffusion_amd import runtime
+    model, _, _, _, _ = gu.make_model(R, C, 16, 16, TINY_UNET, n_fine=64)
+    model.raysampler.n_pts_per_ray_training = P
+    model.renderer.n_pts_per_ray_fine_training = Pf
+    grid = torch.tanh(torch.from_numpy(np_noise(7, (1, C, R, R, R))))
+    cams = hda.get_simple_360_camera_trajectory(2 * math.pi, n_cam, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
+    xys = (torch.from_numpy(np_noise(11, (n_cam, n_rays, 2))).clamp(-2, 2) * 0.45).contiguous()
+    rs = {k: v.to(gu.DEV) for k, v in _streams(n_cam, n_rays, P, Pf, 500 + P).items()}
+    cot = {k: (torch.from_numpy(np_noise(900 + i, (n_cam, n_rays, 1, c))) * (0.05 if "depth" in k else 1.0)).to(gu.DEV)
+           for i, (k, c) in enumerate((("features", 3), ("depths", 1), ("masks", 1), ("features_coarse", 3)))}
+    for fn in model._implicit_functions:
+        fn.bind_args(voxel_grid_features=grid.to(gu.DEV))
+    bundle = model.raysampler(cams.to(gu.DEV), EvaluationMode.TRAINING, xys=xys.to(gu.DEV))
+
+    def run():
+        g, pg = model.renderer.backward_training(bundle, list(model._implicit_functions), rs, cot)
+        return g.clone(), {k: v.clone() for k, v in pg.items()}
+
+    with runtime.deterministic(True, gu.DEV):
+        g1, p1 = run()
+        g2, p2 = run()
+    with runtime.deterministic(False, gu.DEV):
+        a1, pa = run()
+        a2, _ = run()
+    scale = float(g1.abs().max())
+    assert scale > 1e-3 and torch.isfinite(g1).all()
+    assert torch.equal(g1, g2), float((g1 - g2).abs().max()) / scale
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]) and torch.equal(p1[k], pa[k]), k
+    d_modes, d_runs = float((g1 - a1).abs().max()) / scale, float((a1 - a2).abs().max()) / scale
+    print(f"\ndeterministic scatter P={P} Pf={Pf} C={C} R={R} rays={n_cam}x{n_rays}: fixed-point vs atomics {d_modes:.2e}, "
+          f"atomics run to run {d_runs:.2e} (of the gradient's max)")
+    assert d_modes < 2e-5, d_modes
+
+
 @pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
 @pytest.mark.parametrize("bootstrap", [False, True])
 def test_training_backward_chain_vs_oracle_autograd(gu, bootstrap):
@@ -322,31 +366,53 @@ def test_training_forward_is_differentiable_like_the_reference(gu):
     def loss_fn(p):
         return F.mse_loss(p["images_render"], tgt) + 0.2 * p["masks_render"].mean() + 0.01 * p["depths_render"].mean()
 
-    want = model.training_step(camera=cams, voxel_features=vf, rng_streams=rs, loss_fn=loss_fn)
-    model.requires_grad_(True)  # (the plugin's parameters are created frozen: inference is the default use)
-    model.zero_grad(set_to_none=True)
-    x = vf.clone().requires_grad_(True)
-    preds = model(camera=cams, evaluation_mode=EvaluationMode.TRAINING, voxel_features=x, rng_streams=rs)
-    assert preds["images_render"].requires_grad
-    loss = loss_fn(preds)
-    loss.backward()
-    assert abs(float(loss.detach()) - float(want["loss"])) < 1e-6
-    worst = ("voxel_features", _rel(x.grad.cpu(), want["voxel_features"].cpu(), 1e-12))
-    named = dict(model.named_parameters())
-    for group, prefix in (("unet", "net_3d._net."), ("render_mlp", "_implicit_functions.0._fn.render_mlp.")):
-        scale = sorted(float(v.abs().max()) for v in want[group].values())[len(want[group]) // 2]
-        for k, g in want[group].items():
-            got = named[prefix + k].grad
-            assert got is not None, prefix + k
-            e = _rel(got.cpu(), g.cpu(), 1e-2 * scale)
-            if e > worst[1]:
-                worst = (group + "." + k, e)
-    print(f"\nloss.backward() through forward(TRAINING): worst difference to the explicit chain {worst[1]:.2e} ({worst[0]})")
-    assert worst[1] < 1e-4, worst
+    from holo_diffusion_amd import runtime
+
+    def both_routes():
+        """worst difference (tensor, relative to its scale) between loss.backward() through forward(TRAINING) and the
+        explicit chain"""
+        want = model.training_step(camera=cams, voxel_features=vf, rng_streams=rs, loss_fn=loss_fn)
+        model.requires_grad_(True)  # (the plugin's parameters are created frozen: inference is the default use)
+        model.zero_grad(set_to_none=True)
+        x = vf.clone().requires_grad_(True)
+        preds = model(camera=cams, evaluation_mode=EvaluationMode.TRAINING, voxel_features=x, rng_streams=rs)
+        assert preds["images_render"].requires_grad
+        loss = loss_fn(preds)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(want["loss"])) < 1e-6
+        worst = ("voxel_features", _rel(x.grad.cpu(), want["voxel_features"].cpu(), 1e-12))
+        named = dict(model.named_parameters())
+        for group, prefix in (("unet", "net_3d._net."), ("render_mlp", "_implicit_functions.0._fn.render_mlp.")):
+            scale = sorted(float(v.abs().max()) for v in want[group].values())[len(want[group]) // 2]
+            for k, g in want[group].items():
+                got = named[prefix + k].grad
+                assert got is not None, prefix + k
+                e = _rel(got.cpu(), g.cpu(), 1e-2 * scale)
+                if e > worst[1]:
+                    worst = (group + "." + k, e)
+        return worst
+
+    # Both routes are the HIP path; what may differ between them is the ORDER of the grid gradient's scatter-add (fp32
+    # atomics by default: d(grid) differs in its last bits from run to run, and the denoiser's backward amplifies that).
+    # (1) In the deterministic mode (fixed-point scatter, holo_ctx_set_deterministic) the two routes run the same kernels
+    # on the same inputs in an order-independent way: they must agree to rounding of the few torch ops between them.
+    with runtime.deterministic(True):
+        det = both_routes()
+        det2 = both_routes()
+    # (2) In the default (atomics) mode the difference is a sample of the run-to-run spread of the gradients themselves:
+    # it is measured over three pairs of evaluations and held to the tolerance the oracle comparisons of this file use
+    # (1e-3; round 5 held ONE sample of it to 1e-4 and the driver's box drew 1.18e-4).
+    with runtime.deterministic(False):
+        spread = [both_routes() for _ in range(3)]
+    print(f"\nloss.backward() through forward(TRAINING) vs the explicit chain: deterministic mode {det[1]:.2e} ({det[0]}), again "
+          f"{det2[1]:.2e}; atomics mode " + ", ".join(f"{w[1]:.2e}" for w in spread) + f" ({spread[0][0]})")
+    assert det[1] == det2[1], (det, det2)
+    assert det[1] < 5e-6, det
+    assert max(w[1] for w in spread) < 1e-3, spread
 
 
 @pytest.mark.skipif(EMU, reason="the UNet legs are too slow for the host emulation")
-def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu):
+def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu, request):
     """End to end: three plain SGD steps of the TRAINING branch (fresh draws per step, injected on both sides) through
     ``forward`` + ``loss.backward()`` + an in-place parameter update - which the plugin must notice and re-upload (and
     re-transpose for the next backward) - against the oracle pipeline trained with the same rule by torch autograd: the
@@ -360,6 +426,10 @@ def test_three_sgd_steps_follow_the_oracle_trained_the_same_way(gu):
     model.raysampler.n_pts_per_ray_training = P
     model.renderer.n_pts_per_ray_fine_training = Pf
     model.requires_grad_(True)
+    from holo_diffusion_amd import runtime
+    prev_mode = runtime.set_deterministic(True, gu.DEV)  # (the grid gradient's scatter-add in fixed point: the trajectory of the
+    # three updates is then the same on every run; with fp32 atomics it moves by ~1e-5 between runs)
+    request.addfinalizer(lambda: runtime.set_deterministic(prev_mode, gu.DEV))
     cams = hda.get_simple_360_camera_trajectory(2 * math.pi, 3, -0.5, 10, (0.0, -1.0, 0.0), 3.2)
     vf = torch.tanh(torch.from_numpy(np_noise(5, (1, C, R, R, R))))
     orc = do.DiffusionOracle(1000)

@@ -185,6 +185,49 @@ def test_view_pool_backward_released_channel_structure(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("v1", ["0", "1"])
+def test_view_pool_backward_deterministic_mode(v1, monkeypatch):
+    """holo_ctx_set_deterministic on holo_view_pool_backward: the bilinear scatter-add of the feature-map gradients as 64-bit
+    fixed-point sums (one measuring launch for the binary point of every map, one adding launch).  Two calls are bit-identical,
+    the result sits within fp32 summation noise of the default mode's (hardware fp32 atomics), the mapper's gradients - fixed-
+    order sums in both modes - do not change at all; both kernel forms (HOLO_VIEWPOOL_BWD_V1)."""
+    import tests.gpu_utils as gu
+    from holo_diffusion_amd import runtime
+    R, n_src, F = 8, 4, 32
+    feats = {f"res{i}": torch.tanh(torch.from_numpy(np_noise(70 + i, (n_src, 16, s, s + 2)))) for i, s in enumerate((12, 9, 5, 3))}
+    feats["mask"] = torch.sigmoid(torch.from_numpy(np_noise(75, (n_src, 1, 20, 20))))
+    feats["rgb"] = torch.sigmoid(torch.from_numpy(np_noise(76, (n_src, 3, 20, 20))))
+    A = 2 * sum(v.shape[1] for v in feats.values())
+    cams_d = _cams(n_src, radius=6.0)
+    w = synth_state_dict({"w": (F, A), "b": (F,)}, 9)
+    g = torch.from_numpy(np_noise(123, (1, F, R, R, R)))
+    model = hda.HoloDiffusionModel(resol=R, feature_size=F, view_pooler_enabled=True, net_3d_enabled=False,
+                                   diffusion_enabled=False, render_image_width=8, render_image_height=8)
+    model.load_state_dict({"pooled_feature_mapper.weight": w["w"], "pooled_feature_mapper.bias": w["b"]}, strict=False)
+    model.to(gu.DEV)
+    cams = hda.PerspectiveCameras(R=cams_d["R"], T=cams_d["T"], focal_length=cams_d["focal"], principal_point=cams_d["pp"])
+    dev_feats = {k: v.to(gu.DEV) for k, v in feats.items()}
+    monkeypatch.setenv("HOLO_VIEWPOOL_BWD_V1", v1)
+
+    def run():
+        out = model.pool_views_backward(dev_feats, cams.to(gu.DEV), g.to(gu.DEV))
+        return ({k: v.clone() for k, v in out["image_features"].items()},
+                {k: v.clone() for k, v in out["pooled_feature_mapper"].items()})
+
+    with runtime.deterministic(True, gu.DEV):
+        f1, m1 = run()
+        f2, m2 = run()
+    with runtime.deterministic(False, gu.DEV):
+        fa, ma = run()
+    for k in m1:
+        assert torch.equal(m1[k], m2[k]) and torch.equal(m1[k], ma[k]), k
+    for k in feats:
+        scale = float(fa[k].abs().max())
+        assert scale > 0 and torch.equal(f1[k], f2[k]), k
+        assert float((f1[k] - fa[k]).abs().max()) < 2e-5 * scale, (k, float((f1[k] - fa[k]).abs().max()) / scale)
+
+
+@pytest.mark.gpu
 def test_model_forward_from_source_views():
     """HoloDiffusionModel.forward with source-view features (the reconstruction entry, holo_diffusion_model.py:327-374):
     camera batch = [target, sources...]; the pooled grid goes through tanh(net_3d(., 0)) and the renderer like a
@@ -409,6 +452,18 @@ def test_mlp_mean_view_pool_backward_vs_reference_gradients(chunk, monkeypatch):
         assert rel(got["feature_aggregator"][k], r) < 1e-3, (k, rel(got["feature_aggregator"][k], r))
     for k, r in pick("grad.maps.").items():
         assert rel(got["image_features"][k], r) < 1e-3, (k, rel(got["image_features"][k], r))
+    # the deterministic mode (holo_ctx_set_deterministic: fixed-point scatter, one binary point per chunk and map): bit-identical
+    # from call to call, within fp32 summation noise of the default mode, parameter gradients untouched
+    from holo_diffusion_amd import runtime
+    with runtime.deterministic(True, gu.DEV):
+        d1 = model.pool_views_backward(dev, cams.to(gu.DEV), torch.from_numpy(g["cot"]).to(gu.DEV))
+        d1 = {grp: {k: v.clone() for k, v in d1[grp].items()} for grp in ("image_features", "feature_aggregator")}
+        d2 = model.pool_views_backward(dev, cams.to(gu.DEV), torch.from_numpy(g["cot"]).to(gu.DEV))
+    for k in d1["feature_aggregator"]:
+        assert torch.equal(d1["feature_aggregator"][k], got["feature_aggregator"][k]), k
+    for k, v in d1["image_features"].items():
+        assert torch.equal(v, d2["image_features"][k]), k
+        assert rel(v, got["image_features"][k].cpu()) < 2e-5, (k, rel(v, got["image_features"][k].cpu()))
 
 
 @pytest.mark.gpu
