@@ -106,7 +106,7 @@ SIGNATURES = {
     "holo_unet_get_grad": (C.c_int, [_vp, C.c_char_p, _vp, C.c_int64, _vp, _vp]),
     "holo_ddpm_step": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "holo_ddpm_step_philox": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_uint64, C.c_uint64, C.c_int,
-                                        _vp, _vp, _vp, _vp]),
+                                        _vp, _vp, _vp, C.c_int, _vp]),
     "holo_tanh": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "holo_clip": (C.c_int, [_vp, _vp, _vp, C.c_float, C.c_float, C.c_int64, _vp]),
     "holo_renderer_create": (C.c_int, [_vp, C.POINTER(HoloRenderCfg), C.POINTER(_vp)]),

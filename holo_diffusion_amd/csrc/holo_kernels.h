@@ -182,7 +182,7 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
                      void* stream);
 int ddpm_step_philox_launch(const float* tables, int T, const int64_t* timesteps, int batch, int64_t per, const float* x_t,
                             const float* model_out, uint64_t seed, uint64_t offset, int clip, float* sample,
-                            float* pred_xstart, float* noise_out, void* stream);
+                            float* pred_xstart, float* noise_out, int ncdhw_channels, void* stream);
 int tanh_launch(const float* x, float* y, int64_t n, void* stream);
 // dst = src for a SMALL caller-provided tensor, read with system-scope loads (holo_ld_sys, holo_common.h)
 int copy_sys_launch(const float* src, float* dst, int64_t n, void* stream);

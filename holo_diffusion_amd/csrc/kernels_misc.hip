@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(const float* __restrict_
 // stream offset), key (seed low, seed high) - turned into standard normals by two Box-Muller pairs.  A draw depends on
 // nothing but (seed, offset, sample, element): bit-reproducible whatever the launch geometry; no generator state, no
 // separate randn launch, and the 4 B / element of noise never cross HBM (optionally written out for tests).
+// "Element" is the LOGICAL element: the quads are numbered in channels-last order (voxel, channel / 4).  NCDHW = 0: the
+// tensors are in that order in memory (the sampler's channels-last chain) - quad = four consecutive floats.  NCDHW = 1:
+// the tensors are (C, voxels) planes - a thread takes the same quad's four channels of one voxel from four planes
+// (consecutive threads = consecutive voxels: coalesced), so both layouts of a chain draw the same noise.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t (&out)[4]) {
@@ -407,13 +411,14 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
   z1 = r * sn;
 }
 
+template <bool NCDHW>
 __global__ __launch_bounds__(256) void ddpm_step_philox_kernel(const float* __restrict__ tables, int T,
                                                                const int64_t* __restrict__ timesteps, int64_t per,
                                                                const float* __restrict__ x_t,
                                                                const float* __restrict__ model_out, uint32_t seed_lo,
                                                                uint32_t seed_hi, uint32_t offset, int clip,
                                                                float* __restrict__ sample, float* __restrict__ pred,
-                                                               float* __restrict__ noise_out) {
+                                                               float* __restrict__ noise_out, int channels) {
   const int b = blockIdx.y;
   int64_t tt = holo_ld_sys(timesteps + b);
   if (tt < 0) tt = 0;
@@ -422,12 +427,26 @@ __global__ __launch_bounds__(256) void ddpm_step_philox_kernel(const float* __re
   const float c2 = holo_ld_sys(tables + tt * 4 + 1);
   const float lv = holo_ld_sys(tables + tt * 4 + 2);
   const float sig = tt != 0 ? expf(0.5f * lv) : 0.f;
-  const int64_t qd = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t i = qd * 4;
-  if (i >= per) return;
-  const int64_t o = (int64_t)b * per + i;
-  const float4 x = *reinterpret_cast<const float4*>(x_t + o);
-  float4 m = *reinterpret_cast<const float4*>(model_out + o);
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid * 4 >= per) return;
+  int64_t qd = tid;                       // the canonical (channels-last) quad this thread draws for
+  int64_t o = (int64_t)b * per + tid * 4;  // ... and where its first element lives
+  int64_t es = 1;                          // distance between the quad's elements in memory
+  if (NCDHW) {
+    const int64_t V = per / channels;
+    const int64_t cq = tid / V, v = tid - cq * V;
+    qd = v * (channels >> 2) + cq;
+    o = (int64_t)b * per + cq * 4 * V + v;
+    es = V;
+  }
+  float4 x, m;
+  if (NCDHW) {
+    x = make_float4(x_t[o], x_t[o + es], x_t[o + 2 * es], x_t[o + 3 * es]);
+    m = make_float4(model_out[o], model_out[o + es], model_out[o + 2 * es], model_out[o + 3 * es]);
+  } else {
+    x = *reinterpret_cast<const float4*>(x_t + o);
+    m = *reinterpret_cast<const float4*>(model_out + o);
+  }
   uint32_t rnd[4];
   philox4x32_10((uint32_t)qd, (uint32_t)((uint64_t)qd >> 32), (uint32_t)b, offset, seed_lo, seed_hi, rnd);
   float4 e;
@@ -444,9 +463,15 @@ __global__ __launch_bounds__(256) void ddpm_step_philox_kernel(const float* __re
   s.y = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.y), __fmul_rn(c2, x.y)), __fmul_rn(sig, e.y));
   s.z = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.z), __fmul_rn(c2, x.z)), __fmul_rn(sig, e.z));
   s.w = __fadd_rn(__fadd_rn(__fmul_rn(c1, m.w), __fmul_rn(c2, x.w)), __fmul_rn(sig, e.w));
-  *reinterpret_cast<float4*>(sample + o) = s;
-  if (pred) *reinterpret_cast<float4*>(pred + o) = m;
-  if (noise_out) *reinterpret_cast<float4*>(noise_out + o) = e;
+  if (NCDHW) {
+    sample[o] = s.x, sample[o + es] = s.y, sample[o + 2 * es] = s.z, sample[o + 3 * es] = s.w;
+    if (pred) pred[o] = m.x, pred[o + es] = m.y, pred[o + 2 * es] = m.z, pred[o + 3 * es] = m.w;
+    if (noise_out) noise_out[o] = e.x, noise_out[o + es] = e.y, noise_out[o + 2 * es] = e.z, noise_out[o + 3 * es] = e.w;
+  } else {
+    *reinterpret_cast<float4*>(sample + o) = s;
+    if (pred) *reinterpret_cast<float4*>(pred + o) = m;
+    if (noise_out) *reinterpret_cast<float4*>(noise_out + o) = e;
+  }
 }
 
 // copy of a SMALL caller-provided tensor (biases, GroupNorm affine parameters, ...) with system-scope loads (holo_ld_sys)
@@ -666,15 +691,24 @@ int ddpm_step_launch(const float* tables, int T, const int64_t* timesteps, int b
 
 int ddpm_step_philox_launch(const float* tables, int T, const int64_t* timesteps, int batch, int64_t per, const float* x_t,
                             const float* model_out, uint64_t seed, uint64_t offset, int clip, float* sample,
-                            float* pred_xstart, float* noise_out, void* stream) {
+                            float* pred_xstart, float* noise_out, int ncdhw_channels, void* stream) {
   if (per & 3) {
     set_error("ddpm_step: elems_per_sample must be a multiple of 4");
     return -1;
   }
+  if (ncdhw_channels < 0 || (ncdhw_channels & 3) || (ncdhw_channels > 0 && per % ncdhw_channels)) {
+    set_error("ddpm_step_philox: ncdhw_channels must be 0 (channels-last tensors) or a multiple of 4 that divides elems_per_sample");
+    return -1;
+  }
   dim3 grid((unsigned)cdiv(per / 4, 256), (unsigned)batch);
   // (the high half of the offset goes into the key: counters stay distinct for any 64-bit stream offset)
-  HOLO_LAUNCH(ddpm_step_philox_kernel, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, (uint32_t)seed,
-              (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), (uint32_t)offset, clip, sample, pred_xstart, noise_out);
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
+  if (ncdhw_channels)
+    HOLO_LAUNCH(ddpm_step_philox_kernel<true>, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, k0, k1,
+                (uint32_t)offset, clip, sample, pred_xstart, noise_out, ncdhw_channels);
+  else
+    HOLO_LAUNCH(ddpm_step_philox_kernel<false>, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, k0, k1,
+                (uint32_t)offset, clip, sample, pred_xstart, noise_out, 0);
   return 0;
 }
 

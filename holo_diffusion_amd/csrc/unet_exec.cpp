@@ -2129,14 +2129,14 @@ int holo_ddpm_step(HoloCtx* ctx, const float* tables, int num_timesteps, const i
 int holo_ddpm_step_philox(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
                           int64_t elems_per_sample, const float* x_t, const float* model_out, uint64_t seed,
                           uint64_t stream_offset, int clip_denoised, float* sample, float* pred_xstart, float* noise_out,
-                          void* stream) {
+                          int ncdhw_channels, void* stream) {
   if (!tables || !timesteps || !x_t || !model_out || !sample || batch < 1) {
     set_error("holo_ddpm_step_philox: null/invalid argument");
     return HOLO_E_INVALID;
   }
   (void)ctx;
   int rc = ddpm_step_philox_launch(tables, num_timesteps, timesteps, batch, elems_per_sample, x_t, model_out, seed,
-                                   stream_offset, clip_denoised, sample, pred_xstart, noise_out, stream);
+                                   stream_offset, clip_denoised, sample, pred_xstart, noise_out, ncdhw_channels, stream);
   return rc ? HOLO_E_INVALID : 0;
 }
 

@@ -84,10 +84,16 @@ def allreduce_training_gradients(out: dict, group: Optional[dist.ProcessGroup] =
     experiment.py:255-260); the per-rank grid / feature-map gradients are left alone (every rank trains on its own scene
     batch).  A ``None`` gradient (a bias-free mapper) is skipped - identically on every rank."""
     merged: Dict[str, torch.Tensor] = {}
-    for src in (out, encoder or {}):
+    for tag, src in (("", out), ("encoder:", encoder or {})):
         for group_name in PARAMETER_GRADIENT_KEYS:
             for k, v in (src.get(group_name) or {}).items():
-                if v is not None:
-                    merged[group_name + "." + k] = v
+                if v is None:
+                    continue
+                name = group_name + "." + k
+                if name in merged:
+                    if merged[name] is v:  # the same tensor reached through both dicts: exchanged once
+                        continue
+                    name = tag + name      # two DISTINCT tensors under one parameter name: both are averaged
+                merged[name] = v
     allreduce_gradients(merged, group=group, bucket_bytes=bucket_bytes, average=True)
     return out

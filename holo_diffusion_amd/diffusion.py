@@ -156,8 +156,12 @@ class ImplicitronGaussianDiffusion(Configurable):
                                        runtime.ptr(pred), runtime.stream_ptr(dev)), "holo_ddpm_step")
         return sample, pred
 
-    def _step_device_noise(self, x, t, model_output, timestep_index: int, clip_denoised, want_pred=True, want_noise=False):
-        """The step with in-kernel Philox noise (perf mode): (sample, pred_xstart | None, noise | None)."""
+    def _step_device_noise(self, x, t, model_output, timestep_index: int, clip_denoised, want_pred=True, want_noise=False,
+                           channels_last: bool = False):
+        """The step with in-kernel Philox noise (perf mode): (sample, pred_xstart | None, noise | None).  A draw is keyed on the
+        LOGICAL element (seed, stream, timestep, sample, channel, voxel): ``channels_last`` says which layout ``x`` is in - an
+        (N, R, R, R, C) chain and an (N, C, R, R, R) chain of the same seed draw the same noise (C a multiple of 4; otherwise
+        the NCDHW tensor's memory order is the key)."""
         runtime.require_device(x, "ImplicitronGaussianDiffusion")
         L = runtime.lib()
         dev = x.device
@@ -172,7 +176,9 @@ class ImplicitronGaussianDiffusion(Configurable):
             runtime.ctx(dev), runtime.ptr(self._tables_on(dev)), self.num_timesteps, runtime.ptr(t), x.shape[0], x[0].numel(),
             runtime.ptr(x), runtime.ptr(model_output), int(self.device_noise_seed) & 0xFFFFFFFFFFFFFFFF, offset,
             1 if clip_denoised else 0, runtime.ptr(sample), runtime.ptr(pred) if want_pred else None,
-            runtime.ptr(noise) if want_noise else None, runtime.stream_ptr(dev)), "holo_ddpm_step_philox")
+            runtime.ptr(noise) if want_noise else None,
+            0 if (channels_last or x.dim() < 3 or x.shape[1] % 4) else int(x.shape[1]), runtime.stream_ptr(dev)),
+            "holo_ddpm_step_philox")
         return sample, pred, noise
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
@@ -265,7 +271,8 @@ class ImplicitronGaussianDiffusion(Configurable):
                 for k in it:
                     t = ts_all[k]
                     out_cl = model.forward_channels_last(img_cl, t)
-                    sample_cl, pred_cl, _ = self._step_device_noise(img_cl, t, out_cl, indices[k], clip_denoised)
+                    sample_cl, pred_cl, _ = self._step_device_noise(img_cl, t, out_cl, indices[k], clip_denoised,
+                                                                    channels_last=True)
                     yield {"sample": as_ncdhw(sample_cl), "pred_xstart": as_ncdhw(pred_cl), "noise": None}
                     img_cl = sample_cl
             return

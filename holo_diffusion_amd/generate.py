@@ -228,7 +228,8 @@ def render_views_sharded(model, voxel_features: Optional[torch.Tensor], cams, sr
     GPUs cost nothing), and one ``all_gather`` per output puts all frames on all ranks, in camera order.  Bit for bit the
     single-rank ``model.render_views(voxel_features, cams)``: a frame does not depend on which other frames share its
     launch (tests/test_gpu_configs.py::test_teddybear_30_view_turntable_in_one_call).  ``voxel_features`` is read on
-    ``src_rank`` only (pass None elsewhere).  A single-process run is a plain ``render_views``."""
+    ``src_rank`` only (pass None elsewhere); on a multi-rank run the result also carries the broadcast grid as
+    ``"voxel_features"``.  A single-process run is a plain ``render_views``."""
     rank, world = dist_info()
     if world == 1:
         return model.render_views(voxel_features, cams)
@@ -257,6 +258,7 @@ def render_views_sharded(model, voxel_features: Optional[torch.Tensor], cams, sr
     res = {}
     for k in klist[0]:
         res[k] = gather_frames(local.get(k, {}), n, (chans.get(k, 1), H, W), device)
+    res["voxel_features"] = vf  # the broadcast grid: every rank holds it
     return res
 
 
@@ -291,7 +293,8 @@ def render_progressive_turntable_sharded(model, n_views: int = 30, steps_per_ren
         elif vf is None:
             return
         out = render_views_sharded(model, vf, cams, src_rank=src_rank, device=device)
-        out["voxel_features"] = vf
+        if world == 1:
+            out["voxel_features"] = vf  # (a single-process run is a plain render_views; sharded runs return the broadcast grid)
         yield out
 
 
@@ -344,15 +347,23 @@ def generate_samples(model, num_samples: int = 2, n_eval_cameras: int = 25 * 3, 
     local_msk: Dict[int, torch.Tensor] = {}
     H, W = model.render_image_height, model.render_image_width
     diffusion = getattr(model, "diffusion", None)
-    for i in mine:
-        torch.manual_seed(seed + i)  # per-sample seed
-        if device_noise and diffusion is not None and hasattr(diffusion, "device_noise_seed"):
-            diffusion.device_noise_seed, diffusion.device_noise_stream = int(seed), int(i)
-        out = render_flyaround(model, n_flyaround_poses=n_eval_cameras, up=up, camera_elevation=camera_elevation,
-                               device=device,
-                               progressive_sampling_steps_per_render=progressive_sampling_steps_per_render,
-                               sampler_kwargs=sampler_kwargs)
-        local_img[i], local_dep[i], local_msk[i] = out["images_render"], out["depths_render"], out["masks_render"]
+    perf_noise = device_noise and diffusion is not None and hasattr(diffusion, "device_noise_seed")
+    # (the caller's sampler settings come back whatever happens: a later p_sample on this model must not silently stay in
+    # the Philox mode with the last sample's stream)
+    saved = (diffusion.device_noise_seed, diffusion.device_noise_stream) if perf_noise else None
+    try:
+        for i in mine:
+            torch.manual_seed(seed + i)  # per-sample seed
+            if perf_noise:
+                diffusion.device_noise_seed, diffusion.device_noise_stream = int(seed), int(i)
+            out = render_flyaround(model, n_flyaround_poses=n_eval_cameras, up=up, camera_elevation=camera_elevation,
+                                   device=device,
+                                   progressive_sampling_steps_per_render=progressive_sampling_steps_per_render,
+                                   sampler_kwargs=sampler_kwargs)
+            local_img[i], local_dep[i], local_msk[i] = out["images_render"], out["depths_render"], out["masks_render"]
+    finally:
+        if perf_noise:
+            diffusion.device_noise_seed, diffusion.device_noise_stream = saved
     if not gather:
         return {"images_render": local_img, "depths_render": local_dep, "masks_render": local_msk}
     return {

@@ -177,11 +177,16 @@ int holo_ddpm_step(HoloCtx* ctx, const float* tables, int num_timesteps, const i
  * / :604 - SURVEY 8d "on-device Philox"): element quad q of sample b takes the four outputs of Philox4x32-10 with
  * counter (q low, q high, b, stream_offset low) and key (seed low, seed high ^ stream_offset high), as two Box-Muller
  * pairs (24-bit uniforms, |z| <= 5.9).  Statistically equivalent to, NOT bit-equal with, torch's generator: parity
- * tests keep holo_ddpm_step with injected noise.  pred_xstart and noise_out may be null (not written). */
+ * tests keep holo_ddpm_step with injected noise.  pred_xstart and noise_out may be null (not written).
+ * The quads are numbered over the LOGICAL elements in channels-last order, q = voxel * (C / 4) + channel / 4 (ABI 6):
+ *   ncdhw_channels = 0  the tensors are channels-last (N, R, R, R, C) - or any flat order the caller treats as canonical:
+ *                       quad q is four consecutive floats (the sampler's channels-last chain, holo_unet_forward_cl)
+ *   ncdhw_channels = C  the tensors are (N, C, R, R, R) with C a multiple of 4: the same quad's four values are taken from
+ *                       four channel planes, so a chain draws the SAME noise for element (n, c, z, y, x) in either layout. */
 int holo_ddpm_step_philox(HoloCtx* ctx, const float* tables, int num_timesteps, const int64_t* timesteps, int batch,
                           int64_t elems_per_sample, const float* x_t, const float* model_out, uint64_t seed,
                           uint64_t stream_offset, int clip_denoised, float* sample, float* pred_xstart, float* noise_out,
-                          void* stream);
+                          int ncdhw_channels, void* stream);
 
 /* Elementwise helpers on the path: torch.tanh (holo_diffusion_model.py:425) and
  * torch.clip(x,-1,1) (holo_diffusion_model.py:186). */

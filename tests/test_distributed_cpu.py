@@ -107,6 +107,14 @@ def _ddp_worker(rank, world, port, bucket_bytes, q):
             torch.allclose(enc["feature_aggregator"]["_last.weight"], 1.5 * base["b.weight"], rtol=1e-6, atol=1e-6) and \
             torch.all(enc["image_features"]["res"] == float(rank)).item() and torch.allclose(out2["unet"]["c"], 1.5 * base["c"]) and \
             torch.all(out2["voxel_features"] == float(rank)).item()
+        # one parameter name in BOTH dicts (advisor, round 5): distinct tensors are both averaged, a shared one exactly once
+        shared = torch.full((3,), float(4 * rank))
+        out3 = {"pooled_feature_mapper": {"weight": torch.full((2,), float(rank)), "bias": shared}}
+        enc3 = {"pooled_feature_mapper": {"weight": torch.full((2,), float(10 * rank)), "bias": shared}}
+        allreduce_training_gradients(out3, bucket_bytes=bucket_bytes, encoder=enc3)
+        ok = ok and torch.allclose(out3["pooled_feature_mapper"]["weight"], torch.full((2,), 0.5)) and \
+            torch.allclose(enc3["pooled_feature_mapper"]["weight"], torch.full((2,), 5.0)) and \
+            torch.allclose(shared, torch.full((3,), 2.0))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -175,7 +183,8 @@ def _turntable_worker(rank, world, port, n_views, normals, q):
         vf = torch.arange(108, dtype=torch.float32).reshape(1, 4, 3, 3, 3) if rank == 0 else None
         got = render_views_sharded(model, vf, cams, src_rank=0, device=dev)
         want = model.render_views(torch.arange(108, dtype=torch.float32).reshape(1, 4, 3, 3, 3), cams)
-        ok = set(got) == set(want) and all(torch.equal(got[k], want[k]) for k in want)
+        ok = set(got) == set(want) | {"voxel_features"} and all(torch.equal(got[k], want[k]) for k in want)
+        ok = ok and torch.equal(got["voxel_features"], torch.arange(108, dtype=torch.float32).reshape(1, 4, 3, 3, 3))
         # the progressive driver: chain on rank 0, every rank receives every step's frames and the broadcast grid
         steps = list(render_progressive_turntable_sharded(model, n_views=n_views, steps_per_render=1, device=dev))
         ref_grids = list(model.sample_random_voxel_features_progressive())
@@ -183,7 +192,7 @@ def _turntable_worker(rank, world, port, n_views, normals, q):
         for s, g in zip(steps, ref_grids):
             w = model.render_views(g, cams)
             ok = ok and all(torch.equal(s[k], w[k]) for k in w)
-            ok = ok and (s["voxel_features"] is None or torch.equal(s["voxel_features"], g))
+            ok = ok and s["voxel_features"] is not None and torch.equal(s["voxel_features"], g)  # the broadcast grid, on EVERY rank
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -280,6 +280,71 @@ def test_north_star_sampler_chain_vs_oracle(gu, T, max_iter):
         assert any(o_["nsplit"] > 1 and o_["kernel"] == "conv_small_kernel" for o_ in ops)  # the weight-streaming 4^3 level
 
 
+def test_north_star_perf_mode_chain_vs_oracle(gu):
+    """The path bench.py times, at the size it times it: the sampler's PERF MODE (``device_noise_seed``: the chain stays in
+    channels-last tensors, ``holo_unet_forward_cl`` + ``holo_ddpm_step_philox``, gaussian_diffusion.py:568-643) on the 64^3 x 32
+    net.  (1) ``forward_channels_last(x_cl)`` is ``forward(x)`` BIT for bit at this size - conv_wino3_kernel at 64^3 and
+    conv1x1_stream_kernel read / write the caller's tensors there; (2) four steps of the chain with the per-step noise read
+    back from the step kernel (``want_noise``) against ``DiffusionOracle`` driving the pinned UNet oracle with exactly that
+    noise, every step's sample and pred_xstart within 5e-3; (3) ``p_sample_loop_progressive`` in the perf mode - the product
+    loop - yields the same samples as the hand-written loop, bit for bit, and so does the NCDHW fallback route with the same
+    seed (the Philox draw is keyed on the logical element, not on the layout)."""
+    from oracle.common import NORTH_CFG, TINY_CFG
+    cfg = TINY_CFG if EMU else NORTH_CFG
+    T, n_steps, seed, stream = 1000, 4, 20240917, 5
+    net, sd = gu.make_unet(cfg)
+    shape = (1, cfg.in_channels, cfg.image_size, cfg.image_size, cfg.image_size)
+    x_T = torch.from_numpy(np_noise(4242, shape))
+    # (1) the two forward entries
+    t0 = torch.tensor([T - 1], device=gu.DEV)
+    x_dev = x_T.to(gu.DEV)
+    x_cl = x_dev.permute(0, 2, 3, 4, 1).contiguous()
+    with torch.no_grad():
+        y = net(x_dev, t0)
+        y_cl = net.forward_channels_last(x_cl, t0)
+    assert torch.equal(y_cl.permute(0, 4, 1, 2, 3), y)
+    # (2) the hand-written perf chain (bench.py's one_step), noise read back
+    with np.errstate(divide="ignore"):
+        diff = hda.ImplicitronGaussianDiffusion(num_steps=T, device_noise_seed=seed, device_noise_stream=stream)
+    indices = diff._indices(n_steps)
+    steps, noises = [], {}
+    img_cl = x_cl
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for idx in indices:
+            t = torch.tensor([idx], device=gu.DEV)
+            out_cl = net.forward_channels_last(img_cl, t)
+            s_cl, p_cl, e_cl = diff._step_device_noise(img_cl, t, out_cl, idx, True, want_pred=True, want_noise=True,
+                                                       channels_last=True)
+            steps.append({"sample": s_cl.permute(0, 4, 1, 2, 3).contiguous().cpu(), "pred_xstart": p_cl.permute(0, 4, 1, 2, 3).contiguous().cpu()})
+            noises[idx] = e_cl.permute(0, 4, 1, 2, 3).contiguous().cpu()
+            img_cl = s_cl
+        ns_cpu = lambda t, shp, device=None: (x_T if t == T else noises[t])  # noqa: E731  (t == T: the oracle's x_T draw)
+        ref = list(do.DiffusionOracle(T).p_sample_loop_progressive(lambda x, t: uo.unet_forward(sd, cfg, x, t), shape,
+                                                                   ns_cpu, True, n_steps))
+    assert len(ref) == n_steps
+    worst = 0.0
+    for i, (s, r) in enumerate(zip(steps, ref)):
+        for k in ("sample", "pred_xstart"):
+            e = gu.rel_err(s[k], r[k])
+            worst = max(worst, e)
+            assert e < 5e-3, (k, i, e)
+    # the in-kernel draws are standard normals (the oracle chain above would not notice a wrong variance on its own)
+    e_all = torch.cat([v.reshape(-1) for v in noises.values()]).double()
+    se = 5.0 / e_all.numel() ** 0.5  # five standard errors of the mean (the variance's is sqrt(2) times that)
+    assert abs(float(e_all.mean())) < se and abs(float(e_all.var()) - 1.0) < 1.5 * se
+    # (3) the product loop, and the NCDHW fallback route (a wrapped model has no forward_channels_last)
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        prod = [s["sample"].cpu() for s in diff.p_sample_loop_progressive(net, shape, noise=x_dev, max_iter=n_steps)]
+        fallback = [s["sample"].cpu() for s in diff.p_sample_loop_progressive(lambda a, b: net(a, b), shape, noise=x_dev,
+                                                                             max_iter=n_steps, device=gu.DEV)]
+    for i in range(n_steps):
+        assert torch.equal(prod[i], steps[i]["sample"]), i
+        assert torch.equal(fallback[i], steps[i]["sample"]), i
+    print(f"north-star perf-mode chain (channels-last, in-kernel Philox noise), {n_steps} steps: worst relative error {worst:.2e}")
+
+
 def test_config0_plumbing_frame_vs_oracle(gu):
     """configs[0] (unet_with_no_diffusion.yaml: diffusion disabled, the path is tanh(net_3d(vf, 0)) + render): 32^3 x 16
     grid, model_channels 64, one camera at 128x128, n_pts_per_ray_fine_evaluation = 16 (configs/...yaml:155-156): the

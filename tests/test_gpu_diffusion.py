@@ -120,8 +120,10 @@ def test_philox_known_answer():
 def test_device_noise_step_kernel(gu):
     """holo_ddpm_step_philox (perf mode): (1) the noise it reports is the documented Philox4x32-10 / Box-Muller draw
     (numpy statement, pinned to the published known-answer vectors above) to float32 rounding of log / sin / cos; (2) the
-    sample is holo_ddpm_step of that noise BIT for bit; (3) draws depend on (seed, stream, timestep, sample, element) and
-    nothing else; (4) mean / variance / lag-1 correlation / 4th moment of 2 M draws are those of a standard normal."""
+    sample is holo_ddpm_step of that noise BIT for bit; (3) draws depend on (seed, stream, timestep, sample, LOGICAL element)
+    and nothing else - in particular not on the layout: the (N, C, R, R, R) call and the channels-last call (the sampler's
+    perf chain) draw the same value for the same (n, c, z, y, x), quads numbered in channels-last order; (4) mean / variance
+    / lag-1 correlation / 4th moment of 2 M draws are those of a standard normal."""
     from holo_diffusion_amd import _lib, runtime
     L = runtime.lib()
     seed, stream = 0x1234567890ABCDEF, 3
@@ -133,10 +135,15 @@ def test_device_noise_step_kernel(gu):
     for tt in (999, 1, 0):
         t = torch.tensor([tt, tt], device=gu.DEV)
         s1, p1, e1 = diff._step_device_noise(x, t, mo, tt, True, want_noise=True)
-        want = _philox_normals(seed, (stream << 32) | tt, shape[0], per).reshape(shape)
-        assert np.abs(e1.cpu().numpy() - want).max() < 2e-5
+        # (N, C, R, R, R) tensors: the documented draw lives in channels-last order
+        want_cl = _philox_normals(seed, (stream << 32) | tt, shape[0], per).reshape(shape[0], *shape[2:], shape[1])
+        assert np.abs(e1.cpu().numpy() - want_cl.transpose(0, 4, 1, 2, 3)).max() < 2e-5
         s2, p2 = plain._step(x, t, mo, e1, True)
         assert torch.equal(s1, s2) and torch.equal(p1, p2)
+        # the channels-last call on the same logical tensors: the same noise, sample and pred_xstart, bit for bit
+        cl = lambda a: a.permute(0, 2, 3, 4, 1).contiguous()  # noqa: E731
+        s4, p4, e4 = diff._step_device_noise(cl(x), t, cl(mo), tt, True, want_noise=True, channels_last=True)
+        assert torch.equal(e4, cl(e1)) and torch.equal(s4, cl(s1)) and torch.equal(p4, cl(p1))
         s3, p3, e3 = diff._step_device_noise(x, t, mo, tt, True, want_pred=False, want_noise=False)
         assert torch.equal(s3, s1) and p3 is None and e3 is None
     # independence of the draws: another timestep / stream / seed / sample gives another tensor
