@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit: smoke, -m gpu parity tests, render probes, bench line, rocprofv3 trace of the EXACT
+# One GPU-box visit: smoke, -m gpu parity tests (three passes), render probes, bench line, rocprofv3 trace of the EXACT
 # bench command.  bash scripts/gpu_visit.sh <tag> [pytest -k expression]
 TAG=${1:-v}
 OUT=gpurun_out/$TAG
@@ -8,13 +8,20 @@ export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6 > $OUT/device.txt
 nproc >> $OUT/device.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $OUT/device.txt
 echo "== smoke"; timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/smoke.log; tail -2 $OUT/smoke.log
-echo "== pytest -m gpu"
-if [ -n "$2" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=12 -k "$2" > $OUT/pytest_gpu.log 2>&1
-else
-  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --durations=12 > $OUT/pytest_gpu.log 2>&1
-fi
-echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -45 $OUT/pytest_gpu.log
+echo "== pytest -m gpu, THREE times on this HEAD (no -x: every failure of every pass is listed) -> pytest_x3.txt"
+git -C . rev-parse --short HEAD > /dev/null 2>&1 || true
+: > $OUT/pytest_x3.txt
+for pass in 1 2 3; do
+  if [ -n "$2" ]; then
+    timeout 1500 python -m pytest tests -m gpu -q -s --tb=short -p no:cacheprovider --durations=12 -k "$2" > $OUT/pytest_gpu_$pass.log 2>&1
+  else
+    timeout 1500 python -m pytest tests -m gpu -q -s --tb=short -p no:cacheprovider --durations=12 > $OUT/pytest_gpu_$pass.log 2>&1
+  fi
+  echo "pass $pass: pytest rc=$? | $(tail -1 $OUT/pytest_gpu_$pass.log)" | tee -a $OUT/pytest_x3.txt
+  grep -E "^(FAILED|ERROR)" $OUT/pytest_gpu_$pass.log | tee -a $OUT/pytest_x3.txt
+done
+grep -hE "loss.backward\(\) through|deterministic scatter|north-star perf-mode" $OUT/pytest_gpu_*.log >> $OUT/pytest_x3.txt
+tail -30 $OUT/pytest_gpu_1.log
 echo "== render probes"
 timeout 300 python scripts/render_probe.py 1 8 30 > $OUT/render_probe.log 2>&1
 HOLO_RENDER_XCD=1 timeout 300 python scripts/render_probe.py 8 >> $OUT/render_probe.log 2>&1
