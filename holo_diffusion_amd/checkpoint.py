@@ -32,6 +32,7 @@ MODEL_FACTORY_KEY = "model_factory_ImplicitronModelFactory_args"
 MODEL_ARGS_KEY = "model_HoloDiffusionModel_args"
 # state-dict prefixes that ARE the hot path: everything else in a reference checkpoint is encoder side
 PATH_PREFIXES = ("net_3d.", "_implicit_functions.")
+DEFAULT_VIEW_METRICS = "ViewMetrics"  # Implicitron's default `view_metrics_class_type`
 
 
 @dataclass
@@ -87,6 +88,13 @@ def model_args_from_expconfig(cfg: Dict[str, Any], render_size: Optional[Tuple[i
     if margs is None:
         raise ValueError(f"experiment config has no {MODEL_FACTORY_KEY}.{MODEL_ARGS_KEY}")
     ignored: List[str] = []
+    margs = dict(margs)
+    # view metrics are outside the denoise-and-render path (never instantiated).  unet_with_no_diffusion.yaml:183-185 names
+    # `HoloDiffusionMetrics`, a class that exists nowhere in the released code: the default stands in, and the report says so
+    vm = margs.pop("view_metrics_class_type", None)
+    if vm is not None:
+        ignored.append(f"{MODEL_ARGS_KEY}.view_metrics_class_type" + (
+            "" if vm == DEFAULT_VIEW_METRICS else f" ('{vm}' is not a class of the released code -> {DEFAULT_VIEW_METRICS})"))
     kw = _filter_fields(HoloDiffusionModel, margs, MODEL_ARGS_KEY, ignored)
     nested = {
         "net_3d_SimpleUnet3D_args": SimpleUnet3D,
