@@ -225,6 +225,58 @@ def side_batched_chains(net, diff, w, device, batches=(2, 4), warm=5, timed=20):
     return res
 
 
+def side_teddybear_turntable(model, device, n_views=30, warm=2, timed=6):
+    """BASELINE configs[3] (teddybear.yaml): a 30-camera turntable @400x400 after EVERY denoise step
+    (progressive_sampling_steps_per_render = 1, flyaround.py:240-253).  Per step, all inside the timed region: one DDPM step of
+    the 64^3 x 32 chain, the clip, the refinement tanh(net_3d(vf, t = 0)) (holo_diffusion_model.py:420-426 - a second UNet
+    forward, NOT cached: the grid is new every step) and all 30 cameras in ONE holo_render call - the product driver
+    generate.render_progressive_turntable."""
+    from holo_diffusion_amd.generate import render_progressive_turntable
+    H, W = model.render_image_height, model.render_image_width
+    gen = render_progressive_turntable(model, n_views=n_views, steps_per_render=1, device=device)
+    with torch.no_grad():
+        for _ in range(warm):
+            out = next(gen)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            out = next(gen)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        gen.close()
+        # the pieces on their own (same grid, same cameras): refinement + render of one step
+        vf = out["voxel_features"]
+        cams = hda_cams(n_views, device)
+        model.invalidate_refined_cache()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.invalidate_refined_cache()
+            model.render_views(vf, cams)
+        torch.cuda.synchronize()
+        dt_rr = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.render_views(vf, cams)  # (cached refinement: the fixed-grid figure of the main render leg)
+        torch.cuda.synchronize()
+        dt_r = (time.perf_counter() - t0) / 3
+    assert torch.isfinite(out["images_render"]).all() and out["images_render"].shape[0] == n_views
+    rays = n_views * H * W
+    return {"steps_per_s": timed / dt, "ms_per_step": 1e3 * dt / timed, "views_per_step": n_views,
+            "rays_per_sec_whole_step": rays * timed / dt,
+            "rays_per_sec_refine_plus_render": rays / dt_rr, "ms_refine_plus_render": 1e3 * dt_rr,
+            "rays_per_sec_render_only_fixed_grid": rays / dt_r, "ms_render_only": 1e3 * dt_r,
+            "what": f"per denoise step: DDPM step + clip + tanh(net_3d(vf, 0)) + {n_views} frames @{H}x{W} in one holo_render call "
+                    "(generate.render_progressive_turntable); rays_per_sec_whole_step counts the step's rays over the WHOLE step, "
+                    "rays_per_sec_refine_plus_render leaves the DDPM step out, rays_per_sec_render_only_fixed_grid is the main "
+                    "render leg's definition (refinement cached)"}
+
+
+def hda_cams(n, device):
+    import holo_diffusion_amd as hda
+    return hda.get_simple_360_camera_trajectory(2 * math.pi, n, -30.0 * (2 * math.pi / 360), 10, (0.0, -1.0, 0.0), 3.2).to(device)
+
+
 def side_training_step(net, w, device, warm=1, timed=3):
     """forward + backward of the denoiser at the north-star size through holo_unet_backward (the taped
     forward re-run, dgrad on the forward's convolution kernels with transposed weights, row-staged wgrad, GroupNorm /
@@ -454,6 +506,20 @@ def main():
             dtr40 = max_over_ranks(time.perf_counter() - t0, world, device)
         rays_per_s_40 = world * F40 * H * W / dtr40
 
+    # the reference's call shape: one render call PER CAMERA (flyaround.py:247-253 loops over the cameras), same grid, the
+    # t = 0 refinement cached as above
+    n1 = min(F, 8)
+    with torch.no_grad():
+        singles = [cams[[i]] for i in range(n1)]
+        model.render_views(vf, singles[0])
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for c1 in singles:
+            model.render_views(vf, c1)
+        barrier_sync(world)
+        dts = max_over_ranks(time.perf_counter() - t0, world, device)
+    rays_per_s_single = world * n1 * H * W / dts
+
     # the same call with rendered normals (the released YAMLs' render_normals: true): normals of both passes composited
     # inside render2_kernel<.., NRM> (density scalar field + octahedral normals in LDS)
     rays_per_s_nrm = None
@@ -634,7 +700,8 @@ def main():
     # same weights (the UNet's parameters do not depend on the grid size): 3 warm + 5 timed DDPM steps
     side = None
     if world == 1 and args.workload == "north" and args.compute_dtype == "f32" and not args.no_side:
-        side = {"donut128_bf16": side_donut128(usd, device), "batched_chains_f32": side_batched_chains(net, diff, w, device),
+        side = {"teddybear_turntable30": side_teddybear_turntable(model, device),
+                "donut128_bf16": side_donut128(usd, device), "batched_chains_f32": side_batched_chains(net, diff, w, device),
                 "training_step_f32": side_training_step(net, w, device)}
 
     # ---------------- the one exchange of the path: all_gather of the rendered frames over RCCL / xGMI.
@@ -659,6 +726,34 @@ def main():
                   "bytes_per_rank": nbytes, "all_gather_GBps_per_rank": nbytes * (world - 1) / dtg / 1e9,
                   "verified": bool(okt.item() == 1.0),
                   "what": f"all_gather of {F} frames x (rgb, depth, mask) @{H}x{W} fp32 per rank (generate.gather_frames)"}
+
+    # ---------------- the optional row of SURVEY 8e: ONE grid's 30-view turntable with the cameras sharded over the ranks
+    # (generate.render_views_sharded: broadcast of the 33.5 MB grid from rank 0, cameras k mod N per rank in one render call,
+    # one all_gather per output) against the same turntable rendered by rank 0 alone
+    sharded = None
+    if world > 1 and args.workload == "north":
+        from holo_diffusion_amd.generate import render_views_sharded
+        cams30 = hda_cams(30, device)
+        with torch.no_grad():
+            render_views_sharded(model, vf if rank == 0 else None, cams30, src_rank=0, device=device)  # warm-up
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            sh = render_views_sharded(model, vf if rank == 0 else None, cams30, src_rank=0, device=device)
+            barrier_sync(world)
+            dtsh = max_over_ranks(time.perf_counter() - t0, world, device)
+            model.render_views(sh["voxel_features"], cams30)
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            alone = model.render_views(sh["voxel_features"], cams30)
+            torch.cuda.synchronize()
+            dtal = time.perf_counter() - t0
+            barrier_sync(world)
+        oks = torch.tensor([1.0 if torch.equal(sh["images_render"], alone["images_render"]) else 0.0], device=device)
+        dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+        sharded = {"ms_sharded": 1e3 * dtsh, "ms_one_rank_alone": 1e3 * dtal, "speedup": dtal / dtsh, "views": 30,
+                   "rays_per_sec_sharded": 30 * H * W / dtsh, "bit_equal_to_one_rank": bool(oks.item() == 1.0),
+                   "what": "30-view turntable of ONE grid: broadcast (33.5 MB) + cameras k mod N per rank + all_gather of the "
+                           "frames (generate.render_views_sharded), every rank ends up with all 30 frames"}
 
     # ---------------- the training branch's exchange: all-reduce of the denoiser's parameter gradients
     # (165 M fp32 = 0.66 GB at the north-star size) in 64 MB buckets over RCCL / xGMI (holo_diffusion_amd/ddp.py); synthetic
@@ -731,6 +826,7 @@ def main():
                        "parallelism": f"{world} independent chains (sample sharding), no data-path collective"},
             "rays_per_sec": rays_per_s, "ms_per_frame": 1e3 * dtr / F, "frames": F,
             "rays_per_sec_with_normals": rays_per_s_nrm,
+            "rays_per_sec_single_frame_calls": rays_per_s_single, "ms_per_single_frame_call": 1e3 * dts / n1,
             "rays_per_sec_second_call_size": rays_per_s_40, "second_call_frames": F40,
             "ms_per_frame_second_call_size": (1e3 * dtr40 / F40) if F40 > 0 else None,
             "unet_tflops": FLOPS_PER_STEP[w["resol"]] * steps_per_s / world / 1e12,
@@ -746,7 +842,7 @@ def main():
                                 "peak_tflops": PEAK_FP32_MFMA_TFLOPS,
                                 "frac_mfma": mlp_flops_per_ray * rays_per_s / world / 1e12 / PEAK_FP32_MFMA_TFLOPS},
             "cpu_baseline": cpu,
-            "frame_gather": gather, "grad_exchange": grad_exchange,
+            "frame_gather": gather, "grad_exchange": grad_exchange, "camera_sharded_turntable": sharded,
             "rccl_world_size": (gather or {}).get("rccl_world_size", 1), "gather_ms": (gather or {}).get("gather_ms"),
             "per_rank_steps_per_s": per_rank_steps_per_s,
             "step_noise": {"timed": args.noise, "what": {"device": "the sampler's perf chain: grid kept channels-last (holo_unet_forward_cl, no layout "

@@ -85,6 +85,8 @@ struct ConvParams {
   const uint16_t* w_bft;
   const uint16_t* skip_w_bft;
   int bf16t;              // set by conv_plan: the launch runs on conv_bf16t_kernel
+  int bf16p;              // set by conv_plan (with bf16t): ... on its persistent wave-specialised form, conv_bf16p_kernel
+                          // (kernels_conv_bf16p.hip: grid_x workgroups of 8 waves, 4 consumers + 4 producers, no split-K)
   // bf16 STORAGE (compute mode bf16): the buffers behind these float* are bf16 (uint16_t) channels-last tensors;
   // coefficients, bias, statistics and split-K scratch stay fp32 / double
   int in_bf16;            // src0 / src1 / skip_src0 / skip_src1
@@ -97,6 +99,8 @@ int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps);
 int repack_conv_weight_wino3_launch(const float* w, float* out, int Cout, int Cin, int src_taps, int CoutP, int CinP,
                                     void* stream);
 int conv_wino3_launch(const ConvParams& p, void* stream);
+// kernels_conv_bf16p.hip
+int conv_bf16p_launch(const ConvParams& p, void* stream);
 
 // Picks split-K so that the grid fills the chip; returns bytes of `partial` scratch needed (0 if none).
 size_t conv_plan(ConvParams& p, int num_cus);

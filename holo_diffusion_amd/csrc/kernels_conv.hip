@@ -2804,6 +2804,7 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
   }
   p.bf16t = 0;
+  p.bf16p = 0;
   if (p.mode == 1 && p.bf16 == 1 && p.in_bf16 && p.w_bft && (!p.skip_w || p.skip_w_bft) && (p.OD % 8) == 0 && (p.OH % 8) == 0 && (p.OW % 8) == 0 && (p.Cout % 32) == 0 &&
       (p.C0 % 8) == 0 && (p.skip_C0 % 8) == 0 && ((p.skip_C0 + p.skip_C1) % 8) == 0 && (p.Cout >= 64 || !p.skip_w)) {
     // bf16 wide-tile kernel (8^3 voxels x 64 | 32 output channels per workgroup): where it fills the chip without
@@ -2832,9 +2833,29 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       p.chunks_per_split = cps;
       p.skip_chunks_per_split = (int)cdiv(nsk16, nsplit);
       p.grid_x = (int)(M / 512);
+      // the filled levels (every CU gets whole tiles without split-K): the persistent wave-specialised form
+      // (kernels_conv_bf16p.hip).  HOLO_CONV_BF16P=0 keeps conv_bf16t_kernel everywhere (A/B knob), =1 forces the persistent
+      // form onto every wide-tile launch, without split-K (tests: small grids)
+      {
+        const char* ep = getenv("HOLO_CONV_BF16P");
+        const bool force = ep && ep[0] == '1';
+        const int wgs = num_cus & ~7;
+        if (!(ep && ep[0] == '0') && ((nsplit == 1 && wgs >= 8 && t8 >= wgs) || force) &&
+            (!p.skip_w || (((p.skip_C0 + p.skip_C1) % 32) == 0 && (p.skip_C0 % 8) == 0))) {
+          p.bf16p = 1;
+          p.nsplit = nsplit = 1;
+          p.chunks_per_split = ncc16;
+          p.skip_chunks_per_split = nsk16;
+          int64_t g = t8 < wgs ? ((t8 + 7) & ~(int64_t)7) : wgs;
+          const char* eg = getenv("HOLO_CONV_BF16P_WGS");  // test knob: at most this many persistent workgroups
+          if (eg && atoi(eg) > 0 && atoi(eg) < g) g = atoi(eg);
+          p.grid_x = (int)(g < 8 && !eg ? 8 : g);
+        }
+      }
       if (getenv("HOLO_DEBUG_PLAN"))
-        fprintf(stderr, "[plan] conv %d->%d @%d^3: bf16 wide-tile kernel, %d tiles x %d slices, split-K %d%s\n", Cin, p.Cout,
-                p.OD, p.grid_x, (int)cdiv(p.Cout, bn), nsplit, p.skip_w ? ", fused skip" : "");
+        fprintf(stderr, "[plan] conv %d->%d @%d^3: bf16 wide-tile kernel%s, %d tiles x %d slices, split-K %d%s\n", Cin, p.Cout,
+                p.OD, p.bf16p ? " (persistent, wave-specialised)" : "", (int)(M / 512), (int)cdiv(p.Cout, bn), nsplit,
+                p.skip_w ? ", fused skip" : "");
       return nsplit > 1 ? (size_t)nsplit * M * p.Cout * sizeof(float) : 0;
     }
   }
@@ -2973,7 +2994,9 @@ int conv_launch(const ConvParams& p, void* stream) {
   if (p.mode == 1) {
     dim3 hgrid((unsigned)p.grid_x, (unsigned)cdiv(p.Cout, bn), (unsigned)p.nsplit);
     const bool sk = p.skip_w != nullptr;
-    if (p.bf16t) {
+    if (p.bf16t && p.bf16p) {
+      if (conv_bf16p_launch(p, stream)) return -1;
+    } else if (p.bf16t) {
 #define HOLO_BF16T(NT_, SK_) HOLO_LAUNCH((conv_bf16t_kernel<NT_, SK_, true>), hgrid, block, stream, p)
       if (!p.in_bf16 || (p.residual && !p.res_bf16)) {
         set_error("conv_launch: the wide-tile bf16 kernel runs on bf16 activation storage");

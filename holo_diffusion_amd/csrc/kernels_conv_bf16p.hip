@@ -1,0 +1,547 @@
+// kernels_conv_bf16p.hip — the stride-1 3x3x3 convolutions of the FILLED levels of the bf16 storage mode (128^3, 64^3:
+// BASELINE configs[4], donut.yaml) as a persistent, wave-specialised kernel.  Replaces, like conv_bf16t_kernel
+// (kernels_conv.hip), the Conv3d calls of holo_diffusion/guided_diffusion/unet.py:185,211 (ResBlock), :89 (Upsample conv),
+// :657 / :792 (input / output convolution) with GroupNorm32 * FiLM + SiLU (:183-184,207-208,248-252), nearest x2
+// upsampling (:93-97), the skip concat (:829), the 1x1x1 skip_connection (:222), bias and the residual add (:256) fused.
+//
+// Why another form.  conv_bf16t_kernel gives every wave all three jobs - request the raw halo, activate it, multiply - and
+// relies on the second resident workgroup to cover one wave's vector work with the other's MFMAs.  Measured (rounds 2-5):
+// the matrix pipe is busy 38-48 % of the time; a wave that waits for its halo (in-order vmcnt: the weight requests of the
+// next taps queue behind the halo's) or runs its 500 activation instructions per chunk issues no MFMA, and two workgroups
+// drift into the same phase.  On gfx950 the bf16 MFMA does not use the vector lanes, so the jobs can run side by side if
+// DIFFERENT waves do them:
+//   workgroup = 8 waves, ONE per CU, persistent over (8x8x8-voxel tile, 32*NT-output-channel slice) items;
+//   waves 0-3  CONSUMERS: one per SIMD, 2 z-planes of the tile each = 4 x NT register-blocked 32x32 tiles (the blocking of
+//              conv_bf16t_kernel); their instruction stream is ds_read_b128 (A), global_load_dwordx4 (B, L1/L2-resident
+//              weights, two taps ahead) and v_mfma_f32_32x32x16_bf16 - nothing else inside a chunk;
+//   waves 4-7  PRODUCERS: one per SIMD beside a consumer; they request the raw bf16 halo of the chunk AFTER next (two
+//              register sets), apply GroupNorm * FiLM + SiLU, zero padding, upsampling and the concat to the next chunk and
+//              write it MFMA-ready into the other of two 32 KB LDS halo buffers.
+// One barrier per 16-channel chunk hands a buffer over; the producers run one chunk ahead, across tile boundaries, so a
+// tile's first halo is ready when the consumers leave the previous tile's epilogue.  A fused 1x1x1 skip connection is
+// 32-channel steps of their own: the producers copy the raw 8^3 centre (no halo, no activation) into the same buffers.
+// Halo layout, swizzle, weight layout (w_bft), epilogue (per-wave LDS transposition, 16-byte residual / store, one
+// GroupNorm slab per tile) are conv_bf16t_kernel's; no split-K (the planner picks this kernel only where the tiles fill
+// the chip).
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "holo_common.h"
+#include "holo_kernels.h"
+
+namespace holo {
+namespace {
+
+constexpr int P_H = 10;                 // halo edge of an 8^3 tile
+constexpr int P_HV = P_H * P_H * P_H;   // halo voxels
+constexpr int P_CK = 16;                // channels per chunk = K of one v_mfma_f32_32x32x16_bf16
+constexpr int P_RS = 8;                 // LDS words per halo voxel (16 bf16; the two halves swapped on odd halo rows)
+constexpr int P_IT = 8;                 // staging items (voxel, 8-channel half) per producer thread: 2000 / 256
+constexpr int P_BUF = P_HV * P_RS + 192;  // words per halo buffer (8 192: a skip step's two 4 096-word k-step planes fit)
+constexpr int P_EW = 68;                // words per voxel row of a consumer's transposition tile
+
+__device__ __forceinline__ float silu_fast_p(float v) { return v * holo_rcp(1.0f + __expf(-v)); }
+__device__ __forceinline__ void unpack8(const float4& v, float (&f)[8]) {
+  const uint32_t w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
+  f[0] = __uint_as_float(w0 << 16);
+  f[1] = __uint_as_float(w0 & 0xffff0000u);
+  f[2] = __uint_as_float(w1 << 16);
+  f[3] = __uint_as_float(w1 & 0xffff0000u);
+  f[4] = __uint_as_float(w2 << 16);
+  f[5] = __uint_as_float(w2 & 0xffff0000u);
+  f[6] = __uint_as_float(w3 << 16);
+  f[7] = __uint_as_float(w3 & 0xffff0000u);
+}
+__device__ __forceinline__ float4 pack8(const float (&f)[8]) {
+  return make_float4(__uint_as_float(pack_bf16x2(f[0], f[1])), __uint_as_float(pack_bf16x2(f[2], f[3])),
+                     __uint_as_float(pack_bf16x2(f[4], f[5])), __uint_as_float(pack_bf16x2(f[6], f[7])));
+}
+
+// one staged step of a producer thread: the raw 16-byte pieces in flight + what the commit needs to know about them
+struct Pend {
+  float4 h[P_IT];
+  unsigned mask;  // per item: inside the tensor (main step) / channel exists (skip step)
+  int kind;       // 0 = nothing (the list is exhausted), 1 = main 16-channel chunk, 2 = 32-channel skip step
+  int c;          // main: first channel of this thread's 8-channel half (for the affine coefficients)
+  int n;          // sample
+  int first;      // first step of an item that is not the workgroup's first: the consumers' statistics barrier comes first
+};
+
+template <int NT, bool SKIP>
+__global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
+  constexpr int BN = 32 * NT;
+  __shared__ __attribute__((aligned(16))) float s_halo[2 * P_BUF];
+  __shared__ __attribute__((aligned(16))) float s_ep[4 * 32 * P_EW];
+  __shared__ float s_stat[4 * 8 * 16];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int Cin = p.C0 + p.C1;
+  const int ncc = (Cin + P_CK - 1) / P_CK;
+  const int SCin = SKIP ? p.skip_C0 + p.skip_C1 : 0;
+  const int nsp = SKIP ? (SCin + 31) / 32 : 0;  // skip steps of 32 channels (two k-steps)
+  const int nst = ncc + nsp;                    // steps per item
+  const int ntx = p.OW >> 3, nty = p.OH >> 3, ntz = p.OD >> 3;
+  const int tiles_per_sample = ntx * nty * ntz;
+  const int nslices = (p.Cout + BN - 1) / BN;
+  const int nitems = p.N * tiles_per_sample * nslices;
+  const bool with_stats = p.stats != nullptr;  // (uniform)
+  // item list of this workgroup.  Workgroup b runs on XCD b % 8 (observed; for speed only): every XCD walks one contiguous
+  // range of the item list - neighbouring tiles, whose halos overlap, then meet in one L2.
+  const int G = gridDim.x;
+  int it_first, it_step, it_end;
+  if ((G & 7) == 0) {
+    const int per = (nitems + 7) >> 3;
+    const int x = blockIdx.x & 7;
+    it_first = x * per + (blockIdx.x >> 3);
+    it_step = G >> 3;
+    it_end = min((x + 1) * per, nitems);
+  } else {
+    it_first = blockIdx.x;
+    it_step = G;
+    it_end = nitems;
+  }
+  // item -> (sample, tile origin, slice): slices of one tile are neighbours in the list (they share the halo)
+  auto decode = [&](int item, int& n, int& tz0, int& ty0, int& tx0, int& slice) {
+    slice = item % nslices;
+    int bt = item / nslices;
+    tx0 = (bt % ntx) << 3;
+    bt /= ntx;
+    ty0 = (bt % nty) << 3;
+    bt /= nty;
+    tz0 = (bt % ntz) << 3;
+    n = bt / ntz;
+  };
+
+  if (wave >= 4) {
+    // =============================================== PRODUCERS ===============================================
+    const int ptid = tid - 256;
+    const int hh = ptid & 1;  // main steps: which 8-channel half of the 16-channel chunk
+    const int SD = p.ups ? (p.ID >> 1) : p.ID;
+    const int SH = p.ups ? (p.IH >> 1) : p.IH;
+    const int SW = p.ups ? (p.IW >> 1) : p.IW;
+    // iterator over (item, step) in consumption order
+    int item = it_first, ph = 0;
+    int cn = 0, ctz0 = 0, cty0 = 0, ctx0 = 0, cslice = 0;
+    int hvox[P_IT];
+    unsigned hvalid = 0;
+    bool very_first = true;
+    auto setup_tile = [&]() {
+      decode(item, cn, ctz0, cty0, ctx0, cslice);
+      hvalid = 0;
+#pragma unroll
+      for (int i = 0; i < P_IT; ++i) {
+        const int id = ptid + 256 * i;
+        const int hv = min(id >> 1, P_HV - 1);
+        const int hz = hv / (P_H * P_H);
+        const int rem = hv - hz * (P_H * P_H);
+        const int hy = rem / P_H;
+        const int hx = rem - hy * P_H;
+        int z = ctz0 + hz - 1, y = cty0 + hy - 1, x = ctx0 + hx - 1;
+        const bool ok = z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW && id < 2 * P_HV;
+        z = min(max(z, 0), p.ID - 1);
+        y = min(max(y, 0), p.IH - 1);
+        x = min(max(x, 0), p.IW - 1);
+        if (p.ups) {
+          z >>= 1;
+          y >>= 1;
+          x >>= 1;
+        }
+        hvox[i] = (z * SH + y) * SW + x;
+        hvalid |= (ok ? 1u : 0u) << i;
+      }
+    };
+    if (item < it_end) setup_tile();
+    auto issue = [&](Pend& q) {
+      if (item >= it_end) {
+        q.kind = 0;
+        return;
+      }
+      q.n = cn;
+      q.first = (ph == 0 && !very_first) ? 1 : 0;
+      very_first = false;
+      if (ph < ncc) {  // ---- a 16-channel chunk of the activated 10^3 halo
+        q.kind = 1;
+        int c = ph * P_CK + hh * 8;
+        const bool cvalid = c < Cin;
+        if (!cvalid) c = 0;
+        q.c = c;
+        const float* src = p.src0;
+        int Cs = p.C0, cs = c;
+        if (c >= p.C0) {
+          src = p.src1;
+          Cs = p.C1;
+          cs = c - p.C0;
+        }
+        q.mask = cvalid ? hvalid : 0u;
+        // uniform 64-bit base + one 32-bit byte offset per load (conv_plan keeps a source sample below 4 GB on this path)
+        const char* sbase = reinterpret_cast<const char*>(src) + (int64_t)cn * SD * SH * SW * Cs * 2;
+        const unsigned cbytes = (unsigned)Cs * 2u, cofs = (unsigned)cs * 2u;
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) q.h[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)hvox[i] * cbytes + cofs));
+      } else {  // ---- 32 raw channels of the skip connection's input on the tile's 8^3 centre (output geometry, no halo)
+        q.kind = 2;
+        const int sp = ph - ncc;
+        q.mask = 0;
+        q.c = 0;
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) {
+          const int id = ptid + 256 * i;  // (voxel, 8-channel quarter): 512 x 4
+          const int v = id >> 2, qd = id & 3;
+          int c = sp * 32 + qd * 8;
+          const bool cvalid = c < SCin;
+          if (!cvalid) c = 0;
+          const bool second = c >= p.skip_C0;
+          const uint16_t* src = reinterpret_cast<const uint16_t*>(second ? p.skip_src1 : p.skip_src0);
+          const int Cs = second ? p.skip_C1 : p.skip_C0;
+          const int cs = second ? c - p.skip_C0 : c;
+          const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+          const int64_t vox = (((int64_t)cn * p.OD + ctz0 + vz) * p.OH + cty0 + vy) * p.OW + ctx0 + vx;
+          q.h[i] = *reinterpret_cast<const float4*>(src + vox * Cs + cs);
+          q.mask |= (cvalid ? 1u : 0u) << i;
+        }
+      }
+      if (++ph == nst) {  // the iterator moves on; the next tile's geometry is ready for its first issue
+        ph = 0;
+        item += it_step;
+        if (item < it_end) setup_tile();
+      }
+    };
+    auto commit = [&](const Pend& q, float* buf) {
+      if (q.kind == 1) {
+        const bool xform = p.coef != nullptr;
+        float ca[8], cb[8];
+        if (xform) {
+          const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)q.n * Cin + q.c) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 c = cf[j];  // (a, b) interleaved per channel
+            ca[2 * j] = c.x;
+            cb[2 * j] = c.y;
+            ca[2 * j + 1] = c.z;
+            cb[2 * j + 1] = c.w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) {
+          float f[8];
+          unpack8(q.h[i], f);
+          if (xform) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              f[j] = fmaf(f[j], ca[j], cb[j]);
+              if (p.act) f[j] = silu_fast_p(f[j]);
+            }
+          }
+          const bool keep = (q.mask >> i) & 1u;  // zero padding is applied AFTER the activation
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[j] = keep ? f[j] : 0.f;
+          const int id = ptid + 256 * i;
+          const int hy_par = (((id >> 1) / P_H) % P_H) & 1;  // halo row parity: which slot the voxel's halves go to
+          if (id < 2 * P_HV) *reinterpret_cast<float4*>(buf + (id >> 1) * P_RS + ((hh ^ hy_par) * 4)) = pack8(f);
+        }
+      } else {  // raw copy: [k-step][centre voxel][8 words], the halves swapped on odd y rows like the halo's
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) {
+          const int id = ptid + 256 * i;
+          const int v = id >> 2, qd = id & 3;
+          const int vy = (v >> 3) & 7;
+          const bool keep = (q.mask >> i) & 1u;
+          const float4 val = keep ? q.h[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(buf + (qd >> 1) * 4096 + v * P_RS + (((qd & 1) ^ (vy & 1)) * 4)) = val;
+        }
+      }
+    };
+    Pend PA, PB;
+    issue(PA);
+    issue(PB);
+    int s = 0;
+    while (true) {
+      if (PA.kind == 0) break;
+      commit(PA, s_halo + (s & 1) * P_BUF);
+      if (PA.first && with_stats) __syncthreads();  // (the consumers' statistics hand-over of the previous item)
+      __syncthreads();                              // step s is ready / step s - 1 has been consumed
+      issue(PA);
+      ++s;
+      if (PB.kind == 0) break;
+      commit(PB, s_halo + (s & 1) * P_BUF);
+      if (PB.first && with_stats) __syncthreads();
+      __syncthreads();
+      issue(PB);
+      ++s;
+    }
+    if (with_stats && s > 0) __syncthreads();  // the last item's statistics hand-over
+    return;
+  }
+
+  // =============================================== CONSUMERS ===============================================
+  const int li = lane & 31;  // MFMA row (A) / column (B, D)
+  const int kg = lane >> 5;  // MFMA k-group: channels 8*kg .. 8*kg+7 of the chunk
+  const int ys = li >> 3;
+  // A addressing (conv_bf16t_kernel): MFMA row li of row tile mt of this wave: plane z = 2*wave + (mt>>1), y row 4*(mt&1) + ys,
+  // x = li&7; the lane's 16-byte half sits in slot kg ^ (halo row parity) = kg ^ (ys&1) ^ (kh&1)
+  const int a_vox = (((2 * wave) * P_H + ys) * P_H + (li & 7)) * P_RS;
+  const int a_base0 = a_vox + ((kg ^ (ys & 1)) * 4);      // taps with even kh
+  const int a_base1 = a_vox + ((kg ^ (ys & 1) ^ 1) * 4);  // taps with odd kh
+  auto load_a = [&](float4 (&a)[4], int tap, const float* hb) {
+    const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
+    const int toff = ((kd * P_H + kh) * P_H + kw) * P_RS;
+    const int ab = (kh & 1) ? a_base1 : a_base0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      a[mt] = *reinterpret_cast<const float4*>(hb + ab + ((mt >> 1) * P_H * P_H + 4 * (mt & 1) * P_H) * P_RS + toff);
+  };
+  // skip steps: centre voxel v = ((2*wave + (mt>>1))*8 + 4*(mt&1) + ys)*8 + (li&7), row parity = ys&1
+  const int as_base = (((2 * wave) * 8 + ys) * 8 + (li & 7)) * P_RS + ((kg ^ (ys & 1)) * 4);
+  auto load_a_skip = [&](float4 (&a)[4], int kstep, const float* hb) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      a[mt] = *reinterpret_cast<const float4*>(hb + kstep * 4096 + as_base + ((mt >> 1) * 64 + 4 * (mt & 1) * 8) * P_RS);
+  };
+  // B addressing: 1 KB blocks [tap][16-channel chunk][32-Cout slice], 16 bytes per lane
+  const int nsl = p.CoutP >> 5;
+  const int wncc = p.CinP / P_CK;
+  const float* w_lane = reinterpret_cast<const float*>(p.w_bft) + lane * 4;
+  const float* skw_lane = reinterpret_cast<const float*>(p.skip_w_bft) + lane * 4;
+  // entry e of a step: main step = tap e of chunk idx; skip step = k-step e (< 2) of skip step idx
+  auto bptr = [&](bool skip, int idx, int e, int slice) -> const float* {
+    if (skip) return skw_lane + ((int64_t)(2 * idx + e) * nsl + slice * NT) * 256;
+    return w_lane + (((int64_t)e * wncc + idx) * nsl + slice * NT) * 256;
+  };
+  auto load_b = [&](float4 (&b)[NT], const float* wp) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp + nt * 256);
+  };
+  f32x16 acc[4][NT];
+  auto mfma_tap = [&](const float4 (&a)[4], const float4 (&b)[NT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16_32x32x16(a[mt], b[nt], acc[mt][nt]);
+  };
+
+  float4 A[2][4];
+  float4 B[3][NT];
+  int s = 0;
+  if (it_first < it_end) {  // the first step's first two entries
+    int n_, z_, y_, x_, sl_;
+    decode(it_first, n_, z_, y_, x_, sl_);
+    load_b(B[0], bptr(false, 0, 0, sl_));
+    load_b(B[1], bptr(false, 0, 1, sl_));
+  }
+  for (int item = it_first; item < it_end; item += it_step) {
+    int n, tz0, ty0, tx0, slice;
+    decode(item, n, tz0, ty0, tx0, slice);
+    const int n0 = slice * BN;
+    int nslice = 0;  // the next item's slice (its first weights are requested under this item's last entries)
+    const bool has_next_item = item + it_step < it_end;
+    if (has_next_item) {
+      int n_, z_, y_, x_;
+      decode(item + it_step, n_, z_, y_, x_, nslice);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // the step after (item, st): its first two B entries are requested under this step's last entries
+    auto next_of = [&](int st, bool& nx_valid, bool& nx_skip, int& nx_idx, int& nx_slice) {
+      nx_valid = st + 1 < nst || has_next_item;
+      nx_skip = st + 1 < nst && st + 1 >= ncc;
+      nx_idx = st + 1 < nst ? (nx_skip ? st + 1 - ncc : st + 1) : 0;
+      nx_slice = st + 1 < nst ? slice : nslice;
+    };
+    for (int st = 0; st < ncc; ++st, ++s) {  // ---- 16-channel chunks of the activated halo: 27 taps
+      bool nx_valid, nx_skip;
+      int nx_idx, nx_slice;
+      next_of(st, nx_valid, nx_skip, nx_idx, nx_slice);
+      __syncthreads();  // step s is staged (and the producers may overwrite the buffer of step s - 1)
+      const float* hb = s_halo + (s & 1) * P_BUF;
+      load_a(A[0], 0, hb);
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        if (tap + 1 < 27) load_a(A[(tap + 1) & 1], tap + 1, hb);
+        if (tap + 2 < 27) {
+          load_b(B[(tap + 2) % 3], bptr(false, st, tap + 2, slice));
+        } else if (nx_valid) {
+          load_b(B[(tap + 2) % 3], bptr(nx_skip, nx_idx, tap + 2 - 27, nx_slice));
+        }
+        mfma_tap(A[tap & 1], B[tap % 3]);
+        {  // one operand request behind each MFMA (conv_bf16t_kernel's SCHED = 2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 4 - NT, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (SKIP) {
+      for (int st = ncc; st < nst; ++st, ++s) {  // ---- 32 raw channels of the fused 1x1x1 skip connection: two k-steps
+        bool nx_valid, nx_skip;
+        int nx_idx, nx_slice;
+        next_of(st, nx_valid, nx_skip, nx_idx, nx_slice);
+        __syncthreads();
+        const float* hb = s_halo + (s & 1) * P_BUF;
+        load_a_skip(A[0], 0, hb);
+        load_a_skip(A[1], 1, hb);
+        mfma_tap(A[0], B[0]);
+        if (nx_valid) load_b(B[0], bptr(nx_skip, nx_idx, 0, nx_slice));
+        mfma_tap(A[1], B[1]);
+        if (nx_valid) load_b(B[1], bptr(nx_skip, nx_idx, 1, nx_slice));
+      }
+    }
+
+    // ---- epilogue (conv_bf16t_kernel's): each wave passes one 32-voxel row tile at a time through its own transposition
+    // tile as fp32 [voxel][channel] and leaves with 8 channels of one voxel per lane: bias, residual, GroupNorm statistics
+    // and the store are 16-byte operations.  D layout of 32x32: column = li (Cout), row i = (r&3) + 8*(r>>2) + 4*kg.
+    constexpr int LPV = BN / 8;      // lanes per voxel
+    constexpr int VPP = 64 / LPV;    // voxels per pass
+    constexpr int NPASS = 32 / VPP;
+    static_assert(VPP % 8 == 0, "a pass covers whole x rows of the tile (uniform per-pass output offsets)");
+    float* ep = s_ep + wave * (32 * P_EW);
+    const int ch8 = (lane % LPV) * 8;
+    const bool cvalid = n0 + ch8 < p.Cout;
+    const int co8 = cvalid ? n0 + ch8 : 0;
+    float bv[8], es[8], eq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = es[e] = eq[e] = 0.f;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co8), b1 = *reinterpret_cast<const float4*>(p.bias + co8 + 4);
+      bv[0] = b0.x, bv[1] = b0.y, bv[2] = b0.z, bv[3] = b0.w, bv[4] = b1.x, bv[5] = b1.y, bv[6] = b1.z, bv[7] = b1.w;
+    }
+    if (SKIP && p.skip_bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.skip_bias + co8), b1 = *reinterpret_cast<const float4*>(p.skip_bias + co8 + 4);
+      bv[0] += b0.x, bv[1] += b0.y, bv[2] += b0.z, bv[3] += b0.w, bv[4] += b1.x, bv[5] += b1.y, bv[6] += b1.z, bv[7] += b1.w;
+    }
+    const int i0 = lane / LPV;
+    // (32-bit lane part: conv_plan keeps an output sample below 4 GB on this path; the sample base and the pass offset are scalars)
+    const unsigned obase = (unsigned)((((tz0 + 2 * wave) * p.OH + ty0 + (i0 >> 3)) * p.OW + tx0 + (i0 & 7)) * p.Cout + co8);
+    const int64_t nbase = (int64_t)n * p.OD * p.OH * p.OW * p.Cout;
+    auto uoff = [&](int mt, int ps) {
+      return nbase + (int64_t)(((mt >> 1) * p.OH + 4 * (mt & 1) + ((ps * VPP) >> 3)) * p.OW) * p.Cout;
+    };
+    // the residual of TWO row tiles is in flight at any time (all four at once pushed the epilogue into scratch memory)
+    float4 res_q[2][NPASS];
+    const bool with_res = p.residual != nullptr;  // (uniform)
+    auto res_load = [&](int mt) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+        res_q[mt & 1][ps] = *reinterpret_cast<const float4*>(reinterpret_cast<const uint16_t*>(p.residual) + uoff(mt, ps) + obase);
+    };
+    if (with_res) {
+      res_load(0);
+      res_load(1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * kg) * P_EW + nt * 32 + li] = acc[mt][nt][r];
+      HOLO_WAVE_SYNC();  // (the transposition tile is private to the wave)
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int64_t o = uoff(mt, ps) + obase;
+        const int i = ps * VPP + lane / LPV;
+        const float4 v0 = *reinterpret_cast<const float4*>(ep + i * P_EW + ch8);
+        const float4 v1 = *reinterpret_cast<const float4*>(ep + i * P_EW + ch8 + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (with_res) {
+          float rf[8];
+          unpack8(res_q[mt & 1][ps], rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] += bv[e];
+          es[e] += v[e];
+          eq[e] += v[e] * v[e];
+        }
+        if (cvalid) {
+          if (p.out_bf16) {
+            *reinterpret_cast<float4*>(reinterpret_cast<uint16_t*>(p.out) + o) = pack8(v);
+          } else {
+            *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.out + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          }
+        }
+      }
+      if (with_res && mt + 2 < 4) res_load(mt + 2);
+      HOLO_WAVE_SYNC();  // the tile is overwritten by the next row tile
+    }
+    // GroupNorm statistics of the tensor just produced: one slab per tile (512 voxels) -> stats[n][tile][Cout][2]; the four
+    // waves' sums meet in LDS in a fixed order (deterministic).  One barrier of the whole workgroup (the producers take part
+    // in it in front of the next item's first hand-over).
+    if (with_stats) {
+      const int slab = (item / nslices) % tiles_per_sample;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int m = LPV; m < 64; m <<= 1) {
+          es[e] += __shfl_xor(es[e], m);
+          eq[e] += __shfl_xor(eq[e], m);
+        }
+      }
+      if (lane < LPV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s_stat[(wave * LPV + lane) * 16 + e] = es[e];
+          s_stat[(wave * LPV + lane) * 16 + 8 + e] = eq[e];
+        }
+      }
+      __syncthreads();
+      if (wave == 0 && lane < LPV && cvalid) {
+        double* d = p.stats + (((int64_t)n * tiles_per_sample + slab) * p.Cout + co8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            s1 += s_stat[(w * LPV + lane) * 16 + e];
+            s2 += s_stat[(w * LPV + lane) * 16 + 8 + e];
+          }
+          d[2 * e] = (double)s1;
+          d[2 * e + 1] = (double)s2;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Launch of the persistent wave-specialised kernel: p.grid_x workgroups of 512 threads (conv_plan: one per CU, a multiple of 8).
+int conv_bf16p_launch(const ConvParams& p, void* stream) {
+  if (!p.in_bf16 || (p.residual && !p.res_bf16) || p.nsplit != 1 || !p.w_bft || (p.skip_w && !p.skip_w_bft)) {
+    set_error("conv_bf16p_launch: bf16 activation storage, prepared wide-tile weights, no split-K");
+    return -1;
+  }
+  const dim3 grid((unsigned)p.grid_x), block(512);
+  const bool sk = p.skip_w != nullptr;
+  if (p.Cout < 64) {
+    if (sk) {
+      set_error("conv_bf16p_launch: a fused skip needs Cout >= 64");
+      return -1;
+    }
+    HOLO_LAUNCH((conv_bf16p_kernel<1, false>), grid, block, stream, p);
+  } else if (sk) {
+    HOLO_LAUNCH((conv_bf16p_kernel<2, true>), grid, block, stream, p);
+  } else {
+    HOLO_LAUNCH((conv_bf16p_kernel<2, false>), grid, block, stream, p);
+  }
+  return 0;
+}
+
+}  // namespace holo

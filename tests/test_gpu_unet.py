@@ -26,7 +26,7 @@ def gu():
 
 def test_native_library_loaded():
     lib = runtime.lib()
-    assert lib.holo_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.holo_abi_version() == _lib.ABI_VERSION == 6
     assert os.path.basename(_lib.LIB_PATH) == "libholo_mi355x.so"
 
 
@@ -410,14 +410,19 @@ def test_bf16_flash_attention_vs_oracle(gu, image, mc, mult, attn, monkeypatch):
     assert 1e-5 < err < 2e-2, err
 
 
-@pytest.mark.parametrize("wide_tile", ["0", "1"])
+@pytest.mark.parametrize("wide_tile", ["0", "1", "p"])
 def test_bf16_storage_mode_blockwise(gu, wide_tile, monkeypatch):
     """bf16 mode = bf16 activations in HBM: every block output (read back from the bf16 workspace) against the fp32
-    oracle at the bf16 tolerance, once on the 64/128-voxel bf16 halo kernels and once with the wide-tile kernel
+    oracle at the bf16 tolerance, once on the 64/128-voxel bf16 halo kernels, once with the wide-tile kernel
     (8x8x8 tiles, fused skip from global operands, LDS-transposed epilogue, per-tile GroupNorm slabs) forced onto this
-    small grid."""
+    small grid, and once ("p") with its persistent wave-specialised form (conv_bf16p_kernel: producer waves stage the
+    activated halo and the raw centre of a fused skip into two LDS buffers, consumer waves multiply; several tiles per
+    workgroup, the 128-output-channel launches as two slices per tile) forced onto it."""
     monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
-    monkeypatch.setenv("HOLO_CONV_BF16T", wide_tile)
+    monkeypatch.setenv("HOLO_CONV_BF16T", "1" if wide_tile == "p" else wide_tile)
+    monkeypatch.setenv("HOLO_CONV_BF16P", "1" if wide_tile == "p" else "0")
+    if wide_tile == "p":
+        monkeypatch.setenv("HOLO_CONV_BF16P_WGS", "8")  # (8 workgroups: the 16^3 level's 2 x 8 tiles are two items per workgroup)
     cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2,
                      channel_mult=(1, 2, 2), attention_resolutions=(4,), num_heads=2)
     net, sd = gu.make_unet(cfg, seed=99, compute_dtype="bf16")
@@ -434,6 +439,7 @@ def test_bf16_storage_mode_blockwise(gu, wide_tile, monkeypatch):
             assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 2e-2, tag
     kernels = {o.get("kernel") for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv"}
     assert ("conv_bf16t_kernel" in kernels) == (wide_tile == "1"), kernels
+    assert ("conv_bf16p_kernel" in kernels) == (wide_tile == "p"), kernels
 
 
 @pytest.mark.parametrize("image,mc,mult,attn,batch", [(8, 64, (1, 2), (2,), 1), (16, 64, (1, 2, 2), (4,), 2)])
