@@ -543,7 +543,8 @@ def main():
     if rank == 0:
         all_ops = net.time_ops(1, args.conv_iters, device)
         ops = [o for o in all_ops if o["op"] == "conv" and o["ksz"] == 3]
-        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_bf16t_kernel", "conv_wino3_kernel")
+        HALO = ("conv_halo_kernel", "conv_wino_kernel", "conv_wino2_kernel", "conv_bf16t_kernel", "conv_wino3_kernel",
+                "conv_bf16p_kernel")
         variants = {}
         for o in ops:
             key = (o["kernel"], o["tile_depth"], o["fused_skip"], o["out_dim"], 4 if o["cout"] >= 64 else 2) \
@@ -580,6 +581,11 @@ def main():
             label = f"{kname}<{2 if nwn == 4 else 1}, {'true' if sk else 'false'}, true> at {od}^3 output"
             what = ("3x3x3 conv3d on bf16 activations, 8x8x8 output tiles, LDS voxel-halo implicit GEMM, "
                     "v_mfma_f32_32x32x16_bf16 with 4x2 register blocking")
+        elif kname == "conv_bf16p_kernel":
+            label = f"{kname}<{2 if nwn == 4 else 1}, {'true' if sk else 'false'}> at {od}^3 output"
+            what = ("3x3x3 conv3d on bf16 activations, 8x8x8 output tiles, persistent wave-specialised workgroups (4 producer waves "
+                    "stage the activated halo into two LDS buffers, 4 consumer waves run v_mfma_f32_32x32x16_bf16 with 4x2 "
+                    "register blocking)")
         else:
             label, what = kname, "conv3d"
         traffic = None

@@ -2846,7 +2846,8 @@ size_t conv_plan(ConvParams& p, int num_cus) {
           p.nsplit = nsplit = 1;
           p.chunks_per_split = ncc16;
           p.skip_chunks_per_split = nsk16;
-          int64_t g = t8 < wgs ? ((t8 + 7) & ~(int64_t)7) : wgs;
+          const int64_t wcap = wgs >= 8 ? wgs : 8;
+          int64_t g = t8 < wcap ? ((t8 + 7) & ~(int64_t)7) : wcap;
           const char* eg = getenv("HOLO_CONV_BF16P_WGS");  // test knob: at most this many persistent workgroups
           if (eg && atoi(eg) > 0 && atoi(eg) < g) g = atoi(eg);
           p.grid_x = (int)(g < 8 && !eg ? 8 : g);

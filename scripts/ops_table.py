@@ -7,7 +7,7 @@ def load(fn):
         if not l.startswith('# op'): continue
         o = json.loads(l[5:]); tot += o['ms']
         if o['op'] == 'conv':
-            key = f"conv{o['ksz']} {o['kernel'][5:10]} cin{o['cin']} cout{o['cout']} od{o['out_dim']} s{o['stride']}u{int(o['upsample'])} sk{int(o['fused_skip'])}"
+            key = f"conv{o['ksz']} {o['kernel'][5:11]} cin{o['cin']} cout{o['cout']} od{o['out_dim']} s{o['stride']}u{int(o['upsample'])} sk{int(o['fused_skip'])}"
         else:
             key = f"{o['op']} {o['cin']} {o['cout']} {o['out_dim']}"
         a = agg.setdefault(key, [0, 0.0, 0.0]); a[0] += 1; a[1] += o['ms']; a[2] += o['flops']
