@@ -159,6 +159,7 @@ int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);
 int ncdhw_to_ndhwc_launch(const float* in, float* out, int N, int C, int64_t V, int tanh_flag, void* stream,
                           int out_bf16 = 0);  // out_bf16 / in_bf16 / x_bf16: the channels-last tensor is bf16
 int ndhwc_to_ncdhw_launch(const float* in, float* out, int N, int C, int64_t V, void* stream, int in_bf16 = 0);
+int f32_to_bf16_launch(const float* in, float* out_bf16, int64_t n, void* stream);  // element-wise, n % 8 == 0
 
 // GroupNorm statistics, stage 1: partial[n][b][c] = (sum, sumsq) in double over voxel slab b (deterministic,
 // no atomics).  gn_stats_geometry gives the slab count B(C, V) the buffers must be sized for.

@@ -2841,7 +2841,9 @@ size_t conv_plan(ConvParams& p, int num_cus) {
         const bool force = ep && ep[0] == '1';
         const int wgs = num_cus & ~7;
         if (!(ep && ep[0] == '0') && ((nsplit == 1 && wgs >= 8 && t8 >= wgs) || force) &&
-            (!p.skip_w || (((p.skip_C0 + p.skip_C1) % 32) == 0 && (p.skip_C0 % 8) == 0))) {
+            (p.C1 == 0 || (p.C0 % 16) == 0) &&  // (a 16-channel chunk / a 32-channel skip step lies in ONE source)
+            (!p.skip_w || (((p.skip_C0 + p.skip_C1) % 32) == 0 && (p.skip_C1 == 0 || (p.skip_C0 % 32) == 0))) &&
+            (int64_t)p.ID * p.IH * p.IW < ((int64_t)1 << 24)) {  // (24-bit voxel indices in the producers' address arithmetic)
           p.bf16p = 1;
           p.nsplit = nsplit = 1;
           p.chunks_per_split = ncc16;

@@ -29,6 +29,20 @@
 #include "holo_common.h"
 #include "holo_kernels.h"
 
+// Development probes (tools/bf16p_probe.cpp compiles copies of this file with them; never set in the library build):
+//   P_PROBE bits: 1 consumers request no weights, 2 consumers read no A operands, 4 producers stage nothing (barriers only),
+//                 8 no MFMAs, 16 producers skip the activation arithmetic, 32 consumers take their weights from LDS (garbage
+//                 contents), 64 producers also copy a step's 54 KB of weights into that LDS region (unsynchronised), 128 producers
+//                 load but write nothing, 256 producers write (and compute) but load nothing
+//   P_TIMELINE:   p.dbg[workgroup][8] = wall-clock ticks (10 ns) of consumer wave 0 {barrier wait, tap loops, epilogue, steps,
+//                 items} and of producer wave 4 {issue + commit, barrier wait}
+#ifndef P_PROBE
+#define P_PROBE 0
+#endif
+#ifndef P_ENTRY
+#define P_ENTRY conv_bf16p_launch
+#endif
+
 namespace holo {
 namespace {
 
@@ -57,10 +71,40 @@ __device__ __forceinline__ float4 pack8(const float (&f)[8]) {
                      __uint_as_float(pack_bf16x2(f[4], f[5])), __uint_as_float(pack_bf16x2(f[6], f[7])));
 }
 
+// Buffer addressing of the producers' sources: scalar resource (base of the step's source / sample / chunk) + one 32-bit byte
+// offset per item; an offset beyond the resource's range (~0) reads zeros.  A source sample must lie within 4 GB (conv_plan).
+#ifdef HOLO_EMU
+struct pb_rsrc {
+  const char* base;
+};
+static inline pb_rsrc pb_make_rsrc(const void* p) { return pb_rsrc{reinterpret_cast<const char*>(p)}; }
+static inline float4 pb_load(const pb_rsrc& r, unsigned voff) {
+  if (voff >= 0xfffffff0u) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return *reinterpret_cast<const float4*>(r.base + (size_t)voff);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t pb_rsrc;
+typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pb_rsrc pb_make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xfffffff0, 0x00020000);
+}
+__device__ __forceinline__ float4 pb_load(pb_rsrc r, unsigned voff) {
+  const pb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#endif
+
+// a * b + c for a, b < 2^24 (voxel indices x bytes per voxel): v_mad_u32_u24, full rate (the 32-bit multiply is quarter rate)
+#ifdef HOLO_EMU
+static inline unsigned pb_mad24(unsigned a, unsigned b, unsigned c) { return a * b + c; }
+#else
+__device__ __forceinline__ unsigned pb_mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+#endif
+
 // one staged step of a producer thread: the raw 16-byte pieces in flight + what the commit needs to know about them
 struct Pend {
   float4 h[P_IT];
-  unsigned mask;  // per item: inside the tensor (main step) / channel exists (skip step)
+  unsigned mask;  // main step: per item, the voxel lies inside the tensor
   int kind;       // 0 = nothing (the list is exhausted), 1 = main 16-channel chunk, 2 = 32-channel skip step
   int c;          // main: first channel of this thread's 8-channel half (for the affine coefficients)
   int n;          // sample
@@ -73,6 +117,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
   __shared__ __attribute__((aligned(16))) float s_halo[2 * P_BUF];
   __shared__ __attribute__((aligned(16))) float s_ep[4 * 32 * P_EW];
   __shared__ float s_stat[4 * 8 * 16];
+#if P_PROBE & 32  // (probe: the weights of a step in LDS - garbage contents, timing only)
+  __shared__ __attribute__((aligned(16))) float s_bw[27 * 512];
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,15 +163,41 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
 
   if (wave >= 4) {
     // =============================================== PRODUCERS ===============================================
+    // Everything here is written for a LOW INSTRUCTION COUNT: the producers share their SIMD's issue port with a consumer
+    // that wants to issue an MFMA every 32 cycles (the first form of this section took ~1 400 - 2 400 instructions per step
+    // and wave - 64-bit per-lane address arithmetic, eight selects per item - and cost the consumers 35 % of their time:
+    // tools/bf16p_probe).  Sources are addressed through buffer resources (scalar base per step, one 32-bit offset per
+    // item; an offset of ~0 reads zeros), per-thread geometry is computed once per kernel / tile, the arithmetic is packed.
     const int ptid = tid - 256;
     const int hh = ptid & 1;  // main steps: which 8-channel half of the 16-channel chunk
     const int SD = p.ups ? (p.ID >> 1) : p.ID;
     const int SH = p.ups ? (p.IH >> 1) : p.IH;
     const int SW = p.ups ? (p.IW >> 1) : p.IW;
+    // ---- per-thread constants of its P_IT items.  Main steps: item id = ptid + 256 i = (halo voxel id >> 1, half id & 1);
+    // skip steps: id = (centre voxel id >> 2, 8-channel quarter id & 3)
+    int hzyx[P_IT], lds_off[P_IT], slds_off[P_IT];
+    unsigned svoff[P_IT];
+    unsigned live = 0;  // main items that exist (2 000 of 2 048)
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int id = ptid + 256 * i;
+      const int hv = min(id >> 1, P_HV - 1);
+      const int hz = hv / (P_H * P_H);
+      const int rem = hv - hz * (P_H * P_H);
+      const int hy = rem / P_H;
+      const int hx = rem - hy * P_H;
+      hzyx[i] = hz | (hy << 8) | (hx << 16);
+      lds_off[i] = hv * P_RS + ((hh ^ (hy & 1)) * 4);  // the voxel's halves swapped on odd halo rows
+      live |= (id < 2 * P_HV ? 1u : 0u) << i;
+      const int v = id >> 2, qd = id & 3;
+      const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
+      slds_off[i] = (qd >> 1) * 4096 + v * P_RS + (((qd & 1) ^ (vy & 1)) * 4);
+      svoff[i] = (unsigned)((vz * p.OH + vy) * p.OW + vx);  // x (channels of the source * 2) + qd * 16 at issue time
+    }
     // iterator over (item, step) in consumption order
     int item = it_first, ph = 0;
     int cn = 0, ctz0 = 0, cty0 = 0, ctx0 = 0, cslice = 0;
-    int hvox[P_IT];
+    unsigned hvox[P_IT];
     unsigned hvalid = 0;
     bool very_first = true;
     auto setup_tile = [&]() {
@@ -132,14 +205,8 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       hvalid = 0;
 #pragma unroll
       for (int i = 0; i < P_IT; ++i) {
-        const int id = ptid + 256 * i;
-        const int hv = min(id >> 1, P_HV - 1);
-        const int hz = hv / (P_H * P_H);
-        const int rem = hv - hz * (P_H * P_H);
-        const int hy = rem / P_H;
-        const int hx = rem - hy * P_H;
-        int z = ctz0 + hz - 1, y = cty0 + hy - 1, x = ctx0 + hx - 1;
-        const bool ok = z >= 0 && z < p.ID && y >= 0 && y < p.IH && x >= 0 && x < p.IW && id < 2 * P_HV;
+        int z = ctz0 + (hzyx[i] & 0xff) - 1, y = cty0 + ((hzyx[i] >> 8) & 0xff) - 1, x = ctx0 + (hzyx[i] >> 16) - 1;
+        const bool ok = (unsigned)z < (unsigned)p.ID && (unsigned)y < (unsigned)p.IH && (unsigned)x < (unsigned)p.IW;
         z = min(max(z, 0), p.ID - 1);
         y = min(max(y, 0), p.IH - 1);
         x = min(max(x, 0), p.IW - 1);
@@ -148,9 +215,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
           y >>= 1;
           x >>= 1;
         }
-        hvox[i] = (z * SH + y) * SW + x;
+        hvox[i] = (unsigned)((z * SH + y) * SW + x);
         hvalid |= (ok ? 1u : 0u) << i;
       }
+      hvalid &= live;
     };
     if (item < it_end) setup_tile();
     auto issue = [&](Pend& q) {
@@ -158,49 +226,47 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         q.kind = 0;
         return;
       }
-      q.n = cn;
       q.first = (ph == 0 && !very_first) ? 1 : 0;
       very_first = false;
-      if (ph < ncc) {  // ---- a 16-channel chunk of the activated 10^3 halo
+      if (P_PROBE & 4) {  // (probe: the step list without its loads)
+        q.kind = 3;
+      } else if (ph < ncc) {  // ---- a 16-channel chunk of the 10^3 halo.  A chunk lies in ONE source (conv_plan: C0 % 16 == 0)
         q.kind = 1;
-        int c = ph * P_CK + hh * 8;
-        const bool cvalid = c < Cin;
-        if (!cvalid) c = 0;
-        q.c = c;
-        const float* src = p.src0;
-        int Cs = p.C0, cs = c;
-        if (c >= p.C0) {
-          src = p.src1;
-          Cs = p.C1;
-          cs = c - p.C0;
-        }
-        q.mask = cvalid ? hvalid : 0u;
-        // uniform 64-bit base + one 32-bit byte offset per load (conv_plan keeps a source sample below 4 GB on this path)
-        const char* sbase = reinterpret_cast<const char*>(src) + (int64_t)cn * SD * SH * SW * Cs * 2;
-        const unsigned cbytes = (unsigned)Cs * 2u, cofs = (unsigned)cs * 2u;
-#pragma unroll
-        for (int i = 0; i < P_IT; ++i) q.h[i] = *reinterpret_cast<const float4*>(sbase + ((unsigned)hvox[i] * cbytes + cofs));
-      } else {  // ---- 32 raw channels of the skip connection's input on the tile's 8^3 centre (output geometry, no halo)
-        q.kind = 2;
-        const int sp = ph - ncc;
-        q.mask = 0;
-        q.c = 0;
+        q.n = cn;
+        const int c0 = ph * P_CK;
+        q.c = c0 + hh * 8;
+        const bool second = c0 >= p.C0;  // (uniform)
+        const int Cs = second ? p.C1 : p.C0;
+        const char* sb = reinterpret_cast<const char*>(second ? p.src1 : p.src0) +
+                         ((int64_t)cn * SD * SH * SW * Cs + (second ? c0 - p.C0 : c0)) * 2;
+        const pb_rsrc rs = pb_make_rsrc(sb);
+        const unsigned cbytes = (unsigned)Cs * 2u, hoff = (unsigned)hh * 16u;
+        // raw copies (no affine, no activation) read zeros for the padding through an out-of-range offset; activated chunks
+        // read a clamped neighbour and are zeroed AFTER the activation (commit)
+        const bool raw = p.coef == nullptr;
+        q.mask = hvalid;
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
-          const int id = ptid + 256 * i;  // (voxel, 8-channel quarter): 512 x 4
-          const int v = id >> 2, qd = id & 3;
-          int c = sp * 32 + qd * 8;
-          const bool cvalid = c < SCin;
-          if (!cvalid) c = 0;
-          const bool second = c >= p.skip_C0;
-          const uint16_t* src = reinterpret_cast<const uint16_t*>(second ? p.skip_src1 : p.skip_src0);
-          const int Cs = second ? p.skip_C1 : p.skip_C0;
-          const int cs = second ? c - p.skip_C0 : c;
-          const int vz = v >> 6, vy = (v >> 3) & 7, vx = v & 7;
-          const int64_t vox = (((int64_t)cn * p.OD + ctz0 + vz) * p.OH + cty0 + vy) * p.OW + ctx0 + vx;
-          q.h[i] = *reinterpret_cast<const float4*>(src + vox * Cs + cs);
-          q.mask |= (cvalid ? 1u : 0u) << i;
+          unsigned off = pb_mad24(hvox[i], cbytes, hoff);
+          if (raw && !((hvalid >> i) & 1u)) off = 0xffffffffu;
+          if (P_PROBE & 256) {  // (probe: no loads, the LDS writes and the arithmetic stay)
+            q.h[i] = make_float4(__uint_as_float(off), 0.f, 0.f, 0.f);
+          } else {
+            q.h[i] = pb_load(rs, off);
+          }
         }
+      } else {  // ---- 32 raw channels of the skip connection's input on the tile's 8^3 centre (one source: skip_C0 % 32 == 0)
+        q.kind = 2;
+        const int c0 = (ph - ncc) * 32;
+        const bool second = c0 >= p.skip_C0;  // (uniform)
+        const int Cs = second ? p.skip_C1 : p.skip_C0;
+        const int64_t org = (((int64_t)cn * p.OD + ctz0) * p.OH + cty0) * p.OW + ctx0;
+        const char* sb = reinterpret_cast<const char*>(second ? p.skip_src1 : p.skip_src0) +
+                         (org * Cs + (second ? c0 - p.skip_C0 : c0)) * 2;
+        const pb_rsrc rs = pb_make_rsrc(sb);
+        const unsigned cbytes = (unsigned)Cs * 2u, qoff = (unsigned)(ptid & 3) * 16u;
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) q.h[i] = pb_load(rs, pb_mad24(svoff[i], cbytes, qoff));
       }
       if (++ph == nst) {  // the iterator moves on; the next tile's geometry is ready for its first issue
         ph = 0;
@@ -209,69 +275,112 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       }
     };
     auto commit = [&](const Pend& q, float* buf) {
+      if (P_PROBE & 128) {  // (probe: the loads are waited for, nothing is written)
+        float acc_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) acc_ += q.h[i].x;
+        if (acc_ == 1.2345e-30f) buf[0] = acc_;
+        return;
+      }
       if (q.kind == 1) {
-        const bool xform = p.coef != nullptr;
-        float ca[8], cb[8];
-        if (xform) {
+        if (p.coef == nullptr) {  // raw: bf16 in, bf16 out (the padding already reads as zero)
+#pragma unroll
+          for (int i = 0; i < P_IT; ++i)
+            if ((live >> i) & 1u) *reinterpret_cast<float4*>(buf + lds_off[i]) = q.h[i];
+          return;
+        }
+        f32x2 ca[4], cb[4];
+        {
           const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)q.n * Cin + q.c) * 2);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float4 c = cf[j];  // (a, b) interleaved per channel
-            ca[2 * j] = c.x;
-            cb[2 * j] = c.y;
-            ca[2 * j + 1] = c.z;
-            cb[2 * j + 1] = c.w;
+            ca[j] = f32x2{c.x, c.z};
+            cb[j] = f32x2{c.y, c.w};
           }
         }
+        const bool act = p.act != 0 && !(P_PROBE & 16);
+        const bool boundary = q.mask != live;  // (zero padding only where the tile touches the tensor's faces)
+        const f32x2 nl2e = f32x2{-1.4426950408889634f, -1.4426950408889634f}, one = f32x2{1.f, 1.f};
 #pragma unroll
         for (int i = 0; i < P_IT; ++i) {
-          float f[8];
-          unpack8(q.h[i], f);
-          if (xform) {
+          const uint32_t w[4] = {__float_as_uint(q.h[i].x), __float_as_uint(q.h[i].y), __float_as_uint(q.h[i].z),
+                                 __float_as_uint(q.h[i].w)};
+          uint32_t o[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              f[j] = fmaf(f[j], ca[j], cb[j]);
-              if (p.act) f[j] = silu_fast_p(f[j]);
+          for (int j = 0; j < 4; ++j) {
+            f32x2 v = f32x2{__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xffff0000u)};
+            v = pk_fma(v, ca[j], cb[j]);
+            if (act) {  // SiLU: v * rcp(1 + exp2(-v log2 e)), packed where the unit has a packed form
+              f32x2 t = pk_mul(v, nl2e);
+              t = f32x2{holo_exp2(t.x), holo_exp2(t.y)};
+              t = pk_add(t, one);
+              t = f32x2{holo_rcp(t.x), holo_rcp(t.y)};
+              v = pk_mul(v, t);
             }
+            o[j] = pack_bf16x2(v.x, v.y);
           }
-          const bool keep = (q.mask >> i) & 1u;  // zero padding is applied AFTER the activation
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f[j] = keep ? f[j] : 0.f;
-          const int id = ptid + 256 * i;
-          const int hy_par = (((id >> 1) / P_H) % P_H) & 1;  // halo row parity: which slot the voxel's halves go to
-          if (id < 2 * P_HV) *reinterpret_cast<float4*>(buf + (id >> 1) * P_RS + ((hh ^ hy_par) * 4)) = pack8(f);
+          if (boundary && !((q.mask >> i) & 1u)) o[0] = o[1] = o[2] = o[3] = 0u;  // zero padding AFTER the activation
+          if ((live >> i) & 1u)
+            *reinterpret_cast<float4*>(buf + lds_off[i]) =
+                make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]), __uint_as_float(o[3]));
         }
-      } else {  // raw copy: [k-step][centre voxel][8 words], the halves swapped on odd y rows like the halo's
+      } else if (q.kind == 2) {  // raw copy: [k-step][centre voxel][8 words], the halves swapped on odd y rows like the halo's
 #pragma unroll
-        for (int i = 0; i < P_IT; ++i) {
-          const int id = ptid + 256 * i;
-          const int v = id >> 2, qd = id & 3;
-          const int vy = (v >> 3) & 7;
-          const bool keep = (q.mask >> i) & 1u;
-          const float4 val = keep ? q.h[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-          *reinterpret_cast<float4*>(buf + (qd >> 1) * 4096 + v * P_RS + (((qd & 1) ^ (vy & 1)) * 4)) = val;
-        }
+        for (int i = 0; i < P_IT; ++i) *reinterpret_cast<float4*>(buf + slds_off[i]) = q.h[i];
       }
     };
+#ifdef P_TIMELINE
+    unsigned long long pt_work = 0, pt_wait = 0, pt0 = HOLO_PROBE_CLOCK(), pt1;
+#define P_TL_PROD_BAR()                 \
+  pt1 = HOLO_PROBE_CLOCK();             \
+  pt_work += pt1 - pt0;                 \
+  __syncthreads();                      \
+  pt0 = HOLO_PROBE_CLOCK();             \
+  pt_wait += pt0 - pt1
+#else
+#define P_TL_PROD_BAR() __syncthreads()
+#endif
+#if P_PROBE & 64  // (probe: the producers also bring a step's 54 KB of weights into LDS - unsynchronised, timing only)
+#define P_PROBE_WEIGHTS()                                                                                      \
+  {                                                                                                            \
+    const float* wsrc = reinterpret_cast<const float*>(p.w_bft) + (int64_t)(s % ncc) * 512 + ptid * 4;         \
+    float4 wv[14];                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 14; ++i) wv[i] =                                                     \
+        *reinterpret_cast<const float4*>(wsrc + (int64_t)(i * 2 % 27) * (p.CinP / 16) * (p.CoutP >> 5) * 256 + (i & 1) * 1024); \
+    _Pragma("unroll") for (int i = 0; i < 14; ++i) if (i * 1024 + ptid * 4 < 27 * 512)                         \
+        *reinterpret_cast<float4*>(s_bw + i * 1024 + ptid * 4) = wv[i];                                        \
+  }
+#else
+#define P_PROBE_WEIGHTS()
+#endif
     Pend PA, PB;
     issue(PA);
     issue(PB);
     int s = 0;
     while (true) {
       if (PA.kind == 0) break;
+      P_PROBE_WEIGHTS();
       commit(PA, s_halo + (s & 1) * P_BUF);
       if (PA.first && with_stats) __syncthreads();  // (the consumers' statistics hand-over of the previous item)
-      __syncthreads();                              // step s is ready / step s - 1 has been consumed
+      P_TL_PROD_BAR();                              // step s is ready / step s - 1 has been consumed
       issue(PA);
       ++s;
       if (PB.kind == 0) break;
+      P_PROBE_WEIGHTS();
       commit(PB, s_halo + (s & 1) * P_BUF);
       if (PB.first && with_stats) __syncthreads();
-      __syncthreads();
+      P_TL_PROD_BAR();
       issue(PB);
       ++s;
     }
     if (with_stats && s > 0) __syncthreads();  // the last item's statistics hand-over
+#ifdef P_TIMELINE
+    if (p.dbg && tid == 256) {
+      p.dbg[(int64_t)blockIdx.x * 8 + 5] = pt_work;
+      p.dbg[(int64_t)blockIdx.x * 8 + 6] = pt_wait;
+    }
+#endif
     return;
   }
 
@@ -285,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
   const int a_base0 = a_vox + ((kg ^ (ys & 1)) * 4);      // taps with even kh
   const int a_base1 = a_vox + ((kg ^ (ys & 1) ^ 1) * 4);  // taps with odd kh
   auto load_a = [&](float4 (&a)[4], int tap, const float* hb) {
+    if (P_PROBE & 2) return;
     const int kd = tap / 9, kh = (tap - kd * 9) / 3, kw = tap - kd * 9 - kh * 3;
     const int toff = ((kd * P_H + kh) * P_H + kw) * P_RS;
     const int ab = (kh & 1) ? a_base1 : a_base0;
@@ -310,11 +420,27 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     return w_lane + (((int64_t)e * wncc + idx) * nsl + slice * NT) * 256;
   };
   auto load_b = [&](float4 (&b)[NT], const float* wp) {
+    if (P_PROBE & 1) return;
+#if P_PROBE & 32
+    {
+      const float* lb = s_bw + (((uintptr_t)wp >> 11) % 27) * 512 + lane * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(lb + nt * 256);
+      return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp + nt * 256);
   };
   f32x16 acc[4][NT];
   auto mfma_tap = [&](const float4 (&a)[4], const float4 (&b)[NT]) {
+    if (P_PROBE & 8) {  // (probe: the operands are kept alive, nothing is multiplied)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt][0] += a[mt].x + b[nt].x;
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -323,6 +449,19 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
 
   float4 A[2][4];
   float4 B[3][NT];
+  if (P_PROBE & 3) {  // (probes: the operands nobody loads hold something harmless)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) A[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) B[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#ifdef P_TIMELINE
+  unsigned long long ct_wait = 0, ct_loop = 0, ct_epi = 0, ct_steps = 0, ct_items = 0, ct0, ct1;
+#endif
   int s = 0;
   if (it_first < it_end) {  // the first step's first two entries
     int n_, z_, y_, x_, sl_;
@@ -358,7 +497,14 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       bool nx_valid, nx_skip;
       int nx_idx, nx_slice;
       next_of(st, nx_valid, nx_skip, nx_idx, nx_slice);
+#ifdef P_TIMELINE
+      ct0 = HOLO_PROBE_CLOCK();
+#endif
       __syncthreads();  // step s is staged (and the producers may overwrite the buffer of step s - 1)
+#ifdef P_TIMELINE
+      ct1 = HOLO_PROBE_CLOCK();
+      ct_wait += ct1 - ct0;
+#endif
       const float* hb = s_halo + (s & 1) * P_BUF;
       load_a(A[0], 0, hb);
 #pragma unroll
@@ -385,6 +531,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#ifdef P_TIMELINE
+      ct_loop += HOLO_PROBE_CLOCK() - ct1;
+      ++ct_steps;
+#endif
     }
     if (SKIP) {
       for (int st = ncc; st < nst; ++st, ++s) {  // ---- 32 raw channels of the fused 1x1x1 skip connection: two k-steps
@@ -405,6 +555,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     // ---- epilogue (conv_bf16t_kernel's): each wave passes one 32-voxel row tile at a time through its own transposition
     // tile as fp32 [voxel][channel] and leaves with 8 channels of one voxel per lane: bias, residual, GroupNorm statistics
     // and the store are 16-byte operations.  D layout of 32x32: column = li (Cout), row i = (r&3) + 8*(r>>2) + 4*kg.
+#ifdef P_TIMELINE
+    ct0 = HOLO_PROBE_CLOCK();
+#endif
     constexpr int LPV = BN / 8;      // lanes per voxel
     constexpr int VPP = 64 / LPV;    // voxels per pass
     constexpr int NPASS = 32 / VPP;
@@ -517,13 +670,23 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         }
       }
     }
+#ifdef P_TIMELINE
+    ct_epi += HOLO_PROBE_CLOCK() - ct0;
+    ++ct_items;
+#endif
   }
+#ifdef P_TIMELINE
+  if (p.dbg && tid == 0) {
+    unsigned long long* d = p.dbg + (int64_t)blockIdx.x * 8;
+    d[0] = ct_wait, d[1] = ct_loop, d[2] = ct_epi, d[3] = ct_steps, d[4] = ct_items;
+  }
+#endif
 }
 
 }  // namespace
 
 // Launch of the persistent wave-specialised kernel: p.grid_x workgroups of 512 threads (conv_plan: one per CU, a multiple of 8).
-int conv_bf16p_launch(const ConvParams& p, void* stream) {
+int P_ENTRY(const ConvParams& p, void* stream) {
   if (!p.in_bf16 || (p.residual && !p.res_bf16) || p.nsplit != 1 || !p.w_bft || (p.skip_w && !p.skip_w_bft)) {
     set_error("conv_bf16p_launch: bf16 activation storage, prepared wide-tile weights, no split-K");
     return -1;

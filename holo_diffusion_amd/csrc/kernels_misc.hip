@@ -49,6 +49,16 @@ __global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const float* __rest
   }
 }
 
+// fp32 -> bf16 of a tensor that already is channels-last (the bf16 storage mode's input on the channels-last entry,
+// holo_unet_forward_cl): 8 elements per thread, 2 x 16 bytes in, 16 bytes out
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float4* __restrict__ in, float4* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = in[2 * i], b = in[2 * i + 1];
+    out[i] = make_float4(__uint_as_float(pack_bf16x2(a.x, a.y)), __uint_as_float(pack_bf16x2(a.z, a.w)),
+                         __uint_as_float(pack_bf16x2(b.x, b.y)), __uint_as_float(pack_bf16x2(b.z, b.w)));
+  }
+}
+
 __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              int C, int64_t V, int in_bf16) {
   __shared__ float tile[32][33];
@@ -709,6 +719,18 @@ int ddpm_step_philox_launch(const float* tables, int T, const int64_t* timesteps
   else
     HOLO_LAUNCH(ddpm_step_philox_kernel<false>, grid, dim3(256), stream, tables, T, timesteps, per, x_t, model_out, k0, k1,
                 (uint32_t)offset, clip, sample, pred_xstart, noise_out, 0);
+  return 0;
+}
+
+int f32_to_bf16_launch(const float* in, float* out_bf16, int64_t n, void* stream) {
+  if (n & 7) {
+    set_error("f32_to_bf16: the element count must be a multiple of 8");
+    return -1;
+  }
+  int64_t blocks = cdiv(n >> 3, 256);
+  if (blocks > 16384) blocks = 16384;
+  HOLO_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), stream, reinterpret_cast<const float4*>(in),
+              reinterpret_cast<float4*>(out_bf16), n >> 3);
   return 0;
 }
 

@@ -1717,10 +1717,7 @@ int holo_unet_forward_cl(HoloUnet* net, int batch, const float* x_cl, const int6
     set_error("holo_unet_forward_cl: null/invalid argument");
     return HOLO_E_INVALID;
   }
-  if (net->compute_mode == 1) {
-    set_error("holo_unet_forward_cl: the bf16 storage mode converts its input in the layout pass (use holo_unet_forward)");
-    return HOLO_E_UNSUPPORTED;
-  }
+  const bool bf16_storage = net->compute_mode == 1;  // the plan's input buffer is bf16: a cast replaces the layout pass
   int rc = ensure_plan(net, batch, workspace);
   if (rc) return rc;
   if (workspace_bytes < net->ws_need) {
@@ -1748,12 +1745,20 @@ int holo_unet_forward_cl(HoloUnet* net, int batch, const float* x_cl, const int6
     set_error("holo_unet_forward_cl: this plan's first / last convolution cannot take the caller's tensors");
     return HOLO_E_UNSUPPORTED;
   }
+  if (bf16_storage && (net->ops[last_conv].conv.out_bf16 || !net->ops[first_conv].conv.in_bf16)) {
+    set_error("holo_unet_forward_cl: unexpected storage types at the ends of the bf16 plan");
+    return HOLO_E_UNSUPPORTED;
+  }
   for (size_t i = 0; i < net->ops.size(); ++i) {
     const Op& op = net->ops[i];
+    if (op.kind == OP_IN && bf16_storage) {  // fp32 channels-last -> the plan's bf16 channels-last input buffer
+      if (f32_to_bf16_launch(x_cl, op.o0, (int64_t)batch * op.i0 * op.l0, stream)) return HOLO_E_INVALID;
+      continue;
+    }
     if (op.kind == OP_IN || op.kind == OP_OUT) continue;
     if ((int)i == first_conv || (int)i == last_conv) {
       Op o2 = op;
-      if ((int)i == first_conv) o2.conv.src0 = x_cl;
+      if ((int)i == first_conv && !bf16_storage) o2.conv.src0 = x_cl;
       if ((int)i == last_conv) o2.conv.out = y_cl;
       rc = run_op(net, o2, batch, x_cl, timesteps, y_cl, stream);
     } else {

@@ -261,7 +261,7 @@ class ImplicitronGaussianDiffusion(Configurable):
         # hence layout-agnostic, and SimpleUnet3D.forward_channels_last runs without its two layout passes: one conversion
         # at the start of the chain, one per materialised sample (progressive callers get NCDHW-contiguous tensors as ever).
         use_cl = (self.device_noise_seed is not None and noise_sampler is None and denoised_fn is None and not model_kwargs
-                  and hasattr(model, "forward_channels_last") and getattr(model, "compute_dtype", "f32") != "bf16"
+                  and hasattr(model, "forward_channels_last")
                   and getattr(model, "in_channels", None) == shape[1] and img.is_cuda)
         if use_cl:
             as_ncdhw = (lambda a: a.permute(0, 4, 1, 2, 3).contiguous()) if _materialize_every_step else \

@@ -262,11 +262,10 @@ class SimpleUnet3D(Unet3DBase):
     @torch.no_grad()
     def forward_channels_last(self, x_cl: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
         """``forward`` on channels-last tensors (``holo_unet_forward_cl``): ``x_cl`` is (N, R, R, R, C) contiguous fp32 - the
-        library's own layout -, so is the result; the two layout passes of a plain call do not run.  The sampler's perf mode
-        keeps its chain in this form (``ImplicitronGaussianDiffusion.p_sample_loop`` with ``device_noise_seed``)."""
+        library's own layout -, so is the result; the two layout passes of a plain call do not run (in the bf16 storage mode an
+        element-wise fp32 -> bf16 cast takes the place of the first).  The sampler's perf mode keeps its chain in this form
+        (``ImplicitronGaussianDiffusion.p_sample_loop`` with ``device_noise_seed``)."""
         runtime.require_device(x_cl, "SimpleUnet3D.forward_channels_last")
-        if self.compute_dtype == "bf16":
-            raise _lib.HoloError("SimpleUnet3D.forward_channels_last: not in the bf16 storage mode")
         if x_cl.dim() != 5 or x_cl.shape[4] != self.in_channels or len(set(x_cl.shape[1:4])) != 1 or \
                 x_cl.shape[1] % (1 << (len(self.channel_mult) - 1)) or not x_cl.is_contiguous() or x_cl.dtype != torch.float32:
             raise _lib.HoloError(f"SimpleUnet3D.forward_channels_last: expected a contiguous float32 (N,R,R,R,{self.in_channels}), "

@@ -121,7 +121,9 @@ int holo_unet_forward(HoloUnet* net, int batch, const float* x, const int64_t* t
 /* The same forward on CHANNELS-LAST tensors (ABI 5): x_cl / y_cl are (N, R, R, R, C) fp32 - the layout the library works in -
  * so the two layout passes of holo_unet_forward (NCDHW -> channels-last of x, back of y) do not run: the first convolution
  * reads x_cl and the last one writes y_cl directly.  For sampling chains that stay on the device (holo_ddpm_step* is
- * elementwise, hence layout-agnostic): the chain converts once at its start and once at its end.  fp32 / bf16x3 modes. */
+ * elementwise, hence layout-agnostic): the chain converts once at its start and once at its end.  All modes (ABI 6: in the
+ * bf16 storage mode an element-wise fp32 -> bf16 cast of x_cl replaces the transposing layout pass; y_cl is written by the
+ * last convolution as in the other modes). */
 int holo_unet_forward_cl(HoloUnet* net, int batch, const float* x_cl, const int64_t* timesteps, float* y_cl, void* workspace,
                          size_t workspace_bytes, void* stream);
 

@@ -154,11 +154,13 @@ def test_winograd_kernels_blockwise(gu, image, mc, mult, attn, batch, wino_kerne
     assert gu.rel_err(y2, y.cpu()) < 1e-5
 
 
-def test_forward_channels_last_equals_forward(gu):
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_forward_channels_last_equals_forward(gu, compute):
     """holo_unet_forward_cl (ABI 5): the forward on (N, R, R, R, C) tensors - the first convolution reads the caller's tensor, the
     last one writes the caller's tensor, no layout pass - is bit-equal to the NCDHW call; batch 2; also after a plain call on
-    the same handle (the two entries share the plan)."""
-    net, _ = gu.make_unet(TINY_CFG)
+    the same handle (the two entries share the plan).  bf16 storage mode (ABI 6): an element-wise cast of the caller's tensor
+    replaces the transposing layout pass (same rounding), the last convolution writes the caller's fp32 tensor."""
+    net, _ = gu.make_unet(TINY_CFG, compute_dtype=compute)
     x = torch.cat([seeded_input(TINY_CFG, 21), seeded_input(TINY_CFG, 22)]).to(gu.DEV)
     t = torch.tensor([640, 3], device=gu.DEV)
     y = net(x, t)
