@@ -2834,13 +2834,17 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       p.skip_chunks_per_split = (int)cdiv(nsk16, nsplit);
       p.grid_x = (int)(M / 512);
       // the filled levels (every CU gets whole tiles without split-K): the persistent wave-specialised form
-      // (kernels_conv_bf16p.hip).  HOLO_CONV_BF16P=0 keeps conv_bf16t_kernel everywhere (A/B knob), =1 forces the persistent
-      // form onto every wide-tile launch, without split-K (tests: small grids)
+      // (kernels_conv_bf16p.hip) - by default only for launches that stage their input RAW (no GroupNorm / SiLU on load: the
+      // input convolution, the Upsample convolutions): there its producer waves keep up with the consumers (tools/bf16p_probe:
+      // 128^3 32 -> 64 282 vs 293 us); with the activation arithmetic they do not yet (540 vs 479 us) and conv_bf16t_kernel
+      // stays.  HOLO_CONV_BF16P=0 keeps conv_bf16t_kernel everywhere, =2 takes the persistent form for activated input too,
+      // =1 forces it onto every wide-tile launch, without split-K (tests: small grids)
       {
         const char* ep = getenv("HOLO_CONV_BF16P");
         const bool force = ep && ep[0] == '1';
+        const bool any_input = force || (ep && ep[0] == '2');
         const int wgs = num_cus & ~7;
-        if (!(ep && ep[0] == '0') && ((nsplit == 1 && wgs >= 8 && t8 >= wgs) || force) &&
+        if (!(ep && ep[0] == '0') && (any_input || !p.coef) && ((nsplit == 1 && wgs >= 8 && t8 >= wgs) || force) &&
             (p.C1 == 0 || (p.C0 % 16) == 0) &&  // (a 16-channel chunk / a 32-channel skip step lies in ONE source)
             (!p.skip_w || (((p.skip_C0 + p.skip_C1) % 32) == 0 && (p.skip_C1 == 0 || (p.skip_C0 % 32) == 0))) &&
             (int64_t)p.ID * p.IH * p.IW < ((int64_t)1 << 24)) {  // (24-bit voxel indices in the producers' address arithmetic)

@@ -5,35 +5,44 @@
 // upsampling (:93-97), the skip concat (:829), the 1x1x1 skip_connection (:222), bias and the residual add (:256) fused.
 //
 // Why another form.  conv_bf16t_kernel gives every wave all three jobs - request the raw halo, activate it, multiply - and
-// relies on the second resident workgroup to cover one wave's vector work with the other's MFMAs.  Measured (rounds 2-5):
-// the matrix pipe is busy 38-48 % of the time; a wave that waits for its halo (in-order vmcnt: the weight requests of the
-// next taps queue behind the halo's) or runs its 500 activation instructions per chunk issues no MFMA, and two workgroups
-// drift into the same phase.  On gfx950 the bf16 MFMA does not use the vector lanes, so the jobs can run side by side if
-// DIFFERENT waves do them:
+// relies on the second resident workgroup to cover one wave's vector work with the other's MFMAs; it stays at 0.35 - 0.43 of
+// the bf16 pipe.  tools/bf16p_probe (profiles/r06_bf16p_probe.txt) took the work apart on the 128^3 64 -> 64 launch:
+//   MFMAs alone 250 us; + A operands from LDS 315; + weights from L1/L2 alone 280; BOTH operands, nobody staging: 325;
+//   + waves that stage the next halo: 495 - and of that staging the arithmetic and the LDS writes are nearly free (+45);
+//   what costs 170 us is that the halo's LOADS and the weights' LOADS share the CU's vector-memory path, which returns data
+//   in order: a weight request (an L2 hit) issued behind a halo request (a miss to the memory side) waits for it, whichever
+//   wave issued either, and the waves that multiply starve.  (Each kind of request alone is nearly free: halo loads without
+//   weight loads 256 us, weight loads without halo loads 328.)
+// So the waves that multiply must not load from memory at all:
 //   workgroup = 8 waves, ONE per CU, persistent over (8x8x8-voxel tile, 32*NT-output-channel slice) items;
 //   waves 0-3  CONSUMERS: one per SIMD, 2 z-planes of the tile each = 4 x NT register-blocked 32x32 tiles (the blocking of
-//              conv_bf16t_kernel); their instruction stream is ds_read_b128 (A), global_load_dwordx4 (B, L1/L2-resident
-//              weights, two taps ahead) and v_mfma_f32_32x32x16_bf16 - nothing else inside a chunk;
-//   waves 4-7  PRODUCERS: one per SIMD beside a consumer; they request the raw bf16 halo of the chunk AFTER next (two
-//              register sets), apply GroupNorm * FiLM + SiLU, zero padding, upsampling and the concat to the next chunk and
-//              write it MFMA-ready into the other of two 32 KB LDS halo buffers.
-// One barrier per 16-channel chunk hands a buffer over; the producers run one chunk ahead, across tile boundaries, so a
-// tile's first halo is ready when the consumers leave the previous tile's epilogue.  A fused 1x1x1 skip connection is
-// 32-channel steps of their own: the producers copy the raw 8^3 centre (no halo, no activation) into the same buffers.
+//              conv_bf16t_kernel); BOTH operands come from LDS: per tap 4 A fragments from the halo buffer and NT B
+//              fragments from the weight buffer for 4 * NT v_mfma_f32_32x32x16_bf16; no vector-memory instruction
+//              between a tile's first tap and its epilogue;
+//   waves 4-7  PRODUCERS: one per SIMD beside a consumer; per 16-channel chunk they request the raw bf16 halo and the
+//              chunk's 27 * NT KB of weights two steps ahead (two register sets), apply GroupNorm * FiLM + SiLU, zero
+//              padding, upsampling and the concat, and write the halo MFMA-ready into the other of two 32 KB LDS buffers.
+//              The weights have ONE 54 KB buffer (160 KB of LDS do not hold two): it is refilled in thirds (9 taps) behind
+//              the consumers' progress, which every consumer wave publishes in an LDS word after taps 8, 17 and 26.
+// One barrier per chunk hands the halo buffer over; the producers run one chunk ahead, across tile boundaries, so a tile's
+// first halo is ready when the consumers leave the previous tile's epilogue.  A fused 1x1x1 skip connection is 32-channel
+// steps of their own: the producers copy the raw 8^3 centre (no halo, no activation) into the same buffers.
 // Halo layout, swizzle, weight layout (w_bft), epilogue (per-wave LDS transposition, 16-byte residual / store, one
 // GroupNorm slab per tile) are conv_bf16t_kernel's; no split-K (the planner picks this kernel only where the tiles fill
 // the chip).
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "holo_common.h"
 #include "holo_kernels.h"
 
 // Development probes (tools/bf16p_probe.cpp compiles copies of this file with them; never set in the library build):
-//   P_PROBE bits: 1 consumers request no weights, 2 consumers read no A operands, 4 producers stage nothing (barriers only),
-//                 8 no MFMAs, 16 producers skip the activation arithmetic, 32 consumers take their weights from LDS (garbage
-//                 contents), 64 producers also copy a step's 54 KB of weights into that LDS region (unsynchronised), 128 producers
-//                 load but write nothing, 256 producers write (and compute) but load nothing
+//   P_PROBE bits: 1 consumers read no weights, 2 consumers read no A operands, 4 producers stage nothing (barriers only),
+//                 8 no MFMAs, 16 producers skip the activation arithmetic, 128 producers load but write nothing,
+//                 256 producers write (and compute) but load nothing, 512 the weights are not staged (flags and polls stay)
 //   P_TIMELINE:   p.dbg[workgroup][8] = wall-clock ticks (10 ns) of consumer wave 0 {barrier wait, tap loops, epilogue, steps,
 //                 items} and of producer wave 4 {issue + commit, barrier wait}
 #ifndef P_PROBE
@@ -85,8 +94,13 @@ static inline float4 pb_load(const pb_rsrc& r, unsigned voff) {
 #else
 typedef __amdgpu_buffer_rsrc_t pb_rsrc;
 typedef unsigned pb_u4 __attribute__((ext_vector_type(4)));
+// (the base is wave-uniform by construction, but the compiler cannot prove it for values carried through the producers' step
+// records: without the two v_readfirstlane it wraps EVERY buffer load in a waterfall loop - cdna_hip_programming.md T20)
 __device__ __forceinline__ pb_rsrc pb_make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xfffffff0, 0x00020000);
+  const uint64_t a = (uint64_t)p;
+  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(u), 0, 0xfffffff0, 0x00020000);
 }
 __device__ __forceinline__ float4 pb_load(pb_rsrc r, unsigned voff) {
   const pb_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
@@ -101,6 +115,30 @@ static inline unsigned pb_mad24(unsigned a, unsigned b, unsigned c) { return a *
 __device__ __forceinline__ unsigned pb_mad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
 #endif
 
+// The hand-over barrier of a step: LDS traffic of this wave done (lgkmcnt), then s_barrier.  NOT __syncthreads(): that also
+// waits for the wave's outstanding vector-memory loads (vmcnt(0)), and the producers keep the loads of the step after next in
+// flight across it on purpose.
+#ifdef HOLO_EMU
+#define P_STEP_BARRIER() __syncthreads()
+#define P_POLL_SLEEP() std::this_thread::yield()
+#define P_COMPILER_FENCE() std::atomic_thread_fence(std::memory_order_seq_cst)
+#else
+#define P_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define P_POLL_SLEEP() __builtin_amdgcn_s_sleep(4)
+#define P_COMPILER_FENCE() asm volatile("" ::: "memory")
+#endif
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): register arrays indexed with compile-time constants (a
+// `#pragma unroll` loop nested in the unrolled third loop was left rolled and sent the staged weights to scratch memory)
+template <class F, int... K>
+__device__ __forceinline__ void p_static_for_impl(F&& f, std::integer_sequence<int, K...>) {
+  (f(std::integral_constant<int, K>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void p_static_for(F&& f) {
+  p_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // one staged step of a producer thread: the raw 16-byte pieces in flight + what the commit needs to know about them
 struct Pend {
   float4 h[P_IT];
@@ -109,6 +147,7 @@ struct Pend {
   int c;          // main: first channel of this thread's 8-channel half (for the affine coefficients)
   int n;          // sample
   int first;      // first step of an item that is not the workgroup's first: the consumers' statistics barrier comes first
+  int ph, slice;  // the step's place in its item and the item's output-channel slice (for its weights)
 };
 
 template <int NT, bool SKIP>
@@ -117,9 +156,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
   __shared__ __attribute__((aligned(16))) float s_halo[2 * P_BUF];
   __shared__ __attribute__((aligned(16))) float s_ep[4 * 32 * P_EW];
   __shared__ float s_stat[4 * 8 * 16];
-#if P_PROBE & 32  // (probe: the weights of a step in LDS - garbage contents, timing only)
-  __shared__ __attribute__((aligned(16))) float s_bw[27 * 512];
-#endif
+  constexpr int WBLK = 256 * NT;                 // floats of a tap's weights: NT 1 KB blocks
+  constexpr int NWV = (27 * NT * 64 + 255) / 256;  // float4 per producer thread and step (27 taps)
+  constexpr int WT1 = 9 * NT * 64, WT2 = 18 * NT * 64;  // first float4 of the second / last third (taps 9.., 18..)
+  __shared__ __attribute__((aligned(16))) float s_bw[27 * WBLK];  // the current step's weights [tap][nt][lane][4]
+  __shared__ __attribute__((aligned(16))) int s_flag[4];          // per consumer wave: 3 * (steps done) + thirds of the current one
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -161,6 +202,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     n = bt / ntz;
   };
 
+  if (tid < 4) s_flag[tid] = 0;
+  __syncthreads();
+
   if (wave >= 4) {
     // =============================================== PRODUCERS ===============================================
     // Everything here is written for a LOW INSTRUCTION COUNT: the producers share their SIMD's issue port with a consumer
@@ -170,6 +214,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     // item; an offset of ~0 reads zeros), per-thread geometry is computed once per kernel / tile, the arithmetic is packed.
     const int ptid = tid - 256;
     const int hh = ptid & 1;  // main steps: which 8-channel half of the 16-channel chunk
+#if !defined(HOLO_EMU) && defined(P_PRODUCER_PRIO)
+    __builtin_amdgcn_s_setprio(P_PRODUCER_PRIO);  // (probe: the producers' vector work first in the SIMD's issue arbitration)
+#endif
     const int SD = p.ups ? (p.ID >> 1) : p.ID;
     const int SH = p.ups ? (p.IH >> 1) : p.IH;
     const int SW = p.ups ? (p.IW >> 1) : p.IW;
@@ -194,6 +241,15 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       slds_off[i] = (qd >> 1) * 4096 + v * P_RS + (((qd & 1) ^ (vy & 1)) * 4);
       svoff[i] = (unsigned)((vz * p.OH + vy) * p.OW + vx);  // x (channels of the source * 2) + qd * 16 at issue time
     }
+    // weights: float4 number f = ptid + 256 j of a step's blocks; block f / 64 = tap * NT + nt, 16 bytes f % 64 of it.  Byte
+    // offset of that float4 from the step's base (tap 0, the step's chunk, the item's slice) in w_bft
+    // ([tap][16-channel chunk][32-Cout slice][1 KB]); ~0 (reads zeros, never written) beyond the last block
+    const int nsl = p.CoutP >> 5;
+    const int wncc = p.CinP / P_CK;
+    // (f -> f + 256 moves 4 blocks on = 4 / NT taps: the offsets of a thread's float4s are w0 + j wstride)
+    const int wblk0 = ptid >> 6, wtap0 = wblk0 / NT;
+    const unsigned w0 = (unsigned)(((wtap0 * wncc * nsl + (wblk0 - wtap0 * NT)) * 256 + (ptid & 63) * 4) * 4);
+    const unsigned wstride = (unsigned)((4 / NT) * wncc * nsl * 256 * 4);
     // iterator over (item, step) in consumption order
     int item = it_first, ph = 0;
     int cn = 0, ctz0 = 0, cty0 = 0, ctx0 = 0, cslice = 0;
@@ -221,13 +277,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       hvalid &= live;
     };
     if (item < it_end) setup_tile();
-    auto issue = [&](Pend& q) {
+    // (cf: main step with an affine - (a, b) of the thread's 8 channels)
+    auto issue = [&](Pend& q, float4 (&cf)[4]) {
       if (item >= it_end) {
         q.kind = 0;
         return;
       }
       q.first = (ph == 0 && !very_first) ? 1 : 0;
       very_first = false;
+      q.ph = ph;
+      q.slice = cslice;
       if (P_PROBE & 4) {  // (probe: the step list without its loads)
         q.kind = 3;
       } else if (ph < ncc) {  // ---- a 16-channel chunk of the 10^3 halo.  A chunk lies in ONE source (conv_plan: C0 % 16 == 0)
@@ -255,6 +314,12 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
             q.h[i] = pb_load(rs, off);
           }
         }
+        if (!raw) {
+          const float4* cfp = reinterpret_cast<const float4*>(p.coef + ((int64_t)cn * Cin + q.c) * 2);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cf[j] = cfp[j];
+        }
+
       } else {  // ---- 32 raw channels of the skip connection's input on the tile's 8^3 centre (one source: skip_C0 % 32 == 0)
         q.kind = 2;
         const int c0 = (ph - ncc) * 32;
@@ -274,7 +339,26 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         if (item < it_end) setup_tile();
       }
     };
-    auto commit = [&](const Pend& q, float* buf) {
+    // The step's weights (w: float4 number ptid + 256 j of its 27 * NT (main) / 2 * NT (skip) 1 KB blocks): requested at the
+    // END of the previous step's iteration, when its registers are free again (L2 hits, and their first third is needed only
+    // a third of a step into the next one).
+    auto issue_weights = [&](int kind, int wph, int wslice, float4 (&w)[NWV]) {
+      if (P_PROBE & (4 | 128 | 256 | 512)) return;
+      if (kind == 1) {
+        const pb_rsrc rw = pb_make_rsrc(reinterpret_cast<const float*>(p.w_bft) + ((int64_t)wph * nsl + wslice * NT) * 256);
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+          const bool ok = wtap0 + j * (4 / NT) < 27;  // (the last float4 of some threads lies beyond the 27th tap)
+          w[j] = pb_load(rw, ok ? w0 + (unsigned)j * wstride : 0xffffffffu);
+        }
+      } else if (kind == 2 && ptid < 2 * NT * 64) {  // blocks (k-step e, nt) of [skip chunk 2 sp + e][slice]
+        const int e = ptid / (NT * 64), r = ptid - e * (NT * 64);
+        const float* wb = reinterpret_cast<const float*>(p.skip_w_bft) +
+                          ((int64_t)(2 * (wph - ncc) + e) * nsl + wslice * NT) * 256 + r * 4;
+        w[0] = *reinterpret_cast<const float4*>(wb);
+      }
+    };
+    auto commit = [&](const Pend& q, const float4 (&cf)[4], float* buf) {
       if (P_PROBE & 128) {  // (probe: the loads are waited for, nothing is written)
         float acc_ = 0.f;
 #pragma unroll
@@ -290,14 +374,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
           return;
         }
         f32x2 ca[4], cb[4];
-        {
-          const float4* cf = reinterpret_cast<const float4*>(p.coef + ((int64_t)q.n * Cin + q.c) * 2);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 c = cf[j];  // (a, b) interleaved per channel
-            ca[j] = f32x2{c.x, c.z};
-            cb[j] = f32x2{c.y, c.w};
-          }
+        for (int j = 0; j < 4; ++j) {
+          const float4 c = cf[j];  // (a, b) interleaved per channel
+          ca[j] = f32x2{c.x, c.z};
+          cb[j] = f32x2{c.y, c.w};
         }
         const bool act = p.act != 0 && !(P_PROBE & 16);
         const bool boundary = q.mask != live;  // (zero padding only where the tile touches the tensor's faces)
@@ -331,47 +412,79 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       }
     };
 #ifdef P_TIMELINE
+    unsigned long long pt_commit = 0, pt_wts = 0, pt_last = HOLO_PROBE_CLOCK();
+#define P_TL_STAMP(acc_)                                \
+  {                                                     \
+    const unsigned long long t_ = HOLO_PROBE_CLOCK();   \
+    acc_ += t_ - pt_last;                               \
+    pt_last = t_;                                       \
+  }
     unsigned long long pt_work = 0, pt_wait = 0, pt0 = HOLO_PROBE_CLOCK(), pt1;
 #define P_TL_PROD_BAR()                 \
   pt1 = HOLO_PROBE_CLOCK();             \
   pt_work += pt1 - pt0;                 \
-  __syncthreads();                      \
+  P_STEP_BARRIER();                     \
   pt0 = HOLO_PROBE_CLOCK();             \
+  pt_last = pt0;                        \
   pt_wait += pt0 - pt1
 #else
-#define P_TL_PROD_BAR() __syncthreads()
+#define P_TL_PROD_BAR() P_STEP_BARRIER()
+#define P_TL_STAMP(acc_)
 #endif
-#if P_PROBE & 64  // (probe: the producers also bring a step's 54 KB of weights into LDS - unsynchronised, timing only)
-#define P_PROBE_WEIGHTS()                                                                                      \
-  {                                                                                                            \
-    const float* wsrc = reinterpret_cast<const float*>(p.w_bft) + (int64_t)(s % ncc) * 512 + ptid * 4;         \
-    float4 wv[14];                                                                                             \
-    _Pragma("unroll") for (int i = 0; i < 14; ++i) wv[i] =                                                     \
-        *reinterpret_cast<const float4*>(wsrc + (int64_t)(i * 2 % 27) * (p.CinP / 16) * (p.CoutP >> 5) * 256 + (i & 1) * 1024); \
-    _Pragma("unroll") for (int i = 0; i < 14; ++i) if (i * 1024 + ptid * 4 < 27 * 512)                         \
-        *reinterpret_cast<float4*>(s_bw + i * 1024 + ptid * 4) = wv[i];                                        \
-  }
-#else
-#define P_PROBE_WEIGHTS()
-#endif
-    Pend PA, PB;
-    issue(PA);
-    issue(PB);
+    // The step's weights go into the ONE weight buffer behind the consumers' progress: third k (taps 9k .. 9k + 8) of step s
+    // may be overwritten once every consumer wave has published 3 (s - 1) + k + 1 (it has issued the MFMAs of tap 9k + 8 of
+    // step s - 1, hence finished reading that third; LDS serves a wave's requests in order).
+    auto wait_flags = [&](int target) {
+      if (target <= 0) return;
+      for (;;) {
+        P_COMPILER_FENCE();
+        const volatile int* f = s_flag;
+        const int a0 = f[0], a1 = f[1], a2 = f[2], a3 = f[3];
+        if (min(min(a0, a1), min(a2, a3)) >= target) break;
+        P_POLL_SLEEP();
+      }
+      P_COMPILER_FENCE();
+    };
+    auto commit_weights = [&](int kind, const float4 (&w)[NWV], int s) {
+      if (P_PROBE & (4 | 128 | 256)) return;
+      if (kind == 2) {  // a skip step's 2 * NT blocks: the previous step must be over
+        wait_flags(3 * s);
+        if (ptid < 2 * NT * 64 && !(P_PROBE & 512)) *reinterpret_cast<float4*>(s_bw + ptid * 4) = w[0];
+        return;
+      }
+      p_static_for<3>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int lo = k == 0 ? 0 : (k == 1 ? WT1 : WT2), hi = k == 0 ? WT1 : (k == 1 ? WT2 : 27 * NT * 64);
+        wait_flags(3 * (s - 1) + k + 1);
+        if (P_PROBE & 512) return;
+        p_static_for<NWV>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if (256 * j + 255 >= lo && 256 * j < hi) {  // (compile time: this float4 can lie in third k for some thread)
+            const int f = ptid + 256 * j;
+            if (f >= lo && f < hi) *reinterpret_cast<float4*>(s_bw + f * 4) = w[j];
+          }
+        });
+      });
+    };
+    // One register set for each kind of request.  Iteration s (between the hand-overs of steps s - 1 and s) commits step s:
+    //   halo(s) [requested early in iteration s - 1] -> request halo(s + 1) -> weights(s) in thirds behind the consumers
+    //   [requested at the end of iteration s - 1] -> request weights(s + 1) -> hand-over.
+    // Whatever the compiler's s_waitcnt vmcnt(0) in front of a use waits for has been in flight for most of a step.
+    Pend P;
+    float4 W[NWV], CF[4];
+    issue(P, CF);
+    issue_weights(P.kind, P.ph, P.slice, W);
     int s = 0;
-    while (true) {
-      if (PA.kind == 0) break;
-      P_PROBE_WEIGHTS();
-      commit(PA, s_halo + (s & 1) * P_BUF);
-      if (PA.first && with_stats) __syncthreads();  // (the consumers' statistics hand-over of the previous item)
-      P_TL_PROD_BAR();                              // step s is ready / step s - 1 has been consumed
-      issue(PA);
-      ++s;
-      if (PB.kind == 0) break;
-      P_PROBE_WEIGHTS();
-      commit(PB, s_halo + (s & 1) * P_BUF);
-      if (PB.first && with_stats) __syncthreads();
-      P_TL_PROD_BAR();
-      issue(PB);
+    while (P.kind != 0) {
+      const int kind = P.kind, first = P.first;
+      commit(P, CF, s_halo + (s & 1) * P_BUF);
+      P_TL_STAMP(pt_commit);
+      issue(P, CF);  // (step s + 1; its registers are free)
+      commit_weights(kind, W, s);
+      P_TL_STAMP(pt_wts);
+      issue_weights(P.kind, P.ph, P.slice, W);
+      if (first && with_stats) __syncthreads();  // (the consumers' statistics hand-over of the previous item)
+      P_TL_PROD_BAR();                            // step s is ready / step s - 1 has been consumed
       ++s;
     }
     if (with_stats && s > 0) __syncthreads();  // the last item's statistics hand-over
@@ -379,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     if (p.dbg && tid == 256) {
       p.dbg[(int64_t)blockIdx.x * 8 + 5] = pt_work;
       p.dbg[(int64_t)blockIdx.x * 8 + 6] = pt_wait;
+      p.dbg[(int64_t)blockIdx.x * 8 + 7] = pt_commit;  // (issue of the weights + wait for the halo + activation + LDS writes)
     }
 #endif
     return;
@@ -409,28 +523,17 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     for (int mt = 0; mt < 4; ++mt)
       a[mt] = *reinterpret_cast<const float4*>(hb + kstep * 4096 + as_base + ((mt >> 1) * 64 + 4 * (mt & 1) * 8) * P_RS);
   };
-  // B addressing: 1 KB blocks [tap][16-channel chunk][32-Cout slice], 16 bytes per lane
-  const int nsl = p.CoutP >> 5;
-  const int wncc = p.CinP / P_CK;
-  const float* w_lane = reinterpret_cast<const float*>(p.w_bft) + lane * 4;
-  const float* skw_lane = reinterpret_cast<const float*>(p.skip_w_bft) + lane * 4;
-  // entry e of a step: main step = tap e of chunk idx; skip step = k-step e (< 2) of skip step idx
-  auto bptr = [&](bool skip, int idx, int e, int slice) -> const float* {
-    if (skip) return skw_lane + ((int64_t)(2 * idx + e) * nsl + slice * NT) * 256;
-    return w_lane + (((int64_t)e * wncc + idx) * nsl + slice * NT) * 256;
-  };
-  auto load_b = [&](float4 (&b)[NT], const float* wp) {
+  // B operands: the step's weights in LDS, [entry][nt][lane][4 words]; entry = tap (main step) / k-step (skip step)
+  auto load_b = [&](float4 (&b)[NT], int e) {
     if (P_PROBE & 1) return;
-#if P_PROBE & 32
-    {
-      const float* lb = s_bw + (((uintptr_t)wp >> 11) % 27) * 512 + lane * 4;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(lb + nt * 256);
-      return;
-    }
-#endif
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wp + nt * 256);
+    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(s_bw + (e * NT + nt) * 256 + lane * 4);
+  };
+  // progress of this wave through the weight buffer, for the producers that refill it (see commit_weights)
+  auto publish = [&](int v) {
+    P_COMPILER_FENCE();
+    if (lane == 0) *reinterpret_cast<volatile int*>(s_flag + wave) = v;
+    P_COMPILER_FENCE();
   };
   f32x16 acc[4][NT];
   auto mfma_tap = [&](const float4 (&a)[4], const float4 (&b)[NT]) {
@@ -463,22 +566,10 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
   unsigned long long ct_wait = 0, ct_loop = 0, ct_epi = 0, ct_steps = 0, ct_items = 0, ct0, ct1;
 #endif
   int s = 0;
-  if (it_first < it_end) {  // the first step's first two entries
-    int n_, z_, y_, x_, sl_;
-    decode(it_first, n_, z_, y_, x_, sl_);
-    load_b(B[0], bptr(false, 0, 0, sl_));
-    load_b(B[1], bptr(false, 0, 1, sl_));
-  }
   for (int item = it_first; item < it_end; item += it_step) {
     int n, tz0, ty0, tx0, slice;
     decode(item, n, tz0, ty0, tx0, slice);
     const int n0 = slice * BN;
-    int nslice = 0;  // the next item's slice (its first weights are requested under this item's last entries)
-    const bool has_next_item = item + it_step < it_end;
-    if (has_next_item) {
-      int n_, z_, y_, x_;
-      decode(item + it_step, n_, z_, y_, x_, nslice);
-    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -486,50 +577,35 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // the step after (item, st): its first two B entries are requested under this step's last entries
-    auto next_of = [&](int st, bool& nx_valid, bool& nx_skip, int& nx_idx, int& nx_slice) {
-      nx_valid = st + 1 < nst || has_next_item;
-      nx_skip = st + 1 < nst && st + 1 >= ncc;
-      nx_idx = st + 1 < nst ? (nx_skip ? st + 1 - ncc : st + 1) : 0;
-      nx_slice = st + 1 < nst ? slice : nslice;
-    };
     for (int st = 0; st < ncc; ++st, ++s) {  // ---- 16-channel chunks of the activated halo: 27 taps
-      bool nx_valid, nx_skip;
-      int nx_idx, nx_slice;
-      next_of(st, nx_valid, nx_skip, nx_idx, nx_slice);
 #ifdef P_TIMELINE
       ct0 = HOLO_PROBE_CLOCK();
 #endif
-      __syncthreads();  // step s is staged (and the producers may overwrite the buffer of step s - 1)
+      P_STEP_BARRIER();  // step s is staged, halo and weights (and the producers may overwrite the halo buffer of step s - 1)
 #ifdef P_TIMELINE
       ct1 = HOLO_PROBE_CLOCK();
       ct_wait += ct1 - ct0;
 #endif
       const float* hb = s_halo + (s & 1) * P_BUF;
+      load_b(B[0], 0);
+      load_b(B[1], 1);
       load_a(A[0], 0, hb);
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
         if (tap + 1 < 27) load_a(A[(tap + 1) & 1], tap + 1, hb);
-        if (tap + 2 < 27) {
-          load_b(B[(tap + 2) % 3], bptr(false, st, tap + 2, slice));
-        } else if (nx_valid) {
-          load_b(B[(tap + 2) % 3], bptr(nx_skip, nx_idx, tap + 2 - 27, nx_slice));
-        }
+        if (tap + 2 < 27) load_b(B[(tap + 2) % 3], tap + 2);
         mfma_tap(A[tap & 1], B[tap % 3]);
-        {  // one operand request behind each MFMA (conv_bf16t_kernel's SCHED = 2)
+        {  // one operand read behind each MFMA (conv_bf16t_kernel's SCHED = 2)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < 4 + NT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < NT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
           }
           __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT - 4 - NT, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // (the reads of taps <= 8 / <= 17 / all have been issued - B two taps ahead - and LDS serves them in order)
+        if (tap == 8 || tap == 17 || tap == 26) publish(3 * s + (tap + 1) / 9);
       }
 #ifdef P_TIMELINE
       ct_loop += HOLO_PROBE_CLOCK() - ct1;
@@ -538,17 +614,16 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
     }
     if (SKIP) {
       for (int st = ncc; st < nst; ++st, ++s) {  // ---- 32 raw channels of the fused 1x1x1 skip connection: two k-steps
-        bool nx_valid, nx_skip;
-        int nx_idx, nx_slice;
-        next_of(st, nx_valid, nx_skip, nx_idx, nx_slice);
-        __syncthreads();
+        P_STEP_BARRIER();
         const float* hb = s_halo + (s & 1) * P_BUF;
+        load_b(B[0], 0);
+        load_b(B[1], 1);
         load_a_skip(A[0], 0, hb);
         load_a_skip(A[1], 1, hb);
         mfma_tap(A[0], B[0]);
-        if (nx_valid) load_b(B[0], bptr(nx_skip, nx_idx, 0, nx_slice));
         mfma_tap(A[1], B[1]);
-        if (nx_valid) load_b(B[1], bptr(nx_skip, nx_idx, 1, nx_slice));
+        __builtin_amdgcn_sched_barrier(0);
+        publish(3 * s + 3);
       }
     }
 

@@ -27,12 +27,10 @@ int conv_bf16p_launch_p4(const ConvParams& p, void* stream);
 int conv_bf16p_launch_p7(const ConvParams& p, void* stream);
 int conv_bf16p_launch_p8(const ConvParams& p, void* stream);
 int conv_bf16p_launch_p16(const ConvParams& p, void* stream);
-int conv_bf16p_launch_p32(const ConvParams& p, void* stream);
-int conv_bf16p_launch_p96(const ConvParams& p, void* stream);
 int conv_bf16p_launch_p128(const ConvParams& p, void* stream);
 int conv_bf16p_launch_p256(const ConvParams& p, void* stream);
-int conv_bf16p_launch_p129(const ConvParams& p, void* stream);
-int conv_bf16p_launch_p257(const ConvParams& p, void* stream);
+int conv_bf16p_launch_p512(const ConvParams& p, void* stream);
+int conv_bf16p_launch_prio(const ConvParams& p, void* stream);
 }  // namespace holo
 using namespace holo;
 #define CK(x)                                                               \
@@ -182,23 +180,21 @@ int main(int argc, char** argv) {
         for (int j = 0; j < 8; ++j) sum[j] += (double)d[(size_t)i * 8 + j];
       const double items = std::max(sum[4], 1.0), steps = std::max(sum[3], 1.0);
       printf("       timeline (10 ns ticks -> us), consumer wave 0 per item: barrier wait %.2f, tap loops %.2f, epilogue %.2f "
-             "(%.1f steps per item; per step: wait %.2f, taps %.2f) | producer wave per step: work %.2f, barrier wait %.2f\n",
+             "(%.1f steps per item; per step: wait %.2f, taps %.2f) | producer wave per step: work %.2f (of it weights request + halo commit %.2f), barrier wait %.2f\n",
              sum[0] / items * 0.01, sum[1] / items * 0.01, sum[2] / items * 0.01, steps / items, sum[0] / steps * 0.01,
-             sum[1] / steps * 0.01, sum[5] / steps * 0.01, sum[6] / steps * 0.01);
+             sum[1] / steps * 0.01, sum[5] / steps * 0.01, sum[7] / steps * 0.01, sum[6] / steps * 0.01);
       CK(hipFree(dbg));
     }
     struct { const char* what; int (*fn)(const ConvParams&, void*); } probes[] = {
-        {"probe: consumers request no weights", conv_bf16p_launch_p1}, {"probe: consumers read no A operands", conv_bf16p_launch_p2},
+        {"probe: consumers read no weights", conv_bf16p_launch_p1}, {"probe: consumers read no A operands", conv_bf16p_launch_p2},
         {"probe: neither (MFMAs + barriers + producers)", conv_bf16p_launch_p3},
         {"probe: producers stage nothing", conv_bf16p_launch_p4},
         {"probe: MFMAs + barriers only", conv_bf16p_launch_p7}, {"probe: everything but the MFMAs", conv_bf16p_launch_p8},
         {"probe: producers without the activation", conv_bf16p_launch_p16},
-        {"probe: consumers' weights from LDS (nobody fills it)", conv_bf16p_launch_p32},
-        {"probe: weights via LDS, producers fill it", conv_bf16p_launch_p96},
-        {"probe: producers load, write nothing", conv_bf16p_launch_p128},
+        {"probe: producers load the halo, write nothing", conv_bf16p_launch_p128},
         {"probe: producers write + compute, load nothing", conv_bf16p_launch_p256},
-        {"probe: producers load only, consumers no weights", conv_bf16p_launch_p129},
-        {"probe: producers write only, consumers no weights", conv_bf16p_launch_p257}};
+        {"probe: weights not staged (flags and polls stay)", conv_bf16p_launch_p512},
+        {"variant: producers at s_setprio 3", conv_bf16p_launch_prio}};
     for (auto& pr : probes) time_fn(pr.what, pr.fn, qp);
   }
   return 0;
