@@ -614,6 +614,19 @@ def main():
                            "source": ent.get("source")}
         except (OSError, ValueError):
             pass
+        # the same kernel's average duration from the committed rocprofv3 kernel trace, per level (every level launches the same
+        # persistent grid, so --stats mixes them: scripts/wino3_trace_join.py joins the trace with the plan's op order)
+        rocprof_ms = None
+        try:
+            if kname == "conv_wino3_kernel" and args.workload == "north":
+                for l in open(os.path.join(REPO, "profiles", "r06_wino3_64cubed_trace.csv")):
+                    f_ = l.strip().split(",")
+                    if f_[0] == "# level" and int(f_[1]) == od and bool(int(f_[2])) == bool(sk):
+                        rocprof_ms = {"avg_launch_ms": float(f_[4]) * 1e-3, "launches_per_forward": int(f_[3]),
+                                      "source": "profiles/r06_wino3_64cubed_trace.csv (rocprofv3 --kernel-trace of this command, "
+                                                "dispatches joined with the plan's op order)"}
+        except (OSError, ValueError, IndexError):
+            pass
         peak = PEAK_FP32_MFMA_TFLOPS if args.compute_dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         # `achieved` / `frac` = what the matrix pipe was actually given (a fraction of a roofline cannot pass 1): the
         # Winograd kernels issue 4/9 (2/3) of the 27-tap multiply-adds.  The reference's algorithmic multiply-adds per
@@ -626,6 +639,7 @@ def main():
                          "(27 taps, what the reference computes) - the Winograd kernels issue 8/27 (F(2x2x2)) or 4/9 (F(2x2)) of them, so "
                          "effective_frac may pass 1 while frac cannot"),
                 "traffic": traffic, "launches_per_forward": dom["n"], "avg_launch_ms": dom["ms"] / dom["n"],
+                "rocprofv3_trace": rocprof_ms,
                 "algorithmic_gflop_per_launch": dom["flops"] / dom["n"] / 1e9,
                 "executed_gflop_per_launch": dom["fexec"] / dom["n"] / 1e9,
                 "share_of_conv_time": dom["ms"] / all_ms,

@@ -31,8 +31,13 @@ echo "== probes: training step (forward + backward), view pooling forward / back
 timeout 200 python scripts/backward_probe.py 5 > $OUT/backward_probe.log 2>&1; tail -2 $OUT/backward_probe.log
 timeout 300 python scripts/viewpool_probe.py 16 64 > $OUT/viewpool_probe.log 2>&1; grep -E "view pooling|MLPMean" $OUT/viewpool_probe.log
 echo "== bench"; HOLO_DEBUG_PLAN=1 HOLO_BENCH_OPS=1 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; grep -E "per-op totals|\[plan\]" $OUT/bench.err | head -3
+python scripts/ops_table.py $OUT/bench.err > $OUT/ops_table.txt 2>/dev/null
 echo "== rocprofv3 kernel trace of the bench command"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err; echo "rocprof rc=$?" )
 for f in $(find /tmp/prof_$TAG -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
-for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv"); do python3 scripts/trace_by_grid.py "$f" "$OUT/kernel_trace_by_grid.csv"; done
+for f in $(find /tmp/prof_$TAG -name "*kernel_trace.csv"); do
+  python3 scripts/trace_by_grid.py "$f" "$OUT/kernel_trace_by_grid.csv"
+  # conv_wino3_kernel per level (every level launches the same grid): the trace joined with the plan's op order
+  python3 scripts/wino3_trace_join.py "$f" $OUT/bench.err 60 $OUT/wino3_64cubed_trace.csv
+done
 head -14 $OUT/kernel_stats.csv 2>/dev/null | cut -c1-220
