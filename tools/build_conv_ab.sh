@@ -10,5 +10,5 @@ for p in 1 2 4 7 8 16 32 64 128; do
 done
 $H $F -DW3_TIMELINE -DW3_ENTRY=conv_wino3_launch_tl -c holo_diffusion_amd/csrc/kernels_conv3.hip -o /tmp/k3_tl.o
 $H -O2 --offload-arch=gfx950 -c tools/conv_ab.cpp -o /tmp/conv_ab.o
-$H --offload-arch=gfx950 /tmp/conv_ab.o holo_diffusion_amd/csrc/kernels_conv.o holo_diffusion_amd/csrc/kernels_conv3.o \
+$H --offload-arch=gfx950 /tmp/conv_ab.o holo_diffusion_amd/csrc/kernels_conv.o holo_diffusion_amd/csrc/kernels_conv3.o holo_diffusion_amd/csrc/kernels_conv_bf16p.o \
    holo_diffusion_amd/csrc/kernels_misc.o /tmp/k3_p1.o /tmp/k3_p2.o /tmp/k3_p4.o /tmp/k3_p7.o /tmp/k3_p8.o /tmp/k3_p16.o /tmp/k3_p32.o /tmp/k3_p64.o /tmp/k3_p128.o /tmp/k3_tl.o -o tools/conv_ab
