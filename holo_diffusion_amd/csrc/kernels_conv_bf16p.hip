@@ -19,11 +19,16 @@
 //              conv_bf16t_kernel); BOTH operands come from LDS: per tap 4 A fragments from the halo buffer and NT B
 //              fragments from the weight buffer for 4 * NT v_mfma_f32_32x32x16_bf16; no vector-memory instruction
 //              between a tile's first tap and its epilogue;
-//   waves 4-7  PRODUCERS: one per SIMD beside a consumer; per 16-channel chunk they request the raw bf16 halo and the
-//              chunk's 27 * NT KB of weights two steps ahead (two register sets), apply GroupNorm * FiLM + SiLU, zero
-//              padding, upsampling and the concat, and write the halo MFMA-ready into the other of two 32 KB LDS buffers.
+//   waves 4-7  PRODUCERS: one per SIMD beside a consumer; per 16-channel chunk they request the raw bf16 halo (one chunk
+//              ahead of its commit) and the chunk's 27 * NT KB of weights, apply GroupNorm * FiLM + SiLU, zero padding,
+//              upsampling and the concat, and write the halo MFMA-ready into the other of two 32 KB LDS buffers.
 //              The weights have ONE 54 KB buffer (160 KB of LDS do not hold two): it is refilled in thirds (9 taps) behind
 //              the consumers' progress, which every consumer wave publishes in an LDS word after taps 8, 17 and 26.
+// Measured (same probe): the consumers' 27-tap loop then takes 3.3 - 3.4 us per chunk (0.9 of the pipe inside the loop) - and
+// waits for the producers wherever the halo is ACTIVATED: a producer wave gets its ~350 activation instructions per chunk
+// through in ~4.4 us beside a consumer that issues an MFMA every 32 cycles (~1 us alone).  Raw-input launches are faster than
+// on conv_bf16t_kernel (128^3 32 -> 64: 236 vs 262 us) and run here by default; activated ones are not yet (540 vs 480 us;
+// HOLO_CONV_BF16P=2).  DESIGN.md 4b has the whole ledger.
 // One barrier per chunk hands the halo buffer over; the producers run one chunk ahead, across tile boundaries, so a tile's
 // first halo is ready when the consumers leave the previous tile's epilogue.  A fused 1x1x1 skip connection is 32-channel
 // steps of their own: the producers copy the raw 8^3 centre (no halo, no activation) into the same buffers.
@@ -44,7 +49,7 @@
 //                 8 no MFMAs, 16 producers skip the activation arithmetic, 128 producers load but write nothing,
 //                 256 producers write (and compute) but load nothing, 512 the weights are not staged (flags and polls stay)
 //   P_TIMELINE:   p.dbg[workgroup][8] = wall-clock ticks (10 ns) of consumer wave 0 {barrier wait, tap loops, epilogue, steps,
-//                 items} and of producer wave 4 {issue + commit, barrier wait}
+//                 items} and of producer wave 4 {all work, barrier wait, of the work: halo commit}
 #ifndef P_PROBE
 #define P_PROBE 0
 #endif
@@ -63,7 +68,6 @@ constexpr int P_IT = 8;                 // staging items (voxel, 8-channel half)
 constexpr int P_BUF = P_HV * P_RS + 192;  // words per halo buffer (8 192: a skip step's two 4 096-word k-step planes fit)
 constexpr int P_EW = 68;                // words per voxel row of a consumer's transposition tile
 
-__device__ __forceinline__ float silu_fast_p(float v) { return v * holo_rcp(1.0f + __expf(-v)); }
 __device__ __forceinline__ void unpack8(const float4& v, float (&f)[8]) {
   const uint32_t w0 = __float_as_uint(v.x), w1 = __float_as_uint(v.y), w2 = __float_as_uint(v.z), w3 = __float_as_uint(v.w);
   f[0] = __uint_as_float(w0 << 16);
