@@ -56,6 +56,14 @@
 #ifndef P_ENTRY
 #define P_ENTRY conv_bf16p_launch
 #endif
+// P_PHASED 0 (default): the overlapped form (one barrier per chunk, weights refilled in thirds behind the consumers' progress
+// flags).  1: producers and consumers take TURNS - the consumers' tap loop and the producers' commit never run at the same time
+// (two barriers per chunk).  Measured side by side (tools/bf16p_probe, profiles/r06_bf16p_probe_v4_phased.txt): turns win on
+// activated inputs (128^3 64 -> 64: 519 vs 567 us; conv_bf16t_kernel 468) and lose on the raw-input launches this kernel is the
+// planner's default for (32 -> 64: 292 vs 279 us) - the producers' chain per chunk is 4.8 us of exposed latency either way.
+#ifndef P_PHASED
+#define P_PHASED 0
+#endif
 
 namespace holo {
 namespace {
@@ -470,15 +478,46 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         });
       });
     };
-    // One register set for each kind of request.  Iteration s (between the hand-overs of steps s - 1 and s) commits step s:
-    //   halo(s) [requested early in iteration s - 1] -> request halo(s + 1) -> weights(s) in thirds behind the consumers
-    //   [requested at the end of iteration s - 1] -> request weights(s + 1) -> hand-over.
-    // Whatever the compiler's s_waitcnt vmcnt(0) in front of a use waits for has been in flight for most of a step.
+    (void)commit_weights;
     Pend P;
     float4 W[NWV], CF[4];
     issue(P, CF);
     issue_weights(P.kind, P.ph, P.slice, W);
     int s = 0;
+#if P_PHASED
+    // Turns.  A producer wave that activates a halo beside a consumer issuing an MFMA every 32 cycles takes ~4.4 us for what it
+    // does in ~1 us alone (measured, tools/bf16p_probe), and the consumers then wait for it: overlapping the two streams on one
+    // SIMD costs more than it hides.  So: [hand-over A] the consumers multiply step s while the producers only WAIT - their
+    // requests for step s + 1 are in flight - [hand-over B] the producers commit step s + 1 (halo and all of its weights: one
+    // buffer each is enough now) while the consumers wait (or run a tile's epilogue) [hand-over A] ...
+    while (P.kind != 0) {
+      const int kind = P.kind, first = P.first;
+      commit(P, CF, s_halo + (s & 1) * P_BUF);
+      P_TL_STAMP(pt_commit);
+      if (!(P_PROBE & (4 | 128 | 256 | 512))) {
+        if (kind == 2) {
+          if (ptid < 2 * NT * 64) *reinterpret_cast<float4*>(s_bw + ptid * 4) = W[0];
+        } else {
+          p_static_for<NWV>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int f = ptid + 256 * j;
+            if (f < 27 * NT * 64) *reinterpret_cast<float4*>(s_bw + f * 4) = W[j];
+          });
+        }
+      }
+      P_TL_STAMP(pt_wts);
+      issue(P, CF);  // (step s + 1: in flight while the consumers multiply step s)
+      issue_weights(P.kind, P.ph, P.slice, W);
+      if (first && with_stats) __syncthreads();  // (the consumers' statistics hand-over of the previous item)
+      P_TL_PROD_BAR();                            // A: step s is staged
+      P_TL_PROD_BAR();                            // B: step s has been consumed
+      ++s;
+    }
+#else
+    // Overlapped form.  One register set for each kind of request.  Iteration s (between the hand-overs of steps s - 1 and s)
+    // commits step s:
+    //   halo(s) [requested early in iteration s - 1] -> request halo(s + 1) -> weights(s) in thirds behind the consumers
+    //   [requested at the end of iteration s - 1] -> request weights(s + 1) -> hand-over.
     while (P.kind != 0) {
       const int kind = P.kind, first = P.first;
       commit(P, CF, s_halo + (s & 1) * P_BUF);
@@ -491,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
       P_TL_PROD_BAR();                            // step s is ready / step s - 1 has been consumed
       ++s;
     }
+#endif
     if (with_stats && s > 0) __syncthreads();  // the last item's statistics hand-over
 #ifdef P_TIMELINE
     if (p.dbg && tid == 256) {
@@ -609,8 +649,9 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // (the reads of taps <= 8 / <= 17 / all have been issued - B two taps ahead - and LDS serves them in order)
-        if (tap == 8 || tap == 17 || tap == 26) publish(3 * s + (tap + 1) / 9);
+        if (!P_PHASED && (tap == 8 || tap == 17 || tap == 26)) publish(3 * s + (tap + 1) / 9);
       }
+      if (P_PHASED) P_STEP_BARRIER();  // B: the producers may commit step s + 1
 #ifdef P_TIMELINE
       ct_loop += HOLO_PROBE_CLOCK() - ct1;
       ++ct_steps;
@@ -627,7 +668,11 @@ __global__ __launch_bounds__(512, 2) void conv_bf16p_kernel(ConvParams p) {
         mfma_tap(A[0], B[0]);
         mfma_tap(A[1], B[1]);
         __builtin_amdgcn_sched_barrier(0);
-        publish(3 * s + 3);
+        if (P_PHASED) {
+          P_STEP_BARRIER();
+        } else {
+          publish(3 * s + 3);
+        }
       }
     }
 

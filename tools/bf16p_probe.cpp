@@ -194,7 +194,7 @@ int main(int argc, char** argv) {
         {"probe: producers load the halo, write nothing", conv_bf16p_launch_p128},
         {"probe: producers write + compute, load nothing", conv_bf16p_launch_p256},
         {"probe: weights not staged (flags and polls stay)", conv_bf16p_launch_p512},
-        {"variant: producers at s_setprio 3", conv_bf16p_launch_prio}};
+        {"variant: producers and consumers in turns (P_PHASED = 1)", conv_bf16p_launch_prio}};
     for (auto& pr : probes) time_fn(pr.what, pr.fn, qp);
   }
   return 0;

@@ -10,7 +10,7 @@ for p in 1 2 3 4 7 8 16 128 256 512; do
   $H $F -DP_PROBE=$p -DP_ENTRY=conv_bf16p_launch_p$p -c holo_diffusion_amd/csrc/kernels_conv_bf16p.hip -o /tmp/bf16p_p$p.o
   O="$O /tmp/bf16p_p$p.o"
 done
-$H $F -DP_PRODUCER_PRIO=3 -DP_ENTRY=conv_bf16p_launch_prio -c holo_diffusion_amd/csrc/kernels_conv_bf16p.hip -o /tmp/bf16p_prio.o
+$H $F -DP_PHASED=1 -DP_ENTRY=conv_bf16p_launch_prio -c holo_diffusion_amd/csrc/kernels_conv_bf16p.hip -o /tmp/bf16p_prio.o
 O="$O /tmp/bf16p_prio.o"
 $H $F -DP_TIMELINE -DP_ENTRY=conv_bf16p_launch_tl -c holo_diffusion_amd/csrc/kernels_conv_bf16p.hip -o /tmp/bf16p_tl.o
 $H -O2 --offload-arch=gfx950 -c tools/bf16p_probe.cpp -o /tmp/bf16p_probe.o

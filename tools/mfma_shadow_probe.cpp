@@ -10,7 +10,17 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef PROBE_BF16
+// -DPROBE_BF16: the same tables for v_mfma_f32_32x32x16_bf16 (8 passes = 32 cycles alone; 8 independent 16-register accumulators)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA(c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a4), "v"(b4))
+#define NACC 8
+typedef f32x16 acc_t;
+#else
 #define MFMA(c) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b))
+#define NACC 16
+typedef f32x4 acc_t;
+#endif
 
 template <int TYPE, int K>
 __device__ __forceinline__ void fill(float (&v)[8], f32x2 (&pk)[4], unsigned& s, f32x4 (&ld)[4], const float* lds, const float* g,
@@ -25,17 +35,23 @@ __device__ __forceinline__ void fill(float (&v)[8], f32x2 (&pk)[4], unsigned& s,
     if (TYPE == 4) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ld[r & 3]) : "v"(g));
     if (TYPE == 5) asm volatile("s_nop 0");
     if (TYPE == 6) asm volatile("v_exp_f32 %0, %0" : "+v"(v[r]));
+    if (TYPE == 7) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
+    if (TYPE == 8) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[r]) : "v"(1.0f));
+    if (TYPE == 9) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
   }
 }
 
 template <int TYPE, int K>
-__global__ void probe(int iters, float* out, const float* g) {
+__global__ __launch_bounds__(512) void probe(int iters, float* out, const float* g) {
   __shared__ float lds[24 * 1024];  // 96 KB: one workgroup per CU
   lds[threadIdx.x] = 1.f;
   __syncthreads();
-  f32x4 acc[16];
-  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc_t acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int j = 0; j < (int)(sizeof(acc_t) / 4); ++j) acc[i][j] = 0.f;
   const float a = threadIdx.x * 1e-3f, b = 1e-3f;
+  const f32x4 a4 = f32x4{a, a, a, a}, b4 = f32x4{b, b, b, b};
+  (void)a4, (void)b4;
   float v[8];
   f32x2 pk[4];
   f32x4 ld[4];
@@ -46,7 +62,7 @@ __global__ void probe(int iters, float* out, const float* g) {
   const float* gp = g + (threadIdx.x & 63) * 4;
   for (int it = 0; it < iters; ++it) {
 #define STEP(i) \
-  MFMA(acc[i]); \
+  MFMA(acc[(i) % NACC]); \
   fill<TYPE, K>(v, pk, s, ld, lp, gp, i);
     STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14)
     STEP(15)
@@ -54,7 +70,7 @@ __global__ void probe(int iters, float* out, const float* g) {
     if (TYPE == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   float r = 0.f;
-  for (int i = 0; i < 16; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < NACC; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   for (int i = 0; i < 8; ++i) r += v[i];
   for (int i = 0; i < 4; ++i) r += pk[i][0] + pk[i][1] + ld[i][0] + ld[i][1] + ld[i][2] + ld[i][3];
   if (r == 12345.678f) out[threadIdx.x] = r + s;
@@ -104,6 +120,9 @@ int main() {
     row<0>("v_add_f32", threads, out, g);
     row<1>("v_pk_add_f32", threads, out, g);
     row<6>("v_exp_f32", threads, out, g);
+    row<8>("v_fma_f32", threads, out, g);
+    row<9>("v_max_f32", threads, out, g);
+    row<7>("v_cvt_pk_bf16_f32", threads, out, g);
   }
   return 0;
 }
