@@ -357,353 +357,6 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(AttnParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// bf16 attention, second form (bf16 storage mode, T >= 8192).
-//
-// Pre-pass (attn_pack_kernel): qkv fp32 [N][T][3C] -> per (sample, head): Q bf16 [T][CH] scaled by CH^-1/2 * log2(e)
-// (the softmax then runs on v_exp_f32 = 2^x directly), K bf16 [T][CH], V^T bf16 [CH][T].  25 MB in, 25 MB out at
-// T = 32 768: ~20 us, against which the main kernel no longer converts or transposes anything per key block (the first
-// form did both, with 2-byte LDS stores, once per 128-query workgroup: 256 times per attention call).
-//
-// Main kernel: workgroup = 4 waves x 64 queries of one (sample, head, key split); key blocks of 64, double buffered in
-// LDS (one barrier per block): K rows [key][CH] (stride CH/2+4 words) and V^T rows [ch][64 keys] (stride 34 words),
-// both conflict free for the fragment reads.  Transposed formulation on 32x32x16 tiles:
-//   S^T[key][query] = K . Q^T      A = K row li of the 32-key tile, channels 8kg..8kg+7 of the k-step (one ds_read_b128),
-//                                  B = Q^T operands resident in registers
-//   D: column = query li, rows = keys (r&3) + 8(r>>2) + 4kg: a query's 32 keys are the 16 registers of lanes li and
-//   li+32 -> max / sum are register reductions plus ONE cross-half shuffle.
-//   O^T[c][query] += V^T[c][key] . P^T[key][query]: the lane's registers 8h..8h+7 of an S tile are keys
-//   16h + {4kg..4kg+3, 8+4kg..8+4kg+3}: that IS taken as the k order of the k-step, so P goes register -> operand and
-//   the A operand reads the same keys of the V^T row (two ds_read_b64).
-// Per 64-key block and wave: 32 MFMAs (1 024 pipe cycles) against ~300 vector instructions of softmax: the two
-// waves of a SIMD overlap one's softmax with the other's MFMAs, which is why the grid is sized to two workgroups per CU.
-// ---------------------------------------------------------------------------------------------
-template <int CH>
-__global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ qkv, uint16_t* __restrict__ qb,
-                                                        uint16_t* __restrict__ kb, uint16_t* __restrict__ vt, int T, int C,
-                                                        int H, float qscale) {
-  __shared__ float tile[64][CH + 1];
-  const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  const int tb = b % (T / 64);
-  b /= (T / 64);
-  const int head = b % H;
-  const int n = b / H;
-  const int t0 = tb * 64;
-  const float* base = qkv + ((int64_t)n * T + t0) * 3 * C + head * 3 * CH;
-  const int64_t hb = (int64_t)n * H + head;
-  for (int i = tid; i < 64 * CH / 4; i += 256) {
-    const int tok = i / (CH / 4), c4 = i - tok * (CH / 4);
-    const float* rp = base + (int64_t)tok * 3 * C + c4 * 4;
-    const float4 q = *reinterpret_cast<const float4*>(rp);
-    const float4 k = *reinterpret_cast<const float4*>(rp + CH);
-    const float4 v = *reinterpret_cast<const float4*>(rp + 2 * CH);
-    const int64_t o = (hb * T + t0 + tok) * CH + c4 * 4;
-    *reinterpret_cast<uint2*>(qb + o) =
-        make_uint2(pack_bf16x2(q.x * qscale, q.y * qscale), pack_bf16x2(q.z * qscale, q.w * qscale));
-    *reinterpret_cast<uint2*>(kb + o) = make_uint2(pack_bf16x2(k.x, k.y), pack_bf16x2(k.z, k.w));
-    tile[tok][c4 * 4 + 0] = v.x;
-    tile[tok][c4 * 4 + 1] = v.y;
-    tile[tok][c4 * 4 + 2] = v.z;
-    tile[tok][c4 * 4 + 3] = v.w;
-  }
-  __syncthreads();
-  for (int i = tid; i < CH * 8; i += 256) {
-    const int ch = i >> 3, t8 = i & 7;
-    uint32_t w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(tile[t8 * 8 + 2 * e][ch], tile[t8 * 8 + 2 * e + 1][ch]);
-    uint16_t* dst = vt + (hb * CH + ch) * T + t0 + t8 * 8;
-    *reinterpret_cast<uint2*>(dst) = make_uint2(w[0], w[1]);
-    *reinterpret_cast<uint2*>(dst + 4) = make_uint2(w[2], w[3]);
-  }
-}
-
-struct AttnV2 {
-  const uint16_t* qb;
-  const uint16_t* kb;
-  const uint16_t* vt;
-  float* out;     // ksplit == 1: [N][T][C] (fp32 or bf16)
-  float* opart;   // ksplit > 1: [ksplit][N][T][C] un-normalised O
-  float* ml;      // ksplit > 1: [ksplit][N][H][T][2] (running max in the exp2 domain, running sum)
-  int N, T, C, H, ksplit, out_bf16;
-};
-
-// QT: 32-query tiles per wave (2; 1 for head channels 128, whose 64-query wave tile would need 320 registers)
-template <int CH, int QT, bool PIPE = true>
-__global__ __launch_bounds__(256, 2) void flash_attn_bf16v2_kernel(AttnV2 p) {
-  constexpr int KB = 64;
-  constexpr int KW = CH / 2 + 4;  // words per K row
-  constexpr int VW = 34;          // words per V^T row (64 keys + 8 bytes)
-  constexpr int NKS = CH / 16;    // k-steps of S^T
-  constexpr int NCT = CH / 32;    // channel tiles of O^T
-  constexpr int PER = CH / 32;    // 16-byte staging pieces per thread, for K and for V^T
-  __shared__ __attribute__((aligned(16))) uint32_t s_k[2][KB * KW];
-  __shared__ __attribute__((aligned(16))) uint32_t s_v[2][CH * VW];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int li = lane & 31;
-  const int kg = lane >> 5;
-  const int qtiles = p.T / (128 * QT);
-  int b = blockIdx.x;
-  const int qt256 = b % qtiles;
-  b /= qtiles;
-  const int ks = b % p.ksplit;
-  b /= p.ksplit;
-  const int head = b % p.H;
-  const int n = b / p.H;
-  const int64_t hb = (int64_t)n * p.H + head;
-  const int q0 = qt256 * (128 * QT) + wave * (32 * QT);
-  const int klen = p.T / p.ksplit;
-  const int kbeg = ks * klen;
-  const int nblk = klen / KB;
-
-  float4 qf[QT][NKS];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-      qf[qt][s] = *reinterpret_cast<const float4*>(p.qb + (hb * p.T + q0 + qt * 32 + li) * CH + s * 16 + kg * 8);
-
-  f32x16 oacc[NCT][QT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[ct][qt][r] = 0.f;
-  float m_run[QT], d_run[QT], l_run[QT];  // exponent reference, running maximum relative to it, running sum
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) m_run[qt] = 0.f, d_run[qt] = -3.0e38f, l_run[qt] = 0.f;
-
-  f32x4 kreg[PER], vreg[PER];  // (native vectors: as float4 structs one of the two arrays stayed in scratch memory, and a
-                               //  scratch store of a load still in flight stalls the wave for the whole round trip)
-  auto stage_load = [&](int blk) {
-    const int k0 = kbeg + blk * KB;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = tid + 256 * j;
-      const int key = i / (CH / 8), c8 = i - key * (CH / 8);
-      kreg[j] = *reinterpret_cast<const f32x4*>(p.kb + (hb * p.T + k0 + key) * CH + c8 * 8);
-      const int ch = i >> 3, k8 = i & 7;
-      vreg[j] = *reinterpret_cast<const f32x4*>(p.vt + (hb * CH + ch) * p.T + k0 + k8 * 8);
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int i = tid + 256 * j;
-      const int key = i / (CH / 8), c8 = i - key * (CH / 8);
-      *reinterpret_cast<f32x4*>(&s_k[buf][key * KW + c8 * 4]) = kreg[j];
-      const int ch = i >> 3, k8 = i & 7;
-      uint32_t* d = &s_v[buf][ch * VW + k8 * 4];
-      *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(vreg[j][0]), __float_as_uint(vreg[j][1]));
-      *reinterpret_cast<uint2*>(d + 2) = make_uint2(__float_as_uint(vreg[j][2]), __float_as_uint(vreg[j][3]));
-    }
-  };
-
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (int blk = 0; blk < nblk; ++blk) {
-    const int buf = blk & 1;
-    // ---- S^T tiles [key tile kt][query tile qt]; online softmax per query column (exp2 domain), P^T operands straight
-    // from the registers; O^T += V^T . P^T.  The two query tiles are staggered so that the vector work of one tile's
-    // softmax sits between the MFMAs of the other tile (a wave issues in order: 16 MFMAs followed by 150 vector
-    // instructions leave the matrix pipe idle for the length of the softmax): S(0) | S(1) + softmax(0) |
-    // PV(0) + softmax(1) | PV(1).  (Measured alternatives, all within noise or worse: the plain sequential order; sharing
-    // the V^T fragments too; the minimal-register sequential form at three waves per SIMD: 27 % slower; an XCD-aware
-    // workgroup order (each XCD one K / V^T stream): 7 % slower.)
-    f32x16 sacc[2][QT];
-    float4 pf[QT][2][2];  // [qt][kt][h]
-    // The exponent reference m_ref of a query is NOT its exact running maximum: S - m_ref comes out of the MFMAs (the
-    // accumulators start at -m_ref), P = 2^(S - m_ref) may exceed 1, and O, l are re-referenced only when the running
-    // maximum has moved more than 2^32 away from m_ref (or in the first block) - any common reference cancels in O / l.
-    // That takes the per-element subtraction and, almost always, the rescaling of O out of the vector work, which is
-    // what bounds this kernel (softmax ~2x the matrix time at 64 head channels).
-    // the K fragments are shared by the two query tiles (read once per block into registers); the V^T fragments are read
-    // per query tile - holding them too costs 32 registers at the point where the kernel then spills its staging
-    // registers, and a spilled in-flight load stalls the wave for the whole memory round trip
-    float4 kaf[NKS][2];
-    auto load_k = [&]() {
-#pragma unroll
-      for (int s = 0; s < NKS; ++s)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          kaf[s][kt] = *reinterpret_cast<const float4*>(&s_k[buf][(kt * 32 + li) * KW + s * 8 + kg * 4]);
-    };
-    auto s_tile = [&](int qt) {
-      const float init = -m_run[qt];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[kt][qt][r] = init;
-#pragma unroll
-      for (int s = 0; s < NKS; ++s)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) sacc[kt][qt] = mfma_bf16_32x32x16(kaf[s][kt], qf[qt][s], sacc[kt][qt]);
-    };
-    auto softmax_tile = [&](int qt) {
-      float mx = sacc[0][qt][0];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kt][qt][r]);
-      mx = holo_max_xor32(mx);
-      float d = fmaxf(d_run[qt], mx);  // running maximum relative to m_ref
-      if (__any(blk == 0 || d > 32.0f)) {  // re-reference (every lane by its own d: valid for any d)
-        const float sc = holo_exp2(-d);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[kt][qt][r] -= d;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[ct][qt][r] *= sc;
-        l_run[qt] *= sc;
-        m_run[qt] += d;
-        d = 0.f;
-      }
-      d_run[qt] = d;
-      float ls = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sacc[kt][qt][r] = holo_exp2(sacc[kt][qt][r]);
-          ls += sacc[kt][qt][r];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          pf[qt][kt][h] = make_float4(__uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 0], sacc[kt][qt][8 * h + 1])),
-                                      __uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 2], sacc[kt][qt][8 * h + 3])),
-                                      __uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 4], sacc[kt][qt][8 * h + 5])),
-                                      __uint_as_float(pack_bf16x2(sacc[kt][qt][8 * h + 6], sacc[kt][qt][8 * h + 7])));
-      }
-      l_run[qt] += holo_add_xor32(ls);
-    };
-    auto pv_tile = [&](int qt) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            const uint32_t* vr = &s_v[buf][(ct * 32 + li) * VW + (kt * 32 + 16 * h + 4 * kg) / 2];
-            const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 4);
-            const float4 va = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
-            oacc[ct][qt] = mfma_bf16_32x32x16(va, pf[qt][kt][h], oacc[ct][qt]);
-          }
-    };
-    // one MFMA, then a slice of the other tile's softmax
-    auto interleave = [&](int n_mfma) {
-#pragma unroll
-      for (int i = 0; i < n_mfma; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-      }
-    };
-    load_k();
-    s_tile(0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (QT == 2) {
-      s_tile(QT - 1);
-      softmax_tile(0);
-      if (PIPE) interleave(2 * NKS);
-      __builtin_amdgcn_sched_barrier(0);
-      // the next block's K / V^T pieces are requested only now: their 16 staging registers are not live under the S phases,
-      // where the register pressure peaks (requested at the top of the block the kernel spilled Q fragments into the loop)
-      if (blk + 1 < nblk) stage_load(blk + 1);
-      pv_tile(0);
-      softmax_tile(QT - 1);
-      if (PIPE) interleave(4 * NCT);
-      __builtin_amdgcn_sched_barrier(0);
-      pv_tile(QT - 1);
-    } else {
-      softmax_tile(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (blk + 1 < nblk) stage_load(blk + 1);
-      pv_tile(0);
-    }
-    if (blk + 1 < nblk) stage_store(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- D rows = channels ct*32 + (r&3) + 8(r>>2) + 4kg, column = query li
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int q = q0 + qt * 32 + li;
-    if (p.ksplit == 1) {
-      const float inv = 1.f / l_run[qt];
-      const int64_t o = ((int64_t)n * p.T + q) * p.C + head * CH + 4 * kg;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float v0 = oacc[ct][qt][4 * g] * inv, v1 = oacc[ct][qt][4 * g + 1] * inv, v2 = oacc[ct][qt][4 * g + 2] * inv,
-                      v3 = oacc[ct][qt][4 * g + 3] * inv;
-          const int64_t oo = o + ct * 32 + 8 * g;
-          if (p.out_bf16)
-            *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + oo) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-          else
-            *reinterpret_cast<float4*>(p.out + oo) = make_float4(v0, v1, v2, v3);
-        }
-    } else {
-      const int64_t o = (((int64_t)ks * p.N + n) * p.T + q) * p.C + head * CH + 4 * kg;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<float4*>(p.opart + o + ct * 32 + 8 * g) =
-              make_float4(oacc[ct][qt][4 * g], oacc[ct][qt][4 * g + 1], oacc[ct][qt][4 * g + 2], oacc[ct][qt][4 * g + 3]);
-      if (kg == 0) {
-        float* mlp = p.ml + ((((int64_t)ks * p.N + n) * p.H + head) * p.T + q) * 2;
-        mlp[0] = m_run[qt];
-        mlp[1] = l_run[qt];
-      }
-    }
-  }
-}
-
-// recombination of the key splits: out = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s; one thread per (query, 4 channels)
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnV2 p, int CH) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int c4n = p.C / 4;
-  const int64_t total = (int64_t)p.N * p.T * c4n;
-  if (i >= total) return;
-  const int c4 = (int)(i % c4n);
-  const int64_t nt = i / c4n;
-  const int q = (int)(nt % p.T);
-  const int n = (int)(nt / p.T);
-  const int head = c4 * 4 / CH;
-  float m = -3.0e38f;
-  for (int s = 0; s < p.ksplit; ++s) m = fmaxf(m, p.ml[((((int64_t)s * p.N + n) * p.H + head) * p.T + q) * 2]);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  float l = 0.f;
-  for (int s = 0; s < p.ksplit; ++s) {
-    const float* mlp = p.ml + ((((int64_t)s * p.N + n) * p.H + head) * p.T + q) * 2;
-    const float w = holo_exp2(mlp[0] - m);
-    const float4 o = *reinterpret_cast<const float4*>(p.opart + (((int64_t)s * p.N + n) * p.T + q) * p.C + c4 * 4);
-    acc.x += w * o.x;
-    acc.y += w * o.y;
-    acc.z += w * o.z;
-    acc.w += w * o.w;
-    l += w * mlp[1];
-  }
-  const float inv = 1.f / l;
-  const int64_t oo = ((int64_t)n * p.T + q) * p.C + c4 * 4;
-  if (p.out_bf16)
-    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + oo) =
-        make_uint2(pack_bf16x2(acc.x * inv, acc.y * inv), pack_bf16x2(acc.z * inv, acc.w * inv));
-  else
-    *reinterpret_cast<float4*>(p.out + oo) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
-}
-
 }  // namespace
 
 int gemm_launch(const GemmParams& p, void* stream) {
@@ -739,66 +392,6 @@ int flash_attn_launch(const AttnParams& p, void* stream) {
     default:
       HOLO_LAUNCH(flash_attn_kernel<64>, grid, dim3(256), stream, p);
       break;
-  }
-  return 0;
-}
-
-bool flash_attn_bf16v2_supported(int T, int ch) { return (T % 256) == 0 && (ch == 32 || ch == 64 || ch == 128); }
-static int attn_v2_ksplit(const AttnParams& p, int num_cus) {
-  const int64_t wgs = (int64_t)p.N * p.H * (p.T / (p.C / p.H == 128 ? 128 : 256));
-  int ks = 1;
-  while (wgs * ks < 2 * (int64_t)num_cus && ks < 8 && (p.T / (ks * 2)) % 64 == 0) ks *= 2;
-  if (const char* e = getenv("HOLO_FLASH_V2_KSPLIT")) {  // development knob
-    const int v = atoi(e);
-    if (v >= 1 && v <= 8 && (p.T / v) % 64 == 0) ks = v;
-  }
-  return ks;
-}
-size_t flash_attn_bf16v2_workspace_bytes(const AttnParams& p, int num_cus) {
-  const size_t ntc = (size_t)p.N * p.T * p.C;
-  const int ks = attn_v2_ksplit(p, num_cus);
-  size_t b = 3 * ntc * sizeof(uint16_t);
-  if (ks > 1) b += (size_t)ks * ntc * sizeof(float) + (size_t)ks * p.N * p.H * p.T * 2 * sizeof(float);
-  return b;
-}
-int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream) {
-  const int ch = p.C / p.H;
-  if (!flash_attn_bf16v2_supported(p.T, ch)) {
-    set_error("flash_attn_bf16v2: unsupported shape T=%d head channels=%d", p.T, ch);
-    return -1;
-  }
-  const size_t ntc = (size_t)p.N * p.T * p.C;
-  AttnV2 a;
-  uint16_t* w16 = reinterpret_cast<uint16_t*>(work);
-  a.qb = w16;
-  a.kb = w16 + ntc;
-  a.vt = w16 + 2 * ntc;
-  a.out = p.out;
-  a.opart = reinterpret_cast<float*>(w16 + 3 * ntc);
-  a.ksplit = attn_v2_ksplit(p, num_cus);
-  a.ml = a.opart + (size_t)a.ksplit * ntc;
-  a.N = p.N, a.T = p.T, a.C = p.C, a.H = p.H;
-  a.out_bf16 = out_bf16;
-  const float qscale = p.scale2 * 1.4426950408889634f;  // softmax in the exp2 domain
-  dim3 pgrid((unsigned)((int64_t)p.N * p.H * (p.T / 64)));
-  dim3 grid((unsigned)((int64_t)p.N * p.H * a.ksplit * (p.T / (ch == 128 ? 128 : 256))));
-  switch (ch) {
-    case 32:
-      HOLO_LAUNCH(attn_pack_kernel<32>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH((flash_attn_bf16v2_kernel<32, 2>), grid, dim3(256), stream, a);
-      break;
-    case 64:
-      HOLO_LAUNCH(attn_pack_kernel<64>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH((flash_attn_bf16v2_kernel<64, 2>), grid, dim3(256), stream, a);
-      break;
-    default:
-      HOLO_LAUNCH(attn_pack_kernel<128>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
-      HOLO_LAUNCH((flash_attn_bf16v2_kernel<128, 1>), grid, dim3(256), stream, a);
-      break;
-  }
-  if (a.ksplit > 1) {
-    const int64_t total = (int64_t)p.N * p.T * (p.C / 4);
-    HOLO_LAUNCH(attn_combine_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), stream, a, ch);
   }
   return 0;
 }

@@ -13,7 +13,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef PROBE_BF16
 // -DPROBE_BF16: the same tables for v_mfma_f32_32x32x16_bf16 (8 passes = 32 cycles alone; 8 independent 16-register accumulators)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifdef PROBE_ACC_VGPR  // accumulators in ARCHITECTURAL registers (what the compiler does when a kernel's accumulators are read by vector code)
+#define MFMA(c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a4), "v"(b4))
+#else
 #define MFMA(c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a4), "v"(b4))
+#endif
 #define NACC 8
 typedef f32x16 acc_t;
 #else
@@ -38,6 +42,7 @@ __device__ __forceinline__ void fill(float (&v)[8], f32x2 (&pk)[4], unsigned& s,
     if (TYPE == 7) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
     if (TYPE == 8) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[r]) : "v"(1.0f));
     if (TYPE == 9) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
+    if (TYPE == 10) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(pk[r & 3][0]));  // (an AGPR no MFMA writes)
   }
 }
 
@@ -123,6 +128,7 @@ int main() {
     row<8>("v_fma_f32", threads, out, g);
     row<9>("v_max_f32", threads, out, g);
     row<7>("v_cvt_pk_bf16_f32", threads, out, g);
+    row<10>("v_accvgpr_read_b32", threads, out, g);
   }
   return 0;
 }
