@@ -64,7 +64,7 @@ struct ConvParams {
   unsigned long long* dbg;  // optional timeline probe (scripts/conv_timeline.cpp): [tile][8] {t_start, t_first_halo,
                             // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel,
-                          // 3 = streaming 1x1x1 kernel (large grids, raw input)
+                          // 3 = streaming 1x1x1 kernel (large grids, raw input), 4 = stride-2 bf16 halo kernel (kernels_conv_s2.hip)
   // Winograd-in-depth form of the 128-voxel halo kernel (conv_wino_kernel): weights pre-transformed along kz,
   // U_xi = sum_kz G[xi][kz] w[kz], packed like w with 36 pseudo-taps xi*9 + ky*3 + kx; the fused skip as 2 pseudo-taps
   // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
@@ -93,6 +93,11 @@ struct ConvParams {
   int res_bf16;           // residual
   int out_bf16;           // out
 };
+
+// kernels_conv_s2.hip: the stride-2 3x3x3 convolution of a Downsample block on bf16 activation storage (raw input, 2 x 8 x 8
+// output tiles x 64 output channels, GroupNorm statistics: one slab per tile)
+bool conv_s2_bf16_supported(const ConvParams& p);
+int conv_s2_bf16_launch(const ConvParams& p, void* stream);
 
 // kernels_conv3.hip
 int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps);

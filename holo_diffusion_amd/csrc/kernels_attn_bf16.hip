@@ -116,6 +116,7 @@ __device__ __forceinline__ void attn_mfma_o(f32x16& c, const float4& a, const fl
                : "v"(__builtin_bit_cast(f32x4, a)), "v"(__builtin_bit_cast(f32x4, b)));
 }
 __device__ __forceinline__ void attn_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+__device__ __forceinline__ void attn_mfma_s_pad() { asm volatile("s_nop 3"); }
 #else
 static inline void attn_mfma_s(f32x16& c, const float4& a, const float4& b) { c = mfma_bf16_32x32x16(a, b, c); }
 static inline void attn_mfma_o(f32x16& c, const float4& a, const float4& b) { c = mfma_bf16_32x32x16(a, b, c); }
@@ -125,6 +126,7 @@ static inline void attn_mfma_s0(f32x16& c, const float4& a, const float4& b) {
   c = mfma_bf16_32x32x16(a, b, z);
 }
 static inline void attn_mfma_drain() {}
+static inline void attn_mfma_s_pad() {}
 #endif
 
 // QT: 32-query tiles per wave (2; 1 for head channels 128, whose 64-query wave tile would need 320 registers)
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? 1 : 2) void flash_attn_bf16v2_kern
       // of 8 registers follows their second slice
       auto exp_slice = [&](int kt, int i) {
         const int qt = i >> 2, r0 = 4 * (i & 3), e0 = r0 & 4;
-        if ((i & 3) == 0) asm volatile("s_nop 3");  // (the S MFMAs are asm: their write-back is not the compiler's to wait for)
+        if ((i & 3) == 0) attn_mfma_s_pad();  // (the S MFMAs are asm: their write-back is not the compiler's to wait for)
 #pragma unroll
         for (int r = 0; r < 4; ++r) pe[qt][e0 + r] = (HOLO_ATTN_PROBE & 1) ? sacc[kt][qt][r0 + r] : holo_exp2(sacc[kt][qt][r0 + r]);
         if (!(HOLO_ATTN_PROBE & 8)) {

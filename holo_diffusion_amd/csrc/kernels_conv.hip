@@ -2784,6 +2784,21 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       return 0;
     }
   }
+  // the stride-2 convolution of a Downsample block in the bf16 storage mode, where its 128-voxel tiles give the chip at least
+  // a workgroup per four CUs (128^3 net: 128^3 -> 64^3 540 -> ~100 us, and the two levels below; deeper the row-tile kernel's
+  // split-K fills the chip better).  HOLO_CONV_S2T=0 keeps the row-tile kernel, =1 takes this one wherever it is defined (tests)
+  {
+    const char* es = getenv("HOLO_CONV_S2T");
+    const int64_t wgs = (M / 128) * (p.Cout / 64);
+    if (p.mode == 0 && !(es && es[0] == '0') && conv_s2_bf16_supported(p) && (wgs >= num_cus / 4 || (es && es[0] == '1'))) {
+      p.mode = 4;
+      p.nsplit = 1;
+      p.chunks_per_split = Cin / 16;
+      if (getenv("HOLO_DEBUG_PLAN"))
+        fprintf(stderr, "[plan] conv %d->%d @%d^3 stride 2: bf16 halo kernel, %lld workgroups\n", Cin, p.Cout, p.OD, (long long)wgs);
+      return 0;
+    }
+  }
   // 1x1x1, strided and deepest-level convs: row-tile kernel (also for the 32^3 stride-2 convolution with its 32 768 rows: the
   // per-tap gather kernel takes 118 us there, this one 95)
   if (p.mode == 0 && p.Cout >= 64) {
@@ -2963,6 +2978,7 @@ int conv_stats_slabs(const ConvParams& p) {
   if (p.mode == 1 && p.bf16 == 2 && p.w_bf && p.Cout >= 64 && !p.skip_w) return (int)(V / 32);  // bf16x3 kernel: per half 8x8 slab
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
+  if (p.mode == 4) return (int)(V / 128);  // stride-2 bf16 halo kernel: one slab per 2 x 8 x 8 tile
   return 0;
 }
 
@@ -3077,6 +3093,8 @@ int conv_launch(const ConvParams& p, void* stream) {
     }
 #undef HOLO_HALO
     }
+  } else if (p.mode == 4) {
+    if (conv_s2_bf16_launch(p, stream)) return -1;
   } else if (p.mode == 3) {
     if (p.stats || p.residual || p.coef || p.nsplit != 1) {
       set_error("conv_launch: the streaming 1x1x1 kernel takes raw input and produces no statistics");

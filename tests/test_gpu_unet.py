@@ -444,6 +444,46 @@ def test_bf16_storage_mode_blockwise(gu, wide_tile, monkeypatch):
     assert ("conv_bf16p_kernel" in kernels) == (wide_tile == "p"), kernels
 
 
+def test_bf16_stride2_halo_kernel_blockwise(gu, monkeypatch):
+    """The Downsample convolutions of the bf16 storage mode on conv_s2_bf16_kernel (2 x 8 x 8 output tiles, the 5 x 17 x 17
+    input region de-interleaved along x in LDS, per-tile GroupNorm slabs), forced onto a 32^3 net (32^3 -> 16^3 with 64
+    channels, 16^3 -> 8^3 with 128: two output-channel blocks, tiles on every face of the grid, batch 2): every block output
+    against the fp32 oracle at the bf16 tolerance, and the two Downsample outputs against the row-tile kernel's (the first: same bf16
+    operands, fp32 accumulation in another order - at most one bf16 ulp apart, and only rarely) - reference
+    guided_diffusion/unet.py:109-138."""
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+    cfg = uo.UNetCfg(image_size=32, in_channels=16, out_channels=16, model_channels=64, num_res_blocks=2,
+                     channel_mult=(1, 2, 2), attention_resolutions=(), num_heads=2)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(5, (2, 16, 32, 32, 32)))
+    t = torch.tensor([640, 3], dtype=torch.int64)
+    trace = {}
+    outs = {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("HOLO_CONV_S2T", knob)
+        net, sd = gu.make_unet(cfg, seed=41, compute_dtype="bf16")
+        if not trace:
+            ref = uo.unet_forward(sd, cfg, x, t, trace)
+        with torch.no_grad():
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+        assert 1e-5 < gu.rel_err(y, ref) < 2e-2
+        for tag, r in trace.items():
+            if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block":
+                assert gu.rel_err(net.fetch_block(tag, tuple(r.shape)), r) < 2e-2, (knob, tag)
+        outs[knob] = {tag: net.fetch_block(tag, tuple(trace[tag].shape)).float().cpu() for tag in ("input_blocks.3", "input_blocks.6")}
+        kernels = [o.get("kernel") for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv" and o["stride"] == 2]
+        assert len(kernels) == 2 and all((k == "conv_s2_bf16_kernel") == (knob == "1") for k in kernels), kernels
+    for tag in outs["0"]:
+        a, b = outs["0"][tag], outs["1"][tag]
+        d = (a - b).abs()
+        print(f"{tag}: max|d| {float(d.max()):.2e} of {float(a.abs().max()):.2e}, {100 * float((d > 0).float().mean()):.3f} % of the elements differ")
+        assert float(d.max()) <= 2.0 ** -7 * float(a.abs().max()), tag           # one bf16 ulp of the largest value
+        if tag == "input_blocks.3":  # (the first Downsample sees identical input in both runs; the second one's input already differs)
+            assert float((d > 0).float().mean()) < 0.02, tag                     # ... on a few elements that sat on a rounding edge
+        else:
+            assert float(d.mean()) < 2e-3 * float(a.abs().mean()), tag
+
+
 @pytest.mark.parametrize("image,mc,mult,attn,batch", [(8, 64, (1, 2), (2,), 1), (16, 64, (1, 2, 2), (4,), 2)])
 def test_f32_bf16x3_mode_meets_the_fp32_tolerance(gu, image, mc, mult, attn, batch):
     """fp32 operands split exactly into three bf16 terms, six bf16 MFMAs per product: every block output against the
