@@ -64,7 +64,8 @@ struct ConvParams {
   unsigned long long* dbg;  // optional timeline probe (scripts/conv_timeline.cpp): [tile][8] {t_start, t_first_halo,
                             // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel,
-                          // 3 = streaming 1x1x1 kernel (large grids, raw input), 4 = stride-2 bf16 halo kernel (kernels_conv_s2.hip)
+                          // 3 = streaming 1x1x1 kernel (large grids, raw input), 4 = stride-2 bf16 halo kernel (kernels_conv_s2.hip),
+                          // 5 = qkv convolution fused with the attention's operand packing (kernels_conv1x1_bf16.hip)
   // Winograd-in-depth form of the 128-voxel halo kernel (conv_wino_kernel): weights pre-transformed along kz,
   // U_xi = sum_kz G[xi][kz] w[kz], packed like w with 36 pseudo-taps xi*9 + ky*3 + kx; the fused skip as 2 pseudo-taps
   // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
@@ -92,12 +93,26 @@ struct ConvParams {
   int in_bf16;            // src0 / src1 / skip_src0 / skip_src1
   int res_bf16;           // residual
   int out_bf16;           // out
+  // the qkv convolution of an AttentionBlock fused with the operand packing of the bf16 attention (kernels_conv1x1_bf16.hip;
+  // set by the planner when the launch may take that form, conv_plan decides: mode 5): `out` is then NOT written
+  uint16_t* qkv_q;        // bf16 [sample, head][T][CH], scaled by qkv_scale
+  uint16_t* qkv_k;        // bf16 [sample, head][T][CH]
+  uint16_t* qkv_vt;       // bf16 [sample, head][CH][T]
+  float qkv_scale;        // CH^-1/2 * log2 e
+  int qkv_T, qkv_CH, qkv_H;
+  int qkv_sb, qkv_rows;   // set by conv_plan: 32-channel slices / rows per workgroup
 };
 
 // kernels_conv_s2.hip: the stride-2 3x3x3 convolution of a Downsample block on bf16 activation storage (raw input, 2 x 8 x 8
 // output tiles x 64 output channels, GroupNorm statistics: one slab per tile)
 bool conv_s2_bf16_supported(const ConvParams& p);
 int conv_s2_bf16_launch(const ConvParams& p, void* stream);
+
+// kernels_conv1x1_bf16.hip: the qkv convolution of an AttentionBlock (bf16 storage) writing the packed operands of
+// flash_attn_bf16v2_kernel (ConvParams::qkv_*) instead of fp32 qkv
+bool conv1x1_qkv_bf16_supported(const ConvParams& p);
+void conv1x1_qkv_bf16_plan(ConvParams& p, int num_cus);
+int conv1x1_qkv_bf16_launch(const ConvParams& p, void* stream);
 
 // kernels_conv3.hip
 int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps);
@@ -153,7 +168,10 @@ int flash_attn_launch(const AttnParams& p, void* stream);
 // `work` (flash_attn_bf16v2_workspace_bytes) holds the packed operands and the split partials; out_bf16: `out` is bf16.
 bool flash_attn_bf16v2_supported(int T, int head_channels);
 size_t flash_attn_bf16v2_workspace_bytes(const AttnParams& p, int num_cus);
-int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream);
+// packed != 0: the operands in `work` have been written already (the fused qkv convolution), the packing pre-pass is skipped;
+// flash_attn_bf16v2_operands: where they go and the scale folded into Q
+int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream, int packed = 0);
+void flash_attn_bf16v2_operands(const AttnParams& p, void* work, uint16_t** q, uint16_t** k, uint16_t** vt, float* qscale);
 
 // in-place row softmax over `rows` rows of length `cols` (unet.py:453, fp32)
 int softmax_rows_launch(float* s, int64_t rows, int cols, void* stream);

@@ -619,7 +619,14 @@ size_t flash_attn_bf16v2_workspace_bytes(const AttnParams& p, int num_cus) {
   b += (size_t)p.N * p.H * ks * (p.T / 128) * sizeof(int);  // the LAZY kernel's redo flags, one per workgroup
   return b;
 }
-int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream) {
+void flash_attn_bf16v2_operands(const AttnParams& p, void* work, uint16_t** q, uint16_t** k, uint16_t** vt, float* qscale) {
+  const size_t ntc = (size_t)p.N * p.T * p.C;
+  uint16_t* w16 = reinterpret_cast<uint16_t*>(work);
+  *q = w16, *k = w16 + ntc, *vt = w16 + 2 * ntc;
+  *qscale = p.scale2 * 1.4426950408889634f;  // softmax in the exp2 domain
+}
+
+int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int num_cus, void* stream, int packed) {
   const int ch = p.C / p.H;
   if (!flash_attn_bf16v2_supported(p.T, ch)) {
     set_error("flash_attn_bf16v2: unsupported shape T=%d head channels=%d", p.T, ch);
@@ -644,7 +651,7 @@ int flash_attn_bf16v2_launch(const AttnParams& p, void* work, int out_bf16, int 
   // head channels 32 / 64: the LAZY kernel, then the exact one for the workgroups it flagged (normally none: they return at once)
   auto pack = [&](auto chc) {
     constexpr int CHC = decltype(chc)::value;
-    HOLO_LAUNCH(attn_pack_kernel<CHC>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
+    if (!packed) HOLO_LAUNCH(attn_pack_kernel<CHC>, pgrid, dim3(256), stream, p.qkv, w16, w16 + ntc, w16 + 2 * ntc, p.T, p.C, p.H, qscale);
   };
   const bool lazy = HOLO_ATTN_LAZY != 0 && ch != 128 && !getenv("HOLO_ATTN_EXACT");  // (development knob: the exact loop alone)
   switch (ch) {

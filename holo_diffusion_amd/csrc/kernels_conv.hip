@@ -2770,6 +2770,22 @@ size_t conv_plan(ConvParams& p, int num_cus) {
             p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && ((p.C0 + p.C1) % 16) == 0 && fits32)
                ? 1
                : 0;
+  // the qkv convolution of an AttentionBlock, fused with the operand packing of the bf16 attention (the planner offers it by
+  // setting qkv_q; HOLO_CONV_QKV_FUSED=0 keeps the row-tile kernel + attn_pack_kernel)
+  if (p.qkv_q) {
+    const char* eq = getenv("HOLO_CONV_QKV_FUSED");
+    if (!(eq && eq[0] == '0') && conv1x1_qkv_bf16_supported(p)) {
+      p.mode = 5;
+      p.nsplit = 1;
+      p.chunks_per_split = ncc;
+      conv1x1_qkv_bf16_plan(p, num_cus);
+      if (getenv("HOLO_DEBUG_PLAN"))
+        fprintf(stderr, "[plan] qkv conv %d->%d, T %d: fused with the attention's operand packing, %d rows x %d slices per workgroup\n", Cin,
+                p.Cout, p.qkv_T, p.qkv_rows, p.qkv_sb);
+      return 0;
+    }
+    p.qkv_q = nullptr;  // (not this launch: the caller packs)
+  }
   // a 1x1x1 convolution of raw input over a LARGE grid (a ResBlock's skip_connection on the 64^3 level): the streaming GEMM
   // (HOLO_CONV1X1_STREAM_MIN_M=<rows>: development knob, default 131 072 rows; 0 = off)
   {
@@ -3095,6 +3111,8 @@ int conv_launch(const ConvParams& p, void* stream) {
     }
   } else if (p.mode == 4) {
     if (conv_s2_bf16_launch(p, stream)) return -1;
+  } else if (p.mode == 5) {
+    if (conv1x1_qkv_bf16_launch(p, stream)) return -1;
   } else if (p.mode == 3) {
     if (p.stats || p.residual || p.coef || p.nsplit != 1) {
       set_error("conv_launch: the streaming 1x1x1 kernel takes raw input and produces no statistics");

@@ -474,11 +474,15 @@ struct Planner {
                  const float* w, const float* bias, size_t coef_off, bool has_coef, int act, const float* residual,
                  float* out, int Cout, Act* stats_of = nullptr, const Act* skip0 = nullptr,
                  const Act* skip1 = nullptr, const float* skip_w = nullptr, const float* skip_bias = nullptr,
-                 bool in_f32 = false, bool out_f32 = false) {
+                 bool in_f32 = false, bool out_f32 = false, const ConvParams* qkv_pack = nullptr) {
     Op op;
     op.kind = OP_CONV;
     ConvParams& p = op.conv;
     memset(&p, 0, sizeof p);
+    if (qkv_pack) {  // (an attention block's qkv convolution: conv_plan may fuse the attention's operand packing into it)
+      p.qkv_q = qkv_pack->qkv_q, p.qkv_k = qkv_pack->qkv_k, p.qkv_vt = qkv_pack->qkv_vt;
+      p.qkv_scale = qkv_pack->qkv_scale, p.qkv_T = qkv_pack->qkv_T, p.qkv_CH = qkv_pack->qkv_CH, p.qkv_H = qkv_pack->qkv_H;
+    }
     p.in_bf16 = bfs() && !in_f32;
     p.res_bf16 = bfs();
     p.out_bf16 = bfs() && !out_f32;
@@ -644,40 +648,55 @@ struct Planner {
     const size_t s_bytes = (size_t)N * H * T * T * sizeof(float);
     const size_t a_bytes = (size_t)N * T * C * sizeof(float);
     size_t qkv = scratch_alloc(qkv_bytes);
-    // (the attention internals - qkv and the attention output - stay fp32 in every mode)
-    emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
-              ptr<float>(qkv), 3 * C, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true);
     size_t a = scratch_alloc(a_bytes);
     size_t v2_work = 0, v2_bytes = 0;
     bool a_is_bf16 = false;
     const bool flash = flash_attn_supported((int)T, ch) && !getenv("HOLO_NO_FLASH_ATTN");
-    if (flash) {
-      Op op;
-      op.kind = OP_FLASH;
-      op.attn.qkv = ptr<float>(qkv);
-      op.attn.out = ptr<float>(a);
-      op.attn.N = N;
-      op.attn.T = (int)T;
-      op.attn.C = C;
-      op.attn.H = H;
+    Op fop;
+    fop.kind = OP_FLASH;
+    fop.attn.qkv = ptr<float>(qkv);
+    fop.attn.out = ptr<float>(a);
+    fop.attn.N = N;
+    fop.attn.T = (int)T;
+    fop.attn.C = C;
+    fop.attn.H = H;
+    {
       const double sc = 1.0 / sqrt(sqrt((double)ch));
-      op.attn.scale2 = (float)(sc * sc);
-      // bf16 mode, sequences of 1 024 tokens and more: the packed-operand bf16 kernel (it splits the key range to fill
-      // the chip, so it also serves the shorter of them; below that the exact-fp32 kernel is as fast).
-      // HOLO_BF16_FLASH_MIN_T lowers the threshold (tests).  (A first, shared-tile form of the bf16 kernel was removed in
-      // round 3: no shape reached it any more, and forced on by the tests it showed a rare dependence on stale memory.)
+      fop.attn.scale2 = (float)(sc * sc);
+    }
+    // bf16 mode, sequences of 1 024 tokens and more: the packed-operand bf16 kernel (it splits the key range to fill
+    // the chip, so it also serves the shorter of them; below that the exact-fp32 kernel is as fast).
+    // HOLO_BF16_FLASH_MIN_T lowers the threshold (tests).  (A first, shared-tile form of the bf16 kernel was removed in
+    // round 3: no shape reached it any more, and forced on by the tests it showed a rare dependence on stale memory.)
+    ConvParams qp;
+    memset(&qp, 0, sizeof qp);
+    bool offer_pack = false;
+    if (flash) {
       const char* mt = getenv("HOLO_BF16_FLASH_MIN_T");
       const int64_t min_t = mt ? atoll(mt) : 1024;
-      op.i0 = 0;
+      fop.i0 = 0;
       if (u->compute_mode == 1 && T >= min_t && flash_attn_bf16v2_supported((int)T, ch)) {
         // packed bf16 operands (V transposed) in scratch, bf16 attention output
-        op.i0 = 2;
-        v2_bytes = flash_attn_bf16v2_workspace_bytes(op.attn, u->ctx->num_cus);
+        fop.i0 = 2;
+        v2_bytes = flash_attn_bf16v2_workspace_bytes(fop.attn, u->ctx->num_cus);
         v2_work = scratch_alloc(v2_bytes);
-        op.o1 = ptr<float>(v2_work);
-        op.i1 = 1;
+        fop.o1 = ptr<float>(v2_work);
+        fop.i1 = 1;
         a_is_bf16 = true;
+        if (!tape && bfs()) {  // the qkv convolution may write the packed operands itself (the backward's tape keeps fp32 qkv)
+          flash_attn_bf16v2_operands(fop.attn, fop.o1, &qp.qkv_q, &qp.qkv_k, &qp.qkv_vt, &qp.qkv_scale);
+          qp.qkv_T = (int)T, qp.qkv_CH = ch, qp.qkv_H = H;
+          offer_pack = true;
+        }
       }
+    }
+    // (the attention internals - qkv and the attention output - stay fp32 in every mode)
+    emit_conv(x, nullptr, R, 0, R, 1, 1, P(u, p + ".qkv.weight"), P(u, p + ".qkv.bias"), coef, true, 0, nullptr,
+              ptr<float>(qkv), 3 * C, nullptr, nullptr, nullptr, nullptr, nullptr, false, /*out_f32=*/true,
+              offer_pack ? &qp : nullptr);
+    if (flash) {
+      Op op = fop;
+      op.i2 = ops.back().kind == OP_CONV && ops.back().conv.mode == 5 ? 1 : 0;  // operands already packed
       if (getenv("HOLO_DEBUG_PLAN"))
         fprintf(stderr, "[plan] attention %s: T=%lld C=%d heads=%d -> %s flash kernel\n", p.c_str(), (long long)T, C, H,
                 op.i0 == 2 ? "bf16" : "fp32");
@@ -1388,7 +1407,7 @@ int run_op(HoloUnet* u, const Op& op, int N, const float* x, const int64_t* t, f
     case OP_SOFTMAX:
       return softmax_rows_launch(op.o0, op.l0, op.i0, stream);
     case OP_FLASH:
-      if (op.i0 == 2) return flash_attn_bf16v2_launch(op.attn, op.o1, op.i1, u->ctx->num_cus, stream);
+      if (op.i0 == 2) return flash_attn_bf16v2_launch(op.attn, op.o1, op.i1, u->ctx->num_cus, stream, op.i2);
       return flash_attn_launch(op.attn, stream);
     case OP_OUT:
       return ndhwc_to_ncdhw_launch(op.f0, y, N, op.i0, op.l0, stream);
@@ -1873,7 +1892,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.mode == 4 ? 9 : c.mode == 3 ? 7 : (c.bf16t && c.bf16p) ? 8 : c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
+        t.kernel = c.mode == 5 ? 10 : c.mode == 4 ? 9 : c.mode == 3 ? 7 : (c.bf16t && c.bf16p) ? 8 : c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

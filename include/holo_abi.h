@@ -448,7 +448,8 @@ int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t works
  *            6 conv, 7 GEMM, 8 softmax, 9 flash attention, 10 layout-out
  *   conv ops: kernel 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = small-M weight-streaming kernel, 3 / 4 / 6 = the
  *            Winograd forms (depth / depth + height / all three axes), 5 = bf16 wide-tile kernel, 7 = streaming 1x1x1 kernel,
- *            8 = bf16 wide-tile kernel in its persistent wave-specialised form, 9 = stride-2 bf16 halo kernel;
+ *            8 = bf16 wide-tile kernel in its persistent wave-specialised form, 9 = stride-2 bf16 halo kernel,
+ *            10 = qkv convolution fused with the bf16 attention's operand packing;
  *            tile_depth / fused_skip / nsplit describe the variant (they select the template instantiation that
  *            rocprofv3 reports); ms includes the split-K reduce launch when nsplit > 1; flops = 2*MACs incl. the
  *            fused 1x1x1 skip.  Attention/GEMM ops report their 2*MACs as well; other ops report flops 0.

@@ -444,6 +444,41 @@ def test_bf16_storage_mode_blockwise(gu, wide_tile, monkeypatch):
     assert ("conv_bf16p_kernel" in kernels) == (wide_tile == "p"), kernels
 
 
+@pytest.mark.parametrize("mc,heads", [(64, 2), (128, 4), (128, 2)])
+def test_bf16_qkv_convolution_fused_with_the_attention_packing(gu, mc, heads, monkeypatch):
+    """bf16 storage mode: the qkv convolution of the long-sequence attention blocks writing the packed bf16 operands of
+    flash_attn_bf16v2_kernel itself (conv1x1_qkv_bf16_kernel: Q scaled, K, V transposed; 128 and 256 input channels, head
+    channels 64 / 64 / 128) against the unfused chain (row-tile kernel -> fp32 qkv -> attn_pack_kernel) on the same net, and
+    both against the fp32 oracle block by block - reference guided_diffusion/unet.py:300-305, 436-455."""
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+    monkeypatch.setenv("HOLO_BF16_FLASH_MIN_T", "256")  # (the 8^3 level's 512 tokens reach the bf16 attention kernel)
+    cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=1,
+                     channel_mult=(1, 2), attention_resolutions=(2,), num_heads=heads)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(5, (2, 16, 16, 16, 16)))
+    t = torch.tensor([640, 3], dtype=torch.int64)
+    trace, outs = {}, {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("HOLO_CONV_QKV_FUSED", knob)
+        net, sd = gu.make_unet(cfg, seed=41, compute_dtype="bf16")
+        if not trace:
+            ref = uo.unet_forward(sd, cfg, x, t, trace)
+        with torch.no_grad():
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+        assert 1e-5 < gu.rel_err(y, ref) < 2e-2
+        tags = [tag for tag in trace if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block"]
+        outs[knob] = {tag: net.fetch_block(tag, tuple(trace[tag].shape)).float().cpu() for tag in tags}
+        for tag in tags:
+            assert gu.rel_err(outs[knob][tag], trace[tag]) < 2e-2, (knob, tag)
+        kernels = [o.get("kernel") for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv" and o["ksz"] == 1 and o["cout"] == 6 * mc]
+        assert len(kernels) == 4 and all((k == "conv1x1_qkv_bf16_kernel") == (knob == "1") for k in kernels), kernels
+    # the first attention block sees identical input in both runs: its output differs by the rounding of a few elements
+    a, b = outs["0"]["input_blocks.3"], outs["1"]["input_blocks.3"]
+    d = (a - b).abs()
+    print(f"first attention block: max|d| {float(d.max()):.2e} of {float(a.abs().max()):.2e}, {100 * float((d > 0).float().mean()):.3f} % differ")
+    assert float(d.max()) <= 2.0 ** -6 * float(a.abs().max()) and float((d > 0).float().mean()) < 0.05
+
+
 def test_bf16_stride2_halo_kernel_blockwise(gu, monkeypatch):
     """The Downsample convolutions of the bf16 storage mode on conv_s2_bf16_kernel (2 x 8 x 8 output tiles, the 5 x 17 x 17
     input region de-interleaved along x in LDS, per-tile GroupNorm slabs), forced onto a 32^3 net (32^3 -> 16^3 with 64
