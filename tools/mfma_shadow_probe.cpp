@@ -42,6 +42,7 @@ __device__ __forceinline__ void fill(float (&v)[8], f32x2 (&pk)[4], unsigned& s,
     if (TYPE == 7) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
     if (TYPE == 8) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[r]) : "v"(1.0f));
     if (TYPE == 9) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[r]) : "v"(v[(r + 1) & 7]));
+    if (TYPE == 11) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(v[r]) : "v"(v[(r + 1) & 7]), "v"(0x3f803f80u));
     if (TYPE == 10) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[r]) : "a"(pk[r & 3][0]));  // (an AGPR no MFMA writes)
   }
 }
@@ -129,6 +130,7 @@ int main() {
     row<9>("v_max_f32", threads, out, g);
     row<7>("v_cvt_pk_bf16_f32", threads, out, g);
     row<10>("v_accvgpr_read_b32", threads, out, g);
+    row<11>("v_dot2c_f32_bf16", threads, out, g);
   }
   return 0;
 }
