@@ -217,13 +217,39 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
       const int cs0 = p == part0 ? ca : ca - C0;
       const int64_t total = (int64_t)B * nch;
       const double* base = p + ((int64_t)n * B * Cs + cs0) * 2;
+      // record j of the run -> (slab j / nch, channel j % nch): 32-bit, and a shift / mask when the run is a power of two wide
+      // (it is, except where a group straddles the seam of a concat): the 64-bit division this was costs ~150 instructions,
+      // twice per record, in a kernel that is nothing but latency
+      const bool pow2 = (nch & (nch - 1)) == 0;
+      const int sh = 31 - __builtin_clz((unsigned)nch);
+      auto rec = [&](int64_t j64) -> int64_t {
+        const unsigned j = (unsigned)j64;  // (total < 2^31: gn_finalize_launch)
+        const unsigned q = pow2 ? (j >> sh) : j / (unsigned)nch;
+        const unsigned r = pow2 ? (j & (unsigned)(nch - 1)) : j - q * (unsigned)nch;
+        return ((int64_t)q * Cs + r) * 2;
+      };
       int64_t i = tid;
+      // (sixteen loads in flight: the 2 048 x 2 records of a 64^3 tensor of the north-star net - 16 per thread - are ONE round
+      //  trip instead of two; a thread adds its records in the same order whatever the batch width: bit-identical sums)
+      for (; i + 15 * 256 < total; i += 16 * 256) {
+        double2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int64_t j = i + u * 256;
+          v[u] = *reinterpret_cast<const double2*>(base + rec(j));
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          s += v[u].x;
+          sq += v[u].y;
+        }
+      }
       for (; i + 7 * 256 < total; i += 8 * 256) {
         double2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int64_t j = i + u * 256;
-          v[u] = *reinterpret_cast<const double2*>(base + ((j / nch) * Cs + (j % nch)) * 2);
+          v[u] = *reinterpret_cast<const double2*>(base + rec(j));
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         }
       }
       for (; i < total; i += 256) {
-        const double2 v = *reinterpret_cast<const double2*>(base + ((i / nch) * Cs + (i % nch)) * 2);
+        const double2 v = *reinterpret_cast<const double2*>(base + rec(i));
         s += v.x;
         sq += v.y;
       }
