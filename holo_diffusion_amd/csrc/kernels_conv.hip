@@ -2851,9 +2851,13 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     if (!(e && e[0] == '0') && (t8 >= target || long_k || (e && e[0] == '1'))) {
       const int ncc16 = (Cin + 15) / 16;
       const int nsk16 = p.skip_w ? (p.skip_C0 + p.skip_C1 + 15) / 16 : 0;
-      if (t8 < target) {
-        nsplit = (int)cdiv(target, t8);
-        if (nsplit > ncc16) nsplit = ncc16;
+      {
+        const char* st = getenv("HOLO_BF16T_SPLIT_TARGET");  // development knob: workgroups per CU the split-K aims at (default 2)
+        const int64_t tgt = st && atoi(st) > 0 ? atoi(st) * (int64_t)num_cus : target;
+        if (t8 < tgt) {
+          nsplit = (int)cdiv(tgt, t8);
+          if (nsplit > ncc16) nsplit = ncc16;
+        }
       }
       const int cps = (int)cdiv(ncc16, nsplit);
       nsplit = (int)cdiv(ncc16, cps);
