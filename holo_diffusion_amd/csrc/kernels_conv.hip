@@ -2852,8 +2852,13 @@ size_t conv_plan(ConvParams& p, int num_cus) {
       const int ncc16 = (Cin + 15) / 16;
       const int nsk16 = p.skip_w ? (p.skip_C0 + p.skip_C1 + 15) / 16 : 0;
       {
-        const char* st = getenv("HOLO_BF16T_SPLIT_TARGET");  // development knob: workgroups per CU the split-K aims at (default 2)
-        const int64_t tgt = st && atoi(st) > 0 ? atoi(st) * (int64_t)num_cus : target;
+        // workgroups per CU the split-K aims at: two on the 32^3 level and above, ONE below it and for raw-input launches
+        // (measured at 128^3, profiles/r06_bf16t_split_target.txt: the 16^3 / 8^3 launches 43.6 -> 39.0, 41.5 -> 36.4,
+        // 41.2 -> 35.9 us with half the partial sums to write and reduce; the 32^3 launches the other way round, 59.8 vs 66.4;
+        // the raw-input Upsample convolution at 32^3 un-split lands on the persistent form: 126.7 -> 91.5 us).
+        // HOLO_BF16T_SPLIT_TARGET=<n>: development knob
+        const char* st = getenv("HOLO_BF16T_SPLIT_TARGET");
+        const int64_t tgt = st && atoi(st) > 0 ? atoi(st) * (int64_t)num_cus : ((p.OD >= 32 && p.coef) ? target : (int64_t)num_cus);
         if (t8 < tgt) {
           nsplit = (int)cdiv(tgt, t8);
           if (nsplit > ncc16) nsplit = ncc16;
