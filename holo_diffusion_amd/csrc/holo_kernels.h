@@ -65,7 +65,8 @@ struct ConvParams {
                             // t_loops_done, t_end (100 MHz wall clock), HW_ID, XCC_ID, 0, 0}; null in production
   int mode;               // set by conv_plan: 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = row-tile kernel,
                           // 3 = streaming 1x1x1 kernel (large grids, raw input), 4 = stride-2 bf16 halo kernel (kernels_conv_s2.hip),
-                          // 5 = qkv convolution fused with the attention's operand packing (kernels_conv1x1_bf16.hip)
+                          // 5 = qkv convolution fused with the attention's operand packing, 6 = streaming 1x1x1 convolution on bf16
+                          // storage (kernels_conv1x1_bf16.hip)
   // Winograd-in-depth form of the 128-voxel halo kernel (conv_wino_kernel): weights pre-transformed along kz,
   // U_xi = sum_kz G[xi][kz] w[kz], packed like w with 36 pseudo-taps xi*9 + ky*3 + kx; the fused skip as 2 pseudo-taps
   // (+w/2, -w/2).  Null = not prepared for this conv (the direct kernel runs).
@@ -113,6 +114,11 @@ int conv_s2_bf16_launch(const ConvParams& p, void* stream);
 bool conv1x1_qkv_bf16_supported(const ConvParams& p);
 void conv1x1_qkv_bf16_plan(ConvParams& p, int num_cus);
 int conv1x1_qkv_bf16_launch(const ConvParams& p, void* stream);
+// ... and the same streaming GEMM with a plain [M][Cout] bf16 output (+ bias, + residual, GroupNorm slabs: one per workgroup row block)
+bool conv1x1_bf16_stream_supported(const ConvParams& p);
+void conv1x1_bf16_stream_plan(ConvParams& p, int num_cus);
+int conv1x1_bf16_stream_slabs(const ConvParams& p);
+int conv1x1_bf16_stream_launch(const ConvParams& p, void* stream);
 
 // kernels_conv3.hip
 int64_t conv_wino3_weight_floats(int CoutP, int CinP, int src_taps);

@@ -2786,6 +2786,21 @@ size_t conv_plan(ConvParams& p, int num_cus) {
     }
     p.qkv_q = nullptr;  // (not this launch: the caller packs)
   }
+  // any other 1x1x1 convolution of a large grid on bf16 storage (the attention's proj_out): the same streaming GEMM with a plain
+  // output (HOLO_CONV1X1_BF16_STREAM=0 keeps the row-tile kernel)
+  {
+    const char* e5 = getenv("HOLO_CONV1X1_BF16_STREAM");
+    if (!(e5 && e5[0] == '0') && conv1x1_bf16_stream_supported(p)) {
+      p.mode = 6;
+      p.nsplit = 1;
+      p.chunks_per_split = ncc;
+      conv1x1_bf16_stream_plan(p, num_cus);
+      if (getenv("HOLO_DEBUG_PLAN"))
+        fprintf(stderr, "[plan] conv1 %d->%d @%d^3: bf16 streaming GEMM, %d rows x %d slices per workgroup\n", Cin, p.Cout, p.OD, p.qkv_rows,
+                p.qkv_sb);
+      return 0;
+    }
+  }
   // a 1x1x1 convolution of raw input over a LARGE grid (a ResBlock's skip_connection on the 64^3 level): the streaming GEMM
   // (HOLO_CONV1X1_STREAM_MIN_M=<rows>: development knob, default 131 072 rows; 0 = off)
   {
@@ -3004,6 +3019,7 @@ int conv_stats_slabs(const ConvParams& p) {
   if (p.mode == 1) return (int)(V / (64 * p.tz)) * (p.Cout >= 64 ? 1 : 2);
   if (p.mode == 2 && V % SM_ROWS == 0) return (int)(V / SM_ROWS);
   if (p.mode == 4) return (int)(V / 128);  // stride-2 bf16 halo kernel: one slab per 2 x 8 x 8 tile
+  if (p.mode == 6) return conv1x1_bf16_stream_slabs(p);  // bf16 streaming 1x1x1 kernel: one slab per workgroup row block
   return 0;
 }
 
@@ -3122,6 +3138,8 @@ int conv_launch(const ConvParams& p, void* stream) {
     if (conv_s2_bf16_launch(p, stream)) return -1;
   } else if (p.mode == 5) {
     if (conv1x1_qkv_bf16_launch(p, stream)) return -1;
+  } else if (p.mode == 6) {
+    if (conv1x1_bf16_stream_launch(p, stream)) return -1;
   } else if (p.mode == 3) {
     if (p.stats || p.residual || p.coef || p.nsplit != 1) {
       set_error("conv_launch: the streaming 1x1x1 kernel takes raw input and produces no statistics");

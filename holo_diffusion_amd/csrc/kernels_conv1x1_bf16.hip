@@ -14,6 +14,11 @@
 // the B operand, so the ORIENTATION of a slice's product follows its destination: Q and K slices are formed transposed
 // (weights as A: a lane ends up with 4 consecutive channels of one token -> 8-byte stores into [T][CH]), V slices directly
 // (tokens as A: 4 consecutive tokens of one channel -> 8-byte stores into [CH][T]).
+//
+// conv1x1_bf16_stream_kernel is the same streaming GEMM with a plain [M][Cout] bf16 output: the attention's proj_out (+ bias, +
+// residual x, unet.py:306) and any other 1x1x1 convolution of a large grid in this mode; products formed directly (a lane = one
+// output channel x 16 tokens of the wave's 32), so the GroupNorm statistics of the output are register sums: one slab per
+// workgroup row block, [n][block][Cout][2] doubles.
 #include "holo_common.h"
 #include "holo_kernels.h"
 
@@ -118,6 +123,122 @@ __global__ __launch_bounds__(256, 2) void conv1x1_qkv_bf16_kernel(ConvParams p) 
   }
 }
 
+
+constexpr int Q1_MAXSB = 12;  // slices per workgroup (48 KB of weights at 64 input channels)
+
+template <int NK>  // NK = Cin / 16
+__global__ __launch_bounds__(256, 2) void conv1x1_bf16_stream_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) float s_w[12288];            // [NK][SB][256 words]
+  __shared__ __attribute__((aligned(16))) float s_coef[Q1_MAXK * 32];  // [Cin][2]
+  __shared__ float s_st[4 * Q1_MAXSB * 32 * 2];                        // [wave][slice][channel][sum, sumsq]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int kg = lane >> 5;
+  const int Cin = NK * 16;
+  const int SB = p.qkv_sb;
+  const int nsl = p.CoutP >> 5;
+  const int sl0 = blockIdx.y * SB;
+  const int T = p.qkv_T;  // rows (voxels) per sample
+  const int64_t row0 = (int64_t)blockIdx.x * p.qkv_rows;
+  const int n = (int)(row0 / T);
+  {
+    const float* wsrc = reinterpret_cast<const float*>(p.w_bft);
+    for (int i = tid; i < NK * SB * 64; i += 256) {
+      const int blk = i >> 6, piece = i & 63;
+      const int cc = blk / SB, sl = blk - cc * SB;
+      *reinterpret_cast<float4*>(s_w + (int64_t)blk * 256 + piece * 4) =
+          *reinterpret_cast<const float4*>(wsrc + ((int64_t)cc * nsl + sl0 + sl) * 256 + piece * 4);
+    }
+    if (p.coef)
+      for (int i = tid; i < Cin * 2; i += 256) s_coef[i] = p.coef[(int64_t)n * Cin * 2 + i];
+  }
+  __syncthreads();
+  float ssum[Q1_MAXSB], ssq[Q1_MAXSB];
+#pragma unroll
+  for (int sl = 0; sl < Q1_MAXSB; ++sl) ssum[sl] = ssq[sl] = 0.f;
+  const uint16_t* src = reinterpret_cast<const uint16_t*>(p.src0);
+  const uint16_t* res = reinterpret_cast<const uint16_t*>(p.residual);
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+  for (int r0 = 0; r0 < p.qkv_rows; r0 += 128) {
+    const int64_t rw = row0 + r0 + wave * 32;  // first row of the wave
+    float4 xa[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) xa[s] = *reinterpret_cast<const float4*>(src + (rw + li) * Cin + s * 16 + kg * 8);
+    if (p.coef) {
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+        const float4* cf = reinterpret_cast<const float4*>(s_coef + (s * 16 + kg * 8) * 2);
+        const uint32_t w[4] = {__float_as_uint(xa[s].x), __float_as_uint(xa[s].y), __float_as_uint(xa[s].z), __float_as_uint(xa[s].w)};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 c = cf[j];
+          o[j] = pack_bf16x2(fmaf(__uint_as_float(w[j] << 16), c.x, c.y), fmaf(__uint_as_float(w[j] & 0xffff0000u), c.z, c.w));
+        }
+        xa[s] = make_float4(__uint_as_float(o[0]), __uint_as_float(o[1]), __uint_as_float(o[2]), __uint_as_float(o[3]));
+      }
+    }
+#pragma unroll
+    for (int sl = 0; sl < Q1_MAXSB; ++sl) {
+      if (sl < SB) {  // (uniform)
+        const int co = (sl0 + sl) * 32 + li;  // the lane's output channel
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float* wl = s_w + (int64_t)sl * 256 + lane * 4;
+#pragma unroll
+        for (int s = 0; s < NK; ++s)
+          acc = mfma_bf16_32x32x16(xa[s], *reinterpret_cast<const float4*>(wl + (int64_t)s * SB * 256), acc);
+        const float b = p.bias ? p.bias[co] : 0.f;
+        // D rows = tokens (r & 3) + 8 (r >> 2) + 4 kg of the wave's 32
+        float rv[16];
+        if (res) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = __uint_as_float((uint32_t)res[(rw + (r & 3) + 8 * (r >> 2) + 4 * kg) * p.Cout + co] << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[r] + b + (res ? rv[r] : 0.f);
+          ssum[sl] += v;
+          ssq[sl] += v * v;
+          out[(rw + (r & 3) + 8 * (r >> 2) + 4 * kg) * p.Cout + co] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+        }
+      }
+    }
+  }
+  // GroupNorm statistics of the output: the two k-groups of a wave by a shuffle, the four waves in LDS in wave order (deterministic)
+  if (p.stats) {
+#pragma unroll
+    for (int sl = 0; sl < Q1_MAXSB; ++sl) {
+      if (sl < SB) {
+        const float a = ssum[sl] + __shfl_xor(ssum[sl], 32), q = ssq[sl] + __shfl_xor(ssq[sl], 32);
+        if (kg == 0) {
+          s_st[((wave * Q1_MAXSB + sl) * 32 + li) * 2] = a;
+          s_st[((wave * Q1_MAXSB + sl) * 32 + li) * 2 + 1] = q;
+        }
+      }
+    }
+    __syncthreads();
+    const int blocks_per_sample = T / p.qkv_rows;
+    const int slab = (int)(blockIdx.x % blocks_per_sample);
+    for (int i = tid; i < SB * 32; i += 256) {
+      const int sl = i >> 5, c = i & 31;
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += s_st[((w * Q1_MAXSB + sl) * 32 + c) * 2];
+        q += s_st[((w * Q1_MAXSB + sl) * 32 + c) * 2 + 1];
+      }
+      double* d = p.stats + (((int64_t)n * blocks_per_sample + slab) * p.Cout + (sl0 + sl) * 32 + c) * 2;
+      d[0] = (double)a;
+      d[1] = (double)q;
+    }
+  }
+}
+
 }  // namespace
 
 // the 32-channel slices a workgroup takes (its weights <= 48 KB of LDS); 0 = the launch is not for this kernel
@@ -145,6 +266,47 @@ void conv1x1_qkv_bf16_plan(ConvParams& p, int num_cus) {
   int rows = 128;
   while (rows * 2 <= p.qkv_T && (p.qkv_T % (rows * 2)) == 0 && ((int64_t)p.N * p.qkv_T / (rows * 2)) * nby >= 2 * (int64_t)num_cus) rows *= 2;
   p.qkv_rows = rows;
+}
+
+bool conv1x1_bf16_stream_supported(const ConvParams& p) {
+  const int Cin = p.C0 + p.C1;
+  const int64_t V = (int64_t)p.OD * p.OH * p.OW;
+  return !p.qkv_q && p.ksz == 1 && p.stride == 1 && !p.ups && p.bf16 == 1 && p.in_bf16 && p.out_bf16 && (!p.residual || p.res_bf16) &&
+         p.w_bft && !p.skip_w && (!p.coef || !p.act) && p.C1 == 0 && (Cin % 16) == 0 && Cin >= 64 && Cin <= 16 * Q1_MAXK &&
+         (p.Cout % 32) == 0 && p.Cout == p.CoutP && p.ID == p.OD && p.IH == p.OH && p.IW == p.OW && V >= 4096 && (V % 128) == 0 &&
+         V < ((int64_t)1 << 31) && q1_slices_per_block(p) > 0 && q1_slices_per_block(p) <= 12;
+}
+
+// (shares ConvParams::qkv_T / qkv_sb / qkv_rows with the fused qkv form: rows per sample, slices and rows per workgroup)
+void conv1x1_bf16_stream_plan(ConvParams& p, int num_cus) {
+  p.qkv_T = (int)((int64_t)p.OD * p.OH * p.OW);
+  conv1x1_qkv_bf16_plan(p, num_cus);
+}
+
+int conv1x1_bf16_stream_slabs(const ConvParams& p) { return p.qkv_rows > 0 ? p.qkv_T / p.qkv_rows : 0; }
+
+int conv1x1_bf16_stream_launch(const ConvParams& p, void* stream) {
+  if (!conv1x1_bf16_stream_supported(p) || p.qkv_sb < 1 || p.qkv_rows < 128) {
+    set_error("conv1x1_bf16_stream_launch: unsupported launch (%d -> %d channels, %d^3)", p.C0 + p.C1, p.Cout, p.OD);
+    return -1;
+  }
+  const int NK = (p.C0 + p.C1) / 16;
+  const dim3 grid((unsigned)((int64_t)p.N * p.qkv_T / p.qkv_rows), (unsigned)((p.Cout / 32) / p.qkv_sb));
+#define HOLO_S1(NK_)                                                              \
+  case NK_:                                                                       \
+    HOLO_LAUNCH(conv1x1_bf16_stream_kernel<NK_>, grid, dim3(256), stream, p); \
+    break
+  switch (NK) {
+    HOLO_S1(4);
+    HOLO_S1(8);
+    HOLO_S1(12);
+    HOLO_S1(16);
+    default:
+      set_error("conv1x1_bf16_stream_launch: %d input channels", NK * 16);
+      return -1;
+  }
+#undef HOLO_S1
+  return 0;
 }
 
 int conv1x1_qkv_bf16_launch(const ConvParams& p, void* stream) {

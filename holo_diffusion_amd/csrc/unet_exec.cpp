@@ -1892,7 +1892,7 @@ int holo_unet_time_ops(HoloUnet* net, int batch, const float* x, const int64_t* 
       t.ms = ms / iters;
       if (op.kind == OP_CONV) {
         const ConvParams& c = op.conv;
-        t.kernel = c.mode == 5 ? 10 : c.mode == 4 ? 9 : c.mode == 3 ? 7 : (c.bf16t && c.bf16p) ? 8 : c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
+        t.kernel = c.mode == 6 ? 11 : c.mode == 5 ? 10 : c.mode == 4 ? 9 : c.mode == 3 ? 7 : (c.bf16t && c.bf16p) ? 8 : c.bf16t ? 5 : c.wino == 3 ? 6 : c.wino == 2 ? 4 : c.wino ? 3 : c.mode;
         t.tile_depth = c.mode == 1 ? c.tz : 0;
         t.fused_skip = c.skip_w ? 1 : 0;
         t.nsplit = c.nsplit;

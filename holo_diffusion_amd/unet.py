@@ -439,7 +439,7 @@ class SimpleUnet3D(Unet3DBase):
     OP_NAMES = ("memset", "layout_in", "time_embed", "emb_linears", "gn_stats", "gn_finalize", "conv", "gemm",
                 "softmax", "flash_attn", "layout_out")
     CONV_KERNELS = ("conv_igemm_kernel", "conv_halo_kernel", "conv_small_kernel", "conv_wino_kernel", "conv_wino2_kernel",
-                    "conv_bf16t_kernel", "conv_wino3_kernel", "conv1x1_stream_kernel", "conv_bf16p_kernel", "conv_s2_bf16_kernel", "conv1x1_qkv_bf16_kernel")
+                    "conv_bf16t_kernel", "conv_wino3_kernel", "conv1x1_stream_kernel", "conv_bf16p_kernel", "conv_s2_bf16_kernel", "conv1x1_qkv_bf16_kernel", "conv1x1_bf16_stream_kernel")
 
     def time_ops(self, batch: int, iters: int, device: torch.device):
         """Per-op timing of one forward in execution order (hipEvents on the launch stream): list of dicts."""

@@ -449,7 +449,7 @@ int holo_unet_time_convs(HoloUnet* net, int batch, void* workspace, size_t works
  *   conv ops: kernel 0 = per-tap gather kernel, 1 = LDS voxel-halo kernel, 2 = small-M weight-streaming kernel, 3 / 4 / 6 = the
  *            Winograd forms (depth / depth + height / all three axes), 5 = bf16 wide-tile kernel, 7 = streaming 1x1x1 kernel,
  *            8 = bf16 wide-tile kernel in its persistent wave-specialised form, 9 = stride-2 bf16 halo kernel,
- *            10 = qkv convolution fused with the bf16 attention's operand packing;
+ *            10 = qkv convolution fused with the bf16 attention's operand packing, 11 = streaming 1x1x1 convolution on bf16 storage;
  *            tile_depth / fused_skip / nsplit describe the variant (they select the template instantiation that
  *            rocprofv3 reports); ms includes the split-K reduce launch when nsplit > 1; flops = 2*MACs incl. the
  *            fused 1x1x1 skip.  Attention/GEMM ops report their 2*MACs as well; other ops report flops 0.

@@ -528,6 +528,39 @@ def test_bf16_attention_lazy_pass_and_its_exact_fallback(gu, monkeypatch):
                 assert gu.rel_err(outs[""][tag], trace[tag]) < 2e-2, tag
 
 
+@pytest.mark.parametrize("mc", [64, 128])
+def test_bf16_streaming_1x1_convolution(gu, mc, monkeypatch):
+    """bf16 storage mode: the attention's proj_out (+ bias, + residual x, GroupNorm slabs of the block output) on
+    conv1x1_bf16_stream_kernel (weights of the workgroup in LDS, rows straight from global memory in MFMA-operand layout, 64 and
+    128 input channels, two samples) against the row-tile kernel on the same net and against the fp32 oracle block by block -
+    reference guided_diffusion/unet.py:306 (x + proj_out(h))."""
+    monkeypatch.setenv("HOLO_KEEP_INTERMEDIATES", "1")
+    cfg = uo.UNetCfg(image_size=16, in_channels=16, out_channels=16, model_channels=mc, num_res_blocks=1,
+                     channel_mult=(1, 2), attention_resolutions=(1,), num_heads=2)
+    from oracle.common import np_noise
+    x = torch.from_numpy(np_noise(9, (2, 16, 16, 16, 16)))
+    t = torch.tensor([77, 940], dtype=torch.int64)
+    trace, outs = {}, {}
+    for knob in ("0", "1"):
+        monkeypatch.setenv("HOLO_CONV1X1_BF16_STREAM", knob)
+        net, sd = gu.make_unet(cfg, seed=23, compute_dtype="bf16")
+        if not trace:
+            ref = uo.unet_forward(sd, cfg, x, t, trace)
+        with torch.no_grad():
+            y = net(x.to(gu.DEV), t.to(gu.DEV))
+        assert 1e-5 < gu.rel_err(y, ref) < 2e-2
+        tags = [tag for tag in trace if tag.startswith(("input_blocks", "output_blocks")) or tag == "middle_block"]
+        outs[knob] = {tag: net.fetch_block(tag, tuple(trace[tag].shape)).float().cpu() for tag in tags}
+        for tag in tags:
+            assert gu.rel_err(outs[knob][tag], trace[tag]) < 2e-2, (knob, tag)
+        kernels = [o.get("kernel") for o in net.time_ops(2, 1, gu.DEV) if o["op"] == "conv" and o["ksz"] == 1 and o["cout"] == mc and o["out_dim"] == 16]
+        assert len(kernels) == 3 and all((k == "conv1x1_bf16_stream_kernel") == (knob == "1") for k in kernels), kernels  # (one input, two output blocks)
+    a, b = outs["0"]["input_blocks.1"], outs["1"]["input_blocks.1"]  # the first attention block: identical input in both runs
+    d = (a - b).abs()
+    print(f"first attention block: max|d| {float(d.max()):.2e} of {float(a.abs().max()):.2e}, {100 * float((d > 0).float().mean()):.3f} % differ")
+    assert float(d.max()) <= 2.0 ** -6 * float(a.abs().max()) and float((d > 0).float().mean()) < 0.05
+
+
 def test_bf16_stride2_halo_kernel_blockwise(gu, monkeypatch):
     """The Downsample convolutions of the bf16 storage mode on conv_s2_bf16_kernel (2 x 8 x 8 output tiles, the 5 x 17 x 17
     input region de-interleaved along x in LDS, per-tile GroupNorm slabs), forced onto a 32^3 net (32^3 -> 16^3 with 64
